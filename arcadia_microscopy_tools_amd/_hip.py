@@ -1,0 +1,137 @@
+"""ctypes binding of libamt_hip.so (include/amt_hip.h).  No torch types cross this boundary.
+
+The library must be built first (``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C arcadia_microscopy_tools_amd/csrc``).  There is NO CPU fallback: if the shared library is
+missing, or no MI355X is visible when a context is requested, the product raises ``HipUnavailableError``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libamt_hip.so")
+
+# element type codes (amt_hip.h)
+U8, U16, I32, F64, I64, F32 = 0, 1, 2, 3, 4, 5
+MODE_NEAREST, MODE_REFLECT, MODE_MIRROR, MODE_CONSTANT, MODE_WRAP = 0, 1, 2, 3, 4
+MODES = {"nearest": 0, "reflect": 1, "mirror": 2, "constant": 3, "wrap": 4}
+THR_OTSU = 0
+RP_COLS = (
+    "area", "centroid-0", "centroid-1", "bbox-0", "bbox-1", "bbox-2", "bbox-3", "perimeter",
+    "axis_major_length", "axis_minor_length", "eccentricity", "orientation", "area_convex", "solidity",
+)
+RP_NCOLS = len(RP_COLS)
+
+
+class HipUnavailableError(RuntimeError):
+    """libamt_hip.so could not be loaded, or no gfx950 device is usable."""
+
+
+class HipError(RuntimeError):
+    """A libamt_hip call failed (message from amt_last_error)."""
+
+
+_P = c_void_p
+_SIGS = {
+    # name: (restype, argtypes)
+    "amt_device_count": (c_int, []),
+    "amt_ctx_create": (c_int, [c_int, POINTER(c_void_p)]),
+    "amt_ctx_create_on_stream": (c_int, [c_int, c_void_p, POINTER(c_void_p)]),
+    "amt_ctx_destroy": (c_int, [_P]),
+    "amt_last_error": (c_char_p, []),
+    "amt_version": (c_char_p, []),
+    "amt_device_name": (c_int, [_P, c_char_p, c_int]),
+    "amt_malloc": (c_int, [_P, c_size_t, POINTER(c_void_p)]),
+    "amt_free": (c_int, [_P, _P]),
+    "amt_memcpy_h2d": (c_int, [_P, _P, _P, c_size_t]),
+    "amt_memcpy_d2h": (c_int, [_P, _P, _P, c_size_t]),
+    "amt_memcpy_d2d": (c_int, [_P, _P, _P, c_size_t]),
+    "amt_memset": (c_int, [_P, _P, c_int, c_size_t]),
+    "amt_sync": (c_int, [_P]),
+    "amt_host_alloc": (c_int, [c_size_t, POINTER(c_void_p)]),
+    "amt_host_free": (c_int, [_P]),
+    "amt_timer_create": (c_int, [_P, POINTER(c_void_p)]),
+    "amt_timer_start": (c_int, [_P, _P]),
+    "amt_timer_stop": (c_int, [_P, _P]),
+    "amt_timer_elapsed_ms": (c_int, [_P, _P, POINTER(c_float)]),
+    "amt_timer_destroy": (c_int, [_P, _P]),
+    "amt_deinterleave_u16": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int]),
+    "amt_gaussian": (c_int, [_P, _P, c_int, c_double, _P, c_int, c_int, c_int, _P, c_int, c_int, c_double]),
+    "amt_dog": (c_int, [_P, _P, c_int, c_double, _P, c_int, c_int, c_int, _P, c_int, _P, c_int, c_int, c_double]),
+    "amt_sub_clip0_f64": (c_int, [_P, _P, _P, _P, c_int, c_size_t]),
+    "amt_rescale": (c_int, [_P, _P, c_int, _P, c_double, c_double, _P, c_int, c_size_t]),
+    "amt_convert_u16_f64": (c_int, [_P, _P, c_double, _P, c_size_t]),
+    "amt_hist_u16": (c_int, [_P, _P, _P, c_int, c_size_t]),
+    "amt_minmax_f64": (c_int, [_P, _P, _P, c_int, c_size_t]),
+    "amt_hist_f64": (c_int, [_P, _P, _P, _P, c_int, c_int, c_size_t]),
+    "amt_percentile_u16": (c_int, [_P, _P, _P, c_int, _P, c_int, c_size_t]),
+    "amt_percentile_f64": (c_int, [_P, _P, _P, c_int, _P, c_int, c_size_t]),
+    "amt_threshold_value": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, c_int, c_size_t]),
+    "amt_threshold_gt": (c_int, [_P, _P, c_int, _P, _P, c_int, c_size_t]),
+    "amt_threshold_gt_image": (c_int, [_P, _P, c_int, _P, _P, c_size_t]),
+    "amt_binary_erode": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_int, c_int, c_int]),
+    "amt_binary_dilate": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_int, c_int, c_int]),
+    "amt_binary_open": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_int, c_int]),
+    "amt_binary_close": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_int, c_int]),
+    "amt_rank_filter": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_double]),
+    "amt_subtract": (c_int, [_P, _P, _P, _P, c_int, c_size_t]),
+    "amt_label": (c_int, [_P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int]),
+    "amt_clear_border": (c_int, [_P, _P, _P, c_int, c_int, c_int]),
+    "amt_relabel_sequential": (c_int, [_P, _P, _P, _P, c_int, c_size_t, c_int]),
+    "amt_keep_labels": (c_int, [_P, _P, _P, _P, c_int, c_size_t, c_int]),
+    "amt_cast_i32_i64": (c_int, [_P, _P, _P, c_size_t]),
+    "amt_edt": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int]),
+    "amt_peak_mask": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int]),
+    "amt_watershed_edt": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int]),
+    "amt_watershed_f64": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int]),
+    "amt_regionprops": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int]),
+    "amt_regionprops_intensity_u16": (c_int, [_P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int]),
+    "amt_max_i32": (c_int, [_P, _P, _P, c_int, c_size_t]),
+}
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def load_library():
+    """Load libamt_hip.so and declare every prototype.  Raises HipUnavailableError if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise HipUnavailableError(
+                f"{LIB_PATH} not found: build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback"
+            )
+        try:
+            lib = ctypes.CDLL(LIB_PATH)
+        except OSError as e:  # missing ROCm runtime etc.
+            raise HipUnavailableError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(lib, name)  # AttributeError = header / library mismatch: fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def exported_names():
+    return sorted(_SIGS)
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load_library().amt_last_error().decode("utf-8", "replace")
+        if rc == -4:
+            raise HipUnavailableError(msg)
+        if rc == -1:
+            raise ValueError(msg)
+        if rc == -3:
+            raise MemoryError(msg)
+        raise HipError(f"{what}: {msg} (code {rc})")

@@ -1,0 +1,236 @@
+// Context, memory, timers and error plumbing of libamt_hip.so.
+#include "amt_common.h"
+
+static thread_local char g_err[1024] = "";
+
+void amt_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* amt_last_error(void) { return g_err; }
+extern "C" const char* amt_version(void) { return "amt_hip 0.1 (gfx950)"; }
+
+extern "C" int amt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+static int ctx_create_common(int device, hipStream_t stream, bool own, amt_ctx** out) {
+    AMT_REQUIRE(out != nullptr, "amt_ctx_create: out is null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        amt_set_error("no HIP device available (%s); libamt_hip requires an MI355X (gfx950)",
+                      e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+        return AMT_ENODEV;
+    }
+    AMT_REQUIRE(device >= 0 && device < n, "amt_ctx_create: device %d out of range (have %d)", device, n);
+    AMT_HIP_CHECK(hipSetDevice(device));
+    amt_ctx* c = new amt_ctx();
+    c->device = device;
+    c->own_stream = own;
+    c->stream = stream;
+    if (own) {
+        hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (se != hipSuccess) {
+            delete c;
+            amt_set_error("hipStreamCreate failed: %s", hipGetErrorString(se));
+            return AMT_EHIP;
+        }
+    }
+    c->arena = nullptr;
+    c->arena_cap = 0;
+    c->arena_off = 0;
+    c->mailbox = nullptr;
+    c->mailbox_cap = 0;
+    c->mailbox_off = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess)
+        c->num_cus = prop.multiProcessorCount;
+    else
+        c->num_cus = 256;
+    c->mailbox_cap = 1u << 20;
+    if (hipHostMalloc((void**)&c->mailbox, c->mailbox_cap, hipHostMallocDefault) != hipSuccess) {
+        c->mailbox = nullptr;
+        c->mailbox_cap = 0;
+    }
+    *out = c;
+    return AMT_OK;
+}
+
+extern "C" int amt_ctx_create(int device, amt_ctx** out) { return ctx_create_common(device, nullptr, true, out); }
+
+extern "C" int amt_ctx_create_on_stream(int device, void* hip_stream, amt_ctx** out) {
+    return ctx_create_common(device, (hipStream_t)hip_stream, false, out);
+}
+
+extern "C" int amt_ctx_destroy(amt_ctx* ctx) {
+    if (!ctx) return AMT_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->arena) (void)hipFree(ctx->arena);
+    if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return AMT_OK;
+}
+
+extern "C" int amt_device_name(amt_ctx* ctx, char* buf, int buflen) {
+    AMT_TRY(amt_set_device(ctx));
+    AMT_REQUIRE(buf && buflen > 0, "amt_device_name: bad buffer");
+    hipDeviceProp_t prop;
+    AMT_HIP_CHECK(hipGetDeviceProperties(&prop, ctx->device));
+    snprintf(buf, (size_t)buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return AMT_OK;
+}
+
+int amt_arena_begin(amt_ctx* ctx, size_t total_bytes) {
+    total_bytes = amt_align(total_bytes) + 4096;
+    if (total_bytes > ctx->arena_cap) {
+        // previous users of the arena are ordered before us on the stream; drain it before freeing
+        AMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (ctx->arena) AMT_HIP_CHECK(hipFree(ctx->arena));
+        ctx->arena = nullptr;
+        ctx->arena_cap = 0;
+        size_t cap = total_bytes + total_bytes / 4;
+        hipError_t e = hipMalloc((void**)&ctx->arena, cap);
+        if (e != hipSuccess) {
+            amt_set_error("scratch arena allocation of %zu bytes failed: %s", cap, hipGetErrorString(e));
+            return AMT_ENOMEM;
+        }
+        ctx->arena_cap = cap;
+    }
+    ctx->arena_off = 0;
+    return AMT_OK;
+}
+
+int amt_param_upload(amt_ctx* ctx, void* dev_dst, const void* host_src, size_t bytes) {
+    if (bytes == 0) return AMT_OK;
+    size_t need = amt_align(bytes, 256);
+    if (!ctx->mailbox || need > ctx->mailbox_cap) {
+        // too large for the ring: synchronous copy (the caller's buffer is consumed before returning)
+        AMT_HIP_CHECK(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        AMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        return AMT_OK;
+    }
+    if (ctx->mailbox_off + need > ctx->mailbox_cap) {
+        // wrap: older slots may still be in flight
+        AMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        ctx->mailbox_off = 0;
+    }
+    char* slot = ctx->mailbox + ctx->mailbox_off;
+    ctx->mailbox_off += need;
+    memcpy(slot, host_src, bytes);
+    AMT_HIP_CHECK(hipMemcpyAsync(dev_dst, slot, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return AMT_OK;
+}
+
+void* amt_arena_take(amt_ctx* ctx, size_t bytes) {
+    bytes = amt_align(bytes);
+    void* p = ctx->arena + ctx->arena_off;
+    ctx->arena_off += bytes;
+    return p;
+}
+
+extern "C" int amt_malloc(amt_ctx* ctx, size_t bytes, void** dptr) {
+    AMT_TRY(amt_set_device(ctx));
+    AMT_REQUIRE(dptr != nullptr, "amt_malloc: dptr is null");
+    if (bytes == 0) bytes = 256;
+    hipError_t e = hipMalloc(dptr, bytes);
+    if (e != hipSuccess) {
+        amt_set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return AMT_ENOMEM;
+    }
+    return AMT_OK;
+}
+
+extern "C" int amt_free(amt_ctx* ctx, void* dptr) {
+    AMT_TRY(amt_set_device(ctx));
+    if (dptr) AMT_HIP_CHECK(hipFree(dptr));
+    return AMT_OK;
+}
+
+extern "C" int amt_memcpy_h2d(amt_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    AMT_TRY(amt_set_device(ctx));
+    if (bytes) AMT_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return AMT_OK;
+}
+extern "C" int amt_memcpy_d2h(amt_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    AMT_TRY(amt_set_device(ctx));
+    if (bytes) AMT_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return AMT_OK;
+}
+extern "C" int amt_memcpy_d2d(amt_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    AMT_TRY(amt_set_device(ctx));
+    if (bytes) AMT_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return AMT_OK;
+}
+extern "C" int amt_memset(amt_ctx* ctx, void* dst, int value, size_t bytes) {
+    AMT_TRY(amt_set_device(ctx));
+    if (bytes) AMT_HIP_CHECK(hipMemsetAsync(dst, value, bytes, ctx->stream));
+    return AMT_OK;
+}
+extern "C" int amt_sync(amt_ctx* ctx) {
+    AMT_TRY(amt_set_device(ctx));
+    AMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return AMT_OK;
+}
+
+extern "C" int amt_host_alloc(size_t bytes, void** hptr) {
+    AMT_REQUIRE(hptr != nullptr, "amt_host_alloc: hptr is null");
+    hipError_t e = hipHostMalloc(hptr, bytes ? bytes : 64, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        amt_set_error("hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return AMT_ENOMEM;
+    }
+    return AMT_OK;
+}
+extern "C" int amt_host_free(void* hptr) {
+    if (hptr) AMT_HIP_CHECK(hipHostFree(hptr));
+    return AMT_OK;
+}
+
+struct amt_timer {
+    hipEvent_t start, stop;
+};
+
+extern "C" int amt_timer_create(amt_ctx* ctx, void** timer) {
+    AMT_TRY(amt_set_device(ctx));
+    AMT_REQUIRE(timer != nullptr, "amt_timer_create: null");
+    amt_timer* t = new amt_timer();
+    AMT_HIP_CHECK(hipEventCreate(&t->start));
+    AMT_HIP_CHECK(hipEventCreate(&t->stop));
+    *timer = t;
+    return AMT_OK;
+}
+extern "C" int amt_timer_start(amt_ctx* ctx, void* timer) {
+    AMT_TRY(amt_set_device(ctx));
+    AMT_HIP_CHECK(hipEventRecord(((amt_timer*)timer)->start, ctx->stream));
+    return AMT_OK;
+}
+extern "C" int amt_timer_stop(amt_ctx* ctx, void* timer) {
+    AMT_TRY(amt_set_device(ctx));
+    AMT_HIP_CHECK(hipEventRecord(((amt_timer*)timer)->stop, ctx->stream));
+    return AMT_OK;
+}
+extern "C" int amt_timer_elapsed_ms(amt_ctx* ctx, void* timer, float* ms) {
+    AMT_TRY(amt_set_device(ctx));
+    amt_timer* t = (amt_timer*)timer;
+    AMT_HIP_CHECK(hipEventSynchronize(t->stop));
+    AMT_HIP_CHECK(hipEventElapsedTime(ms, t->start, t->stop));
+    return AMT_OK;
+}
+extern "C" int amt_timer_destroy(amt_ctx* ctx, void* timer) {
+    AMT_TRY(amt_set_device(ctx));
+    amt_timer* t = (amt_timer*)timer;
+    if (t) {
+        (void)hipEventDestroy(t->start);
+        (void)hipEventDestroy(t->stop);
+        delete t;
+    }
+    return AMT_OK;
+}

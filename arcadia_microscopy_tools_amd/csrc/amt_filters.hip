@@ -1,0 +1,432 @@
+// Separable Gaussian / difference-of-Gaussians and the elementwise ops of R/operations.py.
+//
+// Numerics contract: float64 everywhere, NO fma contraction (the library is
+// built with -ffp-contract=off), per-sample evaluation order of scipy's symmetric correlate1d:
+//     acc = x[i]*w[c];  for j = r, r-1, ..., 1:  acc += (x[i-j] + x[i+j]) * w[c-j]
+// axis 0 first, its float64 result is the input of axis 1.  The weights arrive from the host
+// (numpy), so np.exp rounding is shared with the CPU path.
+#include "amt_common.h"
+
+// ------------------------------------------------------------------------------------------------
+// Generic two-pass path (any radius up to 128): each pass stages a tile plus halo in LDS.
+// Vertical pass: block (64, 4) covers 64 columns x TH rows; LDS tile (TH + 2r) x 64 doubles.
+// ------------------------------------------------------------------------------------------------
+template <typename TIn>
+__device__ __forceinline__ double load_as_f64(const TIn* p, size_t i, double scale);
+template <>
+__device__ __forceinline__ double load_as_f64<uint16_t>(const uint16_t* p, size_t i, double scale) {
+    return (double)p[i] * scale;
+}
+template <>
+__device__ __forceinline__ double load_as_f64<double>(const double* p, size_t i, double scale) {
+    return p[i];
+}
+
+template <typename TIn>
+__global__ void __launch_bounds__(256) conv_axis0_kernel(const TIn* __restrict__ in, double scale,
+                                                         double* __restrict__ out, int H, int W,
+                                                         const double* __restrict__ wts, int r, int mode, double cval,
+                                                         int TH) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* tile = reinterpret_cast<double*>(smem_raw);  // (TH + 2r) x 64
+    double* w = tile + (size_t)(TH + 2 * r) * 64;        // 2r + 1
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int x = blockIdx.x * 64 + tx;
+    const int y0 = blockIdx.y * TH;
+    const size_t plane = (size_t)blockIdx.z * H * W;
+    const int tid = ty * 64 + tx;
+    for (int i = tid; i < 2 * r + 1; i += 256) w[i] = wts[i];
+    const int rows = TH + 2 * r;
+    for (int k = ty; k < rows; k += 4) {
+        int yy = amt_map_index(y0 - r + k, H, mode);
+        double v = cval;
+        if (x < W && yy >= 0) v = load_as_f64<TIn>(in, plane + (size_t)yy * W + x, scale);
+        tile[k * 64 + tx] = v;
+    }
+    __syncthreads();
+    if (x >= W) return;
+    for (int k = ty; k < TH; k += 4) {
+        int y = y0 + k;
+        if (y >= H) break;
+        const double* c = tile + (size_t)(k + r) * 64 + tx;
+        double acc = c[0] * w[r];
+        for (int j = r; j >= 1; --j) acc += (c[-j * 64] + c[j * 64]) * w[r - j];
+        out[plane + (size_t)y * W + x] = acc;
+    }
+}
+
+// Horizontal pass: block 256 threads covers TW = 256 columns x 4 rows; LDS tile 4 x (256 + 2r).
+__global__ void __launch_bounds__(256) conv_axis1_kernel(const double* __restrict__ in, double* __restrict__ out,
+                                                         int H, int W, const double* __restrict__ wts, int r, int mode,
+                                                         double cval) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int TWP = 256 + 2 * r;
+    double* tile = reinterpret_cast<double*>(smem_raw);  // 4 x TWP
+    double* w = tile + (size_t)4 * TWP;
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * 256;
+    const int y0 = blockIdx.y * 4;
+    const size_t plane = (size_t)blockIdx.z * H * W;
+    for (int i = tid; i < 2 * r + 1; i += 256) w[i] = wts[i];
+    for (int row = 0; row < 4; ++row) {
+        int y = y0 + row;
+        if (y >= H) break;
+        for (int k = tid; k < TWP; k += 256) {
+            int xx = amt_map_index(x0 - r + k, W, mode);
+            tile[row * TWP + k] = (xx >= 0) ? in[plane + (size_t)y * W + xx] : cval;
+        }
+    }
+    __syncthreads();
+    const int x = x0 + tid;
+    if (x >= W) return;
+    for (int row = 0; row < 4; ++row) {
+        int y = y0 + row;
+        if (y >= H) break;
+        const double* c = tile + row * TWP + tid + r;
+        double acc = c[0] * w[r];
+        for (int j = r; j >= 1; --j) acc += (c[-j] + c[j]) * w[r - j];
+        out[plane + (size_t)y * W + x] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused single-kernel path for small radii (r <= 12): one HBM read of the input, one write of the
+// result; the axis-0 intermediate lives in LDS only.  Tile 32 rows x 64 cols per 256-thread block.
+//   stage 1: load (32 + 2r) x (64 + 2r) samples (converted to f64) into LDS  [src]
+//   stage 2: axis-0 pass for 32 rows x (64 + 2r) columns                    [mid]
+//   stage 3: axis-1 pass for 32 x 64 outputs, written straight to HBM.
+// Each thread keeps a sliding register window along the filter axis so every LDS value is read once
+// per 8 outputs instead of once per tap.
+// ------------------------------------------------------------------------------------------------
+constexpr int FT_H = 32;
+constexpr int FT_W = 64;
+constexpr int FR_MAX = 12;
+
+template <typename TIn, int R>
+__global__ void __launch_bounds__(256) gauss_fused_kernel(const TIn* __restrict__ in, double scale,
+                                                          double* __restrict__ out, int H, int W,
+                                                          const double* __restrict__ wts, int mode, double cval) {
+    constexpr int SW = FT_W + 2 * R;      // staged width
+    constexpr int SH = FT_H + 2 * R;      // staged height
+    constexpr int SWP = SW + 1;           // +1 double of padding against bank conflicts on column walks
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* src = reinterpret_cast<double*>(smem_raw);  // SH x SWP
+    double* mid = src + (size_t)SH * SWP;               // FT_H x SWP
+    double* w = mid + (size_t)FT_H * SWP;               // 2R + 1 (kept in the dynamic region: G17)
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H;
+    const size_t plane = (size_t)blockIdx.z * H * W;
+    if (tid < 2 * R + 1) w[tid] = wts[tid];
+    for (int i = tid; i < SH * SW; i += 256) {
+        int ky = i / SW, kx = i - ky * SW;
+        int yy = amt_map_index(y0 - R + ky, H, mode);
+        int xx = amt_map_index(x0 - R + kx, W, mode);
+        double v = cval;
+        if (yy >= 0 && xx >= 0) v = load_as_f64<TIn>(in, plane + (size_t)yy * W + xx, scale);
+        src[ky * SWP + kx] = v;
+    }
+    __syncthreads();
+    // stage 2: SW columns, FT_H rows; a thread owns one column and a strip of 8 rows.
+    // work items = SW * (FT_H / 8)
+    for (int item = tid; item < SW * (FT_H / 8); item += 256) {
+        int col = item % SW;
+        int strip = item / SW;
+        const double* c = src + (size_t)(strip * 8) * SWP + col;  // row (strip*8) of src == y0 - R + strip*8
+        double win[8 + 2 * R];
+#pragma unroll
+        for (int k = 0; k < 8 + 2 * R; ++k) win[k] = c[(size_t)k * SWP];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            double acc = win[o + R] * w[R];
+#pragma unroll
+            for (int j = R; j >= 1; --j) acc += (win[o + R - j] + win[o + R + j]) * w[R - j];
+            mid[(size_t)(strip * 8 + o) * SWP + col] = acc;
+        }
+    }
+    __syncthreads();
+    // stage 3: FT_H rows x FT_W outputs; a thread owns one row and a strip of 8 consecutive columns.
+    {
+        int row = tid / 8;        // 0..31
+        int strip = tid % 8;      // 0..7 -> columns strip*8 .. strip*8+7
+        const double* c = mid + (size_t)row * SWP + strip * 8;
+        double win[8 + 2 * R];
+#pragma unroll
+        for (int k = 0; k < 8 + 2 * R; ++k) win[k] = c[k];
+        int y = y0 + row;
+        if (y < H) {
+#pragma unroll
+            for (int o = 0; o < 8; ++o) {
+                double acc = win[o + R] * w[R];
+#pragma unroll
+                for (int j = R; j >= 1; --j) acc += (win[o + R - j] + win[o + R + j]) * w[R - j];
+                int x = x0 + strip * 8 + o;
+                if (x < W) out[plane + (size_t)y * W + x] = acc;
+            }
+        }
+    }
+}
+
+template <typename TIn, int R>
+static int launch_fused(amt_ctx* ctx, const TIn* in, double scale, double* out, int nplanes, int H, int W,
+                        const double* wdev, int mode, double cval) {
+    constexpr int SW = FT_W + 2 * R, SH = FT_H + 2 * R, SWP = SW + 1;
+    size_t smem = ((size_t)(SH + FT_H) * SWP + 2 * R + 1) * sizeof(double);
+    dim3 grid((W + FT_W - 1) / FT_W, (H + FT_H - 1) / FT_H, nplanes);
+    hipLaunchKernelGGL((gauss_fused_kernel<TIn, R>), grid, dim3(256), smem, ctx->stream, in, scale, out, H, W, wdev,
+                       mode, cval);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+
+template <typename TIn>
+static int gaussian_typed(amt_ctx* ctx, const TIn* in, double scale, double* out, double* tmp, int nplanes, int H,
+                          int W, const double* wdev, int r, int mode, double cval) {
+    switch (r) {
+#define AMT_FUSED_CASE(RR) \
+    case RR:               \
+        return launch_fused<TIn, RR>(ctx, in, scale, out, nplanes, H, W, wdev, mode, cval);
+        AMT_FUSED_CASE(1)
+        AMT_FUSED_CASE(2)
+        AMT_FUSED_CASE(3)
+        AMT_FUSED_CASE(4)
+        AMT_FUSED_CASE(5)
+        AMT_FUSED_CASE(6)
+        AMT_FUSED_CASE(7)
+        AMT_FUSED_CASE(8)
+        AMT_FUSED_CASE(9)
+        AMT_FUSED_CASE(10)
+        AMT_FUSED_CASE(11)
+        AMT_FUSED_CASE(12)
+#undef AMT_FUSED_CASE
+        default:
+            break;
+    }
+    // generic two-pass path
+    int TH = (r <= 32) ? 64 : 32;
+    size_t smem0 = ((size_t)(TH + 2 * r) * 64 + (2 * r + 1)) * sizeof(double);
+    dim3 g0((W + 63) / 64, (H + TH - 1) / TH, nplanes);
+    hipLaunchKernelGGL((conv_axis0_kernel<TIn>), g0, dim3(64, 4), smem0, ctx->stream, in, scale, tmp, H, W, wdev, r,
+                       mode, cval, TH);
+    AMT_LAUNCH_CHECK();
+    size_t smem1 = ((size_t)4 * (256 + 2 * r) + (2 * r + 1)) * sizeof(double);
+    dim3 g1((W + 255) / 256, (H + 3) / 4, nplanes);
+    hipLaunchKernelGGL(conv_axis1_kernel, g1, dim3(256), smem1, ctx->stream, tmp, out, H, W, wdev, r, mode, cval);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+
+static int check_gauss_args(const void* in, int in_dtype, double* out, int nplanes, int H, int W, const double* w,
+                            int r) {
+    AMT_REQUIRE(in && out && w, "gaussian: null pointer");
+    AMT_REQUIRE(in_dtype == AMT_U16 || in_dtype == AMT_F64, "gaussian: in_dtype must be AMT_U16 or AMT_F64");
+    AMT_REQUIRE(nplanes >= 0 && H > 0 && W > 0, "gaussian: bad shape %d x %d x %d", nplanes, H, W);
+    AMT_REQUIRE(r >= 0 && r <= 128, "gaussian: radius %d unsupported (0..128, i.e. sigma <= 32)", r);
+    return AMT_OK;
+}
+
+static int gaussian_dispatch(amt_ctx* ctx, const void* in, int in_dtype, double scale, double* out, double* tmp,
+                             int nplanes, int H, int W, const double* wdev, int r, int mode, double cval) {
+    if (in_dtype == AMT_U16)
+        return gaussian_typed<uint16_t>(ctx, (const uint16_t*)in, scale, out, tmp, nplanes, H, W, wdev, r, mode, cval);
+    return gaussian_typed<double>(ctx, (const double*)in, 1.0, out, tmp, nplanes, H, W, wdev, r, mode, cval);
+}
+
+__global__ void convert_u16_f64_kernel(const uint16_t* __restrict__ in, double scale, double* __restrict__ out,
+                                       size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) out[i] = (double)in[i] * scale;
+}
+
+__global__ void copy_f64_kernel(const double* __restrict__ in, double* __restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) out[i] = in[i];
+}
+
+extern "C" int amt_convert_u16_f64(amt_ctx* ctx, const uint16_t* in, double scale, double* out, size_t n) {
+    AMT_TRY(amt_set_device(ctx));
+    AMT_REQUIRE(in && out, "convert_u16_f64: null pointer");
+    if (n == 0) return AMT_OK;
+    hipLaunchKernelGGL(convert_u16_f64_kernel, dim3(amt_grid_for(n, 256)), dim3(256), 0, ctx->stream, in, scale, out,
+                       n);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+
+extern "C" int amt_gaussian(amt_ctx* ctx, const void* in, int in_dtype, double scale, double* out, int nplanes, int H,
+                            int W, const double* weights, int radius, int mode, double cval) {
+    AMT_TRY(amt_set_device(ctx));
+    AMT_TRY(check_gauss_args(in, in_dtype, out, nplanes, H, W, weights, radius));
+    if (nplanes == 0) return AMT_OK;
+    size_t n = (size_t)nplanes * H * W;
+    if (radius == 0) {  // sigma too small: scipy's kernel is the single weight 1.0
+        if (in_dtype == AMT_U16) return amt_convert_u16_f64(ctx, (const uint16_t*)in, scale, out, n);
+        hipLaunchKernelGGL(copy_f64_kernel, dim3(amt_grid_for(n, 256)), dim3(256), 0, ctx->stream, (const double*)in,
+                           out, n);
+        AMT_LAUNCH_CHECK();
+        return AMT_OK;
+    }
+    size_t wbytes = amt_align((2 * radius + 1) * sizeof(double));
+    size_t tmpbytes = radius > FR_MAX ? amt_align(n * sizeof(double)) : 0;
+    AMT_TRY(amt_arena_begin(ctx, wbytes + tmpbytes));
+    double* wdev = (double*)amt_arena_take(ctx, wbytes);
+    double* tmp = tmpbytes ? (double*)amt_arena_take(ctx, tmpbytes) : nullptr;
+    AMT_TRY(amt_param_upload(ctx, wdev, weights, (2 * radius + 1) * sizeof(double)));
+    return gaussian_dispatch(ctx, in, in_dtype, scale, out, tmp, nplanes, H, W, wdev, radius, mode, cval);
+}
+
+__global__ void sub_inplace_kernel(double* __restrict__ a, const double* __restrict__ b, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) a[i] = a[i] - b[i];
+}
+
+extern "C" int amt_dog(amt_ctx* ctx, const void* in, int in_dtype, double scale, double* out, int nplanes, int H,
+                       int W, const double* w_lo, int r_lo, const double* w_hi, int r_hi, int mode, double cval) {
+    AMT_TRY(amt_set_device(ctx));
+    AMT_TRY(check_gauss_args(in, in_dtype, out, nplanes, H, W, w_lo, r_lo));
+    AMT_TRY(check_gauss_args(in, in_dtype, out, nplanes, H, W, w_hi, r_hi));
+    AMT_REQUIRE(r_lo >= 1 && r_hi >= 1, "dog: radii must be >= 1");
+    if (nplanes == 0) return AMT_OK;
+    size_t n = (size_t)nplanes * H * W;
+    size_t wl = amt_align((2 * r_lo + 1) * sizeof(double)), wh = amt_align((2 * r_hi + 1) * sizeof(double));
+    size_t nb = amt_align(n * sizeof(double));
+    bool need_tmp = (r_lo > FR_MAX) || (r_hi > FR_MAX);
+    AMT_TRY(amt_arena_begin(ctx, wl + wh + nb + (need_tmp ? nb : 0)));
+    double* wlo_d = (double*)amt_arena_take(ctx, wl);
+    double* whi_d = (double*)amt_arena_take(ctx, wh);
+    double* ghi = (double*)amt_arena_take(ctx, nb);
+    double* tmp = need_tmp ? (double*)amt_arena_take(ctx, nb) : nullptr;
+    AMT_TRY(amt_param_upload(ctx, wlo_d, w_lo, (2 * r_lo + 1) * sizeof(double)));
+    AMT_TRY(amt_param_upload(ctx, whi_d, w_hi, (2 * r_hi + 1) * sizeof(double)));
+    AMT_TRY(gaussian_dispatch(ctx, in, in_dtype, scale, out, tmp, nplanes, H, W, wlo_d, r_lo, mode, cval));
+    AMT_TRY(gaussian_dispatch(ctx, in, in_dtype, scale, ghi, tmp, nplanes, H, W, whi_d, r_hi, mode, cval));
+    hipLaunchKernelGGL(sub_inplace_kernel, dim3(amt_grid_for(n, 256)), dim3(256), 0, ctx->stream, out, ghi, n);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+
+// ---- elementwise -------------------------------------------------------------------------------
+__global__ void sub_clip0_kernel(const double* __restrict__ in, const double* __restrict__ level,
+                                 double* __restrict__ out, size_t n) {
+    const double lv = level[blockIdx.y];
+    const size_t base = (size_t)blockIdx.y * n;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        double v = in[base + i] - lv;
+        // np.clip(v, 0, None) == maximum(v, 0): NaN propagates, -0.0 -> compares equal to 0
+        out[base + i] = (v < 0.0) ? 0.0 : v;
+    }
+}
+
+extern "C" int amt_sub_clip0_f64(amt_ctx* ctx, const double* in, const double* level_dev, double* out, int nplanes,
+                                 size_t n) {
+    AMT_TRY(amt_set_device(ctx));
+    AMT_REQUIRE(in && level_dev && out, "sub_clip0: null pointer");
+    if (nplanes == 0 || n == 0) return AMT_OK;
+    dim3 grid(amt_grid_for(n, 256, 2048), nplanes);
+    hipLaunchKernelGGL(sub_clip0_kernel, grid, dim3(256), 0, ctx->stream, in, level_dev, out, n);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+
+// SK/exposure/exposure.py:405-428: image = clip(image, imin, imax) IN THE INPUT DTYPE'S VALUE SPACE
+// (np.clip of a uint16 array with float bounds yields float64), then (image - imin) / (imax - imin),
+// then * (omax - omin) + omin.  imin == imax -> clip(image, omin, omax).
+template <typename TIn>
+__global__ void rescale_kernel(const TIn* __restrict__ in, const double* __restrict__ range, double omin, double omax,
+                               double* __restrict__ out, size_t n) {
+    const double imin = range[2 * blockIdx.y], imax = range[2 * blockIdx.y + 1];
+    const size_t base = (size_t)blockIdx.y * n;
+    const double den = imax - imin;
+    const double osc = omax - omin;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        double v = (double)in[base + i];
+        if (imin != imax) {
+            v = v < imin ? imin : (v > imax ? imax : v);
+            v = (v - imin) / den;
+            out[base + i] = v * osc + omin;
+        } else {
+            v = v < imin ? imin : (v > imax ? imax : v);
+            out[base + i] = v < omin ? omin : (v > omax ? omax : v);
+        }
+    }
+}
+
+extern "C" int amt_rescale(amt_ctx* ctx, const void* in, int in_dtype, const double* range_dev, double omin,
+                           double omax, double* out, int nplanes, size_t n) {
+    AMT_TRY(amt_set_device(ctx));
+    AMT_REQUIRE(in && range_dev && out, "rescale: null pointer");
+    AMT_REQUIRE(in_dtype == AMT_U16 || in_dtype == AMT_F64, "rescale: in_dtype must be AMT_U16 or AMT_F64");
+    if (nplanes == 0 || n == 0) return AMT_OK;
+    dim3 grid(amt_grid_for(n, 256, 2048), nplanes);
+    if (in_dtype == AMT_U16)
+        hipLaunchKernelGGL((rescale_kernel<uint16_t>), grid, dim3(256), 0, ctx->stream, (const uint16_t*)in, range_dev,
+                           omin, omax, out, n);
+    else
+        hipLaunchKernelGGL((rescale_kernel<double>), grid, dim3(256), 0, ctx->stream, (const double*)in, range_dev,
+                           omin, omax, out, n);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+
+template <typename T>
+__global__ void subtract_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) out[i] = (T)(a[i] - b[i]);
+}
+
+extern "C" int amt_subtract(amt_ctx* ctx, const void* a, const void* b, void* out, int dtype, size_t n) {
+    AMT_TRY(amt_set_device(ctx));
+    AMT_REQUIRE(a && b && out, "subtract: null pointer");
+    if (n == 0) return AMT_OK;
+    dim3 grid(amt_grid_for(n, 256));
+    switch (dtype) {
+        case AMT_U16:
+            hipLaunchKernelGGL((subtract_kernel<uint16_t>), grid, dim3(256), 0, ctx->stream, (const uint16_t*)a,
+                               (const uint16_t*)b, (uint16_t*)out, n);
+            break;
+        case AMT_F64:
+            hipLaunchKernelGGL((subtract_kernel<double>), grid, dim3(256), 0, ctx->stream, (const double*)a,
+                               (const double*)b, (double*)out, n);
+            break;
+        case AMT_U8:
+            hipLaunchKernelGGL((subtract_kernel<uint8_t>), grid, dim3(256), 0, ctx->stream, (const uint8_t*)a,
+                               (const uint8_t*)b, (uint8_t*)out, n);
+            break;
+        default:
+            amt_set_error("subtract: unsupported dtype %d", dtype);
+            return AMT_EINVAL;
+    }
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+
+__global__ void deinterleave_u16_kernel(const uint16_t* __restrict__ yxc, uint16_t* __restrict__ cyx, size_t npix,
+                                        int C) {
+    const size_t fbase = (size_t)blockIdx.y * npix * C;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < npix * C; i += stride) {
+        size_t p = i / C;
+        int c = (int)(i - p * C);
+        cyx[fbase + (size_t)c * npix + p] = yxc[fbase + i];
+    }
+}
+
+extern "C" int amt_deinterleave_u16(amt_ctx* ctx, const uint16_t* yxc, uint16_t* cyx, int nplanes, int H, int W,
+                                    int C) {
+    AMT_TRY(amt_set_device(ctx));
+    AMT_REQUIRE(yxc && cyx && H > 0 && W > 0 && C > 0, "deinterleave: bad arguments");
+    if (nplanes == 0) return AMT_OK;
+    size_t npix = (size_t)H * W;
+    dim3 grid(amt_grid_for(npix * C, 256, 4096), nplanes);
+    hipLaunchKernelGGL(deinterleave_u16_kernel, grid, dim3(256), 0, ctx->stream, yxc, cyx, npix, C);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}

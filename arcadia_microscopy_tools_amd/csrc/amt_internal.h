@@ -1,0 +1,75 @@
+// Cross-translation-unit internals of libamt_hip.so (not part of the C ABI).
+#pragma once
+#include "amt_common.h"
+
+// ---- exclusive prefix sum over int32 arrays: one 1024-thread workgroup per plane ---------------
+// data[plane][0..len) is replaced by its exclusive scan; total[plane] (optional) receives the sum.
+template <int ITEMS>
+__global__ void __launch_bounds__(1024) amt_scan_excl_kernel(int* __restrict__ data, int len, size_t plane_stride,
+                                                             int* __restrict__ total,
+                                                             const int* __restrict__ len_dev = nullptr) {
+    __shared__ int s[1024];
+    __shared__ int carry;
+    int* d = data + (size_t)blockIdx.x * plane_stride;
+    if (len_dev) len = len_dev[blockIdx.x];  // per-plane length that only the device knows
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int start = 0; start < len; start += 1024 * ITEMS) {
+        const int b = start + threadIdx.x * ITEMS;
+        int v[ITEMS];
+        int sum = 0;
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) {
+            v[k] = (b + k < len) ? d[b + k] : 0;
+            sum += v[k];
+        }
+        s[threadIdx.x] = sum;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            int t = threadIdx.x >= off ? s[threadIdx.x - off] : 0;
+            __syncthreads();
+            s[threadIdx.x] += t;
+            __syncthreads();
+        }
+        const int c = carry;
+        int run = c + s[threadIdx.x] - sum;
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) {
+            if (b + k < len) d[b + k] = run;
+            run += v[k];
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = c + s[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && total) total[blockIdx.x] = carry;
+}
+
+static inline int amt_scan_excl(amt_ctx* ctx, int* data, int len, size_t plane_stride, int* total, int nplanes) {
+    if (len <= 4096)
+        hipLaunchKernelGGL((amt_scan_excl_kernel<4>), dim3(nplanes), dim3(1024), 0, ctx->stream, data, len,
+                           plane_stride, total, (const int*)nullptr);
+    else
+        hipLaunchKernelGGL((amt_scan_excl_kernel<16>), dim3(nplanes), dim3(1024), 0, ctx->stream, data, len,
+                           plane_stride, total, (const int*)nullptr);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+
+// same, with the per-plane length read from device memory (len_dev[plane] <= plane_stride)
+static inline int amt_scan_excl_dev(amt_ctx* ctx, int* data, const int* len_dev, size_t plane_stride, int* total,
+                                    int nplanes) {
+    hipLaunchKernelGGL((amt_scan_excl_kernel<8>), dim3(nplanes), dim3(1024), 0, ctx->stream, data, 0, plane_stride,
+                       total, len_dev);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+
+// ---- connected components (amt_label.hip) -------------------------------------------------------
+// L[plane][p] = flat index of the component's first pixel (its union-find root), -1 for background.
+// Components are sets of equal-valued non-zero pixels; conn8 selects 8- vs 4-connectivity.
+int amt_i_ccl_roots(amt_ctx* ctx, const void* in, int in_dtype, int* L, int nplanes, int H, int W, int conn8);
+// T[plane][root] = 1-based rank of the root in raster order; count_dev[plane] = number of roots.
+// blk = scratch of nplanes * amt_i_rank_blocks(n) ints.
+int amt_i_rank_blocks(size_t n);
+int amt_i_rank_roots(amt_ctx* ctx, const int* L, int* T, int* blk, int* count_dev, int nplanes, size_t n);

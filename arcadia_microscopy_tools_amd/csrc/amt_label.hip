@@ -1,0 +1,410 @@
+// Connected-component labelling, clear_border, relabel_sequential and label utilities.
+//
+// Reference call sites: R/masks.py:56 (ski.segmentation.clear_border), :63 (ski.measure.label),
+// :65 (ski.segmentation.relabel_sequential), :399-403 (np.isin / np.where in filter()).
+// Contract: components of EQUAL-valued non-zero pixels, 8-connected by default,
+// numbered 1..K in raster order of each component's first pixel.
+//
+// Algorithm: lock-free union-find in HBM whose root is the component's minimum flat index (= its
+// first pixel in raster order), so the raster numbering is a prefix sum over the root flags.
+#include "amt_internal.h"
+
+__device__ __forceinline__ int uf_find(const int* __restrict__ L, int a) {
+    int p = L[a];
+    while (p != a) {
+        a = p;
+        p = L[a];
+    }
+    return a;
+}
+
+__device__ __forceinline__ int uf_find_volatile(int* L, int a) {
+    int p = __hip_atomic_load(&L[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (p != a) {
+        a = p;
+        p = __hip_atomic_load(&L[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return a;
+}
+
+// union by minimum index (Komura-style): the larger root is redirected to the smaller one.
+__device__ __forceinline__ void uf_union(int* L, int a, int b) {
+    while (true) {
+        a = uf_find_volatile(L, a);
+        b = uf_find_volatile(L, b);
+        if (a == b) return;
+        if (a < b) {
+            int t = a;
+            a = b;
+            b = t;
+        }
+        // a > b: try to hang a below b
+        int old = atomicMin(&L[a], b);
+        if (old == a) return;
+        a = old;  // someone else moved a meanwhile; retry from there
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) ccl_init_kernel(const T* __restrict__ in, int* __restrict__ L, size_t n) {
+    const size_t base = (size_t)blockIdx.y * n;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        L[base + i] = in[base + i] != 0 ? (int)i : -1;
+}
+
+// Merge step: every foreground pixel unions with its backward neighbours of equal value.  West and
+// north are always tested; the two diagonals only when north differs (if north matches, NW and NE are
+// already tied to it through row y-1's west unions), and NW only when west differs (otherwise west
+// reaches NW as its own north).
+template <typename T>
+__global__ void __launch_bounds__(256) ccl_merge_kernel(const T* __restrict__ in, int* __restrict__ Lall, int H, int W,
+                                                        int conn8) {
+    const size_t n = (size_t)H * W;
+    const T* img = in + (size_t)blockIdx.z * n;
+    int* L = Lall + (size_t)blockIdx.z * n;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const int p = y * W + x;
+    const T v = img[p];
+    if (v == 0) return;
+    const bool w_same = x > 0 && img[p - 1] == v;
+    if (w_same) uf_union(L, p, p - 1);
+    if (y > 0) {
+        const int q = p - W;
+        if (img[q] == v) {
+            uf_union(L, p, q);
+        } else if (conn8) {
+            // north differs: the two diagonals are not linked through row y-1, test both
+            if (x > 0 && img[q - 1] == v && !w_same) uf_union(L, p, q - 1);  // if west is same, west links to NW (its north)
+            if (x + 1 < W && img[q + 1] == v) uf_union(L, p, q + 1);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) ccl_compress_kernel(int* __restrict__ L, size_t n) {
+    const size_t base = (size_t)blockIdx.y * n;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        int l = L[base + i];
+        if (l >= 0) {
+            int r = l;
+            int p = L[base + r];
+            while (p != r) {
+                r = p;
+                p = L[base + r];
+            }
+            L[base + i] = r;
+        }
+    }
+}
+
+// ---- raster renumbering: exclusive prefix sum over root flags ----------------------------------
+constexpr int RN_CHUNK = 2048;  // pixels per block in the count / rank passes (256 threads x 8)
+
+__global__ void __launch_bounds__(256) root_count_kernel(const int* __restrict__ L, int* __restrict__ blockcnt, size_t n,
+                                                         int nblk) {
+    const size_t base = (size_t)blockIdx.y * n;
+    const size_t start = (size_t)blockIdx.x * RN_CHUNK;
+    int c = 0;
+    for (int k = 0; k < 8; ++k) {
+        size_t i = start + (size_t)k * 256 + threadIdx.x;
+        if (i < n) c += (L[base + i] == (int)i) ? 1 : 0;
+    }
+    for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off);
+    __shared__ int s[4];
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) blockcnt[(size_t)blockIdx.y * nblk + blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
+// rank of every root (1-based) written at the root's own position of T
+__global__ void __launch_bounds__(256) root_rank_kernel(const int* __restrict__ L, const int* __restrict__ blockoff,
+                                                        int* __restrict__ T, size_t n, int nblk) {
+    const size_t base = (size_t)blockIdx.y * n;
+    const size_t start = (size_t)blockIdx.x * RN_CHUNK;
+    __shared__ int wave_tot[4];
+    __shared__ int running;
+    if (threadIdx.x == 0) running = blockoff[(size_t)blockIdx.y * nblk + blockIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = 0; k < 8; ++k) {
+        size_t i = start + (size_t)k * 256 + threadIdx.x;
+        bool is_root = i < n && L[base + i] == (int)i;
+        unsigned long long m = __ballot(is_root);
+        int before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_tot[wave] = __popcll(m);
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wave_tot[w];
+        int run = running;
+        if (is_root) T[base + i] = run + woff + before + 1;
+        __syncthreads();
+        if (threadIdx.x == 0) running = run + wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256) apply_rank_kernel(const int* __restrict__ L, const int* __restrict__ T,
+                                                         int* __restrict__ out, size_t n) {
+    const size_t base = (size_t)blockIdx.y * n;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        int l = L[base + i];
+        out[base + i] = l >= 0 ? T[base + l] : 0;
+    }
+}
+
+template <typename T>
+static int ccl_roots(amt_ctx* ctx, const T* in, int* L, int nplanes, int H, int W, int conn8) {
+    const size_t n = (size_t)H * W;
+    dim3 g1(amt_grid_for(n, 256, 4096), nplanes);
+    hipLaunchKernelGGL((ccl_init_kernel<T>), g1, dim3(256), 0, ctx->stream, in, L, n);
+    AMT_LAUNCH_CHECK();
+    dim3 g2((W + 63) / 64, (H + 3) / 4, nplanes);
+    hipLaunchKernelGGL((ccl_merge_kernel<T>), g2, dim3(256), 0, ctx->stream, in, L, H, W, conn8);
+    AMT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ccl_compress_kernel, g1, dim3(256), 0, ctx->stream, L, n);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+
+int amt_i_ccl_roots(amt_ctx* ctx, const void* in, int in_dtype, int* L, int nplanes, int H, int W, int conn8) {
+    if (in_dtype == AMT_U8) return ccl_roots<uint8_t>(ctx, (const uint8_t*)in, L, nplanes, H, W, conn8);
+    return ccl_roots<int32_t>(ctx, (const int32_t*)in, L, nplanes, H, W, conn8);
+}
+
+int amt_i_rank_blocks(size_t n) { return (int)((n + RN_CHUNK - 1) / RN_CHUNK); }
+
+int amt_i_rank_roots(amt_ctx* ctx, const int* L, int* T, int* blk, int* count_dev, int nplanes, size_t n) {
+    const int nblk = amt_i_rank_blocks(n);
+    hipLaunchKernelGGL(root_count_kernel, dim3(nblk, nplanes), dim3(256), 0, ctx->stream, L, blk, n, nblk);
+    AMT_LAUNCH_CHECK();
+    AMT_TRY(amt_scan_excl(ctx, blk, nblk, (size_t)nblk, count_dev, nplanes));
+    hipLaunchKernelGGL(root_rank_kernel, dim3(nblk, nplanes), dim3(256), 0, ctx->stream, L, blk, T, n, nblk);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+
+extern "C" int amt_label(amt_ctx* ctx, const void* in, int in_dtype, int32_t* out, int32_t* count_dev, int nplanes,
+                         int H, int W, int connectivity) {
+    AMT_TRY(amt_set_device(ctx));
+    AMT_REQUIRE(in && out && nplanes >= 0 && H > 0 && W > 0, "label: bad arguments");
+    AMT_REQUIRE(in_dtype == AMT_U8 || in_dtype == AMT_I32, "label: in_dtype must be AMT_U8 or AMT_I32");
+    AMT_REQUIRE(connectivity == 1 || connectivity == 2, "label: connectivity must be 1 or 2");
+    AMT_REQUIRE((size_t)H * W < 0x7fffffffull, "label: plane too large");
+    AMT_REQUIRE((const void*)in != (const void*)out, "label: in-place operation is not supported");
+    if (nplanes == 0) return AMT_OK;
+    const size_t n = (size_t)H * W;
+    const int nblk = amt_i_rank_blocks(n);
+    AMT_TRY(amt_arena_begin(ctx, amt_align((size_t)nplanes * n * 4) + amt_align((size_t)nplanes * nblk * 4)));
+    int* T = arena_take_t<int>(ctx, (size_t)nplanes * n);
+    int* blk = arena_take_t<int>(ctx, (size_t)nplanes * nblk);
+    int* L = out;
+    AMT_TRY(amt_i_ccl_roots(ctx, in, in_dtype, L, nplanes, H, W, connectivity == 2));
+    AMT_TRY(amt_i_rank_roots(ctx, L, T, blk, count_dev, nplanes, n));
+    dim3 g1(amt_grid_for(n, 256, 4096), nplanes);
+    hipLaunchKernelGGL(apply_rank_kernel, g1, dim3(256), 0, ctx->stream, L, T, out, n);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+
+// ---- clear_border ------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) frame_flag_kernel(const int* __restrict__ L, int* __restrict__ T, int H, int W) {
+    const size_t n = (size_t)H * W;
+    const size_t base = (size_t)blockIdx.y * n;
+    const int perim = 2 * W + 2 * H;
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < perim; k += gridDim.x * 256) {
+        int y, x;
+        if (k < W) {
+            y = 0;
+            x = k;
+        } else if (k < 2 * W) {
+            y = H - 1;
+            x = k - W;
+        } else if (k < 2 * W + H) {
+            y = k - 2 * W;
+            x = 0;
+        } else {
+            y = k - 2 * W - H;
+            x = W - 1;
+        }
+        int l = L[base + (size_t)y * W + x];
+        if (l >= 0) T[base + l] = 1;
+    }
+}
+
+__global__ void __launch_bounds__(256) clear_flagged_kernel(const int* __restrict__ in, const int* __restrict__ L,
+                                                            const int* __restrict__ T, int* __restrict__ out,
+                                                            size_t n) {
+    const size_t base = (size_t)blockIdx.y * n;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        int l = L[base + i];
+        int v = in[base + i];
+        out[base + i] = (l >= 0 && T[base + l]) ? 0 : v;
+    }
+}
+
+extern "C" int amt_clear_border(amt_ctx* ctx, const int32_t* in, int32_t* out, int nplanes, int H, int W) {
+    AMT_TRY(amt_set_device(ctx));
+    AMT_REQUIRE(in && out && nplanes >= 0 && H > 0 && W > 0, "clear_border: bad arguments");
+    AMT_REQUIRE((size_t)H * W < 0x7fffffffull, "clear_border: plane too large");
+    if (nplanes == 0) return AMT_OK;
+    const size_t n = (size_t)H * W;
+    AMT_TRY(amt_arena_begin(ctx, 2 * amt_align((size_t)nplanes * n * 4)));
+    int* L = arena_take_t<int>(ctx, (size_t)nplanes * n);
+    int* T = arena_take_t<int>(ctx, (size_t)nplanes * n);
+    AMT_HIP_CHECK(hipMemsetAsync(T, 0, (size_t)nplanes * n * 4, ctx->stream));
+    AMT_TRY(ccl_roots<int32_t>(ctx, in, L, nplanes, H, W, 1));
+    dim3 gf(amt_grid_for((size_t)2 * W + 2 * H, 256, 64), nplanes);
+    hipLaunchKernelGGL(frame_flag_kernel, gf, dim3(256), 0, ctx->stream, L, T, H, W);
+    AMT_LAUNCH_CHECK();
+    dim3 g1(amt_grid_for(n, 256, 4096), nplanes);
+    hipLaunchKernelGGL(clear_flagged_kernel, g1, dim3(256), 0, ctx->stream, in, L, T, out, n);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+
+// ---- relabel_sequential ------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) presence_kernel(const int* __restrict__ in, int* __restrict__ present, size_t n,
+                                                       int max_label) {
+    const size_t base = (size_t)blockIdx.y * n;
+    int* P = present + (size_t)blockIdx.y * (max_label + 1);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        int v = in[base + i];
+        if (v > 0 && v <= max_label && P[v] == 0) P[v] = 1;
+    }
+}
+
+// in place: present[l] (0/1) -> new label of l (0 if absent); label 0 -> 0
+__global__ void __launch_bounds__(1024) presence_scan_kernel(int* __restrict__ present, int max_label,
+                                                             int* __restrict__ count_dev) {
+    __shared__ int s[1024];
+    __shared__ int carry;
+    int* P = present + (size_t)blockIdx.x * (max_label + 1);
+    if (threadIdx.x == 0) {
+        carry = 0;
+        P[0] = 0;
+    }
+    __syncthreads();
+    for (int start = 1; start <= max_label; start += 1024) {
+        int i = start + threadIdx.x;
+        int v = i <= max_label ? P[i] : 0;
+        s[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            int t = threadIdx.x >= off ? s[threadIdx.x - off] : 0;
+            __syncthreads();
+            s[threadIdx.x] += t;
+            __syncthreads();
+        }
+        int incl = s[threadIdx.x];
+        int c = carry;
+        if (i <= max_label) P[i] = v ? c + incl : 0;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = c + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && count_dev) count_dev[blockIdx.x] = carry;
+}
+
+__global__ void __launch_bounds__(256) map_labels_kernel(const int* __restrict__ in, const int* __restrict__ map,
+                                                         int* __restrict__ out, size_t n, int max_label) {
+    const size_t base = (size_t)blockIdx.y * n;
+    const int* M = map + (size_t)blockIdx.y * (max_label + 1);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        int v = in[base + i];
+        out[base + i] = (v > 0 && v <= max_label) ? M[v] : 0;
+    }
+}
+
+extern "C" int amt_relabel_sequential(amt_ctx* ctx, const int32_t* in, int32_t* out, int32_t* count_dev, int nplanes,
+                                      size_t n, int max_label) {
+    AMT_TRY(amt_set_device(ctx));
+    AMT_REQUIRE(in && out && nplanes >= 0 && max_label >= 0, "relabel_sequential: bad arguments");
+    if (nplanes == 0) return AMT_OK;
+    size_t msz = (size_t)nplanes * ((size_t)max_label + 1);
+    AMT_TRY(amt_arena_begin(ctx, amt_align(msz * 4)));
+    int* P = arena_take_t<int>(ctx, msz);
+    AMT_HIP_CHECK(hipMemsetAsync(P, 0, msz * 4, ctx->stream));
+    dim3 g1(amt_grid_for(n, 256, 4096), nplanes);
+    if (n) {
+        hipLaunchKernelGGL(presence_kernel, g1, dim3(256), 0, ctx->stream, in, P, n, max_label);
+        AMT_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(presence_scan_kernel, dim3(nplanes), dim3(1024), 0, ctx->stream, P, max_label, count_dev);
+    AMT_LAUNCH_CHECK();
+    if (n) {
+        hipLaunchKernelGGL(map_labels_kernel, g1, dim3(256), 0, ctx->stream, in, P, out, n, max_label);
+        AMT_LAUNCH_CHECK();
+    }
+    return AMT_OK;
+}
+
+__global__ void __launch_bounds__(256) keep_labels_kernel(const int* __restrict__ in, const uint8_t* __restrict__ keep,
+                                                          int* __restrict__ out, size_t n, int max_label) {
+    const size_t base = (size_t)blockIdx.y * n;
+    const uint8_t* K = keep + (size_t)blockIdx.y * (max_label + 1);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        int v = in[base + i];
+        out[base + i] = (v > 0 && v <= max_label && K[v]) ? v : 0;
+    }
+}
+
+extern "C" int amt_keep_labels(amt_ctx* ctx, const int32_t* in, const uint8_t* keep_dev, int32_t* out, int nplanes,
+                               size_t n, int max_label) {
+    AMT_TRY(amt_set_device(ctx));
+    AMT_REQUIRE(in && keep_dev && out && nplanes >= 0 && max_label >= 0, "keep_labels: bad arguments");
+    if (nplanes == 0 || n == 0) return AMT_OK;
+    dim3 g1(amt_grid_for(n, 256, 4096), nplanes);
+    hipLaunchKernelGGL(keep_labels_kernel, g1, dim3(256), 0, ctx->stream, in, keep_dev, out, n, max_label);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+
+__global__ void cast_i32_i64_kernel(const int* __restrict__ in, long long* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = (long long)in[i];
+}
+
+extern "C" int amt_cast_i32_i64(amt_ctx* ctx, const int32_t* in, int64_t* out, size_t n) {
+    AMT_TRY(amt_set_device(ctx));
+    AMT_REQUIRE(in && out, "cast_i32_i64: null pointer");
+    if (n == 0) return AMT_OK;
+    hipLaunchKernelGGL(cast_i32_i64_kernel, dim3(amt_grid_for(n, 256)), dim3(256), 0, ctx->stream, in,
+                       (long long*)out, n);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+
+__global__ void __launch_bounds__(256) max_i32_kernel(const int* __restrict__ in, int* __restrict__ mx, size_t n) {
+    const size_t base = (size_t)blockIdx.y * n;
+    int m = -2147483647 - 1;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        int v = in[base + i];
+        m = v > m ? v : m;
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        int o = __shfl_xor(m, off);
+        m = o > m ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(&mx[blockIdx.y], m);
+}
+
+__global__ void fill_i32_kernel(int* p, int v, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+extern "C" int amt_max_i32(amt_ctx* ctx, const int32_t* in, int32_t* max_dev, int nplanes, size_t n) {
+    AMT_TRY(amt_set_device(ctx));
+    AMT_REQUIRE(in && max_dev && nplanes >= 0, "max_i32: bad arguments");
+    if (nplanes == 0) return AMT_OK;
+    hipLaunchKernelGGL(fill_i32_kernel, dim3((nplanes + 63) / 64), dim3(64), 0, ctx->stream, max_dev,
+                       -2147483647 - 1, nplanes);
+    AMT_LAUNCH_CHECK();
+    if (n) {
+        dim3 g(amt_grid_for(n, 256 * 8, 512), nplanes);
+        hipLaunchKernelGGL(max_i32_kernel, g, dim3(256), 0, ctx->stream, in, max_dev, n);
+        AMT_LAUNCH_CHECK();
+    }
+    return AMT_OK;
+}

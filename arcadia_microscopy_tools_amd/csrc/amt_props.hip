@@ -1,0 +1,536 @@
+// Region properties as segmented integer reductions keyed by label.
+//
+// Reference call site: R/masks.py:286-326 (ski.measure.regionprops_table, once for morphology and once
+// per channel for intensity).  Property definitions: SK/measure/_regionprops.py:277-468,
+// SK/measure/_regionprops_utils.py:186-249 (perimeter), SK/measure/_moments.py:379-445 (inertia tensor),
+// SK/morphology/convex_hull.py (area_convex) -- SURVEY.md section 8a row A12, A.7, A.12.
+//
+// All accumulation is integer (counts, coordinate sums, intensity sums) and therefore independent of
+// the order in which pixels arrive; floating point only enters in the final per-label kernel.
+// A wave covers 64 consecutive pixels of one row; equal-label runs inside it are reduced in closed
+// form (coordinates) or with wave prefix sums (intensities), so each run costs one set of atomics.
+#include "amt_internal.h"
+
+typedef unsigned long long u64;
+
+// accumulator slots per (plane, label)
+enum { A_N = 0, A_SY, A_SX, A_SYY, A_SXX, A_SXY, A_C1, A_C2, A_C3, A_NACC };
+// bbox ints per (plane, label): miny, minx, maxy, maxx
+
+__global__ void __launch_bounds__(256) rp_init_kernel(u64* __restrict__ acc, int* __restrict__ bbox, size_t nlab) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nlab; i += (size_t)gridDim.x * 256) {
+        for (int k = 0; k < A_NACC; ++k) acc[i * A_NACC + k] = 0;
+        bbox[i * 4 + 0] = 0x7fffffff;
+        bbox[i * 4 + 1] = 0x7fffffff;
+        bbox[i * 4 + 2] = -1;
+        bbox[i * 4 + 3] = -1;
+    }
+}
+
+__device__ __forceinline__ u64 sum_sq_upto(u64 m) { return m * (m + 1) * (2 * m + 1) / 6; }  // 0^2 + ... + m^2
+
+// moments + bbox + (optionally) per-row extents for the convex hull
+__global__ void __launch_bounds__(256) rp_moments_kernel(const int* __restrict__ labels, u64* __restrict__ acc,
+                                                         int* __restrict__ bbox, int H, int W, int max_label) {
+    const int lane = threadIdx.x & 63;
+    const int x = blockIdx.x * 64 + lane;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (y >= H) return;
+    const size_t n = (size_t)H * W;
+    const int plane = blockIdx.z;
+    int lab = 0;
+    if (x < W) lab = labels[(size_t)plane * n + (size_t)y * W + x];
+    if (lab < 0 || lab > max_label) lab = 0;
+    const int left = __shfl_up(lab, 1);
+    const bool head = (lane == 0) || (left != lab);
+    const u64 heads = __ballot(head);
+    if (lab != 0 && head) {
+        // run end = lane before the next head
+        u64 later = heads & ~((2ull << lane) - 1ull);
+        int end_lane = later ? (__ffsll((long long)later) - 2) : 63;
+        u64 a = (u64)x, b = (u64)(x + (end_lane - lane));
+        u64 len = b - a + 1;
+        u64 sx = (a + b) * len / 2;
+        u64 sxx = sum_sq_upto(b) - (a ? sum_sq_upto(a - 1) : 0);
+        u64* A = acc + ((size_t)plane * max_label + (lab - 1)) * A_NACC;
+        atomicAdd(&A[A_N], len);
+        atomicAdd(&A[A_SY], (u64)y * len);
+        atomicAdd(&A[A_SX], sx);
+        atomicAdd(&A[A_SYY], (u64)y * (u64)y * len);
+        atomicAdd(&A[A_SXX], sxx);
+        atomicAdd(&A[A_SXY], (u64)y * sx);
+        int* B = bbox + ((size_t)plane * max_label + (lab - 1)) * 4;
+        atomicMin(&B[0], y);
+        atomicMin(&B[1], (int)a);
+        atomicMax(&B[2], y);
+        atomicMax(&B[3], (int)b);
+    }
+}
+
+// perimeter: border pixels (4-neighbourhood, outside = background) and their 3x3 weighted codes.
+constexpr int PT_H = 16, PT_W = 64;
+__global__ void __launch_bounds__(256) rp_perimeter_kernel(const int* __restrict__ labels, u64* __restrict__ acc, int H,
+                                                           int W, int max_label) {
+    __shared__ int lab[(PT_H + 4) * (PT_W + 4)];
+    __shared__ uint8_t bor[(PT_H + 2) * (PT_W + 2)];
+    const int x0 = blockIdx.x * PT_W, y0 = blockIdx.y * PT_H;
+    const size_t n = (size_t)H * W;
+    const int plane = blockIdx.z;
+    const int* L = labels + (size_t)plane * n;
+    constexpr int LP = PT_W + 4, BP = PT_W + 2;
+    for (int i = threadIdx.x; i < (PT_H + 4) * LP; i += 256) {
+        int ky = i / LP, kx = i - ky * LP;
+        int y = y0 - 2 + ky, x = x0 - 2 + kx;
+        int v = 0;
+        if (y >= 0 && y < H && x >= 0 && x < W) {
+            v = L[(size_t)y * W + x];
+            if (v < 0 || v > max_label) v = 0;
+        }
+        lab[i] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < (PT_H + 2) * BP; i += 256) {
+        int ky = i / BP, kx = i - ky * BP;  // position (y0-1+ky, x0-1+kx) == lab index (ky+1, kx+1)
+        const int* c = lab + (ky + 1) * LP + (kx + 1);
+        int v = c[0];
+        bor[i] = (v != 0 && (c[-LP] != v || c[LP] != v || c[-1] != v || c[1] != v)) ? 1 : 0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < PT_H * PT_W; i += 256) {
+        int ky = i / PT_W, kx = i - ky * PT_W;
+        int y = y0 + ky, x = x0 + kx;
+        if (y >= H || x >= W) continue;
+        const int v = lab[(ky + 2) * LP + (kx + 2)];
+        const uint8_t* b = bor + (ky + 1) * BP + (kx + 1);
+        if (v == 0 || !b[0]) continue;
+        const int* c = lab + (ky + 2) * LP + (kx + 2);
+        int code = 1;
+        code += 2 * ((b[-BP] && c[-LP] == v) + (b[BP] && c[LP] == v) + (b[-1] && c[-1] == v) + (b[1] && c[1] == v));
+        code += 10 * ((b[-BP - 1] && c[-LP - 1] == v) + (b[-BP + 1] && c[-LP + 1] == v) +
+                      (b[BP - 1] && c[LP - 1] == v) + (b[BP + 1] && c[LP + 1] == v));
+        int cls = -1;
+        switch (code) {
+            case 5: case 7: case 15: case 17: case 25: case 27: cls = A_C1; break;
+            case 21: case 33: cls = A_C2; break;
+            case 13: case 23: cls = A_C3; break;
+            default: break;
+        }
+        if (cls >= 0) atomicAdd(&acc[((size_t)plane * max_label + (v - 1)) * A_NACC + cls], 1ull);
+    }
+}
+
+// ---- convex area (exact integer hull of the pixel diamonds) -------------------------------------
+// rows[plane][off(label) + (y - miny)] = {min x, max x} of the label in that row
+__global__ void __launch_bounds__(256) rp_heights_kernel(const int* __restrict__ bbox, int* __restrict__ hoff,
+                                                         int max_label) {
+    const int plane = blockIdx.y;
+    for (int l = blockIdx.x * 256 + threadIdx.x; l < max_label; l += gridDim.x * 256) {
+        const int* B = bbox + ((size_t)plane * max_label + l) * 4;
+        hoff[(size_t)plane * max_label + l] = B[2] >= B[0] ? B[2] - B[0] + 1 : 0;
+    }
+}
+
+__global__ void __launch_bounds__(256) rp_rows_init_kernel(int2* __restrict__ rows, const int* __restrict__ total,
+                                                           size_t cap) {
+    int2* r = rows + (size_t)blockIdx.y * cap;
+    size_t tot = (size_t)total[blockIdx.y];
+    if (tot > cap) tot = cap;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (size_t)gridDim.x * 256)
+        r[i] = make_int2(0x7fffffff, -1);
+}
+
+__global__ void __launch_bounds__(256) rp_rows_fill_kernel(const int* __restrict__ labels, const int* __restrict__ bbox,
+                                                           const int* __restrict__ hoff, int2* __restrict__ rows,
+                                                           size_t cap, int H, int W, int max_label) {
+    const int lane = threadIdx.x & 63;
+    const int x = blockIdx.x * 64 + lane;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (y >= H) return;
+    const size_t n = (size_t)H * W;
+    const int plane = blockIdx.z;
+    int lab = 0;
+    if (x < W) lab = labels[(size_t)plane * n + (size_t)y * W + x];
+    if (lab < 0 || lab > max_label) lab = 0;
+    const int left = __shfl_up(lab, 1);
+    const bool head = (lane == 0) || (left != lab);
+    const u64 heads = __ballot(head);
+    if (lab != 0 && head) {
+        u64 later = heads & ~((2ull << lane) - 1ull);
+        int end_lane = later ? (__ffsll((long long)later) - 2) : 63;
+        const size_t li = (size_t)plane * max_label + (lab - 1);
+        size_t idx = (size_t)hoff[li] + (size_t)(y - bbox[li * 4 + 0]);
+        if (idx < cap) {
+            int2* r = rows + (size_t)plane * cap + idx;
+            atomicMin(&r->x, x);
+            atomicMax(&r->y, x + (end_lane - lane));
+        }
+    }
+}
+
+__device__ __forceinline__ long long floor_div(long long a, long long b) {  // b > 0
+    long long q = a / b;
+    return (a % b != 0 && a < 0) ? q - 1 : q;
+}
+__device__ __forceinline__ long long ceil_div(long long a, long long b) {  // b > 0
+    long long q = a / b;
+    return (a % b != 0 && a > 0) ? q + 1 : q;
+}
+
+// One lane per label.  Work in doubled coordinates (Y = 2y, X = 2x): row y with extent [a, b]
+// contributes the diamond points (2y-1, 2a), (2y+1, 2a), (2y, 2a-1) on the left and
+// (2y-1, 2b), (2y+1, 2b), (2y, 2b+1) on the right (the inner diamond points can never be extreme).
+// Left chain = lower-left convex boundary of {(Y, minX(Y))}, right chain of {(Y, maxX(Y))}, built by a
+// monotone scan in Y; then pixel centres (2y, 2x) with XL(2y) <= 2x <= XR(2y) are counted exactly.
+__global__ void __launch_bounds__(64) rp_hull_kernel(const int* __restrict__ bbox, const int* __restrict__ hoff,
+                                                     const int* __restrict__ htot, const int2* __restrict__ rows,
+                                                     int2* __restrict__ chainL, int2* __restrict__ chainR, size_t cap,
+                                                     double* __restrict__ table, int max_label) {
+    const int plane = blockIdx.y;
+    const int l = blockIdx.x * 64 + threadIdx.x;
+    if (l >= max_label) return;
+    const size_t li = (size_t)plane * max_label + l;
+    double* trow = table + li * AMT_RP_NCOLS;
+    const int miny = bbox[li * 4 + 0], maxy = bbox[li * 4 + 2];
+    if (maxy < miny) {
+        trow[AMT_RP_AREA_CONVEX] = 0.0;
+        return;
+    }
+    const int h = maxy - miny + 1;
+    const size_t off = (size_t)hoff[li];
+    if ((size_t)htot[plane] > cap || off + (size_t)h > cap) {  // capacity exceeded (fragmented labels)
+        trow[AMT_RP_AREA_CONVEX] = __longlong_as_double(0x7ff8000000000000ll);
+        return;
+    }
+    const int2* r = rows + (size_t)plane * cap + off;
+    // chains hold up to 2h+1 vertices each; scratch capacity per plane is 3*cap: offset 3*off, len 3*h
+    int2* CL = chainL + (size_t)plane * 3 * cap + 3 * off;
+    int2* CR = chainR + (size_t)plane * 3 * cap + 3 * off;
+    int nl = 0, nr = 0;
+    // iterate Y = 2*miny-1 .. 2*maxy+1
+    for (int Y = 2 * miny - 1; Y <= 2 * maxy + 1; ++Y) {
+        int mn = 0x7fffffff, mx = -0x7fffffff;
+        if (Y & 1) {  // odd: shared by rows (Y-1)/2 and (Y+1)/2
+            int ya = (Y - 1) / 2, yb = (Y + 1) / 2;
+            if (Y < 0) {  // only for miny == 0: Y = -1 -> rows -1 (none) and 0
+                ya = -1;
+                yb = 0;
+            }
+            if (ya >= miny && ya <= maxy) {
+                int2 e = r[ya - miny];
+                if (e.y >= e.x) {
+                    mn = min(mn, 2 * e.x);
+                    mx = max(mx, 2 * e.y);
+                }
+            }
+            if (yb >= miny && yb <= maxy) {
+                int2 e = r[yb - miny];
+                if (e.y >= e.x) {
+                    mn = min(mn, 2 * e.x);
+                    mx = max(mx, 2 * e.y);
+                }
+            }
+        } else {
+            int2 e = r[Y / 2 - miny];
+            if (e.y >= e.x) {
+                mn = 2 * e.x - 1;
+                mx = 2 * e.y + 1;
+            }
+        }
+        if (mx < mn) continue;  // no pixel of this label contributes at this Y
+        // left chain: keep it convex towards -X: pop while the last vertex is not strictly left of the
+        // segment (prev -> new)
+        while (nl >= 2) {
+            int2 p0 = CL[nl - 2], p1 = CL[nl - 1];
+            long long cr = (long long)(p1.x - p0.x) * (mn - p0.y) - (long long)(p1.y - p0.y) * (Y - p0.x);
+            // points are (Y, X) stored as (x=Y, y=X); cr = dY1*dX2 - dX1*dY2 ; left chain needs cr > 0 to keep p1
+            if (cr <= 0) --nl; else break;
+        }
+        CL[nl++] = make_int2(Y, mn);
+        while (nr >= 2) {
+            int2 p0 = CR[nr - 2], p1 = CR[nr - 1];
+            long long cr = (long long)(p1.x - p0.x) * (mx - p0.y) - (long long)(p1.y - p0.y) * (Y - p0.x);
+            if (cr >= 0) --nr; else break;
+        }
+        CR[nr++] = make_int2(Y, mx);
+    }
+    // count pixel centres
+    long long count = 0;
+    int il = 0, ir = 0;
+    for (int y = miny; y <= maxy; ++y) {
+        const int Y = 2 * y;
+        while (il + 1 < nl && CL[il + 1].x <= Y) ++il;
+        while (ir + 1 < nr && CR[ir + 1].x <= Y) ++ir;
+        // left bound XL(Y) on segment il -> il+1 (or vertex if exactly at / past the end)
+        long long xmin, xmax;
+        {
+            int2 p0 = CL[il];
+            if (p0.x == Y || il + 1 >= nl) {
+                xmin = ceil_div(p0.y, 2);
+            } else {
+                int2 p1 = CL[il + 1];
+                long long dY = p1.x - p0.x;  // > 0
+                long long num = (long long)p0.y * dY + (long long)(p1.y - p0.y) * (Y - p0.x);  // XL * dY
+                xmin = ceil_div(num, 2 * dY);
+            }
+        }
+        {
+            int2 p0 = CR[ir];
+            if (p0.x == Y || ir + 1 >= nr) {
+                xmax = floor_div(p0.y, 2);
+            } else {
+                int2 p1 = CR[ir + 1];
+                long long dY = p1.x - p0.x;
+                long long num = (long long)p0.y * dY + (long long)(p1.y - p0.y) * (Y - p0.x);
+                xmax = floor_div(num, 2 * dY);
+            }
+        }
+        if (xmax >= xmin) count += xmax - xmin + 1;
+    }
+    trow[AMT_RP_AREA_CONVEX] = (double)count;
+}
+
+// ---- final per-label columns ------------------------------------------------------------------------
+// exact a*b - c*d for 64-bit operands, as a double (the difference itself must fit in 127 bits)
+__device__ __forceinline__ double diff_of_products(u64 a, u64 b, u64 c, u64 d) {
+    u64 lo1 = a * b, hi1 = __umul64hi(a, b);
+    u64 lo2 = c * d, hi2 = __umul64hi(c, d);
+    // (hi1:lo1) - (hi2:lo2), signed
+    bool neg = (hi1 < hi2) || (hi1 == hi2 && lo1 < lo2);
+    u64 hi, lo;
+    if (!neg) {
+        lo = lo1 - lo2;
+        hi = hi1 - hi2 - (lo1 < lo2 ? 1 : 0);
+    } else {
+        lo = lo2 - lo1;
+        hi = hi2 - hi1 - (lo2 < lo1 ? 1 : 0);
+    }
+    double v = (double)hi * 18446744073709551616.0 + (double)lo;
+    return neg ? -v : v;
+}
+
+__global__ void __launch_bounds__(256) rp_final_kernel(const u64* __restrict__ acc, const int* __restrict__ bbox,
+                                                       double* __restrict__ table, size_t nlab) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nlab; i += (size_t)gridDim.x * 256) {
+        const u64* A = acc + i * A_NACC;
+        const int* B = bbox + i * 4;
+        double* t = table + i * AMT_RP_NCOLS;
+        const u64 n = A[A_N];
+        if (n == 0) {
+            for (int k = 0; k < AMT_RP_NCOLS; ++k)
+                if (k != AMT_RP_AREA_CONVEX) t[k] = 0.0;
+            continue;
+        }
+        const double dn = (double)n;
+        t[AMT_RP_AREA] = dn;
+        t[AMT_RP_CENTROID_Y] = (double)A[A_SY] / dn;
+        t[AMT_RP_CENTROID_X] = (double)A[A_SX] / dn;
+        t[AMT_RP_BBOX_Y0] = (double)B[0];
+        t[AMT_RP_BBOX_X0] = (double)B[1];
+        t[AMT_RP_BBOX_Y1] = (double)(B[2] + 1);
+        t[AMT_RP_BBOX_X1] = (double)(B[3] + 1);
+        const double SQ2 = 1.4142135623730951;
+        t[AMT_RP_PERIMETER] = (double)A[A_C1] + (double)A[A_C2] * SQ2 + (double)A[A_C3] * ((1.0 + SQ2) / 2.0);
+        // n * mu20 etc. as exact integers (translation invariant)
+        const double Nyy = diff_of_products(n, A[A_SYY], A[A_SY], A[A_SY]);  // n*Syy - Sy^2 = n * mu20
+        const double Nxx = diff_of_products(n, A[A_SXX], A[A_SX], A[A_SX]);  // n * mu02
+        const double Nxy = diff_of_products(n, A[A_SXY], A[A_SX], A[A_SY]);  // n * mu11
+        const double n2 = dn * dn;
+        const double a = Nxx / n2;   // T[0,0] = mu02 / mu00
+        const double c = Nyy / n2;   // T[1,1] = mu20 / mu00
+        const double b = -Nxy / n2;  // T[0,1] = -mu11 / mu00
+        const double tr = (a + c) * 0.5;
+        const double hd = (a - c) * 0.5;
+        const double rad = sqrt(hd * hd + b * b);
+        double l1 = tr + rad, l2 = tr - rad;
+        l1 = l1 < 0.0 ? 0.0 : l1;
+        l2 = l2 < 0.0 ? 0.0 : l2;
+        t[AMT_RP_AXIS_MAJOR] = 4.0 * sqrt(l1);
+        t[AMT_RP_AXIS_MINOR] = 4.0 * sqrt(l2);
+        t[AMT_RP_ECCENTRICITY] = l1 == 0.0 ? 0.0 : sqrt(1.0 - l2 / l1);
+        double orient;
+        if (Nxx == Nyy) {  // a - c == 0, decided on the exact integer numerators
+            orient = (Nxy > 0.0) ? -0.78539816339744828 : 0.78539816339744828;  // b < 0 <=> mu11 > 0
+        } else {
+            orient = 0.5 * atan2(-2.0 * b, c - a);
+        }
+        t[AMT_RP_ORIENTATION] = orient;
+    }
+}
+
+__global__ void __launch_bounds__(256) rp_solidity_kernel(double* __restrict__ table, size_t nlab) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nlab; i += (size_t)gridDim.x * 256) {
+        double* t = table + i * AMT_RP_NCOLS;
+        t[AMT_RP_SOLIDITY] = t[AMT_RP_AREA] > 0.0 ? t[AMT_RP_AREA] / t[AMT_RP_AREA_CONVEX] : 0.0;
+    }
+}
+
+extern "C" int amt_regionprops(amt_ctx* ctx, const int32_t* labels, double* table_dev, int nplanes, int H, int W,
+                               int max_label) {
+    AMT_TRY(amt_set_device(ctx));
+    AMT_REQUIRE(labels && table_dev && nplanes >= 0 && H > 0 && W > 0 && max_label >= 0, "regionprops: bad arguments");
+    if (nplanes == 0 || max_label == 0) return AMT_OK;
+    const size_t n = (size_t)H * W;
+    const size_t nlab = (size_t)nplanes * max_label;
+    const size_t cap = 2 * n;  // row-extent entries per plane (sum of bbox heights; <= n for connected labels)
+    size_t need = amt_align(nlab * A_NACC * 8) + amt_align(nlab * 16) + amt_align(nlab * 4) + amt_align(nplanes * 4) +
+                  amt_align((size_t)nplanes * cap * 8) + 2 * amt_align((size_t)nplanes * 3 * cap * 8);
+    AMT_TRY(amt_arena_begin(ctx, need));
+    u64* acc = arena_take_t<u64>(ctx, nlab * A_NACC);
+    int* bbox = arena_take_t<int>(ctx, nlab * 4);
+    int* hoff = arena_take_t<int>(ctx, nlab);
+    int* htot = arena_take_t<int>(ctx, nplanes);
+    int2* rows = arena_take_t<int2>(ctx, (size_t)nplanes * cap);
+    int2* chainL = arena_take_t<int2>(ctx, (size_t)nplanes * 3 * cap);
+    int2* chainR = arena_take_t<int2>(ctx, (size_t)nplanes * 3 * cap);
+    hipLaunchKernelGGL(rp_init_kernel, dim3(amt_grid_for(nlab, 256, 1024)), dim3(256), 0, ctx->stream, acc, bbox, nlab);
+    AMT_LAUNCH_CHECK();
+    dim3 gpix((W + 63) / 64, (H + 3) / 4, nplanes);
+    hipLaunchKernelGGL(rp_moments_kernel, gpix, dim3(256), 0, ctx->stream, labels, acc, bbox, H, W, max_label);
+    AMT_LAUNCH_CHECK();
+    dim3 gper((W + PT_W - 1) / PT_W, (H + PT_H - 1) / PT_H, nplanes);
+    hipLaunchKernelGGL(rp_perimeter_kernel, gper, dim3(256), 0, ctx->stream, labels, acc, H, W, max_label);
+    AMT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(rp_final_kernel, dim3(amt_grid_for(nlab, 256, 1024)), dim3(256), 0, ctx->stream, acc, bbox,
+                       table_dev, nlab);
+    AMT_LAUNCH_CHECK();
+    // convex area
+    hipLaunchKernelGGL(rp_heights_kernel, dim3(amt_grid_for(max_label, 256, 256), nplanes), dim3(256), 0, ctx->stream,
+                       bbox, hoff, max_label);
+    AMT_LAUNCH_CHECK();
+    AMT_TRY(amt_scan_excl(ctx, hoff, max_label, (size_t)max_label, htot, nplanes));
+    hipLaunchKernelGGL(rp_rows_init_kernel, dim3(512, nplanes), dim3(256), 0, ctx->stream, rows, htot, cap);
+    AMT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(rp_rows_fill_kernel, gpix, dim3(256), 0, ctx->stream, labels, bbox, hoff, rows, cap, H, W,
+                       max_label);
+    AMT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(rp_hull_kernel, dim3((max_label + 63) / 64, nplanes), dim3(64), 0, ctx->stream, bbox, hoff, htot,
+                       rows, chainL, chainR, cap, table_dev, max_label);
+    AMT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(rp_solidity_kernel, dim3(amt_grid_for(nlab, 256, 1024)), dim3(256), 0, ctx->stream, table_dev,
+                       nlab);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+
+// ---- intensity statistics ----------------------------------------------------------------------------
+// per (plane, label, channel): sum, sum of squares (u64), min, max (u32)
+__global__ void __launch_bounds__(256) rpi_init_kernel(u64* __restrict__ s, unsigned* __restrict__ mm, size_t cnt) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < cnt; i += (size_t)gridDim.x * 256) {
+        s[2 * i] = 0;
+        s[2 * i + 1] = 0;
+        mm[2 * i] = 0xffffffffu;
+        mm[2 * i + 1] = 0;
+    }
+}
+
+__global__ void __launch_bounds__(256) rpi_accum_kernel(const int* __restrict__ labels,
+                                                        const uint16_t* __restrict__ inten, int C, u64* __restrict__ s,
+                                                        unsigned* __restrict__ mm, u64* __restrict__ cnt, int H, int W,
+                                                        int max_label) {
+    const int lane = threadIdx.x & 63;
+    const int x = blockIdx.x * 64 + lane;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (y >= H) return;
+    const size_t n = (size_t)H * W;
+    const int plane = blockIdx.z;
+    int lab = 0;
+    if (x < W) lab = labels[(size_t)plane * n + (size_t)y * W + x];
+    if (lab < 0 || lab > max_label) lab = 0;
+    const int left = __shfl_up(lab, 1);
+    const bool head = (lane == 0) || (left != lab);
+    const u64 heads = __ballot(head);
+    const u64 any = __ballot(lab != 0);
+    if (!any) return;
+    // start lane of my run = highest head at or before me ; end lane = lane before next head
+    const u64 upto = heads & ((2ull << lane) - 1ull);
+    const int start_lane = 63 - __clzll((long long)upto);
+    const u64 later = heads & ~((2ull << lane) - 1ull);
+    const int end_lane = later ? (__ffsll((long long)later) - 2) : 63;
+    const size_t pix = (size_t)y * W + (x < W ? x : W - 1);
+    if (cnt && lab != 0 && head) atomicAdd(&cnt[(size_t)plane * max_label + (lab - 1)], (u64)(end_lane - lane + 1));
+    for (int c = 0; c < C; ++c) {
+        unsigned v = (x < W) ? inten[((size_t)plane * C + c) * n + pix] : 0u;
+        // wave inclusive prefix sums of v and v^2
+        unsigned ps = v;
+        u64 pq = (u64)v * v;
+        unsigned mn = v, mx = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            unsigned t = __shfl_up(ps, off);
+            u64 tq = __shfl_up(pq, off);
+            if (lane >= off) {
+                ps += t;
+                pq += tq;
+            }
+            // segmented min/max: combine with lane+off while it stays inside the run
+            unsigned tmn = __shfl_down(mn, off), tmx = __shfl_down(mx, off);
+            if (lane + off <= end_lane) {
+                mn = tmn < mn ? tmn : mn;
+                mx = tmx > mx ? tmx : mx;
+            }
+        }
+        // run totals at the head lane: prefix[end] - prefix[start-1]
+        unsigned pe = __shfl(ps, end_lane);
+        u64 qe = __shfl(pq, end_lane);
+        unsigned pb = __shfl(ps, start_lane > 0 ? start_lane - 1 : 0);
+        u64 qb = __shfl(pq, start_lane > 0 ? start_lane - 1 : 0);
+        if (start_lane == 0) {
+            pb = 0;
+            qb = 0;
+        }
+        if (lab != 0 && head) {
+            size_t k = ((size_t)plane * max_label + (lab - 1)) * C + c;
+            atomicAdd(&s[2 * k], (u64)(pe - pb));
+            atomicAdd(&s[2 * k + 1], qe - qb);
+            atomicMin(&mm[2 * k], mn);
+            atomicMax(&mm[2 * k + 1], mx);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) rpi_final_kernel(const u64* __restrict__ s, const unsigned* __restrict__ mm,
+                                                        const u64* __restrict__ cnt, double* __restrict__ table, int C,
+                                                        size_t nlab) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nlab * C; i += (size_t)gridDim.x * 256) {
+        const size_t li = i / C;
+        const u64 n = cnt[li];
+        double* t = table + i * 4;
+        if (n == 0) {
+            t[0] = t[1] = t[2] = t[3] = 0.0;
+            continue;
+        }
+        const double dn = (double)n;
+        t[0] = (double)s[2 * i] / dn;
+        t[1] = (double)mm[2 * i + 1];
+        t[2] = (double)mm[2 * i];
+        double nv = diff_of_products(n, s[2 * i + 1], s[2 * i], s[2 * i]);  // n*Sxx - Sx^2 = n^2 * var
+        double var = nv / (dn * dn);
+        t[3] = sqrt(var < 0.0 ? 0.0 : var);
+    }
+}
+
+extern "C" int amt_regionprops_intensity_u16(amt_ctx* ctx, const int32_t* labels, const uint16_t* intensity, int C,
+                                             double* table_dev, int nplanes, int H, int W, int max_label) {
+    AMT_TRY(amt_set_device(ctx));
+    AMT_REQUIRE(labels && intensity && table_dev && nplanes >= 0 && H > 0 && W > 0 && max_label >= 0 && C >= 1,
+                "regionprops_intensity: bad arguments");
+    if (nplanes == 0 || max_label == 0) return AMT_OK;
+    const size_t nlab = (size_t)nplanes * max_label;
+    size_t need = amt_align(nlab * C * 16) + amt_align(nlab * C * 8) + amt_align(nlab * 8);
+    AMT_TRY(amt_arena_begin(ctx, need));
+    u64* s = arena_take_t<u64>(ctx, nlab * C * 2);
+    unsigned* mm = arena_take_t<unsigned>(ctx, nlab * C * 2);
+    u64* cnt = arena_take_t<u64>(ctx, nlab);
+    AMT_HIP_CHECK(hipMemsetAsync(cnt, 0, nlab * 8, ctx->stream));
+    hipLaunchKernelGGL(rpi_init_kernel, dim3(amt_grid_for(nlab * C, 256, 1024)), dim3(256), 0, ctx->stream, s, mm,
+                       nlab * C);
+    AMT_LAUNCH_CHECK();
+    dim3 gpix((W + 63) / 64, (H + 3) / 4, nplanes);
+    hipLaunchKernelGGL(rpi_accum_kernel, gpix, dim3(256), 0, ctx->stream, labels, intensity, C, s, mm, cnt, H, W,
+                       max_label);
+    AMT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(rpi_final_kernel, dim3(amt_grid_for(nlab * C, 256, 1024)), dim3(256), 0, ctx->stream, s, mm, cnt,
+                       table_dev, C, nlab);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}

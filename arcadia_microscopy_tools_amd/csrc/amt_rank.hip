@@ -1,0 +1,136 @@
+// Grey-scale erosion / dilation / median over an arbitrary footprint (uint16 or float64 images).
+//
+// Semantics: scipy.ndimage.grey_erosion / grey_dilation / median_filter(footprint=...), which is what
+// skimage.morphology.erosion / dilation / opening / closing / white_tophat and skimage.filters.median
+// call (SK/morphology/grey.py:185,251; SK/filters/_median.py) -- ImageOperation callables in the
+// reference (R/pipeline.py:25-45).  Flat footprint, anchor at the centre:
+//   erosion  out[p] = min_{s in S} in[p + s]
+//   dilation out[p] = max_{s in S} in[p - s]   (the caller passes skimage's already-mirrored footprint,
+//                                               scipy mirrors it again, so offsets are applied as +s of
+//                                               the ORIGINAL footprint's reflection -> see host layer)
+//   median   out[p] = element of rank |S| // 2 of {in[p + s]}
+// Boundary: scipy's `mode` (reflect for grey morphology, nearest for skimage's median).
+// One 256-thread workgroup produces a 16 x 64 tile from an LDS-staged tile with halo.
+#include "amt_common.h"
+
+constexpr int RT_H = 16, RT_W = 64;
+constexpr int RK_MAX_OFFS = 1024;
+
+template <typename T>
+struct key_traits;
+template <>
+struct key_traits<uint16_t> {
+    typedef unsigned key_t;
+    static constexpr int BITS = 16;
+    __device__ static __forceinline__ key_t to_key(uint16_t v) { return v; }
+    __device__ static __forceinline__ uint16_t from_key(key_t k) { return (uint16_t)k; }
+};
+template <>
+struct key_traits<double> {
+    typedef unsigned long long key_t;
+    static constexpr int BITS = 64;
+    __device__ static __forceinline__ key_t to_key(double v) { return amt_f64_key(v); }
+    __device__ static __forceinline__ double from_key(key_t k) { return amt_key_f64(k); }
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) rank_kernel(const T* __restrict__ in, T* __restrict__ out, int H, int W,
+                                                   const int2* __restrict__ offs_g, int noffs, int ry, int rx, int op,
+                                                   int mode, T cval) {
+    typedef typename key_traits<T>::key_t key_t;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int pitch = RT_W + 2 * rx;
+    const int rows = RT_H + 2 * ry;
+    key_t* tile = reinterpret_cast<key_t*>(smem_raw);
+    int2* offs = reinterpret_cast<int2*>(smem_raw + amt_align((size_t)rows * pitch * sizeof(key_t), 16));
+    const int x0 = blockIdx.x * RT_W, y0 = blockIdx.y * RT_H;
+    const size_t plane = (size_t)blockIdx.z * H * W;
+    for (int i = threadIdx.x; i < noffs; i += 256) offs[i] = offs_g[i];
+    for (int i = threadIdx.x; i < rows * pitch; i += 256) {
+        int ky = i / pitch, kx = i - ky * pitch;
+        int yy = amt_map_index(y0 - ry + ky, H, mode);
+        int xx = amt_map_index(x0 - rx + kx, W, mode);
+        T v = cval;
+        if (yy >= 0 && xx >= 0) v = in[plane + (size_t)yy * W + xx];
+        tile[i] = key_traits<T>::to_key(v);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < RT_H * RT_W; i += 256) {
+        int ky = i / RT_W, kx = i - ky * RT_W;
+        int y = y0 + ky, x = x0 + kx;
+        if (y >= H || x >= W) continue;
+        const key_t* c = tile + (ky + ry) * pitch + (kx + rx);
+        key_t r;
+        if (op == 0) {
+            r = ~(key_t)0;
+            for (int k = 0; k < noffs; ++k) {
+                key_t v = c[offs[k].y * pitch + offs[k].x];
+                r = v < r ? v : r;
+            }
+        } else if (op == 1) {
+            r = 0;
+            for (int k = 0; k < noffs; ++k) {
+                key_t v = c[-offs[k].y * pitch - offs[k].x];
+                r = v > r ? v : r;
+            }
+        } else {
+            // rank select: smallest key K such that #{v <= K} >= rank + 1, found bit by bit
+            const int rank = noffs / 2;
+            key_t prefix = 0;
+            for (int bit = key_traits<T>::BITS - 1; bit >= 0; --bit) {
+                // candidates share `prefix` above `bit`; count those with this bit clear
+                const key_t himask = (bit == key_traits<T>::BITS - 1 && key_traits<T>::BITS == 64)
+                                         ? (key_t)0
+                                         : (~(key_t)0) << (bit + 1);
+                const key_t trial = prefix | (((key_t)1 << bit) - 1);  // largest key with bit clear under prefix
+                int cnt = 0;
+                for (int k = 0; k < noffs; ++k) {
+                    key_t v = c[offs[k].y * pitch + offs[k].x];
+                    cnt += (v <= trial) ? 1 : 0;
+                }
+                (void)himask;
+                if (cnt < rank + 1) prefix |= ((key_t)1 << bit);
+            }
+            r = prefix;
+        }
+        out[plane + (size_t)y * W + x] = key_traits<T>::from_key(r);
+    }
+}
+
+extern "C" int amt_rank_filter(amt_ctx* ctx, const void* in, void* out, int dtype, int nplanes, int H, int W,
+                               const uint8_t* footprint, int fh, int fw, int op, int mode, double cval) {
+    AMT_TRY(amt_set_device(ctx));
+    AMT_REQUIRE(in && out && footprint && nplanes >= 0 && H > 0 && W > 0, "rank_filter: bad arguments");
+    AMT_REQUIRE(in != out, "rank_filter: in-place operation is not supported");
+    AMT_REQUIRE(dtype == AMT_U16 || dtype == AMT_F64, "rank_filter: dtype must be AMT_U16 or AMT_F64");
+    AMT_REQUIRE(op >= 0 && op <= 2, "rank_filter: op must be 0 (erosion), 1 (dilation) or 2 (median)");
+    AMT_REQUIRE((fh & 1) && (fw & 1) && fh >= 1 && fw >= 1 && fh <= 63 && fw <= 63,
+                "rank_filter: footprint must be odd-sized and at most 63 x 63 (got %d x %d)", fh, fw);
+    static thread_local int2 host[RK_MAX_OFFS];
+    int noffs = 0;
+    for (int y = 0; y < fh; ++y)
+        for (int x = 0; x < fw; ++x)
+            if (footprint[y * fw + x]) {
+                AMT_REQUIRE(noffs < RK_MAX_OFFS, "rank_filter: footprint has more than %d cells", RK_MAX_OFFS);
+                host[noffs].x = x - fw / 2;
+                host[noffs].y = y - fh / 2;
+                ++noffs;
+            }
+    AMT_REQUIRE(noffs > 0, "rank_filter: empty footprint");
+    if (nplanes == 0) return AMT_OK;
+    const int ry = fh / 2, rx = fw / 2;
+    AMT_TRY(amt_arena_begin(ctx, amt_align(sizeof(int2) * noffs)));
+    int2* offs = (int2*)amt_arena_take(ctx, sizeof(int2) * noffs);
+    AMT_TRY(amt_param_upload(ctx, offs, host, sizeof(int2) * noffs));
+    dim3 grid((W + RT_W - 1) / RT_W, (H + RT_H - 1) / RT_H, nplanes);
+    const size_t ksz = dtype == AMT_U16 ? sizeof(unsigned) : sizeof(unsigned long long);
+    size_t smem = amt_align((size_t)(RT_H + 2 * ry) * (RT_W + 2 * rx) * ksz, 16) + sizeof(int2) * noffs;
+    if (dtype == AMT_U16)
+        hipLaunchKernelGGL((rank_kernel<uint16_t>), grid, dim3(256), smem, ctx->stream, (const uint16_t*)in,
+                           (uint16_t*)out, H, W, offs, noffs, ry, rx, op, mode, (uint16_t)cval);
+    else
+        hipLaunchKernelGGL((rank_kernel<double>), grid, dim3(256), smem, ctx->stream, (const double*)in, (double*)out,
+                           H, W, offs, noffs, ry, rx, op, mode, cval);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}

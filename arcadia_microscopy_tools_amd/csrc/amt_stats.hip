@@ -1,0 +1,708 @@
+// Histograms, min/max, exact percentiles, Otsu threshold and comparison kernels.
+//
+// Reference call sites: R/operations.py:47,94 (np.percentile), :186-216 (apply_threshold ->
+// ski.filters.threshold_*), SK/exposure/exposure.py:38-144 (histogram), SK/filters/thresholding.py:321-350.
+// All counting is integer and therefore order-independent; the only floating-point sequences whose
+// order matters (the 256-bin cumulative sums of Otsu on float images) are evaluated sequentially, in
+// numpy's order, by one lane.
+#include "amt_common.h"
+
+// ------------------------------------------------------------------------------------------------
+// uint16 histogram: 65536 uint32 bins per plane.  Each 1024-thread workgroup privatises the window
+// [0, 32768) in 128 KiB of LDS (microscopy cameras rarely fill the top bit) and sends the rest to
+// global atomics; the LDS window is flushed with one global atomic per non-empty bin.
+// ------------------------------------------------------------------------------------------------
+constexpr int HIST_LDS_BINS = 32768;
+
+__global__ void __launch_bounds__(1024) hist_u16_kernel(const uint16_t* __restrict__ in, uint32_t* __restrict__ hist,
+                                                        size_t n, int blocks_per_plane) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    uint32_t* lh = reinterpret_cast<uint32_t*>(smem_raw);
+    const int plane = blockIdx.x / blocks_per_plane;
+    const int part = blockIdx.x - plane * blocks_per_plane;
+    const uint16_t* src = in + (size_t)plane * n;
+    uint32_t* gh = hist + (size_t)plane * 65536;
+    for (int i = threadIdx.x; i < HIST_LDS_BINS; i += 1024) lh[i] = 0;
+    __syncthreads();
+    // 8 pixels (16 bytes) per thread per step when aligned
+    const size_t nvec = ((reinterpret_cast<uintptr_t>(src) & 15) == 0) ? n / 8 : 0;
+    const uint4* v4 = reinterpret_cast<const uint4*>(src);
+    for (size_t i = (size_t)part * 1024 + threadIdx.x; i < nvec; i += (size_t)blocks_per_plane * 1024) {
+        uint4 q = v4[i];
+        uint32_t wds[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint32_t a = wds[k] & 0xffffu, b = wds[k] >> 16;
+            if (a < HIST_LDS_BINS) atomicAdd(&lh[a], 1u); else atomicAdd(&gh[a], 1u);
+            if (b < HIST_LDS_BINS) atomicAdd(&lh[b], 1u); else atomicAdd(&gh[b], 1u);
+        }
+    }
+    for (size_t i = nvec * 8 + (size_t)part * 1024 + threadIdx.x; i < n; i += (size_t)blocks_per_plane * 1024) {
+        uint32_t a = src[i];
+        if (a < HIST_LDS_BINS) atomicAdd(&lh[a], 1u); else atomicAdd(&gh[a], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < HIST_LDS_BINS; i += 1024) {
+        uint32_t c = lh[i];
+        if (c) atomicAdd(&gh[i], c);
+    }
+}
+
+static int hist_u16_launch(amt_ctx* ctx, const uint16_t* in, uint32_t* hist, int nplanes, size_t n) {
+    AMT_HIP_CHECK(hipMemsetAsync(hist, 0, (size_t)nplanes * 65536 * sizeof(uint32_t), ctx->stream));
+    if (n == 0) return AMT_OK;
+    int bpp = (int)((n + 65535) / 65536);
+    int cap = (2 * ctx->num_cus + nplanes - 1) / nplanes;
+    if (cap < 1) cap = 1;
+    if (bpp > cap) bpp = cap;
+    if (bpp < 1) bpp = 1;
+    hipLaunchKernelGGL(hist_u16_kernel, dim3(nplanes * bpp), dim3(1024), HIST_LDS_BINS * sizeof(uint32_t), ctx->stream,
+                       in, hist, n, bpp);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+
+extern "C" int amt_hist_u16(amt_ctx* ctx, const uint16_t* in, uint32_t* hist, int nplanes, size_t n) {
+    AMT_TRY(amt_set_device(ctx));
+    AMT_REQUIRE(in && hist && nplanes >= 0, "hist_u16: bad arguments");
+    if (nplanes == 0) return AMT_OK;
+    return hist_u16_launch(ctx, in, hist, nplanes, n);
+}
+
+// ------------------------------------------------------------------------------------------------
+// float64 min / max per plane (wave shuffle reduction -> one 64-bit atomic per wave on ordered keys)
+// ------------------------------------------------------------------------------------------------
+__global__ void minmax_init_kernel(unsigned long long* keys, int nplanes) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nplanes) {
+        keys[2 * i] = ~0ull;
+        keys[2 * i + 1] = 0ull;
+    }
+}
+
+__global__ void __launch_bounds__(256) minmax_f64_kernel(const double* __restrict__ in,
+                                                         unsigned long long* __restrict__ keys, size_t n) {
+    const int plane = blockIdx.y;
+    const double* src = in + (size_t)plane * n;
+    unsigned long long lo = ~0ull, hi = 0ull;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        unsigned long long k = amt_f64_key(src[i]);
+        lo = k < lo ? k : lo;
+        hi = k > hi ? k : hi;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        unsigned long long l2 = __shfl_xor(lo, off), h2 = __shfl_xor(hi, off);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&keys[2 * plane], lo);
+        atomicMax(&keys[2 * plane + 1], hi);
+    }
+}
+
+__global__ void minmax_finish_kernel(const unsigned long long* keys, double* out, int nplanes) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 2 * nplanes) out[i] = amt_key_f64(keys[i]);
+}
+
+static int minmax_f64_launch(amt_ctx* ctx, const double* in, unsigned long long* keys, double* out, int nplanes,
+                             size_t n) {
+    hipLaunchKernelGGL(minmax_init_kernel, dim3((nplanes + 63) / 64), dim3(64), 0, ctx->stream, keys, nplanes);
+    AMT_LAUNCH_CHECK();
+    if (n) {
+        dim3 grid(amt_grid_for(n, 256 * 8, 1024), nplanes);
+        hipLaunchKernelGGL(minmax_f64_kernel, grid, dim3(256), 0, ctx->stream, in, keys, n);
+        AMT_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(minmax_finish_kernel, dim3((2 * nplanes + 63) / 64), dim3(64), 0, ctx->stream, keys, out,
+                       nplanes);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+
+extern "C" int amt_minmax_f64(amt_ctx* ctx, const double* in, double* minmax_dev, int nplanes, size_t n) {
+    AMT_TRY(amt_set_device(ctx));
+    AMT_REQUIRE(in && minmax_dev && nplanes >= 0, "minmax_f64: bad arguments");
+    if (nplanes == 0) return AMT_OK;
+    AMT_TRY(amt_arena_begin(ctx, amt_align(2 * nplanes * sizeof(unsigned long long))));
+    unsigned long long* keys = arena_take_t<unsigned long long>(ctx, 2 * nplanes);
+    return minmax_f64_launch(ctx, in, keys, minmax_dev, nplanes, n);
+}
+
+// ------------------------------------------------------------------------------------------------
+// np.histogram(x, bins=nbins, range=(min,max)): edges = np.linspace(min, max, nbins+1) i.e.
+// edges[i] = i*step + min with step = (max-min)/nbins and edges[nbins] = max; a sample belongs to the
+// bin with edges[i] <= x < edges[i+1] (last bin closed).  numpy estimates the bin by scaling and then
+// repairs it against the edges; repairing from any estimate gives the same bin.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double linspace_edge(double lo, double hi, double step, int i, int nbins) {
+    return i == nbins ? hi : (double)i * step + lo;
+}
+
+__global__ void __launch_bounds__(256) hist_f64_kernel(const double* __restrict__ in,
+                                                       const double* __restrict__ minmax,
+                                                       uint32_t* __restrict__ hist, int nbins, size_t n) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* edges = reinterpret_cast<double*>(smem_raw);              // nbins + 1
+    uint32_t* lh = reinterpret_cast<uint32_t*>(edges + nbins + 1);    // 4 waves x nbins
+    const int plane = blockIdx.y;
+    const double lo = minmax[2 * plane], hi = minmax[2 * plane + 1];
+    const double step = (hi - lo) / (double)nbins;
+    for (int i = threadIdx.x; i <= nbins; i += 256) edges[i] = linspace_edge(lo, hi, step, i, nbins);
+    for (int i = threadIdx.x; i < 4 * nbins; i += 256) lh[i] = 0;
+    __syncthreads();
+    uint32_t* mine = lh + (threadIdx.x >> 6) * nbins;
+    const double norm = (double)nbins / (hi - lo);
+    const double* src = in + (size_t)plane * n;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        double v = src[i];
+        if (!(v >= lo && v <= hi)) continue;  // NaN / out of range: not counted
+        double f = (v - lo) * norm;
+        int b = (int)f;
+        if (b < 0) b = 0;
+        if (b > nbins - 1) b = nbins - 1;
+        while (b > 0 && v < edges[b]) --b;
+        while (b < nbins - 1 && v >= edges[b + 1]) ++b;
+        atomicAdd(&mine[b], 1u);
+    }
+    __syncthreads();
+    uint32_t* gh = hist + (size_t)plane * nbins;
+    for (int i = threadIdx.x; i < nbins; i += 256) {
+        uint32_t c = lh[i] + lh[nbins + i] + lh[2 * nbins + i] + lh[3 * nbins + i];
+        if (c) atomicAdd(&gh[i], c);
+    }
+}
+
+static int hist_f64_launch(amt_ctx* ctx, const double* in, const double* minmax, uint32_t* hist, int nbins,
+                           int nplanes, size_t n) {
+    AMT_HIP_CHECK(hipMemsetAsync(hist, 0, (size_t)nplanes * nbins * sizeof(uint32_t), ctx->stream));
+    if (n == 0) return AMT_OK;
+    size_t smem = (size_t)(nbins + 1) * sizeof(double) + (size_t)4 * nbins * sizeof(uint32_t);
+    dim3 grid(amt_grid_for(n, 256 * 16, 512), nplanes);
+    hipLaunchKernelGGL(hist_f64_kernel, grid, dim3(256), smem, ctx->stream, in, minmax, hist, nbins, n);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+
+extern "C" int amt_hist_f64(amt_ctx* ctx, const double* in, const double* minmax_dev, uint32_t* hist, int nbins,
+                            int nplanes, size_t n) {
+    AMT_TRY(amt_set_device(ctx));
+    AMT_REQUIRE(in && minmax_dev && hist && nplanes >= 0, "hist_f64: bad arguments");
+    AMT_REQUIRE(nbins >= 1 && nbins <= 4096, "hist_f64: nbins %d out of range 1..4096", nbins);
+    if (nplanes == 0) return AMT_OK;
+    return hist_f64_launch(ctx, in, minmax_dev, hist, nbins, nplanes, n);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Otsu (SK/filters/thresholding.py:336-348) on a histogram, one 1024-thread workgroup per plane.
+//   EXACT_INT: uint16 images -- bins image_min..image_max, bin centre = value; all cumulative sums
+//              are exact integers, so the parallel scan equals numpy's sequential float64 cumsum.
+//   else     : float images -- nbins (256) bins, centres = edge midpoints; the cumulative sums are
+//              evaluated sequentially by lane 0 in numpy's order.
+// threshold = centre[argmax(w1[:-1] * w2[1:] * (m1[:-1] - m2[1:])**2)], first maximum wins.
+// A constant image returns its value (skimage's early exit).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void block_argmax_first(double v, int idx, double* s_val, int* s_idx, double& best,
+                                                   int& best_idx) {
+    // NaN never wins (np.argmax would return the first NaN, which cannot occur here: all weights > 0)
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        double v2 = __shfl_xor(v, off);
+        int i2 = __shfl_xor(idx, off);
+        if (v2 > v || (v2 == v && i2 < idx)) {
+            v = v2;
+            idx = i2;
+        }
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        s_val[wave] = v;
+        s_idx[wave] = idx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double bv = s_val[0];
+        int bi = s_idx[0];
+        for (int k = 1; k < (int)(blockDim.x >> 6); ++k)
+            if (s_val[k] > bv || (s_val[k] == bv && s_idx[k] < bi)) {
+                bv = s_val[k];
+                bi = s_idx[k];
+            }
+        s_val[0] = bv;
+        s_idx[0] = bi;
+    }
+    __syncthreads();
+    best = s_val[0];
+    best_idx = s_idx[0];
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(1024) otsu_u16_kernel(const uint32_t* __restrict__ hist, double* __restrict__ thr) {
+    // 65536 bins, 64 per thread
+    __shared__ unsigned long long s_cnt[1024];
+    __shared__ unsigned long long s_sum[1024];
+    __shared__ double s_val[16];
+    __shared__ int s_idx[16];
+    __shared__ int s_min, s_max;
+    const int plane = blockIdx.x;
+    const uint32_t* h = hist + (size_t)plane * 65536;
+    const int t = threadIdx.x;
+    const int b0 = t * 64;
+    if (t == 0) {
+        s_min = 65536;
+        s_max = -1;
+    }
+    __syncthreads();
+    unsigned long long cnt = 0, sum = 0;
+    int lmin = 65536, lmax = -1;
+    for (int k = 0; k < 64; ++k) {
+        uint32_t c = h[b0 + k];
+        if (c) {
+            if (lmin == 65536) lmin = b0 + k;
+            lmax = b0 + k;
+        }
+        cnt += c;
+        sum += (unsigned long long)c * (unsigned)(b0 + k);
+    }
+    if (lmin < 65536) atomicMin(&s_min, lmin);
+    if (lmax >= 0) atomicMax(&s_max, lmax);
+    s_cnt[t] = cnt;
+    s_sum[t] = sum;
+    __syncthreads();
+    // inclusive Hillis-Steele scan over the 1024 per-thread totals
+    for (int off = 1; off < 1024; off <<= 1) {
+        unsigned long long c2 = 0, s2 = 0;
+        if (t >= off) {
+            c2 = s_cnt[t - off];
+            s2 = s_sum[t - off];
+        }
+        __syncthreads();
+        s_cnt[t] += c2;
+        s_sum[t] += s2;
+        __syncthreads();
+    }
+    const unsigned long long total_cnt = s_cnt[1023], total_sum = s_sum[1023];
+    const int vmin = s_min, vmax = s_max;
+    if (vmax < 0 || vmin == vmax) {  // empty or constant image
+        if (t == 0) thr[plane] = vmax < 0 ? 0.0 : (double)vmin;
+        return;
+    }
+    unsigned long long run_cnt = s_cnt[t] - cnt, run_sum = s_sum[t] - sum;  // exclusive prefix
+    double best = -1.0;
+    int best_idx = 0x7fffffff;
+    for (int k = 0; k < 64; ++k) {
+        int v = b0 + k;
+        uint32_t c = h[v];
+        run_cnt += c;
+        run_sum += (unsigned long long)c * (unsigned)v;
+        if (v >= vmin && v < vmax) {
+            double w1 = (double)run_cnt;
+            double w2 = (double)(total_cnt - run_cnt);
+            double m1 = (double)run_sum / w1;
+            double m2 = (double)(total_sum - run_sum) / w2;
+            double d = m1 - m2;
+            double var = (w1 * w2) * (d * d);
+            if (var > best) {
+                best = var;
+                best_idx = v;
+            }
+        }
+    }
+    double bv;
+    int bi;
+    block_argmax_first(best, best_idx, s_val, s_idx, bv, bi);
+    if (t == 0) thr[plane] = (double)bi;
+}
+
+__global__ void __launch_bounds__(256) otsu_f64_kernel(const uint32_t* __restrict__ hist,
+                                                       const double* __restrict__ minmax, int nbins,
+                                                       double* __restrict__ thr) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* ctr = reinterpret_cast<double*>(smem_raw);  // nbins
+    double* w1 = ctr + nbins;
+    double* w2 = w1 + nbins;
+    double* m1 = w2 + nbins;
+    double* m2 = m1 + nbins;
+    __shared__ double s_val[4];
+    __shared__ int s_idx[4];
+    const int plane = blockIdx.x;
+    const uint32_t* h = hist + (size_t)plane * nbins;
+    const double lo = minmax[2 * plane], hi = minmax[2 * plane + 1];
+    if (!(lo < hi)) {  // constant image (or NaN): skimage returns the first pixel
+        if (threadIdx.x == 0) thr[plane] = lo;
+        return;
+    }
+    const double step = (hi - lo) / (double)nbins;
+    for (int i = threadIdx.x; i < nbins; i += 256) {
+        double e0 = linspace_edge(lo, hi, step, i, nbins), e1 = linspace_edge(lo, hi, step, i + 1, nbins);
+        ctr[i] = (e0 + e1) / 2.0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double cw = 0.0, cs = 0.0;
+        for (int i = 0; i < nbins; ++i) {  // np.cumsum(counts), np.cumsum(counts * centers)
+            double c = (double)h[i];
+            cw = (i == 0) ? c : cw + c;
+            cs = (i == 0) ? c * ctr[i] : cs + c * ctr[i];
+            w1[i] = cw;
+            m1[i] = cs / cw;
+        }
+        for (int i = nbins - 1; i >= 0; --i) {  // reversed cumsums
+            double c = (double)h[i];
+            cw = (i == nbins - 1) ? c : cw + c;
+            cs = (i == nbins - 1) ? c * ctr[i] : cs + c * ctr[i];
+            w2[i] = cw;
+            m2[i] = cs / cw;
+        }
+    }
+    __syncthreads();
+    double best = -1.0;
+    int best_idx = 0x7fffffff;
+    for (int i = threadIdx.x; i < nbins - 1; i += 256) {
+        double d = m1[i] - m2[i + 1];
+        double var = (w1[i] * w2[i + 1]) * (d * d);
+        if (var > best) {  // NaN (0/0 for leading empty bins cannot occur: bin 0 holds the minimum)
+            best = var;
+            best_idx = i;
+        }
+    }
+    double bv;
+    int bi;
+    block_argmax_first(best, best_idx, s_val, s_idx, bv, bi);
+    if (threadIdx.x == 0) thr[plane] = ctr[bi == 0x7fffffff ? 0 : bi];
+}
+
+extern "C" int amt_threshold_value(amt_ctx* ctx, const void* in, int in_dtype, int method, int nbins, double* thr_dev,
+                                   int32_t* status_dev, int nplanes, size_t n) {
+    AMT_TRY(amt_set_device(ctx));
+    AMT_REQUIRE(in && thr_dev && nplanes >= 0, "threshold_value: bad arguments");
+    AMT_REQUIRE(method == AMT_THR_OTSU,
+                "threshold_value: only AMT_THR_OTSU runs fully on the device; other methods are evaluated by the "
+                "host layer on amt_hist_* output");
+    AMT_REQUIRE(in_dtype == AMT_U16 || in_dtype == AMT_F64, "threshold_value: dtype must be AMT_U16 or AMT_F64");
+    if (nplanes == 0) return AMT_OK;
+    if (status_dev) AMT_HIP_CHECK(hipMemsetAsync(status_dev, 0, (size_t)nplanes * sizeof(int32_t), ctx->stream));
+    if (in_dtype == AMT_U16) {
+        AMT_TRY(amt_arena_begin(ctx, amt_align((size_t)nplanes * 65536 * sizeof(uint32_t))));
+        uint32_t* hist = arena_take_t<uint32_t>(ctx, (size_t)nplanes * 65536);
+        AMT_TRY(hist_u16_launch(ctx, (const uint16_t*)in, hist, nplanes, n));
+        hipLaunchKernelGGL(otsu_u16_kernel, dim3(nplanes), dim3(1024), 0, ctx->stream, hist, thr_dev);
+        AMT_LAUNCH_CHECK();
+        return AMT_OK;
+    }
+    AMT_REQUIRE(nbins >= 2 && nbins <= 4096, "threshold_value: nbins %d out of range", nbins);
+    AMT_TRY(amt_arena_begin(ctx, amt_align(2 * nplanes * 8) * 2 + amt_align((size_t)nplanes * nbins * 4)));
+    unsigned long long* keys = arena_take_t<unsigned long long>(ctx, 2 * nplanes);
+    double* mm = arena_take_t<double>(ctx, 2 * nplanes);
+    uint32_t* hist = arena_take_t<uint32_t>(ctx, (size_t)nplanes * nbins);
+    AMT_TRY(minmax_f64_launch(ctx, (const double*)in, keys, mm, nplanes, n));
+    AMT_TRY(hist_f64_launch(ctx, (const double*)in, mm, hist, nbins, nplanes, n));
+    hipLaunchKernelGGL(otsu_f64_kernel, dim3(nplanes), dim3(256), (size_t)5 * nbins * sizeof(double), ctx->stream, hist,
+                       mm, nbins, thr_dev);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// comparisons
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void threshold_gt_kernel(const T* __restrict__ in, const double* __restrict__ thr, uint8_t* __restrict__ out,
+                                    size_t n) {
+    const double t = thr[blockIdx.y];
+    const size_t base = (size_t)blockIdx.y * n;
+    // 4 pixels per thread -> one 32-bit store
+    size_t nq = n / 4;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (size_t)gridDim.x * blockDim.x) {
+        size_t i = base + q * 4;
+        uint32_t m = ((double)in[i] > t ? 1u : 0u) | ((double)in[i + 1] > t ? 0x100u : 0u) |
+                     ((double)in[i + 2] > t ? 0x10000u : 0u) | ((double)in[i + 3] > t ? 0x1000000u : 0u);
+        if (((base + q * 4) & 3) == 0)
+            *reinterpret_cast<uint32_t*>(out + i) = m;
+        else {
+            out[i] = m & 1;
+            out[i + 1] = (m >> 8) & 1;
+            out[i + 2] = (m >> 16) & 1;
+            out[i + 3] = (m >> 24) & 1;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        size_t i = base + nq * 4 + threadIdx.x;
+        out[i] = (double)in[i] > t ? 1 : 0;
+    }
+}
+
+extern "C" int amt_threshold_gt(amt_ctx* ctx, const void* in, int in_dtype, const double* thr_dev, uint8_t* out,
+                                int nplanes, size_t n) {
+    AMT_TRY(amt_set_device(ctx));
+    AMT_REQUIRE(in && thr_dev && out && nplanes >= 0, "threshold_gt: bad arguments");
+    if (nplanes == 0 || n == 0) return AMT_OK;
+    dim3 grid(amt_grid_for(n / 4 + 1, 256, 2048), nplanes);
+    if (in_dtype == AMT_U16)
+        hipLaunchKernelGGL((threshold_gt_kernel<uint16_t>), grid, dim3(256), 0, ctx->stream, (const uint16_t*)in,
+                           thr_dev, out, n);
+    else if (in_dtype == AMT_F64)
+        hipLaunchKernelGGL((threshold_gt_kernel<double>), grid, dim3(256), 0, ctx->stream, (const double*)in, thr_dev,
+                           out, n);
+    else {
+        amt_set_error("threshold_gt: dtype must be AMT_U16 or AMT_F64");
+        return AMT_EINVAL;
+    }
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+
+template <typename T>
+__global__ void threshold_gt_image_kernel(const T* __restrict__ in, const double* __restrict__ thr,
+                                          uint8_t* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = (double)in[i] > thr[i] ? 1 : 0;
+}
+
+extern "C" int amt_threshold_gt_image(amt_ctx* ctx, const void* in, int in_dtype, const double* thr_image,
+                                      uint8_t* out, size_t n) {
+    AMT_TRY(amt_set_device(ctx));
+    AMT_REQUIRE(in && thr_image && out, "threshold_gt_image: bad arguments");
+    if (n == 0) return AMT_OK;
+    dim3 grid(amt_grid_for(n, 256));
+    if (in_dtype == AMT_U16)
+        hipLaunchKernelGGL((threshold_gt_image_kernel<uint16_t>), grid, dim3(256), 0, ctx->stream, (const uint16_t*)in,
+                           thr_image, out, n);
+    else if (in_dtype == AMT_F64)
+        hipLaunchKernelGGL((threshold_gt_image_kernel<double>), grid, dim3(256), 0, ctx->stream, (const double*)in,
+                           thr_image, out, n);
+    else {
+        amt_set_error("threshold_gt_image: dtype must be AMT_U16 or AMT_F64");
+        return AMT_EINVAL;
+    }
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// np.percentile, method 'linear' (numpy _function_base_impl.py: virtual index (n-1)*q/100, _lerp):
+//   lerp = a + (b-a)*t, and for t >= 0.5: b - (b-a)*(1-t).
+// uint16: exact order statistics from the 65536-bin histogram.
+// float64: exact MSB-first radix select on order-preserving 64-bit keys, 8 bits per pass, all
+//          requested ranks resolved together.
+// ------------------------------------------------------------------------------------------------
+struct rank_req {
+    long long lo;  // floor(virtual index); hi = min(lo + 1, n - 1), or lo == n-1 when above bounds
+    long long hi;
+    double t;
+};
+
+static void make_rank_reqs(const double* q_host, int nq, size_t n, rank_req* out) {
+    for (int i = 0; i < nq; ++i) {
+        double quant = q_host[i] / 100.0;
+        double v = (double)(n - 1) * quant;
+        long long lo, hi;
+        if (v >= (double)(n - 1)) {
+            lo = hi = (long long)n - 1;
+        } else if (v < 0) {
+            lo = hi = 0;
+        } else {
+            lo = (long long)__builtin_floor(v);
+            hi = lo + 1;
+        }
+        // gamma = virtual - previous index as numpy computes it (previous = -1 -> n when above bounds,
+        // where a == b makes the value irrelevant)
+        out[i].lo = lo;
+        out[i].hi = hi;
+        out[i].t = v - __builtin_floor(v);
+        if (v >= (double)(n - 1) || v < 0) out[i].t = 0.0;
+    }
+}
+
+__device__ __forceinline__ double np_lerp(double a, double b, double t) {
+    double d = b - a;
+    double r = a + d * t;
+    if (t >= 0.5) r = b - d * (1.0 - t);
+    return r;
+}
+
+__global__ void __launch_bounds__(1024) percentile_u16_kernel(const uint32_t* __restrict__ hist,
+                                                              const rank_req* __restrict__ reqs, int nq,
+                                                              double* __restrict__ out) {
+    __shared__ unsigned long long s_cnt[1024];
+    const int plane = blockIdx.x;
+    const uint32_t* h = hist + (size_t)plane * 65536;
+    const int t = threadIdx.x, b0 = t * 64;
+    unsigned long long cnt = 0;
+    for (int k = 0; k < 64; ++k) cnt += h[b0 + k];
+    s_cnt[t] = cnt;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        unsigned long long c2 = (t >= off) ? s_cnt[t - off] : 0;
+        __syncthreads();
+        s_cnt[t] += c2;
+        __syncthreads();
+    }
+    const unsigned long long before = s_cnt[t] - cnt;  // samples with value < b0
+    __shared__ int s_lo[64], s_hi[64];
+    for (int qi = 0; qi < nq; ++qi) {
+        unsigned long long rlo = (unsigned long long)reqs[qi].lo, rhi = (unsigned long long)reqs[qi].hi;
+        unsigned long long run = before;
+        for (int k = 0; k < 64; ++k) {
+            unsigned long long nxt = run + h[b0 + k];
+            if (rlo >= run && rlo < nxt) s_lo[qi] = b0 + k;
+            if (rhi >= run && rhi < nxt) s_hi[qi] = b0 + k;
+            run = nxt;
+        }
+    }
+    __syncthreads();
+    if (t < nq) out[(size_t)plane * nq + t] = np_lerp((double)s_lo[t], (double)s_hi[t], reqs[t].t);
+}
+
+extern "C" int amt_percentile_u16(amt_ctx* ctx, const uint16_t* in, const double* q_host, int nq, double* out_dev,
+                                  int nplanes, size_t n) {
+    AMT_TRY(amt_set_device(ctx));
+    AMT_REQUIRE(in && q_host && out_dev && nplanes >= 0, "percentile_u16: bad arguments");
+    AMT_REQUIRE(nq >= 1 && nq <= 64, "percentile_u16: nq %d out of range 1..64", nq);
+    AMT_REQUIRE(n >= 1, "percentile_u16: empty image");
+    for (int i = 0; i < nq; ++i)
+        AMT_REQUIRE(q_host[i] >= 0.0 && q_host[i] <= 100.0, "Percentiles must be in the range [0, 100]");
+    if (nplanes == 0) return AMT_OK;
+    rank_req reqs[64];
+    make_rank_reqs(q_host, nq, n, reqs);
+    AMT_TRY(amt_arena_begin(ctx, amt_align((size_t)nplanes * 65536 * 4) + amt_align(sizeof(reqs))));
+    uint32_t* hist = arena_take_t<uint32_t>(ctx, (size_t)nplanes * 65536);
+    rank_req* rd = arena_take_t<rank_req>(ctx, 64);
+    AMT_TRY(amt_param_upload(ctx, rd, reqs, sizeof(rank_req) * nq));
+    AMT_TRY(hist_u16_launch(ctx, in, hist, nplanes, n));
+    hipLaunchKernelGGL(percentile_u16_kernel, dim3(nplanes), dim3(1024), 0, ctx->stream, hist, rd, nq, out_dev);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+
+// radix select state per (plane, rank): prefix (resolved high bits), remaining rank within prefix
+struct sel_state {
+    unsigned long long prefix;
+    unsigned long long rank;
+};
+
+__global__ void sel_init_kernel(sel_state* st, const rank_req* reqs, int nq, int nplanes) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nplanes * nq * 2) {
+        int r = i % (2 * nq);
+        int qi = r >> 1;
+        st[i].prefix = 0;
+        st[i].rank = (unsigned long long)((r & 1) ? reqs[qi].hi : reqs[qi].lo);
+    }
+}
+
+// counts[plane][slot][256]: histogram of the next 8-bit digit among keys matching each slot's prefix
+__global__ void __launch_bounds__(256) sel_count_kernel(const double* __restrict__ in,
+                                                        const sel_state* __restrict__ st,
+                                                        uint32_t* __restrict__ counts, int nslots, int pass, size_t n) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    uint32_t* lh = reinterpret_cast<uint32_t*>(smem_raw);  // nslots x 256
+    unsigned long long* pre = reinterpret_cast<unsigned long long*>(lh + nslots * 256);
+    const int plane = blockIdx.y;
+    for (int i = threadIdx.x; i < nslots * 256; i += 256) lh[i] = 0;
+    if (threadIdx.x < nslots) pre[threadIdx.x] = st[plane * nslots + threadIdx.x].prefix;
+    __syncthreads();
+    const int shift = 56 - 8 * pass;
+    const unsigned long long himask = pass == 0 ? 0ull : (~0ull << (shift + 8));
+    const double* src = in + (size_t)plane * n;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        unsigned long long k = amt_f64_key(src[i]);
+        unsigned digit = (unsigned)(k >> shift) & 255u;
+        unsigned long long hk = k & himask;
+        for (int s = 0; s < nslots; ++s) {
+            // identical prefixes (e.g. lo and hi of one percentile) share the first matching slot
+            if (hk == pre[s]) {
+                bool dup = false;
+                for (int s2 = 0; s2 < s; ++s2) dup |= (pre[s2] == pre[s]);
+                if (!dup) atomicAdd(&lh[s * 256 + digit], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t* g = counts + (size_t)plane * nslots * 256;
+    for (int i = threadIdx.x; i < nslots * 256; i += 256)
+        if (lh[i]) atomicAdd(&g[i], lh[i]);
+}
+
+__global__ void sel_pick_kernel(sel_state* st, uint32_t* counts, int nslots, int pass, int nplanes) {
+    // one thread per (plane, slot)
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nplanes * nslots) return;
+    int plane = i / nslots, s = i - plane * nslots;
+    // find the first slot with the same prefix (that is where the counts were accumulated)
+    int src = s;
+    for (int s2 = 0; s2 < s; ++s2)
+        if (st[plane * nslots + s2].prefix == st[i].prefix) {
+            src = s2;
+            break;
+        }
+    const uint32_t* c = counts + ((size_t)plane * nslots + src) * 256;
+    unsigned long long rank = st[i].rank, run = 0;
+    int d = 0;
+    for (; d < 256; ++d) {
+        unsigned long long nxt = run + c[d];
+        if (rank < nxt) break;
+        run = nxt;
+    }
+    if (d == 256) d = 255;
+    const int shift = 56 - 8 * pass;
+    // all threads must finish reading prefixes before anyone writes: done by a separate commit kernel
+    st[i + (size_t)nplanes * nslots].prefix = st[i].prefix | ((unsigned long long)d << shift);
+    st[i + (size_t)nplanes * nslots].rank = rank - run;
+}
+
+__global__ void sel_commit_kernel(sel_state* st, int total) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) st[i] = st[i + total];
+}
+
+__global__ void sel_finish_kernel(const sel_state* st, const rank_req* reqs, int nq, int nplanes, double* out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nplanes * nq) return;
+    int plane = i / nq, qi = i - plane * nq;
+    double a = amt_key_f64(st[(size_t)plane * 2 * nq + 2 * qi].prefix);
+    double b = amt_key_f64(st[(size_t)plane * 2 * nq + 2 * qi + 1].prefix);
+    out[i] = np_lerp(a, b, reqs[qi].t);
+}
+
+extern "C" int amt_percentile_f64(amt_ctx* ctx, const double* in, const double* q_host, int nq, double* out_dev,
+                                  int nplanes, size_t n) {
+    AMT_TRY(amt_set_device(ctx));
+    AMT_REQUIRE(in && q_host && out_dev && nplanes >= 0, "percentile_f64: bad arguments");
+    AMT_REQUIRE(nq >= 1 && nq <= 8, "percentile_f64: nq %d out of range 1..8", nq);
+    AMT_REQUIRE(n >= 1, "percentile_f64: empty image");
+    for (int i = 0; i < nq; ++i)
+        AMT_REQUIRE(q_host[i] >= 0.0 && q_host[i] <= 100.0, "Percentiles must be in the range [0, 100]");
+    if (nplanes == 0) return AMT_OK;
+    rank_req reqs[8];
+    make_rank_reqs(q_host, nq, n, reqs);
+    const int nslots = 2 * nq;
+    const int total = nplanes * nslots;
+    size_t need = amt_align(sizeof(rank_req) * 8) + amt_align(sizeof(sel_state) * 2 * total) +
+                  amt_align((size_t)total * 256 * 4);
+    AMT_TRY(amt_arena_begin(ctx, need));
+    rank_req* rd = arena_take_t<rank_req>(ctx, 8);
+    sel_state* st = arena_take_t<sel_state>(ctx, 2 * (size_t)total);
+    uint32_t* counts = arena_take_t<uint32_t>(ctx, (size_t)total * 256);
+    AMT_TRY(amt_param_upload(ctx, rd, reqs, sizeof(rank_req) * nq));
+    hipLaunchKernelGGL(sel_init_kernel, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, st, rd, nq, nplanes);
+    AMT_LAUNCH_CHECK();
+    size_t smem = (size_t)nslots * 256 * 4 + (size_t)nslots * 8;
+    for (int pass = 0; pass < 8; ++pass) {
+        AMT_HIP_CHECK(hipMemsetAsync(counts, 0, (size_t)total * 256 * 4, ctx->stream));
+        dim3 grid(amt_grid_for(n, 256 * 16, 512), nplanes);
+        hipLaunchKernelGGL(sel_count_kernel, grid, dim3(256), smem, ctx->stream, in, st, counts, nslots, pass, n);
+        AMT_LAUNCH_CHECK();
+        hipLaunchKernelGGL(sel_pick_kernel, dim3((total + 63) / 64), dim3(64), 0, ctx->stream, st, counts, nslots, pass,
+                           nplanes);
+        AMT_LAUNCH_CHECK();
+        hipLaunchKernelGGL(sel_commit_kernel, dim3((total + 63) / 64), dim3(64), 0, ctx->stream, st, total);
+        AMT_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(sel_finish_kernel, dim3((nplanes * nq + 63) / 64), dim3(64), 0, ctx->stream, st, rd, nq, nplanes,
+                       out_dev);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}

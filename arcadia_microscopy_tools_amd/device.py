@@ -1,0 +1,253 @@
+"""Device context and device-resident arrays (HBM buffers addressed through the C ABI).
+
+``Context`` owns one HIP stream + scratch arena on one GPU; it is NOT thread-safe, so every host thread
+gets its own via ``get_context()`` (thread-local).  That is what makes the operators re-entrant for
+``Pipeline(parallel=True)`` (reference: R/pipeline.py:145-146).
+
+``DeviceArray`` is a typed, shaped view of device memory.  Leading axes are independent planes; the last
+two axes are (Y, X).  A (C, Y, X) field of view is channel-major, so ``get_channel_intensities`` on the
+device is a pointer offset (reference: R/microscopy.py:279-282 returns a numpy view).
+"""
+from __future__ import annotations
+
+import ctypes
+import threading
+
+import numpy as np
+
+from . import _hip
+
+_DTYPE_CODE = {
+    np.dtype(np.uint8): _hip.U8,
+    np.dtype(np.bool_): _hip.U8,
+    np.dtype(np.uint16): _hip.U16,
+    np.dtype(np.int32): _hip.I32,
+    np.dtype(np.float64): _hip.F64,
+    np.dtype(np.int64): _hip.I64,
+    np.dtype(np.float32): _hip.F32,
+    np.dtype(np.uint32): _hip.I32,
+}
+
+
+def dtype_code(dt) -> int:
+    dt = np.dtype(dt)
+    if dt not in _DTYPE_CODE:
+        raise TypeError(f"dtype {dt} is not supported on the device path")
+    return _DTYPE_CODE[dt]
+
+
+class Context:
+    """One GPU + one HIP stream + one scratch arena."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self._lib = _hip.load_library()
+        h = ctypes.c_void_p()
+        if stream is None:
+            _hip.check(self._lib.amt_ctx_create(int(device), ctypes.byref(h)), "amt_ctx_create")
+        else:
+            _hip.check(self._lib.amt_ctx_create_on_stream(int(device), ctypes.c_void_p(stream), ctypes.byref(h)),
+                       "amt_ctx_create_on_stream")
+        self.handle = h
+        self.device = int(device)
+
+    # -- lifetime -------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.amt_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- memory ---------------------------------------------------------------------------------
+    def empty(self, shape, dtype) -> "DeviceArray":
+        shape = tuple(int(s) for s in shape)
+        dt = np.dtype(dtype)
+        nbytes = int(np.prod(shape, dtype=np.int64)) * dt.itemsize
+        p = ctypes.c_void_p()
+        _hip.check(self._lib.amt_malloc(self.handle, nbytes, ctypes.byref(p)), "amt_malloc")
+        return DeviceArray(self, p.value, shape, dt, owner=True)
+
+    def zeros(self, shape, dtype) -> "DeviceArray":
+        a = self.empty(shape, dtype)
+        _hip.check(self._lib.amt_memset(self.handle, a.ptr, 0, a.nbytes), "amt_memset")
+        return a
+
+    def asarray(self, arr: np.ndarray) -> "DeviceArray":
+        """Host -> device copy (bool becomes uint8 0/1)."""
+        a = np.ascontiguousarray(arr)
+        if a.dtype == np.bool_:
+            a = a.view(np.uint8)
+        d = self.empty(a.shape, a.dtype)
+        if a.nbytes:
+            _hip.check(self._lib.amt_memcpy_h2d(self.handle, d.ptr, a.ctypes.data, a.nbytes), "amt_memcpy_h2d")
+            self.synchronize()  # the host buffer may be a temporary
+        if arr.dtype == np.bool_:
+            d.is_bool = True
+        return d
+
+    def synchronize(self):
+        _hip.check(self._lib.amt_sync(self.handle), "amt_sync")
+
+    def device_name(self) -> str:
+        buf = ctypes.create_string_buffer(256)
+        _hip.check(self._lib.amt_device_name(self.handle, buf, 256), "amt_device_name")
+        return buf.value.decode()
+
+    # -- timing (HIP events on this context's stream) ---------------------------------------------
+    def timer(self) -> "Timer":
+        return Timer(self)
+
+
+class Timer:
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+        h = ctypes.c_void_p()
+        _hip.check(ctx._lib.amt_timer_create(ctx.handle, ctypes.byref(h)), "amt_timer_create")
+        self.h = h
+
+    def start(self):
+        _hip.check(self.ctx._lib.amt_timer_start(self.ctx.handle, self.h), "amt_timer_start")
+
+    def stop(self):
+        _hip.check(self.ctx._lib.amt_timer_stop(self.ctx.handle, self.h), "amt_timer_stop")
+
+    def elapsed_ms(self) -> float:
+        ms = ctypes.c_float()
+        _hip.check(self.ctx._lib.amt_timer_elapsed_ms(self.ctx.handle, self.h, ctypes.byref(ms)), "amt_timer_elapsed")
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            if self.ctx.handle:
+                self.ctx._lib.amt_timer_destroy(self.ctx.handle, self.h)
+        except Exception:
+            pass
+
+
+class DeviceArray:
+    """A typed view of device memory; frees the allocation when the owning object dies."""
+
+    __slots__ = ("ctx", "ptr", "shape", "dtype", "_owner", "_base", "is_bool")
+
+    def __init__(self, ctx: Context, ptr: int, shape, dtype, owner: bool = False, base=None):
+        self.ctx = ctx
+        self.ptr = int(ptr) if ptr else 0
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self._owner = owner
+        self._base = base  # keeps the owning array alive for views
+        self.is_bool = False
+
+    # -- geometry -------------------------------------------------------------------------------
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    @property
+    def size(self):
+        return int(np.prod(self.shape, dtype=np.int64))
+
+    @property
+    def nbytes(self):
+        return self.size * self.dtype.itemsize
+
+    @property
+    def nplanes(self):
+        return int(np.prod(self.shape[:-2], dtype=np.int64)) if self.ndim >= 2 else 1
+
+    @property
+    def plane_shape(self):
+        if self.ndim < 2:
+            raise ValueError("device ops need at least 2-D arrays")
+        return self.shape[-2:]
+
+    def __getitem__(self, idx) -> "DeviceArray":
+        """Integer / contiguous-slice indexing of the LEADING axis only (a pointer offset, no copy)."""
+        if self.ndim < 1:
+            raise IndexError("0-d DeviceArray")
+        inner = int(np.prod(self.shape[1:], dtype=np.int64)) * self.dtype.itemsize
+        if isinstance(idx, (int, np.integer)):
+            i = int(idx)
+            if i < 0:
+                i += self.shape[0]
+            if not 0 <= i < self.shape[0]:
+                raise IndexError(idx)
+            v = DeviceArray(self.ctx, self.ptr + i * inner, self.shape[1:], self.dtype, base=self._base or self)
+        elif isinstance(idx, slice):
+            start, stop, step = idx.indices(self.shape[0])
+            if step != 1:
+                raise IndexError("only contiguous slices of the leading axis are device views")
+            n = max(0, stop - start)
+            v = DeviceArray(self.ctx, self.ptr + start * inner, (n,) + self.shape[1:], self.dtype,
+                            base=self._base or self)
+        else:
+            raise IndexError("DeviceArray supports int or slice indexing of the leading axis only")
+        v.is_bool = self.is_bool
+        return v
+
+    def reshape(self, *shape) -> "DeviceArray":
+        if len(shape) == 1 and isinstance(shape[0], (tuple, list)):
+            shape = tuple(shape[0])
+        if int(np.prod(shape, dtype=np.int64)) != self.size:
+            raise ValueError("cannot reshape DeviceArray: size mismatch")
+        v = DeviceArray(self.ctx, self.ptr, shape, self.dtype, base=self._base or self)
+        v.is_bool = self.is_bool
+        return v
+
+    # -- transfers ------------------------------------------------------------------------------
+    def numpy(self) -> np.ndarray:
+        """Device -> host copy (synchronises the stream). uint8 masks flagged as bool come back as bool."""
+        out = np.empty(self.shape, dtype=self.dtype)
+        if out.nbytes:
+            lib = self.ctx._lib
+            _hip.check(lib.amt_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr, out.nbytes), "amt_memcpy_d2h")
+            self.ctx.synchronize()
+        if self.is_bool and self.dtype == np.uint8:
+            return out.view(np.bool_)
+        return out
+
+    def copy(self) -> "DeviceArray":
+        d = self.ctx.empty(self.shape, self.dtype)
+        _hip.check(self.ctx._lib.amt_memcpy_d2d(self.ctx.handle, d.ptr, self.ptr, self.nbytes), "amt_memcpy_d2d")
+        d.is_bool = self.is_bool
+        return d
+
+    def __del__(self):
+        try:
+            if self._owner and self.ptr and self.ctx.handle:
+                # frees are stream-ordered by hipFree's implicit synchronisation
+                self.ctx._lib.amt_free(self.ctx.handle, self.ptr)
+                self.ptr = 0
+        except Exception:
+            pass
+
+    def __repr__(self):
+        return f"<DeviceArray shape={self.shape} dtype={self.dtype} device={self.ctx.device}>"
+
+
+_tls = threading.local()
+_default_device = 0
+
+
+def set_default_device(device: int):
+    """Select the GPU used by contexts created after this call (one process per GPU: LOCAL_RANK)."""
+    global _default_device
+    _default_device = int(device)
+    _tls.__dict__.pop("ctx", None)
+
+
+def get_context() -> Context:
+    """The calling thread's context (created on first use).  Raises HipUnavailableError without a GPU."""
+    ctx = getattr(_tls, "ctx", None)
+    if ctx is None or ctx.handle is None or ctx.device != _default_device:
+        ctx = Context(_default_device)
+        _tls.ctx = ctx
+    return ctx
+
+
+def is_device_array(x) -> bool:
+    return isinstance(x, DeviceArray)

@@ -1,0 +1,468 @@
+"""Batch device operators: thin, shape-checked Python wrappers over the C ABI (include/amt_hip.h).
+
+Every function takes ``DeviceArray`` inputs whose LAST TWO axes are (Y, X); all leading axes are
+independent planes processed by one launch.  ``out=`` lets a caller reuse buffers (no allocation, no
+implicit synchronisation inside a pipeline).  Nothing here touches the host except where stated
+(small parameter tables; results are only copied back by ``DeviceArray.numpy()``).
+
+The functions mirror the scikit-image / scipy calls the reference makes (file:line in each docstring).
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _hip
+from .device import Context, DeviceArray
+
+_c_double_p = ctypes.POINTER(ctypes.c_double)
+
+
+def _lib():
+    return _hip.load_library()
+
+
+def _planes(a: DeviceArray):
+    if a.ndim < 2:
+        raise ValueError(f"expected at least a 2-D array, got shape {a.shape}")
+    H, W = a.shape[-2:]
+    return a.nplanes, int(H), int(W)
+
+
+def _out(ctx: Context, out, shape, dtype) -> DeviceArray:
+    if out is None:
+        return ctx.empty(shape, dtype)
+    if tuple(out.shape) != tuple(shape) or out.dtype != np.dtype(dtype):
+        raise ValueError(f"out has shape {out.shape} dtype {out.dtype}, need {tuple(shape)} {np.dtype(dtype)}")
+    return out
+
+
+def _in_code(a: DeviceArray) -> int:
+    if a.dtype == np.uint16:
+        return _hip.U16
+    if a.dtype == np.float64:
+        return _hip.F64
+    raise TypeError(f"device filters accept uint16 or float64 images, got {a.dtype}")
+
+
+def _host_f64(arr):
+    a = np.ascontiguousarray(arr, dtype=np.float64)
+    return a, a.ctypes.data_as(ctypes.c_void_p)
+
+
+# --------------------------------------------------------------------------------------------------
+# filters
+# --------------------------------------------------------------------------------------------------
+def gaussian_weights(sigma: float, truncate: float = 4.0) -> np.ndarray:
+    """The 1-D kernel scipy builds (SP/_filters.py:226-236,314-323); computed with the host's numpy so the
+    device shares np.exp's rounding with the CPU path."""
+    sigma = float(sigma)
+    radius = int(truncate * sigma + 0.5)
+    x = np.arange(-radius, radius + 1)
+    phi = np.exp(-0.5 / (sigma * sigma) * x**2)
+    return phi / phi.sum()
+
+
+def gaussian(a: DeviceArray, sigma: float, mode: str = "nearest", cval: float = 0.0, truncate: float = 4.0,
+             scale: float | None = None, out: DeviceArray | None = None) -> DeviceArray:
+    """``skimage.filters.gaussian`` per plane (SK/filters/_gaussian.py:119-126): uint16 input is first
+    converted like ``img_as_float`` (x * (1/65535), SK/util/dtype.py:319) unless ``scale`` is given."""
+    ctx = a.ctx
+    n, H, W = _planes(a)
+    o = _out(ctx, out, a.shape, np.float64)
+    if sigma <= 1e-15:  # scipy skips axes with sigma <= 1e-15 (SP/_filters.py:423)
+        w = np.ones(1)
+    else:
+        w = gaussian_weights(sigma, truncate)
+    r = (len(w) - 1) // 2
+    wa, wp = _host_f64(w)
+    if scale is None:
+        scale = 1.0 / 65535 if a.dtype == np.uint16 else 1.0
+    _hip.check(_lib().amt_gaussian(ctx.handle, a.ptr, _in_code(a), float(scale), o.ptr, n, H, W, wp, r,
+                                   _hip.MODES[mode], float(cval)), "amt_gaussian")
+    return o
+
+
+def difference_of_gaussians(a: DeviceArray, low_sigma: float, high_sigma: float, mode: str = "nearest",
+                            cval: float = 0.0, truncate: float = 4.0, out: DeviceArray | None = None) -> DeviceArray:
+    """``skimage.filters.difference_of_gaussians`` (SK/filters/_gaussian.py:258-290; R/operations.py:91)."""
+    ctx = a.ctx
+    n, H, W = _planes(a)
+    o = _out(ctx, out, a.shape, np.float64)
+    wl, wh = gaussian_weights(low_sigma, truncate), gaussian_weights(high_sigma, truncate)
+    wla, wlp = _host_f64(wl)
+    wha, whp = _host_f64(wh)
+    scale = 1.0 / 65535 if a.dtype == np.uint16 else 1.0
+    _hip.check(_lib().amt_dog(ctx.handle, a.ptr, _in_code(a), scale, o.ptr, n, H, W, wlp, (len(wl) - 1) // 2, whp,
+                              (len(wh) - 1) // 2, _hip.MODES[mode], float(cval)), "amt_dog")
+    return o
+
+
+def sub_clip0(a: DeviceArray, level: DeviceArray, out: DeviceArray | None = None) -> DeviceArray:
+    """``np.clip(a - level, 0, None)`` with one level per plane (R/operations.py:97)."""
+    ctx = a.ctx
+    n, H, W = _planes(a)
+    o = _out(ctx, out, a.shape, np.float64)
+    _hip.check(_lib().amt_sub_clip0_f64(ctx.handle, a.ptr, level.ptr, o.ptr, n, H * W), "amt_sub_clip0_f64")
+    return o
+
+
+def rescale(a: DeviceArray, in_range: DeviceArray, out_range=(0.0, 1.0), out: DeviceArray | None = None):
+    """``skimage.exposure.rescale_intensity(a, in_range=(p1, p2), out_range=(lo, hi))`` per plane with the
+    (p1, p2) pairs on the device (SK/exposure/exposure.py:405-428; R/operations.py:50)."""
+    ctx = a.ctx
+    n, H, W = _planes(a)
+    o = _out(ctx, out, a.shape, np.float64)
+    _hip.check(_lib().amt_rescale(ctx.handle, a.ptr, _in_code(a), in_range.ptr, float(out_range[0]),
+                                  float(out_range[1]), o.ptr, n, H * W), "amt_rescale")
+    return o
+
+
+def deinterleave(yxc: DeviceArray, C: int, out: DeviceArray | None = None) -> DeviceArray:
+    """(..., Y, X, C) interleaved ND2 frames -> (..., C, Y, X) (R/nikon.py:25-43)."""
+    ctx = yxc.ctx
+    if yxc.ndim < 3 or yxc.shape[-1] != C:
+        raise ValueError("deinterleave expects (..., Y, X, C)")
+    H, W = yxc.shape[-3:-1]
+    lead = yxc.shape[:-3]
+    n = int(np.prod(lead, dtype=np.int64)) if lead else 1
+    o = _out(ctx, out, tuple(lead) + (C, H, W), np.uint16)
+    _hip.check(_lib().amt_deinterleave_u16(ctx.handle, yxc.ptr, o.ptr, n, H, W, C), "amt_deinterleave_u16")
+    return o
+
+
+# --------------------------------------------------------------------------------------------------
+# statistics and thresholds
+# --------------------------------------------------------------------------------------------------
+def histogram_u16(a: DeviceArray, out: DeviceArray | None = None) -> DeviceArray:
+    """65536-bin uint32 histogram per plane (np.bincount of SK/exposure/exposure.py:70)."""
+    ctx = a.ctx
+    n, H, W = _planes(a)
+    o = _out(ctx, out, (n, 65536), np.uint32)
+    _hip.check(_lib().amt_hist_u16(ctx.handle, a.ptr, o.ptr, n, H * W), "amt_hist_u16")
+    return o
+
+
+def minmax(a: DeviceArray, out: DeviceArray | None = None) -> DeviceArray:
+    ctx = a.ctx
+    n, H, W = _planes(a)
+    o = _out(ctx, out, (n, 2), np.float64)
+    _hip.check(_lib().amt_minmax_f64(ctx.handle, a.ptr, o.ptr, n, H * W), "amt_minmax_f64")
+    return o
+
+
+def histogram_f64(a: DeviceArray, nbins: int = 256, mm: DeviceArray | None = None, out: DeviceArray | None = None):
+    """``np.histogram(a, bins=nbins)`` counts per plane + the (min, max) pairs (SK/exposure/exposure.py:139)."""
+    ctx = a.ctx
+    n, H, W = _planes(a)
+    if mm is None:
+        mm = minmax(a)
+    o = _out(ctx, out, (n, nbins), np.uint32)
+    _hip.check(_lib().amt_hist_f64(ctx.handle, a.ptr, mm.ptr, o.ptr, nbins, n, H * W), "amt_hist_f64")
+    return o, mm
+
+
+def percentile(a: DeviceArray, q, out: DeviceArray | None = None) -> DeviceArray:
+    """``np.percentile(a, q)`` (method 'linear') per plane -> (nplanes, len(q)) float64 on the device."""
+    ctx = a.ctx
+    n, H, W = _planes(a)
+    qa = np.atleast_1d(np.asarray(q, dtype=np.float64))
+    if np.any(qa < 0) or np.any(qa > 100):
+        raise ValueError("Percentiles must be in the range [0, 100]")
+    o = _out(ctx, out, (n, len(qa)), np.float64)
+    qh, qp = _host_f64(qa)
+    if a.dtype == np.uint16:
+        _hip.check(_lib().amt_percentile_u16(ctx.handle, a.ptr, qp, len(qa), o.ptr, n, H * W), "amt_percentile_u16")
+    elif a.dtype == np.float64:
+        _hip.check(_lib().amt_percentile_f64(ctx.handle, a.ptr, qp, len(qa), o.ptr, n, H * W), "amt_percentile_f64")
+    else:
+        raise TypeError(f"percentile: unsupported dtype {a.dtype}")
+    return o
+
+
+def threshold_otsu(a: DeviceArray, nbins: int = 256, out: DeviceArray | None = None) -> DeviceArray:
+    """``skimage.filters.threshold_otsu`` per plane, value stays on the device (SK/filters/thresholding.py:321-350)."""
+    ctx = a.ctx
+    n, H, W = _planes(a)
+    o = _out(ctx, out, (n,), np.float64)
+    _hip.check(_lib().amt_threshold_value(ctx.handle, a.ptr, _in_code(a), _hip.THR_OTSU, nbins, o.ptr, None, n, H * W),
+               "amt_threshold_value")
+    return o
+
+
+def greater_than(a: DeviceArray, thr: DeviceArray, out: DeviceArray | None = None) -> DeviceArray:
+    """``a > thr[plane]`` -> uint8 0/1 mask (R/operations.py:216)."""
+    ctx = a.ctx
+    n, H, W = _planes(a)
+    o = _out(ctx, out, a.shape, np.uint8)
+    _hip.check(_lib().amt_threshold_gt(ctx.handle, a.ptr, _in_code(a), thr.ptr, o.ptr, n, H * W), "amt_threshold_gt")
+    o.is_bool = True
+    return o
+
+
+def greater_than_image(a: DeviceArray, thr_image: DeviceArray, out: DeviceArray | None = None) -> DeviceArray:
+    ctx = a.ctx
+    o = _out(ctx, out, a.shape, np.uint8)
+    _hip.check(_lib().amt_threshold_gt_image(ctx.handle, a.ptr, _in_code(a), thr_image.ptr, o.ptr, a.size),
+               "amt_threshold_gt_image")
+    o.is_bool = True
+    return o
+
+
+# --------------------------------------------------------------------------------------------------
+# morphology
+# --------------------------------------------------------------------------------------------------
+def disk(radius: int) -> np.ndarray:
+    """``skimage.morphology.disk`` (X**2 + Y**2 <= r**2)."""
+    L = np.arange(-radius, radius + 1)
+    X, Y = np.meshgrid(L, L)
+    return np.array((X**2 + Y**2) <= radius**2, dtype=np.uint8)
+
+
+def cross3() -> np.ndarray:
+    """skimage's default footprint: ndi.generate_binary_structure(2, 1)."""
+    return np.array([[0, 1, 0], [1, 1, 1], [0, 1, 0]], dtype=np.uint8)
+
+
+def _fp(footprint):
+    fp = np.ascontiguousarray(cross3() if footprint is None else np.asarray(footprint) != 0, dtype=np.uint8)
+    if fp.ndim != 2:
+        raise ValueError("footprint must be 2-D")
+    if fp.shape[0] % 2 == 0 or fp.shape[1] % 2 == 0:
+        raise NotImplementedError("even-sized footprints are not supported on the device path")
+    return fp
+
+
+def _binary(which: str, a: DeviceArray, footprint, out, border_value=None):
+    ctx = a.ctx
+    if a.dtype != np.uint8:
+        raise TypeError("binary morphology expects a uint8 / bool mask on the device")
+    n, H, W = _planes(a)
+    fp = _fp(footprint)
+    o = _out(ctx, out, a.shape, np.uint8)
+    fpp = fp.ctypes.data_as(ctypes.c_void_p)
+    lib = _lib()
+    if which == "erode":
+        rc = lib.amt_binary_erode(ctx.handle, a.ptr, o.ptr, n, H, W, fpp, fp.shape[0], fp.shape[1],
+                                  1 if border_value is None else int(border_value))
+    elif which == "dilate":
+        rc = lib.amt_binary_dilate(ctx.handle, a.ptr, o.ptr, n, H, W, fpp, fp.shape[0], fp.shape[1],
+                                   0 if border_value is None else int(border_value))
+    elif which == "open":
+        rc = lib.amt_binary_open(ctx.handle, a.ptr, o.ptr, n, H, W, fpp, fp.shape[0], fp.shape[1])
+    else:
+        rc = lib.amt_binary_close(ctx.handle, a.ptr, o.ptr, n, H, W, fpp, fp.shape[0], fp.shape[1])
+    _hip.check(rc, "amt_binary_" + which)
+    o.is_bool = True
+    return o
+
+
+def binary_erosion(a, footprint=None, out=None):
+    """``skimage.morphology.binary_erosion`` (SK/morphology/binary.py:42; outside counts as True)."""
+    return _binary("erode", a, footprint, out)
+
+
+def binary_dilation(a, footprint=None, out=None):
+    """``skimage.morphology.binary_dilation`` (SK/morphology/binary.py:77)."""
+    return _binary("dilate", a, footprint, out)
+
+
+def binary_opening(a, footprint=None, out=None):
+    """``skimage.morphology.binary_opening`` = dilation(erosion(a)), fused (SK/morphology/binary.py:82-113)."""
+    return _binary("open", a, footprint, out)
+
+
+def binary_closing(a, footprint=None, out=None):
+    """``skimage.morphology.binary_closing`` = erosion(dilation(a)), fused (SK/morphology/binary.py:116-147)."""
+    return _binary("close", a, footprint, out)
+
+
+def _rank(a: DeviceArray, footprint, op: int, mode: str, cval: float, out):
+    ctx = a.ctx
+    n, H, W = _planes(a)
+    fp = _fp(footprint)
+    o = _out(ctx, out, a.shape, a.dtype)
+    _hip.check(_lib().amt_rank_filter(ctx.handle, a.ptr, o.ptr, _in_code(a), n, H, W,
+                                      fp.ctypes.data_as(ctypes.c_void_p), fp.shape[0], fp.shape[1], op,
+                                      _hip.MODES[mode], float(cval)), "amt_rank_filter")
+    return o
+
+
+def erosion(a, footprint=None, out=None):
+    """``skimage.morphology.erosion`` -> ndi.grey_erosion(footprint), mode 'reflect' (SK/morphology/grey.py:185)."""
+    return _rank(a, footprint, 0, "reflect", 0.0, out)
+
+
+def dilation(a, footprint=None, out=None):
+    """``skimage.morphology.dilation``: skimage mirrors the footprint and scipy mirrors it back
+    (SK/morphology/grey.py:242-251), i.e. max over in[p + s] for s in the ORIGINAL footprint."""
+    fp = _fp(footprint)
+    return _rank(a, fp[::-1, ::-1], 1, "reflect", 0.0, out)
+
+
+def opening(a, footprint=None, out=None):
+    """``skimage.morphology.opening`` = dilation(erosion(a)) (SK/morphology/grey.py:257-303)."""
+    return dilation(erosion(a, footprint), footprint, out=out)
+
+
+def closing(a, footprint=None, out=None):
+    """``skimage.morphology.closing`` = erosion(dilation(a)) (SK/morphology/grey.py:307-353)."""
+    return erosion(dilation(a, footprint), footprint, out=out)
+
+
+def white_tophat(a, footprint=None, out=None):
+    """``skimage.morphology.white_tophat`` -> ndi.white_tophat = a - grey_opening(a) with scipy's own
+    opening (grey_erosion then grey_dilation, both with the footprint as given; SK/morphology/grey.py:425)."""
+    fp = _fp(footprint)
+    er = _rank(a, fp, 0, "reflect", 0.0, None)
+    op = _rank(er, fp, 1, "reflect", 0.0, None)
+    o = _out(a.ctx, out, a.shape, a.dtype)
+    _hip.check(_lib().amt_subtract(a.ctx.handle, a.ptr, op.ptr, o.ptr, _in_code(a), a.size), "amt_subtract")
+    return o
+
+
+def median(a, footprint=None, mode: str = "nearest", cval: float = 0.0, out=None):
+    """``skimage.filters.median`` -> ndi.median_filter(footprint, mode='nearest') (SK/filters/_median.py)."""
+    fp = np.ones((3, 3), dtype=np.uint8) if footprint is None else footprint
+    return _rank(a, fp, 2, mode, cval, out)
+
+
+# --------------------------------------------------------------------------------------------------
+# labelling
+# --------------------------------------------------------------------------------------------------
+def label(a: DeviceArray, connectivity: int = 2, out: DeviceArray | None = None, count: DeviceArray | None = None):
+    """``skimage.measure.label`` per plane (default 8-connected; raster numbering) -> (int32 labels, counts).
+    R/masks.py:63; SURVEY.md A.5."""
+    ctx = a.ctx
+    n, H, W = _planes(a)
+    if a.dtype == np.uint8:
+        code = _hip.U8
+    elif a.dtype == np.int32:
+        code = _hip.I32
+    else:
+        raise TypeError(f"label: unsupported dtype {a.dtype}")
+    o = _out(ctx, out, a.shape, np.int32)
+    c = _out(ctx, count, (n,), np.int32)
+    _hip.check(_lib().amt_label(ctx.handle, a.ptr, code, o.ptr, c.ptr, n, H, W, int(connectivity)), "amt_label")
+    return o, c
+
+
+def clear_border(labels: DeviceArray, out: DeviceArray | None = None) -> DeviceArray:
+    """``skimage.segmentation.clear_border`` (buffer_size 0) per plane (R/masks.py:56)."""
+    ctx = labels.ctx
+    n, H, W = _planes(labels)
+    if labels.dtype != np.int32:
+        raise TypeError("clear_border expects int32 labels on the device")
+    o = _out(ctx, out, labels.shape, np.int32)
+    _hip.check(_lib().amt_clear_border(ctx.handle, labels.ptr, o.ptr, n, H, W), "amt_clear_border")
+    return o
+
+
+def relabel_sequential(labels: DeviceArray, max_label: int, out=None, count=None):
+    """``skimage.segmentation.relabel_sequential`` per plane -> (labels, counts) (R/masks.py:65)."""
+    ctx = labels.ctx
+    n, H, W = _planes(labels)
+    o = _out(ctx, out, labels.shape, np.int32)
+    c = _out(ctx, count, (n,), np.int32)
+    _hip.check(_lib().amt_relabel_sequential(ctx.handle, labels.ptr, o.ptr, c.ptr, n, H * W, int(max_label)),
+               "amt_relabel_sequential")
+    return o, c
+
+
+def keep_labels(labels: DeviceArray, keep: DeviceArray, max_label: int, out=None) -> DeviceArray:
+    """``np.where(np.isin(labels, kept), labels, 0)`` with keep = (nplanes, max_label+1) uint8 (R/masks.py:399-403)."""
+    ctx = labels.ctx
+    n, H, W = _planes(labels)
+    o = _out(ctx, out, labels.shape, np.int32)
+    _hip.check(_lib().amt_keep_labels(ctx.handle, labels.ptr, keep.ptr, o.ptr, n, H * W, int(max_label)),
+               "amt_keep_labels")
+    return o
+
+
+def to_int64(labels: DeviceArray, out=None) -> DeviceArray:
+    o = _out(labels.ctx, out, labels.shape, np.int64)
+    _hip.check(_lib().amt_cast_i32_i64(labels.ctx.handle, labels.ptr, o.ptr, labels.size), "amt_cast_i32_i64")
+    return o
+
+
+def max_per_plane(labels: DeviceArray, out=None) -> DeviceArray:
+    ctx = labels.ctx
+    n, H, W = _planes(labels)
+    o = _out(ctx, out, (n,), np.int32)
+    _hip.check(_lib().amt_max_i32(ctx.handle, labels.ptr, o.ptr, n, H * W), "amt_max_i32")
+    return o
+
+
+# --------------------------------------------------------------------------------------------------
+# distance transform, markers, watershed
+# --------------------------------------------------------------------------------------------------
+def edt(mask: DeviceArray, want_d2: bool = True, want_edt: bool = True, d2_out=None, edt_out=None):
+    """``scipy.ndimage.distance_transform_edt`` per plane -> (d2 int32 | None, edt float64 | None)."""
+    ctx = mask.ctx
+    n, H, W = _planes(mask)
+    d2 = _out(ctx, d2_out, mask.shape, np.int32) if want_d2 else None
+    e = _out(ctx, edt_out, mask.shape, np.float64) if want_edt else None
+    _hip.check(_lib().amt_edt(ctx.handle, mask.ptr, d2.ptr if d2 else None, e.ptr if e else None, n, H, W), "amt_edt")
+    return d2, e
+
+
+def peak_mask(d2: DeviceArray, mask: DeviceArray, min_distance: int = 5, out=None) -> DeviceArray:
+    """Peaks of the EDT per the config-3 marker recipe."""
+    ctx = d2.ctx
+    n, H, W = _planes(d2)
+    o = _out(ctx, out, d2.shape, np.uint8)
+    _hip.check(_lib().amt_peak_mask(ctx.handle, d2.ptr, mask.ptr, o.ptr, n, H, W, int(min_distance)), "amt_peak_mask")
+    o.is_bool = True
+    return o
+
+
+def watershed_edt(d2: DeviceArray, markers: DeviceArray, mask: DeviceArray, seeds_first: bool = True, out=None):
+    """``skimage.segmentation.watershed(relief, markers, mask=mask)`` with relief = -sqrt(d2)
+    (seeds_first: the seeded relief of oracle/skops.py:seeded_flood_image)."""
+    ctx = d2.ctx
+    n, H, W = _planes(d2)
+    o = _out(ctx, out, d2.shape, np.int32)
+    _hip.check(_lib().amt_watershed_edt(ctx.handle, d2.ptr, markers.ptr, mask.ptr, o.ptr, n, H, W,
+                                        1 if seeds_first else 0), "amt_watershed_edt")
+    return o
+
+
+def watershed(relief: DeviceArray, markers: DeviceArray, mask: DeviceArray, out=None):
+    """``skimage.segmentation.watershed(relief, markers, connectivity=1, mask=mask)`` for float64 relief."""
+    ctx = relief.ctx
+    n, H, W = _planes(relief)
+    o = _out(ctx, out, relief.shape, np.int32)
+    _hip.check(_lib().amt_watershed_f64(ctx.handle, relief.ptr, markers.ptr, mask.ptr, o.ptr, n, H, W),
+               "amt_watershed_f64")
+    return o
+
+
+# --------------------------------------------------------------------------------------------------
+# region properties
+# --------------------------------------------------------------------------------------------------
+def regionprops(labels: DeviceArray, max_label: int, out=None) -> DeviceArray:
+    """Morphology table (nplanes, max_label, RP_NCOLS) float64; column order ``_hip.RP_COLS``."""
+    ctx = labels.ctx
+    n, H, W = _planes(labels)
+    o = _out(ctx, out, (n, max_label, _hip.RP_NCOLS), np.float64)
+    _hip.check(_lib().amt_regionprops(ctx.handle, labels.ptr, o.ptr, n, H, W, int(max_label)), "amt_regionprops")
+    return o
+
+
+def regionprops_intensity(labels: DeviceArray, intensity: DeviceArray, max_label: int, out=None) -> DeviceArray:
+    """Intensity table (nplanes, max_label, C, 4) = {mean, max, min, std}; ``intensity`` is (..., C, Y, X)
+    uint16 with one (C, Y, X) stack per label plane."""
+    ctx = labels.ctx
+    n, H, W = _planes(labels)
+    if intensity.dtype != np.uint16:
+        raise TypeError("intensity images must be uint16 on the device path")
+    if intensity.ndim < 3 or intensity.shape[-2:] != labels.shape[-2:]:
+        raise ValueError("intensity must be (..., C, Y, X) matching the label planes")
+    C = int(intensity.shape[-3])
+    if intensity.size != n * C * H * W:
+        raise ValueError("intensity / labels plane count mismatch")
+    o = _out(ctx, out, (n, max_label, C, 4), np.float64)
+    _hip.check(_lib().amt_regionprops_intensity_u16(ctx.handle, labels.ptr, intensity.ptr, C, o.ptr, n, H, W,
+                                                    int(max_label)), "amt_regionprops_intensity_u16")
+    return o

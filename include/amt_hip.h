@@ -1,0 +1,226 @@
+/* amt_hip.h -- C ABI of libamt_hip.so: the MI355X (gfx950) implementation of the
+ * arcadia-microscopy-tools per-image preprocessing + segmentation + region-props hot path.
+ *
+ * Nothing native exists upstream: the reference (pure Python) reaches its arithmetic through
+ * scikit-image / scipy.ndimage / numpy calls.  Each entry point below therefore cites the
+ * REFERENCE CALL SITE it serves (R/ = src/arcadia_microscopy_tools/) and the scikit-image /
+ * scipy function whose result it reproduces (SK/ = skimage 0.18.3 source, SP/ = scipy.ndimage).
+ * INTEGRATION.md shows the ctypes stubs a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every image argument is a DEVICE pointer to a batch of `nplanes` C-contiguous (H, W)
+ *     planes of the stated element type; planes are independent (one per FOV-channel);
+ *   - functions enqueue work on the context's HIP stream and return without synchronising
+ *     unless stated; amt_sync() waits for the stream;
+ *   - return value: 0 on success, a negative AMT_E* code otherwise; amt_last_error() returns a
+ *     thread-local message for the last failure on the calling thread;
+ *   - a context is not thread-safe; use one context per host thread (they are cheap), which
+ *     makes the library re-entrant for Pipeline(parallel=True) (R/pipeline.py:145-146).
+ */
+#ifndef AMT_HIP_H
+#define AMT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AMT_OK 0
+#define AMT_EINVAL (-1)   /* bad argument */
+#define AMT_EHIP (-2)     /* HIP runtime error */
+#define AMT_ENOMEM (-3)   /* device allocation failed */
+#define AMT_ENODEV (-4)   /* no usable gfx950 device */
+#define AMT_ECAPACITY (-5)/* a caller-provided capacity was too small (see amt_last_error) */
+
+/* element types */
+#define AMT_U8 0
+#define AMT_U16 1
+#define AMT_I32 2
+#define AMT_F64 3
+#define AMT_I64 4
+#define AMT_F32 5
+
+/* scipy.ndimage boundary modes */
+#define AMT_MODE_NEAREST 0
+#define AMT_MODE_REFLECT 1  /* half-sample symmetric  d c b a | a b c d | d c b a */
+#define AMT_MODE_MIRROR 2   /* whole-sample symmetric d c b | a b c d | c b a     */
+#define AMT_MODE_CONSTANT 3
+#define AMT_MODE_WRAP 4
+
+typedef struct amt_ctx amt_ctx;
+
+/* ---- context, memory, stream ------------------------------------------------------------- */
+int amt_device_count(void);
+int amt_ctx_create(int device, amt_ctx** out);
+/* Share an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); 0 = null stream. */
+int amt_ctx_create_on_stream(int device, void* hip_stream, amt_ctx** out);
+int amt_ctx_destroy(amt_ctx* ctx);
+const char* amt_last_error(void);
+const char* amt_version(void);
+int amt_device_name(amt_ctx* ctx, char* buf, int buflen);
+int amt_malloc(amt_ctx* ctx, size_t bytes, void** dptr);
+int amt_free(amt_ctx* ctx, void* dptr);
+int amt_memcpy_h2d(amt_ctx* ctx, void* dst, const void* src, size_t bytes); /* async on ctx stream */
+int amt_memcpy_d2h(amt_ctx* ctx, void* dst, const void* src, size_t bytes); /* async; amt_sync before reading */
+int amt_memcpy_d2d(amt_ctx* ctx, void* dst, const void* src, size_t bytes);
+int amt_memset(amt_ctx* ctx, void* dst, int value, size_t bytes);
+int amt_sync(amt_ctx* ctx);
+/* pinned host staging buffers for the FOV feeder */
+int amt_host_alloc(size_t bytes, void** hptr);
+int amt_host_free(void* hptr);
+/* HIP-event timing on the context's stream (bench.py roofline: kernel time measured live) */
+int amt_timer_create(amt_ctx* ctx, void** timer);
+int amt_timer_start(amt_ctx* ctx, void* timer);
+int amt_timer_stop(amt_ctx* ctx, void* timer);
+int amt_timer_elapsed_ms(amt_ctx* ctx, void* timer, float* ms); /* synchronises on the stop event */
+int amt_timer_destroy(amt_ctx* ctx, void* timer);
+
+/* ---- channel access: R/microscopy.py:241-282 (get_channel_intensities) --------------------- */
+/* (C,Y,X) stacks are channel-major, so a channel is a pointer offset; ND2 frames are (Y,X,C)
+ * interleaved: this de-interleaves nplanes frames into (C,Y,X). */
+int amt_deinterleave_u16(amt_ctx* ctx, const uint16_t* yxc, uint16_t* cyx, int nplanes, int H, int W, int C);
+
+/* ---- filters: R/operations.py:91 (difference_of_gaussians), SK/filters/_gaussian.py,
+ *      SP/_filters.py:226-236,314-430 (gaussian_filter1d -> correlate1d) ------------------------ */
+/* Separable symmetric correlation, axis 0 then axis 1, float64 accumulate in scipy's order
+ * (centre tap, then pairs outermost->innermost); `weights` = HOST pointer to 2*radius+1 doubles as
+ * scipy builds them (computed by the caller with numpy so that np.exp rounding is shared).
+ * in_dtype AMT_U16 (scaled by `scale`, 1/65535 for img_as_float) or AMT_F64 (scale ignored if 1). */
+int amt_gaussian(amt_ctx* ctx, const void* in, int in_dtype, double scale, double* out, int nplanes, int H, int W,
+                 const double* weights, int radius, int mode, double cval);
+/* out = G(w_lo) - G(w_hi) of the same converted input (SK/filters/_gaussian.py:284-290). */
+int amt_dog(amt_ctx* ctx, const void* in, int in_dtype, double scale, double* out, int nplanes, int H, int W,
+            const double* w_lo, int r_lo, const double* w_hi, int r_hi, int mode, double cval);
+
+/* ---- elementwise (R/operations.py:50,97; SK/exposure/exposure.py:405-428) ------------------- */
+/* out = max(in - level[plane], 0)  -- np.clip(dog - background_level, 0, None) */
+int amt_sub_clip0_f64(amt_ctx* ctx, const double* in, const double* level_dev, double* out, int nplanes, size_t n);
+/* rescale_intensity with tuple ranges: clip to [imin,imax]; (x-imin)/(imax-imin)*(omax-omin)+omin.
+ * range_dev = nplanes x {imin, imax} doubles on the device. */
+int amt_rescale(amt_ctx* ctx, const void* in, int in_dtype, const double* range_dev, double omin, double omax,
+                double* out, int nplanes, size_t n);
+int amt_convert_u16_f64(amt_ctx* ctx, const uint16_t* in, double scale, double* out, size_t n);
+
+/* ---- statistics: np.percentile (R/operations.py:47,94), histogram (SK/exposure/exposure.py) -- */
+/* One 65536-bin histogram per plane (uint32 counts), bin = pixel value. */
+int amt_hist_u16(amt_ctx* ctx, const uint16_t* in, uint32_t* hist, int nplanes, size_t n);
+/* minmax_dev[plane] = {min, max} */
+int amt_minmax_f64(amt_ctx* ctx, const double* in, double* minmax_dev, int nplanes, size_t n);
+/* np.histogram(x, bins=nbins, range=(min,max)) counts per plane; edges follow np.linspace. */
+int amt_hist_f64(amt_ctx* ctx, const double* in, const double* minmax_dev, uint32_t* hist, int nbins, int nplanes,
+                 size_t n);
+/* np.percentile(x, q) (linear): q_host = nq percentiles in [0,100]; out_dev = nplanes x nq doubles.
+ * u16: exact order statistics from the histogram; f64: exact radix select. */
+int amt_percentile_u16(amt_ctx* ctx, const uint16_t* in, const double* q_host, int nq, double* out_dev, int nplanes,
+                       size_t n);
+int amt_percentile_f64(amt_ctx* ctx, const double* in, const double* q_host, int nq, double* out_dev, int nplanes,
+                       size_t n);
+
+/* ---- thresholds: R/operations.py:186-216 (apply_threshold), SK/filters/thresholding.py ------- */
+#define AMT_THR_OTSU 0
+#define AMT_THR_YEN 1
+#define AMT_THR_ISODATA 2
+#define AMT_THR_TRIANGLE 3
+#define AMT_THR_MEAN 4
+#define AMT_THR_MINIMUM 5
+#define AMT_THR_LI 6
+/* Global threshold value per plane (thr_dev[plane], float64 -- for integer images the bin centre).
+ * status_dev[plane] != 0 flags "no threshold" (threshold_minimum: fewer/more than two maxima). */
+int amt_threshold_value(amt_ctx* ctx, const void* in, int in_dtype, int method, int nbins, double* thr_dev,
+                        int32_t* status_dev, int nplanes, size_t n);
+/* out = in > thr[plane] (uint8 0/1) */
+int amt_threshold_gt(amt_ctx* ctx, const void* in, int in_dtype, const double* thr_dev, uint8_t* out, int nplanes,
+                     size_t n);
+/* out = in > thr_image (per-pixel thresholds: local / niblack / sauvola) */
+int amt_threshold_gt_image(amt_ctx* ctx, const void* in, int in_dtype, const double* thr_image, uint8_t* out,
+                           size_t n);
+
+/* ---- morphology: SK/morphology/binary.py, grey.py (ImageOperation callables, north_star) ----- */
+/* Footprint = HOST uint8 (fh, fw), odd sizes, anchor at the centre.
+ * binary erosion: outside the image counts as `border_value` (skimage: 1); dilation: 0. */
+int amt_binary_erode(amt_ctx* ctx, const uint8_t* in, uint8_t* out, int nplanes, int H, int W,
+                     const uint8_t* footprint, int fh, int fw, int border_value);
+int amt_binary_dilate(amt_ctx* ctx, const uint8_t* in, uint8_t* out, int nplanes, int H, int W,
+                      const uint8_t* footprint, int fh, int fw, int border_value);
+/* fused opening = dilate(erode(x)) and closing = erode(dilate(x)) with skimage's border rules */
+int amt_binary_open(amt_ctx* ctx, const uint8_t* in, uint8_t* out, int nplanes, int H, int W,
+                    const uint8_t* footprint, int fh, int fw);
+int amt_binary_close(amt_ctx* ctx, const uint8_t* in, uint8_t* out, int nplanes, int H, int W,
+                     const uint8_t* footprint, int fh, int fw);
+/* grey erosion / dilation / median over a footprint (uint16 or float64 images), scipy boundary `mode`.
+ * op: 0 = erosion (min), 1 = dilation (max, footprint already mirrored by the caller), 2 = median */
+int amt_rank_filter(amt_ctx* ctx, const void* in, void* out, int dtype, int nplanes, int H, int W,
+                    const uint8_t* footprint, int fh, int fw, int op, int mode, double cval);
+/* out = a - b (same dtype; white_tophat = image - opening) */
+int amt_subtract(amt_ctx* ctx, const void* a, const void* b, void* out, int dtype, size_t n);
+
+/* ---- labelling: R/masks.py:56-65 (clear_border, label, relabel_sequential) ------------------- */
+/* Connected components of equal-valued non-zero pixels (uint8 mask or int32 label image),
+ * connectivity 1 (4-conn) or 2 (8-conn, skimage default in 2-D); labels 1..K per plane in raster
+ * order of each component's first pixel; count_dev[plane] = K. */
+int amt_label(amt_ctx* ctx, const void* in, int in_dtype, int32_t* out, int32_t* count_dev, int nplanes, int H, int W,
+              int connectivity);
+/* skimage.segmentation.clear_border(labels) with buffer_size=0: zero every 8-connected component of
+ * equal-valued pixels that touches the 1-px frame; other pixels keep their value. */
+int amt_clear_border(amt_ctx* ctx, const int32_t* in, int32_t* out, int nplanes, int H, int W);
+/* relabel_sequential: surviving labels -> 1..K in ascending order of the old label; count_dev = K.
+ * max_label = upper bound of label values in `in` (any plane). */
+int amt_relabel_sequential(amt_ctx* ctx, const int32_t* in, int32_t* out, int32_t* count_dev, int nplanes, size_t n,
+                           int max_label);
+/* np.where(np.isin(labels, keep), labels, 0): keep_dev = nplanes x (max_label+1) uint8 flags */
+int amt_keep_labels(amt_ctx* ctx, const int32_t* in, const uint8_t* keep_dev, int32_t* out, int nplanes, size_t n,
+                    int max_label);
+int amt_cast_i32_i64(amt_ctx* ctx, const int32_t* in, int64_t* out, size_t n);
+
+/* ---- distance transform, markers, watershed (north_star) ------------ */
+/* Exact squared Euclidean distance to the nearest zero pixel (int32), and its correctly rounded
+ * float64 square root = scipy.ndimage.distance_transform_edt.  Either output may be NULL. */
+int amt_edt(amt_ctx* ctx, const uint8_t* mask, int32_t* d2_out, double* edt_out, int nplanes, int H, int W);
+/* peaks = (d2 == maximum_filter(d2, (2m+1)^2, constant 0)) & mask & (d2 > 0), border of width m cleared */
+int amt_peak_mask(amt_ctx* ctx, const int32_t* d2, const uint8_t* mask, uint8_t* peaks, int nplanes, int H, int W,
+                  int min_distance);
+/* Priority flood restricted to `mask` (skimage.segmentation.watershed, connectivity 1, no compactness,
+ * no watershed line).  Priority = (value, insertion age); marker pixels enter with age 0 and equal-valued
+ * age-0 markers pop in raster order (see DESIGN.md "watershed": scikit-image orders those by the
+ * internals of its binary heap).
+ *   amt_watershed_edt : relief = -sqrt(d2) given as the exact integer d2 (bucket queue);
+ *                       seeds_first != 0 pops every marker pixel first, in raster order
+ *                       (the config-3 recipe's seeded relief).
+ *   amt_watershed_f64 : general float64 relief (per-component binary heap). */
+int amt_watershed_edt(amt_ctx* ctx, const int32_t* d2, const int32_t* markers, const uint8_t* mask, int32_t* out,
+                      int nplanes, int H, int W, int seeds_first);
+int amt_watershed_f64(amt_ctx* ctx, const double* relief, const int32_t* markers, const uint8_t* mask, int32_t* out,
+                      int nplanes, int H, int W);
+
+/* ---- region properties: R/masks.py:286-326 (regionprops_table) ------------------------------- */
+/* Morphology columns per label 1..max_label (row = label-1), float64, column order: */
+#define AMT_RP_AREA 0
+#define AMT_RP_CENTROID_Y 1
+#define AMT_RP_CENTROID_X 2
+#define AMT_RP_BBOX_Y0 3
+#define AMT_RP_BBOX_X0 4
+#define AMT_RP_BBOX_Y1 5
+#define AMT_RP_BBOX_X1 6
+#define AMT_RP_PERIMETER 7
+#define AMT_RP_AXIS_MAJOR 8
+#define AMT_RP_AXIS_MINOR 9
+#define AMT_RP_ECCENTRICITY 10
+#define AMT_RP_ORIENTATION 11
+#define AMT_RP_AREA_CONVEX 12
+#define AMT_RP_SOLIDITY 13
+#define AMT_RP_NCOLS 14
+/* table_dev = nplanes x max_label x AMT_RP_NCOLS doubles.  Labels absent from a plane give area 0. */
+int amt_regionprops(amt_ctx* ctx, const int32_t* labels, double* table_dev, int nplanes, int H, int W, int max_label);
+/* Intensity columns per label and channel: {mean, max, min, std} (population std).
+ * intensity = nplanes x C planes of uint16 (one (C,Y,X) FOV per label plane);
+ * table_dev = nplanes x max_label x C x 4 doubles. */
+int amt_regionprops_intensity_u16(amt_ctx* ctx, const int32_t* labels, const uint16_t* intensity, int C,
+                                  double* table_dev, int nplanes, int H, int W, int max_label);
+int amt_max_i32(amt_ctx* ctx, const int32_t* in, int32_t* max_dev, int nplanes, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AMT_HIP_H */

@@ -1,0 +1,281 @@
+"""GPU parity: every HIP operator against the CPU oracle and the committed golden vectors.
+All calls go through the C ABI (ctypes -> libamt_hip.so)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from arcadia_microscopy_tools_amd.device import get_context
+
+    return get_context()
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from arcadia_microscopy_tools_amd import hipops
+
+    return hipops
+
+
+def test_gaussian_bit_exact(ctx, ops, golden):
+    from oracle import skops
+
+    g = golden("ops_192")
+    u = g["u16"]
+    d = ctx.asarray(u)
+    for s in (0.6, 1.0, 2.0, 3.0, 5.0, 16.0):
+        out = ops.gaussian(d, s).numpy()
+        ref = skops.gaussian(u, s)
+        assert np.array_equal(out, ref), f"sigma={s}: max abs diff {np.abs(out - ref).max()}"
+    for mode in ("reflect", "mirror", "constant", "wrap", "nearest"):
+        out = ops.gaussian(d, 2.0, mode=mode, cval=0.25).numpy()
+        from scipy import ndimage as ndi
+
+        ref = ndi.gaussian_filter(skops.img_as_float(u), 2.0, mode=mode, cval=0.25)
+        assert np.array_equal(out, ref), mode
+    # float64 input, batch of planes, odd sizes
+    rng = np.random.default_rng(0)
+    f = rng.random((3, 37, 101))
+    out = ops.gaussian(ctx.asarray(f), 1.5).numpy()
+    for i in range(3):
+        assert np.array_equal(out[i], skops.gaussian(f[i], 1.5))
+    # golden (skimage 0.18.3 + numpy 1.26 weights): last-bit agreement
+    np.testing.assert_allclose(ops.gaussian(d, 2.0).numpy(), g["gauss_2.0"], rtol=0, atol=3e-16)
+
+
+def test_dog_bit_exact(ctx, ops, golden):
+    from oracle import skops
+
+    u = golden("ops_192")["u16"]
+    out = ops.difference_of_gaussians(ctx.asarray(u), 0.6, 16.0).numpy()
+    assert np.array_equal(out, skops.difference_of_gaussians(u, 0.6, 16.0))
+
+
+def test_histograms_otsu_threshold(ctx, ops, golden):
+    from oracle import skops
+
+    g = golden("ops_192")
+    u = g["u16"]
+    d = ctx.asarray(u)
+    h = ops.histogram_u16(d).numpy()[0]
+    assert np.array_equal(h, np.bincount(u.ravel(), minlength=65536))
+    t = ops.threshold_otsu(d).numpy()[0]
+    assert t == skops.threshold_otsu(u) == g["thr_otsu_u16"]
+    gz = skops.gaussian(u, 2.0)
+    dg = ctx.asarray(gz)
+    hf, mm = ops.histogram_f64(dg)
+    rh, rc = skops.histogram(gz)
+    assert np.array_equal(hf.numpy()[0], rh)
+    assert np.array_equal(mm.numpy()[0], [gz.min(), gz.max()])
+    tf = ops.threshold_otsu(dg).numpy()[0]
+    assert tf == skops.threshold_otsu(gz)
+    m = ops.greater_than(dg, ctx.asarray(np.array([tf]))).numpy()
+    assert m.dtype == bool and np.array_equal(m, gz > tf)
+    # bright image: values above the LDS window of the histogram kernel
+    big = (u.astype(np.uint32) * 5 % 65536).astype(np.uint16)
+    assert np.array_equal(ops.histogram_u16(ctx.asarray(big)).numpy()[0], np.bincount(big.ravel(), minlength=65536))
+    assert ops.threshold_otsu(ctx.asarray(big)).numpy()[0] == skops.threshold_otsu(big)
+    # constant image: skimage returns the value itself
+    const = np.full((16, 16), 77, np.uint16)
+    assert ops.threshold_otsu(ctx.asarray(const)).numpy()[0] == 77
+
+
+def test_nd2_fixture_otsu_label(ctx, ops, golden):
+    """BASELINE configs[0] on the GPU: fixture DAPI -> Otsu 2742 -> 1297 px -> 20 labels."""
+    g = golden("nd2_multichannel")
+    px = ctx.asarray(g["pixels"])  # (4, 256, 256): channel = pointer offset
+    dapi = px[1]
+    t = ops.threshold_otsu(dapi)
+    assert t.numpy()[0] == 2742
+    m = ops.greater_than(dapi, t)
+    assert int(m.numpy().sum()) == 1297
+    lab, cnt = ops.label(m)
+    assert cnt.numpy()[0] == 20
+    assert np.array_equal(lab.numpy(), g["labels8"])
+    lab4, cnt4 = ops.label(m, connectivity=1)
+    assert cnt4.numpy()[0] == 25 and np.array_equal(lab4.numpy(), g["labels4"])
+    assert np.array_equal(ops.clear_border(lab).numpy(), g["cleared"])
+
+
+def test_percentile_rescale(ctx, ops, golden):
+    g = golden("ops_192")
+    u = g["u16"]
+    gz = g["gauss_2.0"]
+    for img in (u, gz):
+        d = ctx.asarray(img)
+        for q in ((0, 100), (1, 99), (0.1, 99.9), (2, 98), (37.123, 50)):
+            p = ops.percentile(d, q)
+            ref = np.percentile(img, q)
+            assert np.array_equal(p.numpy()[0], ref), (img.dtype, q)
+            r = ops.rescale(d, p, (0, 1)).numpy()
+            from oracle import skops
+
+            assert np.array_equal(r, skops.rescale_intensity(img, (ref[0], ref[1]), (0, 1)))
+        single = ops.percentile(d, 90).numpy()
+        assert single.shape == (1, 1) and single[0, 0] == np.percentile(img, 90)
+
+
+def test_binary_morphology(ctx, ops, golden):
+    from oracle import skops
+
+    g = golden("ops_192")
+    m = g["mask"]
+    d = ctx.asarray(m)
+    for r in (1, 2, 3):
+        se = skops.disk(r)
+        assert np.array_equal(ops.binary_erosion(d, se).numpy(), g[f"berode_d{r}"])
+        assert np.array_equal(ops.binary_dilation(d, se).numpy(), g[f"bdilate_d{r}"])
+        assert np.array_equal(ops.binary_opening(d, se).numpy(), g[f"bopen_d{r}"])
+        assert np.array_equal(ops.binary_closing(d, se).numpy(), g[f"bclose_d{r}"])
+    assert np.array_equal(ops.binary_erosion(d).numpy(), g["berode_cross"])
+    assert np.array_equal(ops.binary_dilation(d).numpy(), g["bdilate_cross"])
+    # masks touching the border, non-multiple-of-tile sizes, batch
+    rng = np.random.default_rng(3)
+    mb = rng.random((2, 45, 70)) < 0.6
+    db = ctx.asarray(mb)
+    se = skops.disk(2)
+    for i in range(2):
+        assert np.array_equal(ops.binary_opening(db, se).numpy()[i], skops.binary_opening(mb[i], se))
+        assert np.array_equal(ops.binary_closing(db, se).numpy()[i], skops.binary_closing(mb[i], se))
+        assert np.array_equal(ops.binary_erosion(db, se).numpy()[i], skops.binary_erosion(mb[i], se))
+
+
+def test_grey_morphology_median_tophat(ctx, ops, golden):
+    from oracle import skops
+
+    g = golden("ops_192")
+    u = g["u16"]
+    d = ctx.asarray(u)
+    for r in (1, 2, 3):
+        se = skops.disk(r)
+        assert np.array_equal(ops.erosion(d, se).numpy(), g[f"erode_d{r}"])
+        assert np.array_equal(ops.dilation(d, se).numpy(), g[f"dilate_d{r}"])
+        assert np.array_equal(ops.opening(d, se).numpy(), g[f"open_d{r}"])
+        assert np.array_equal(ops.closing(d, se).numpy(), g[f"close_d{r}"])
+        assert np.array_equal(ops.median(d, se).numpy(), g[f"median_d{r}"])
+    assert np.array_equal(ops.median(d).numpy(), g["median_3x3"])
+    assert np.array_equal(ops.white_tophat(d, skops.disk(3)).numpy(), g["tophat_d3"])
+    assert np.array_equal(ops.white_tophat(d, skops.disk(7)).numpy(), g["tophat_d7"])
+    gz = g["gauss_2.0"]
+    assert np.array_equal(ops.median(ctx.asarray(gz), skops.disk(2)).numpy(), skops.median(gz, skops.disk(2)))
+    assert np.array_equal(ops.erosion(ctx.asarray(gz), skops.disk(2)).numpy(), skops.erosion(gz, skops.disk(2)))
+
+
+def test_label_random(ctx, ops):
+    from oracle import skops
+
+    rng = np.random.default_rng(5)
+    for shape, p in (((64, 64), 0.5), ((33, 130), 0.59), ((200, 77), 0.4), ((1, 50), 0.5), ((50, 1), 0.5)):
+        m = rng.random(shape) < p
+        for conn in (1, 2):
+            lab, cnt = ops.label(ctx.asarray(m), connectivity=conn)
+            ref = skops.label(m, conn)
+            assert cnt.numpy()[0] == ref.max()
+            assert np.array_equal(lab.numpy(), ref), (shape, conn)
+    # integer input: touching regions with different values stay separate
+    vals = rng.integers(0, 4, (60, 90)).astype(np.int32)
+    lab, cnt = ops.label(ctx.asarray(vals))
+    assert np.array_equal(lab.numpy(), skops.label(vals))
+    # empty
+    lab, cnt = ops.label(ctx.asarray(np.zeros((20, 20), bool)))
+    assert cnt.numpy()[0] == 0 and lab.numpy().max() == 0
+
+
+def test_clear_border_relabel(ctx, ops):
+    from oracle import skops
+
+    rng = np.random.default_rng(6)
+    vals = (rng.integers(0, 6, (80, 120)) * (rng.random((80, 120)) < 0.7)).astype(np.int32)
+    cb = ops.clear_border(ctx.asarray(vals)).numpy()
+    assert np.array_equal(cb, skops.clear_border(vals))
+    sparse = (vals * 7).astype(np.int32)
+    rl, cnt = ops.relabel_sequential(ctx.asarray(sparse), int(sparse.max()))
+    assert np.array_equal(rl.numpy(), skops.relabel_sequential(sparse))
+    assert cnt.numpy()[0] == len(np.unique(sparse)) - 1
+
+
+def test_edt_peaks(ctx, ops, golden):
+    from oracle import skops
+
+    g = golden("c2c3_256")
+    m = g["mask"]
+    d2, e = ops.edt(ctx.asarray(m))
+    assert np.array_equal(e.numpy(), g["edt"])
+    assert np.array_equal(d2.numpy().astype(np.float64), np.round(g["edt"] ** 2))
+    pk = ops.peak_mask(d2, ctx.asarray(m), 5)
+    markers, cnt = ops.label(pk, connectivity=1)
+    assert np.array_equal(markers.numpy(), g["markers"])
+    # random masks incl. rows/columns without background, thick blobs
+    rng = np.random.default_rng(8)
+    for shape, p in (((50, 64), 0.9), ((97, 33), 0.97), ((40, 40), 0.5)):
+        mm = rng.random(shape) < p
+        mm[0, 0] = False
+        d2, e = ops.edt(ctx.asarray(mm))
+        assert np.array_equal(e.numpy(), skops.distance_transform_edt(mm)), shape
+
+
+def test_watershed(ctx, ops, golden):
+    from oracle import skops
+    from oracle.watershed import watershed
+
+    g = golden("c2c3_256")
+    m, markers = g["mask"], g["markers"]
+    dm, dmk = ctx.asarray(m), ctx.asarray(markers)
+    d2, e = ops.edt(dm)
+    ws = ops.watershed_edt(d2, dmk, dm, seeds_first=True).numpy()
+    assert np.array_equal(ws, g["watershed"])
+    # general float64 relief (heap flood) on the same seeded relief
+    ws2 = ops.watershed(ctx.asarray(g["relief"]), dmk, dm).numpy()
+    assert np.array_equal(ws2, g["watershed"])
+    # random smooth reliefs with distinct marker values, no mask restriction
+    rng = np.random.default_rng(11)
+    from scipy import ndimage as ndi
+
+    for i in range(6):
+        H, W = rng.integers(20, 70, 2)
+        img = ndi.gaussian_filter(rng.random((H, W)), 2.0)
+        mk = np.zeros((H, W), np.int32)
+        k = int(rng.integers(2, 9))
+        ys, xs = rng.integers(0, H, k), rng.integers(0, W, k)
+        mk[ys, xs] = np.arange(1, k + 1)
+        mask = rng.random((H, W)) < 0.9 if i % 2 else np.ones((H, W), bool)
+        out = ops.watershed(ctx.asarray(img), ctx.asarray(mk), ctx.asarray(mask)).numpy()
+        assert np.array_equal(out, watershed(img, mk, mask=mask)), i
+
+
+def test_regionprops(ctx, ops, golden):
+    from arcadia_microscopy_tools_amd import _hip
+
+    for name, key in (("disks_80", "labels"), ("c2c3_256", "labels"), ("nd2_multichannel", "labels8")):
+        g = golden(name)
+        lab = g[key].astype(np.int32)
+        K = int(lab.max())
+        t = ops.regionprops(ctx.asarray(lab), K).numpy()[0]
+        cols = {c: t[:, i] for i, c in enumerate(_hip.RP_COLS)}
+        assert np.array_equal(cols["area"], g["rp_area"])
+        assert np.array_equal(cols["area_convex"], g["rp_area_convex"]), name
+        for i in range(4):
+            assert np.array_equal(cols[f"bbox-{i}"], g[f"rp_bbox-{i}"])
+        np.testing.assert_allclose(cols["centroid-0"], g["rp_centroid-0"], rtol=1e-12)
+        np.testing.assert_allclose(cols["centroid-1"], g["rp_centroid-1"], rtol=1e-12)
+        np.testing.assert_allclose(cols["perimeter"], g["rp_perimeter"], rtol=1e-12)
+        np.testing.assert_allclose(cols["axis_major_length"], g["rp_axis_major_length"], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(cols["axis_minor_length"], g["rp_axis_minor_length"], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(cols["eccentricity"], g["rp_eccentricity"], atol=1e-6)
+        np.testing.assert_allclose(cols["solidity"], g["rp_solidity"], rtol=1e-12)
+        sym = np.isclose(np.abs(g["rp_orientation"]), np.pi / 4)
+        np.testing.assert_allclose(cols["orientation"][~sym], g["rp_orientation"][~sym], atol=1e-8)
+        np.testing.assert_allclose(np.abs(cols["orientation"][sym]), np.pi / 4)
+
+
+def test_regionprops_intensity(ctx, ops, golden):
+    g = golden("c2c3_256")
+    lab = g["labels"].astype(np.int32)
+    K = int(lab.max())
+    t = ops.regionprops_intensity(ctx.asarray(lab), ctx.asarray(g["fov"]), K).numpy()[0]
+    for ci, name in enumerate(("brightfield", "dapi", "fitc", "tritc")):
+        for j, k in enumerate(("intensity_mean", "intensity_max", "intensity_min", "intensity_std")):
+            np.testing.assert_allclose(t[:, ci, j], g[f"rp_{k}_{name}"], rtol=1e-10, err_msg=f"{k}_{name}")
