@@ -59,7 +59,8 @@ _SIGS = {
     "amt_timer_elapsed_ms": (c_int, [_P, _P, POINTER(c_float)]),
     "amt_timer_destroy": (c_int, [_P, _P]),
     "amt_deinterleave_u16": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int]),
-    "amt_gaussian": (c_int, [_P, _P, c_int, c_double, _P, c_int, c_int, c_int, _P, c_int, c_int, c_double]),
+    "amt_gaussian": (c_int, [_P, _P, c_int, c_double, _P, c_int, c_int, c_int, _P, c_int, c_int, c_double,
+                             c_size_t]),
     "amt_dog": (c_int, [_P, _P, c_int, c_double, _P, c_int, c_int, c_int, _P, c_int, _P, c_int, c_int, c_double]),
     "amt_sub_clip0_f64": (c_int, [_P, _P, _P, _P, c_int, c_size_t]),
     "amt_rescale": (c_int, [_P, _P, c_int, _P, c_double, c_double, _P, c_int, c_size_t]),

@@ -26,7 +26,7 @@ template <typename TIn>
 __global__ void __launch_bounds__(256) conv_axis0_kernel(const TIn* __restrict__ in, double scale,
                                                          double* __restrict__ out, int H, int W,
                                                          const double* __restrict__ wts, int r, int mode, double cval,
-                                                         int TH) {
+                                                         int TH, size_t in_stride) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* tile = reinterpret_cast<double*>(smem_raw);  // (TH + 2r) x 64
     double* w = tile + (size_t)(TH + 2 * r) * 64;        // 2r + 1
@@ -34,13 +34,14 @@ __global__ void __launch_bounds__(256) conv_axis0_kernel(const TIn* __restrict__
     const int x = blockIdx.x * 64 + tx;
     const int y0 = blockIdx.y * TH;
     const size_t plane = (size_t)blockIdx.z * H * W;
+    const size_t iplane = (size_t)blockIdx.z * in_stride;
     const int tid = ty * 64 + tx;
     for (int i = tid; i < 2 * r + 1; i += 256) w[i] = wts[i];
     const int rows = TH + 2 * r;
     for (int k = ty; k < rows; k += 4) {
         int yy = amt_map_index(y0 - r + k, H, mode);
         double v = cval;
-        if (x < W && yy >= 0) v = load_as_f64<TIn>(in, plane + (size_t)yy * W + x, scale);
+        if (x < W && yy >= 0) v = load_as_f64<TIn>(in, iplane + (size_t)yy * W + x, scale);
         tile[k * 64 + tx] = v;
     }
     __syncthreads();
@@ -105,7 +106,8 @@ constexpr int FR_MAX = 12;
 template <typename TIn, int R>
 __global__ void __launch_bounds__(256) gauss_fused_kernel(const TIn* __restrict__ in, double scale,
                                                           double* __restrict__ out, int H, int W,
-                                                          const double* __restrict__ wts, int mode, double cval) {
+                                                          const double* __restrict__ wts, int mode, double cval,
+                                                          size_t in_stride) {
     constexpr int SW = FT_W + 2 * R;      // staged width
     constexpr int SH = FT_H + 2 * R;      // staged height
     constexpr int SWP = SW + 1;           // +1 double of padding against bank conflicts on column walks
@@ -116,13 +118,14 @@ __global__ void __launch_bounds__(256) gauss_fused_kernel(const TIn* __restrict_
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H;
     const size_t plane = (size_t)blockIdx.z * H * W;
+    const size_t iplane = (size_t)blockIdx.z * in_stride;
     if (tid < 2 * R + 1) w[tid] = wts[tid];
     for (int i = tid; i < SH * SW; i += 256) {
         int ky = i / SW, kx = i - ky * SW;
         int yy = amt_map_index(y0 - R + ky, H, mode);
         int xx = amt_map_index(x0 - R + kx, W, mode);
         double v = cval;
-        if (yy >= 0 && xx >= 0) v = load_as_f64<TIn>(in, plane + (size_t)yy * W + xx, scale);
+        if (yy >= 0 && xx >= 0) v = load_as_f64<TIn>(in, iplane + (size_t)yy * W + xx, scale);
         src[ky * SWP + kx] = v;
     }
     __syncthreads();
@@ -168,23 +171,23 @@ __global__ void __launch_bounds__(256) gauss_fused_kernel(const TIn* __restrict_
 
 template <typename TIn, int R>
 static int launch_fused(amt_ctx* ctx, const TIn* in, double scale, double* out, int nplanes, int H, int W,
-                        const double* wdev, int mode, double cval) {
+                        const double* wdev, int mode, double cval, size_t in_stride) {
     constexpr int SW = FT_W + 2 * R, SH = FT_H + 2 * R, SWP = SW + 1;
     size_t smem = ((size_t)(SH + FT_H) * SWP + 2 * R + 1) * sizeof(double);
     dim3 grid((W + FT_W - 1) / FT_W, (H + FT_H - 1) / FT_H, nplanes);
     hipLaunchKernelGGL((gauss_fused_kernel<TIn, R>), grid, dim3(256), smem, ctx->stream, in, scale, out, H, W, wdev,
-                       mode, cval);
+                       mode, cval, in_stride);
     AMT_LAUNCH_CHECK();
     return AMT_OK;
 }
 
 template <typename TIn>
 static int gaussian_typed(amt_ctx* ctx, const TIn* in, double scale, double* out, double* tmp, int nplanes, int H,
-                          int W, const double* wdev, int r, int mode, double cval) {
+                          int W, const double* wdev, int r, int mode, double cval, size_t in_stride) {
     switch (r) {
 #define AMT_FUSED_CASE(RR) \
     case RR:               \
-        return launch_fused<TIn, RR>(ctx, in, scale, out, nplanes, H, W, wdev, mode, cval);
+        return launch_fused<TIn, RR>(ctx, in, scale, out, nplanes, H, W, wdev, mode, cval, in_stride);
         AMT_FUSED_CASE(1)
         AMT_FUSED_CASE(2)
         AMT_FUSED_CASE(3)
@@ -206,7 +209,7 @@ static int gaussian_typed(amt_ctx* ctx, const TIn* in, double scale, double* out
     size_t smem0 = ((size_t)(TH + 2 * r) * 64 + (2 * r + 1)) * sizeof(double);
     dim3 g0((W + 63) / 64, (H + TH - 1) / TH, nplanes);
     hipLaunchKernelGGL((conv_axis0_kernel<TIn>), g0, dim3(64, 4), smem0, ctx->stream, in, scale, tmp, H, W, wdev, r,
-                       mode, cval, TH);
+                       mode, cval, TH, in_stride);
     AMT_LAUNCH_CHECK();
     size_t smem1 = ((size_t)4 * (256 + 2 * r) + (2 * r + 1)) * sizeof(double);
     dim3 g1((W + 255) / 256, (H + 3) / 4, nplanes);
@@ -225,10 +228,13 @@ static int check_gauss_args(const void* in, int in_dtype, double* out, int nplan
 }
 
 static int gaussian_dispatch(amt_ctx* ctx, const void* in, int in_dtype, double scale, double* out, double* tmp,
-                             int nplanes, int H, int W, const double* wdev, int r, int mode, double cval) {
+                             int nplanes, int H, int W, const double* wdev, int r, int mode, double cval,
+                             size_t in_stride = 0) {
+    if (in_stride == 0) in_stride = (size_t)H * W;
     if (in_dtype == AMT_U16)
-        return gaussian_typed<uint16_t>(ctx, (const uint16_t*)in, scale, out, tmp, nplanes, H, W, wdev, r, mode, cval);
-    return gaussian_typed<double>(ctx, (const double*)in, 1.0, out, tmp, nplanes, H, W, wdev, r, mode, cval);
+        return gaussian_typed<uint16_t>(ctx, (const uint16_t*)in, scale, out, tmp, nplanes, H, W, wdev, r, mode, cval,
+                                        in_stride);
+    return gaussian_typed<double>(ctx, (const double*)in, 1.0, out, tmp, nplanes, H, W, wdev, r, mode, cval, in_stride);
 }
 
 __global__ void convert_u16_f64_kernel(const uint16_t* __restrict__ in, double scale, double* __restrict__ out,
@@ -255,9 +261,12 @@ extern "C" int amt_convert_u16_f64(amt_ctx* ctx, const uint16_t* in, double scal
 }
 
 extern "C" int amt_gaussian(amt_ctx* ctx, const void* in, int in_dtype, double scale, double* out, int nplanes, int H,
-                            int W, const double* weights, int radius, int mode, double cval) {
+                            int W, const double* weights, int radius, int mode, double cval, size_t in_plane_stride) {
     AMT_TRY(amt_set_device(ctx));
     AMT_TRY(check_gauss_args(in, in_dtype, out, nplanes, H, W, weights, radius));
+    AMT_REQUIRE(in_plane_stride == 0 || in_plane_stride >= (size_t)H * W, "gaussian: in_plane_stride smaller than a plane");
+    AMT_REQUIRE(radius > 0 || in_plane_stride == 0 || in_plane_stride == (size_t)H * W,
+                "gaussian: strided input needs radius >= 1");
     if (nplanes == 0) return AMT_OK;
     size_t n = (size_t)nplanes * H * W;
     if (radius == 0) {  // sigma too small: scipy's kernel is the single weight 1.0
@@ -273,7 +282,8 @@ extern "C" int amt_gaussian(amt_ctx* ctx, const void* in, int in_dtype, double s
     double* wdev = (double*)amt_arena_take(ctx, wbytes);
     double* tmp = tmpbytes ? (double*)amt_arena_take(ctx, tmpbytes) : nullptr;
     AMT_TRY(amt_param_upload(ctx, wdev, weights, (2 * radius + 1) * sizeof(double)));
-    return gaussian_dispatch(ctx, in, in_dtype, scale, out, tmp, nplanes, H, W, wdev, radius, mode, cval);
+    return gaussian_dispatch(ctx, in, in_dtype, scale, out, tmp, nplanes, H, W, wdev, radius, mode, cval,
+                             in_plane_stride);
 }
 
 __global__ void sub_inplace_kernel(double* __restrict__ a, const double* __restrict__ b, size_t n) {

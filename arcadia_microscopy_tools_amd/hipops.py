@@ -65,12 +65,19 @@ def gaussian_weights(sigma: float, truncate: float = 4.0) -> np.ndarray:
 
 
 def gaussian(a: DeviceArray, sigma: float, mode: str = "nearest", cval: float = 0.0, truncate: float = 4.0,
-             scale: float | None = None, out: DeviceArray | None = None) -> DeviceArray:
+             scale: float | None = None, out: DeviceArray | None = None, channel: int | None = None) -> DeviceArray:
     """``skimage.filters.gaussian`` per plane (SK/filters/_gaussian.py:119-126): uint16 input is first
     converted like ``img_as_float`` (x * (1/65535), SK/util/dtype.py:319) unless ``scale`` is given."""
     ctx = a.ctx
     n, H, W = _planes(a)
-    o = _out(ctx, out, a.shape, np.float64)
+    ptr, stride, oshape = a.ptr, 0, a.shape
+    if channel is not None:  # a is (..., C, Y, X): filter that channel of every stack in one launch
+        if a.ndim < 3:
+            raise ValueError("channel= needs a (..., C, Y, X) array")
+        C = a.shape[-3]
+        n, stride, oshape = n // C, C * H * W, a.shape[:-3] + (H, W)
+        ptr = a.ptr + int(channel) * H * W * a.dtype.itemsize
+    o = _out(ctx, out, oshape, np.float64)
     if sigma <= 1e-15:  # scipy skips axes with sigma <= 1e-15 (SP/_filters.py:423)
         w = np.ones(1)
     else:
@@ -79,8 +86,8 @@ def gaussian(a: DeviceArray, sigma: float, mode: str = "nearest", cval: float = 
     wa, wp = _host_f64(w)
     if scale is None:
         scale = 1.0 / 65535 if a.dtype == np.uint16 else 1.0
-    _hip.check(_lib().amt_gaussian(ctx.handle, a.ptr, _in_code(a), float(scale), o.ptr, n, H, W, wp, r,
-                                   _hip.MODES[mode], float(cval)), "amt_gaussian")
+    _hip.check(_lib().amt_gaussian(ctx.handle, ptr, _in_code(a), float(scale), o.ptr, n, H, W, wp, r,
+                                   _hip.MODES[mode], float(cval), stride), "amt_gaussian")
     return o
 
 

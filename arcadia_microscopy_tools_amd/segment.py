@@ -1,0 +1,250 @@
+"""Batch segmentation + region-props drivers for the BASELINE.json configurations, fully on the device.
+
+Stages (CPU restatement: oracle/chains.py):
+  C2  Gaussian(sigma) -> Otsu -> '>' -> binary opening(disk r) -> binary closing(disk r) -> label (8-conn)
+  C3  C2 mask on the DAPI channel -> EDT -> peak markers (min_distance) -> watershed (seeded relief)
+      -> clear_border -> relabel_sequential -> morphology table + per-channel intensity table
+
+``FovSegmenter`` preallocates every buffer for a batch of B fields of view, enqueues the whole chain
+on one HIP stream without any host synchronisation, and only copies labels / tables back on request.
+This is the classical backend behind ``SegmentationModel.segment`` (reference signature:
+R/model.py:171-215) and what bench.py times.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _hip, hipops
+from .device import Context, DeviceArray, get_context
+
+DEFAULT_CHANNELS = ("BRIGHTFIELD", "DAPI", "FITC", "TRITC")
+
+
+class StageTimes:
+    """HIP-event timers around each stage of one run (all on the segmenter's stream)."""
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+        self.timers: dict[str, object] = {}
+        self.order: list[str] = []
+
+    def begin(self, name):
+        t = self.timers.get(name)
+        if t is None:
+            t = self.ctx.timer()
+            self.timers[name] = t
+            self.order.append(name)
+        t.start()
+        return t
+
+    def ms(self) -> dict[str, float]:
+        return {k: self.timers[k].elapsed_ms() for k in self.order}
+
+
+class FovSegmenter:
+    """Preallocated config-2 / config-3 chain for B fields of view of shape (C, H, W) uint16."""
+
+    def __init__(self, batch: int, C: int, H: int, W: int, *, sigma: float = 2.0, radius: int = 2,
+                 min_distance: int = 5, max_cells: int = 4096, dapi_index: int = 1, ctx: Context | None = None,
+                 props: bool = True, profile: bool = False):
+        self.ctx = ctx or get_context()
+        self.B, self.C, self.H, self.W = int(batch), int(C), int(H), int(W)
+        self.sigma, self.radius, self.min_distance = float(sigma), int(radius), int(min_distance)
+        self.max_cells, self.dapi_index, self.props = int(max_cells), int(dapi_index), bool(props)
+        self.footprint = hipops.disk(self.radius)
+        c, B = self.ctx, self.B
+        shp = (B, self.H, self.W)
+        self.gauss = c.empty(shp, np.float64)
+        self.thr = c.empty((B,), np.float64)
+        self.mask_a = c.empty(shp, np.uint8)
+        self.mask_b = c.empty(shp, np.uint8)
+        self.labels8 = None  # config 2 only, allocated on demand
+        self.count8 = c.empty((B,), np.int32)
+        self.d2 = c.empty(shp, np.int32)
+        self.peaks = c.empty(shp, np.uint8)
+        self.markers = c.empty(shp, np.int32)
+        self.nmarkers = c.empty((B,), np.int32)
+        self.ws = c.empty(shp, np.int32)
+        self.labels = c.empty(shp, np.int32)
+        self.ncells = c.empty((B,), np.int32)
+        self.table = c.empty((B, self.max_cells, _hip.RP_NCOLS), np.float64)
+        self.itable = c.empty((B, self.max_cells, self.C, 4), np.float64)
+        self.times = StageTimes(self.ctx) if profile else None
+        self._ran = None
+
+    # ---------------------------------------------------------------------------------------------
+    def _stage(self, name):
+        if self.times is not None:
+            if getattr(self, "_open", None) is not None:
+                self._open.stop()
+            self._open = self.times.begin(name)
+
+    def _end(self):
+        if self.times is not None and getattr(self, "_open", None) is not None:
+            self._open.stop()
+            self._open = None
+
+    def _check_fovs(self, fovs: DeviceArray):
+        if fovs.dtype != np.uint16 or fovs.shape != (self.B, self.C, self.H, self.W):
+            raise ValueError(f"expected uint16 FOV batch of shape {(self.B, self.C, self.H, self.W)}, got "
+                             f"{fovs.dtype} {fovs.shape}")
+
+    def mask_chain(self, fovs: DeviceArray) -> DeviceArray:
+        """Gaussian -> Otsu -> '>' -> opening -> closing on the DAPI channel of every FOV."""
+        self._stage("gaussian")
+        hipops.gaussian(fovs, self.sigma, channel=self.dapi_index, out=self.gauss)
+        self._stage("otsu")
+        hipops.threshold_otsu(self.gauss, out=self.thr)
+        self._stage("threshold")
+        hipops.greater_than(self.gauss, self.thr, out=self.mask_a)
+        self._stage("opening")
+        hipops.binary_opening(self.mask_a, self.footprint, out=self.mask_b)
+        self._stage("closing")
+        hipops.binary_closing(self.mask_b, self.footprint, out=self.mask_a)
+        return self.mask_a
+
+    def run_c2(self, fovs: DeviceArray) -> DeviceArray:
+        """BASELINE configs[1]: the mask chain + 8-connected labelling.  Returns int32 labels (B, H, W)."""
+        self._check_fovs(fovs)
+        if self.labels8 is None:
+            self.labels8 = self.ctx.empty((self.B, self.H, self.W), np.int32)
+        mask = self.mask_chain(fovs)
+        self._stage("label8")
+        hipops.label(mask, 2, out=self.labels8, count=self.count8)
+        self._end()
+        self._ran = "c2"
+        return self.labels8
+
+    def run_c3(self, fovs: DeviceArray) -> DeviceArray:
+        """BASELINE configs[2]: nuclei watershed + morphology / intensity tables.  Returns int32 labels."""
+        self._check_fovs(fovs)
+        mask = self.mask_chain(fovs)
+        self._stage("edt")
+        hipops.edt(mask, want_edt=False, d2_out=self.d2)
+        self._stage("peaks")
+        hipops.peak_mask(self.d2, mask, self.min_distance, out=self.peaks)
+        self._stage("markers")
+        hipops.label(self.peaks, 1, out=self.markers, count=self.nmarkers)
+        self._stage("watershed")
+        hipops.watershed_edt(self.d2, self.markers, mask, seeds_first=True, out=self.ws)
+        self._stage("clear_border")
+        hipops.clear_border(self.ws, out=self.markers)  # markers buffer is free again
+        self._stage("relabel")
+        hipops.relabel_sequential(self.markers, self.max_cells, out=self.labels, count=self.ncells)
+        if self.props:
+            self._stage("regionprops")
+            hipops.regionprops(self.labels, self.max_cells, out=self.table)
+            self._stage("intensity")
+            hipops.regionprops_intensity(self.labels, fovs, self.max_cells, out=self.itable)
+        self._end()
+        self._ran = "c3"
+        return self.labels
+
+    # ---------------------------------------------------------------------------------------------
+    def result(self, channel_names=DEFAULT_CHANNELS) -> "SegmentationResult":
+        if self._ran != "c3":
+            raise RuntimeError("run_c3() has not been called")
+        nm = self.nmarkers.numpy()
+        if (nm > self.max_cells).any():
+            raise _hip.HipError(
+                f"a field of view produced {int(nm.max())} markers but max_cells={self.max_cells}; "
+                "raise max_cells")
+        return SegmentationResult(self, channel_names)
+
+
+class SegmentationResult:
+    """Views onto a finished config-3 run; host copies are made lazily."""
+
+    def __init__(self, seg: FovSegmenter, channel_names):
+        self.seg = seg
+        self.channel_names = tuple(channel_names)
+        self.ncells = seg.ncells.numpy()
+
+    def labels_device(self) -> DeviceArray:
+        return self.seg.labels
+
+    def labels_numpy(self) -> np.ndarray:
+        """int64 label images (B, H, W), background 0 (dtype contract: R/model.py:215, R/masks.py:63-65)."""
+        return self.seg.labels.numpy().astype(np.int64)
+
+    def feature_tables(self) -> list[dict[str, np.ndarray]]:
+        """One dict per FOV with the keys of ``SegmentationMask.cell_properties`` (R/masks.py:247-328,
+        default property lists R/masks.py:15-35)."""
+        t = self.seg.table.numpy()
+        it = self.seg.itable.numpy() if self.seg.props else None
+        out = []
+        for b in range(self.seg.B):
+            k = int(self.ncells[b])
+            out.append(assemble_cell_properties(t[b, :k], None if it is None else it[b, :k], self.channel_names))
+        return out
+
+
+def assemble_cell_properties(morph: np.ndarray, inten: np.ndarray | None, channel_names,
+                             property_names=None, intensity_property_names=None) -> dict[str, np.ndarray]:
+    """Device tables -> the dict R/masks.py:247-328 builds (same keys, same order, derived columns on the
+    host exactly as the reference derives them: circularity :292-297, volume :302-305, renames :311-314)."""
+    from .masks import DEFAULT_CELL_PROPERTY_NAMES, DEFAULT_INTENSITY_PROPERTY_NAMES
+
+    property_names = list(DEFAULT_CELL_PROPERTY_NAMES if property_names is None else property_names)
+    if intensity_property_names is None:
+        intensity_property_names = list(DEFAULT_INTENSITY_PROPERTY_NAMES) if inten is not None else []
+    col = {c: morph[:, i] for i, c in enumerate(_hip.RP_COLS)}
+    k = morph.shape[0]
+    needs_circ = "circularity" in property_names
+    needs_vol = "volume" in property_names
+    sk_props = [p for p in property_names if p not in ("circularity", "volume")]
+    added = set()
+    for dep in ["area", "perimeter"] if needs_circ else []:
+        if dep not in sk_props:
+            sk_props.append(dep)
+            added.add(dep)
+    for dep in ["axis_major_length", "axis_minor_length"] if needs_vol else []:
+        if dep not in sk_props:
+            sk_props.append(dep)
+            added.add(dep)
+    props: dict[str, np.ndarray] = {}
+    for p in sk_props:
+        if p == "label":
+            props["label"] = np.arange(1, k + 1, dtype=np.int64)
+        elif p == "centroid":
+            props["centroid-0"] = col["centroid-0"].copy()
+            props["centroid-1"] = col["centroid-1"].copy()
+        elif p == "bbox":
+            for i in range(4):
+                props[f"bbox-{i}"] = col[f"bbox-{i}"].astype(np.int64)
+        elif p in col:
+            props[p] = col[p].copy()
+        else:
+            raise AttributeError(f"property '{p}' is not available on the device path")
+    if needs_circ:
+        area, per = props["area"], props["perimeter"]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            props["circularity"] = np.where(per > 0, (4.0 * np.pi * area) / (per**2), 0.0)
+    if needs_vol:
+        a = props["axis_major_length"] / 2.0
+        b = props["axis_minor_length"] / 2.0
+        props["volume"] = np.where((a > 0) & (b > 0), (4.0 / 3.0) * np.pi * a * b * b, 0.0)
+    for p in added:
+        props.pop(p, None)
+    if "centroid-0" in props:
+        props["centroid_y"] = props.pop("centroid-0")
+    if "centroid-1" in props:
+        props["centroid_x"] = props.pop("centroid-1")
+    if inten is not None and intensity_property_names:
+        order = {"intensity_mean": 0, "intensity_max": 1, "intensity_min": 2, "intensity_std": 3}
+        for ci, name in enumerate(channel_names):
+            for p in intensity_property_names:
+                if p not in order:
+                    raise AttributeError(f"intensity property '{p}' is not available on the device path")
+                props[f"{p}_{str(name).lower()}"] = inten[:, ci, order[p]].copy()
+    return props
+
+
+def segment_fovs(fovs, *, ctx: Context | None = None, channel_names=DEFAULT_CHANNELS, **kw) -> SegmentationResult:
+    """Convenience: (B, C, H, W) uint16 (numpy or DeviceArray) -> config-3 ``SegmentationResult``."""
+    ctx = ctx or get_context()
+    d = fovs if isinstance(fovs, DeviceArray) else ctx.asarray(np.ascontiguousarray(fovs, dtype=np.uint16))
+    B, C, H, W = d.shape
+    seg = FovSegmenter(B, C, H, W, ctx=ctx, **kw)
+    seg.run_c3(d)
+    return seg.result(channel_names)

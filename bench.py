@@ -1,0 +1,235 @@
+"""bench.py -- fields-of-view/sec of the end-to-end segment + props hot path on MI355X.
+
+    python bench.py [--gpus N --steps K --warmup W --batch B]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = the whole config-3 chain (BASELINE.json configs[2]: Gaussian -> Otsu -> threshold -> open ->
+close -> EDT -> peak markers -> watershed -> clear_border -> relabel -> morphology + 4-channel intensity
+tables) over one batch of B synthetic 4 x 2048 x 2048 uint16 fields of view that are ALREADY RESIDENT in
+HBM when the timed region starts.  For N > 1 every rank processes its own B fields of view (weak scaling)
+and each step ends with the RCCL all-gather of the per-rank feature tables (BASELINE configs[3]).
+Rank 0 prints ONE JSON line (contract in the task statement).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (G/MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+# algorithmic bytes per pixel per stage: narrowest dtypes, one read + one write
+STAGE_BYTES_PER_PX = {
+    "gaussian": 10, "otsu": 8, "threshold": 9, "opening": 4, "closing": 4, "label8": 5, "edt": 9, "peaks": 17,
+    "markers": 5, "watershed": 17, "clear_border": 4, "relabel": 4, "regionprops": 4, "intensity": 12,
+}
+
+
+def log(msg):
+    print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8, help="fields of view per GPU per step")
+    ap.add_argument("--size", type=int, default=2048)
+    ap.add_argument("--workload", choices=["c3", "c2"], default="c3")
+    ap.add_argument("--cpu-fovs", type=int, default=2, help="FOVs timed through the single-thread CPU oracle")
+    ap.add_argument("--no-cpu", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(fovs: np.ndarray, workload: str, n_single: int):
+    """Time the CPU oracle (numpy/scipy restatement of the reference's scikit-image path, kind 'port') on a
+    bounded sample of the same workload: single thread, then all host cores with the reference's own
+    ThreadPoolExecutor mode (R/pipeline.py:145)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from oracle import chains
+
+    fn = (lambda f: chains.c3_chain(f)) if workload == "c3" else (lambda f: chains.c2_chain(f[1]))
+    n_single = max(1, min(n_single, len(fovs)))
+    t0 = time.perf_counter()
+    for i in range(n_single):
+        fn(fovs[i])
+        log(f"cpu baseline: FOV {i + 1}/{n_single} single-thread done")
+    t1 = time.perf_counter() - t0
+    # this process's CPU share (a 1-GPU box grants 16 cores of a much larger host)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))
+    sample = [fovs[i % len(fovs)] for i in range(cores)]
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        list(ex.map(fn, sample))
+    tall = time.perf_counter() - t0
+    return {
+        "value": n_single / t1,
+        "unit": "FOV/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{n_single} synthetic 4x{fovs.shape[-1]}^2 FOVs through oracle/chains.py ({workload}), 1 thread",
+        "all_cores": {"value": len(sample) / tall, "cores": cores,
+                      "sample": f"{len(sample)} FOVs, ThreadPoolExecutor(max_workers={cores})"},
+    }
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = world > 1
+
+    from arcadia_microscopy_tools_amd import synth
+    from arcadia_microscopy_tools_amd.device import Context, set_default_device
+    from arcadia_microscopy_tools_amd.segment import FovSegmenter
+
+    torch = dist = None
+    if distributed:
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        stream = torch.cuda.current_stream().cuda_stream
+        set_default_device(local_rank)
+        ctx = Context(local_rank, stream=stream)
+    else:
+        set_default_device(local_rank)
+        ctx = Context(local_rank)
+
+    B, S = args.batch, args.size
+    # every rank owns B distinct FOV indices of the plate (weak scaling)
+    t0 = time.perf_counter()
+    fovs = np.stack([synth.synth_fov(rank * B + i, size=S) for i in range(B)])
+    gen_s = time.perf_counter() - t0
+    log(f"rank {rank}: generated {B} synthetic FOVs in {gen_s:.1f}s; device = {ctx.device_name()}")
+    d_fovs = ctx.asarray(fovs)
+    seg = FovSegmenter(B, 4, S, S, ctx=ctx)
+    packed = None
+    if distributed:
+        from arcadia_microscopy_tools_amd.plate import DevicePackedTables
+
+        packed = DevicePackedTables(seg, torch.device("cuda", local_rank))
+        packed.adopt()
+
+    def step():
+        if args.workload == "c3":
+            seg.run_c3(d_fovs)
+            if packed is not None:
+                packed.all_gather()
+        else:
+            seg.run_c2(d_fovs)
+
+    def sync():
+        if distributed:
+            torch.cuda.synchronize()
+        else:
+            ctx.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    log("warmup done")
+    if distributed:
+        dist.barrier()
+        sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    if distributed:
+        dist.barrier()
+        sync()
+    elapsed = time.perf_counter() - t0
+    log(f"timed region: {args.steps} steps in {elapsed:.3f}s")
+    if distributed:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # ---- per-stage device times (HIP events on the kernels' own stream), outside the timed region ----
+    prof = FovSegmenter(B, 4, S, S, ctx=ctx, profile=True)
+    stage_ms: dict[str, list[float]] = {}
+    reps = 3
+    for _ in range(reps):
+        (prof.run_c3 if args.workload == "c3" else prof.run_c2)(d_fovs)
+        for k, v in prof.times.ms().items():
+            stage_ms.setdefault(k, []).append(v)
+    stage_avg = {k: float(np.mean(v)) for k, v in stage_ms.items()}
+    ncells = prof.ncells.numpy() if args.workload == "c3" else prof.count8.numpy()
+    log("stage ms: " + ", ".join(f"{k}={v:.3f}" for k, v in stage_avg.items()))
+
+    if rank == 0:
+        npx = B * S * S
+        dom = max(stage_avg, key=stage_avg.get)
+        dom_bytes = STAGE_BYTES_PER_PX[dom] * npx
+        achieved = dom_bytes / (stage_avg[dom] * 1e-3) / 1e9
+        chain_bytes = sum(STAGE_BYTES_PER_PX[k] for k in stage_avg) * npx
+        chain_ms = sum(stage_avg.values())
+        fm = [k for k in ("gaussian", "opening", "closing") if k in stage_avg]
+        fm_bytes = sum(STAGE_BYTES_PER_PX[k] for k in fm) * npx
+        fm_ms = sum(stage_avg[k] for k in fm)
+        roofline = {
+            "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "algorithmic_bytes_per_launch": dom_bytes, "launch_ms": stage_avg[dom],
+            "chain": {"achieved": chain_bytes / (chain_ms * 1e-3) / 1e9, "frac": chain_bytes / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                      "ms": chain_ms},
+            "filter_morphology_chain": {"achieved": fm_bytes / (fm_ms * 1e-3) / 1e9,
+                                        "frac": fm_bytes / (fm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms": fm_ms},
+            "stage_ms": stage_avg,
+        }
+        total_fovs = world * B * args.steps
+        out = {
+            "metric": "fields-of-view/sec (4x2048^2 uint16) end-to-end segment+props",
+            "value": total_fovs / elapsed,
+            "unit": "FOV/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": ("configs[2]: synthetic 4-channel 2048x2048 uint16 FOVs, DAPI Gaussian+Otsu+open/close+EDT+"
+                             "watershed nuclei + morphology and 4-channel intensity regionprops"
+                             if args.workload == "c3" else
+                             "configs[1]: synthetic 2048x2048 uint16 DAPI plane, Gaussian(2)+Otsu+open/close+CCL"),
+                "fovs_per_gpu_per_step": B, "fov_shape": [4, S, S], "resident_in_hbm": True,
+                "cells_per_fov_mean": float(np.mean(ncells)),
+                "feature_table_all_gather": bool(distributed and args.workload == "c3"),
+            },
+            "roofline": roofline,
+            "host_gen_s": gen_s,
+        }
+        if not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(fovs, args.workload, args.cpu_fovs)
+            out["gpu_over_cpu_1thread"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

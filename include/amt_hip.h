@@ -87,9 +87,11 @@ int amt_deinterleave_u16(amt_ctx* ctx, const uint16_t* yxc, uint16_t* cyx, int n
 /* Separable symmetric correlation, axis 0 then axis 1, float64 accumulate in scipy's order
  * (centre tap, then pairs outermost->innermost); `weights` = HOST pointer to 2*radius+1 doubles as
  * scipy builds them (computed by the caller with numpy so that np.exp rounding is shared).
- * in_dtype AMT_U16 (scaled by `scale`, 1/65535 for img_as_float) or AMT_F64 (scale ignored if 1). */
+ * in_dtype AMT_U16 (scaled by `scale`, 1/65535 for img_as_float) or AMT_F64 (scale ignored if 1).
+ * in_plane_stride = elements between consecutive INPUT planes (0 = H*W); C*H*W filters one channel of
+ * every (C,Y,X) field of view of a batch in a single launch.  Output planes are always contiguous. */
 int amt_gaussian(amt_ctx* ctx, const void* in, int in_dtype, double scale, double* out, int nplanes, int H, int W,
-                 const double* weights, int radius, int mode, double cval);
+                 const double* weights, int radius, int mode, double cval, size_t in_plane_stride);
 /* out = G(w_lo) - G(w_hi) of the same converted input (SK/filters/_gaussian.py:284-290). */
 int amt_dog(amt_ctx* ctx, const void* in, int in_dtype, double scale, double* out, int nplanes, int H, int W,
             const double* w_lo, int r_lo, const double* w_hi, int r_hi, int mode, double cval);
