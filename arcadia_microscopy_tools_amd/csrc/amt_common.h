@@ -23,7 +23,15 @@ struct amt_ctx {
     size_t mailbox_cap;
     size_t mailbox_off;
     int num_cus;
+    // auxiliary streams + events for fork/join of independent latency-bound kernels inside one op
+    hipStream_t aux[2];
+    hipEvent_t ev[3];
+    bool aux_ready;
 };
+
+// fork: aux streams wait for everything enqueued so far on the main stream; join: main waits for them
+int amt_fork(amt_ctx* ctx);
+int amt_join(amt_ctx* ctx);
 
 void amt_set_error(const char* fmt, ...);
 

@@ -48,6 +48,7 @@ static int ctx_create_common(int device, hipStream_t stream, bool own, amt_ctx**
     c->mailbox = nullptr;
     c->mailbox_cap = 0;
     c->mailbox_off = 0;
+    c->aux_ready = false;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess)
         c->num_cus = prop.multiProcessorCount;
@@ -74,6 +75,10 @@ extern "C" int amt_ctx_destroy(amt_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
+    if (ctx->aux_ready) {
+        for (int i = 0; i < 2; ++i) (void)hipStreamDestroy(ctx->aux[i]);
+        for (int i = 0; i < 3; ++i) (void)hipEventDestroy(ctx->ev[i]);
+    }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return AMT_OK;
@@ -105,6 +110,25 @@ int amt_arena_begin(amt_ctx* ctx, size_t total_bytes) {
         ctx->arena_cap = cap;
     }
     ctx->arena_off = 0;
+    return AMT_OK;
+}
+
+int amt_fork(amt_ctx* ctx) {
+    if (!ctx->aux_ready) {
+        for (int i = 0; i < 2; ++i) AMT_HIP_CHECK(hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking));
+        for (int i = 0; i < 3; ++i) AMT_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev[i], hipEventDisableTiming));
+        ctx->aux_ready = true;
+    }
+    AMT_HIP_CHECK(hipEventRecord(ctx->ev[0], ctx->stream));
+    for (int i = 0; i < 2; ++i) AMT_HIP_CHECK(hipStreamWaitEvent(ctx->aux[i], ctx->ev[0], 0));
+    return AMT_OK;
+}
+
+int amt_join(amt_ctx* ctx) {
+    for (int i = 0; i < 2; ++i) {
+        AMT_HIP_CHECK(hipEventRecord(ctx->ev[1 + i], ctx->aux[i]));
+        AMT_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev[1 + i], 0));
+    }
     return AMT_OK;
 }
 

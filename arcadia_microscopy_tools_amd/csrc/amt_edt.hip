@@ -2,76 +2,74 @@
 //
 // scipy.ndimage.distance_transform_edt(mask) == sqrt(float64(d2)) bitwise, with d2 the exact integer
 // squared distance to the nearest zero pixel.  d2 is computed separably:
-//   pass 1 (columns): g(y,x) = distance to the nearest zero pixel in column x (INF if none);
-//   pass 2 (rows)   : d2(y,x) = min_k (k^2 + g(y,x+-k)^2), scanning k outward while k^2 < best.
-// The outward scan is exact and costs O(distance) per pixel, which is what nuclei-sized objects need;
-// it degrades (never fails) on very large solid regions.
+//   pass 1 (rows)   : g(y,x) = distance to the nearest zero pixel in row y (G_INF if none), found by an
+//                     outward search in an LDS copy of the row;
+//   pass 2 (columns): d2(y,x) = min_k (k^2 + g(y+-k,x)^2), scanning k outward while k^2 < best; a wave
+//                     reads 64 consecutive x of row y+-k, so every access is coalesced.
+// Both searches are exact and cost O(distance) per pixel, which is what nuclei-sized objects need; they
+// degrade (never fail) on very large solid regions.
 #include "amt_internal.h"
 
 constexpr int G_INF = 0x3fffffff;
 
-// one thread per column, two sweeps; coalesced across the wave (consecutive x).
-__global__ void __launch_bounds__(256) edt_cols_kernel(const uint8_t* __restrict__ mask, int* __restrict__ g, int H,
+__global__ void __launch_bounds__(256) edt_rows_kernel(const uint8_t* __restrict__ mask, int* __restrict__ g, int H,
                                                        int W) {
-    const int x = blockIdx.x * 256 + threadIdx.x;
-    if (x >= W) return;
-    const size_t base = (size_t)blockIdx.y * H * W;
-    int d = G_INF;  // distance to the last zero seen above
-    for (int y = 0; y < H; ++y) {
-        size_t i = base + (size_t)y * W + x;
-        if (mask[i] == 0)
-            d = 0;
-        else if (d != G_INF)
-            d += 1;
-        g[i] = d;
-    }
-    d = G_INF;
-    for (int y = H - 1; y >= 0; --y) {
-        size_t i = base + (size_t)y * W + x;
-        int up = g[i];
-        if (up == 0)
-            d = 0;
-        else if (d != G_INF)
-            d += 1;
-        g[i] = d < up ? d : up;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    uint8_t* row = reinterpret_cast<uint8_t*>(smem_raw);
+    const size_t base = ((size_t)blockIdx.y * H + blockIdx.x) * W;
+    for (int x = threadIdx.x; x < W; x += 256) row[x] = mask[base + x];
+    __syncthreads();
+    for (int x = threadIdx.x; x < W; x += 256) {
+        int d = 0;
+        if (row[x]) {
+            d = G_INF;
+            for (int k = 1; x - k >= 0 || x + k < W; ++k) {
+                if ((x - k >= 0 && row[x - k] == 0) || (x + k < W && row[x + k] == 0)) {
+                    d = k;
+                    break;
+                }
+            }
+        }
+        g[base + x] = d;
     }
 }
 
-__global__ void __launch_bounds__(256) edt_rows_kernel(const int* __restrict__ g, int* __restrict__ d2_out,
+__global__ void __launch_bounds__(256) edt_cols_kernel(const int* __restrict__ g, int* __restrict__ d2_out,
                                                        double* __restrict__ edt_out, int H, int W) {
-    const int x = blockIdx.x * 256 + threadIdx.x;
-    const int y = blockIdx.y;
-    if (x >= W) return;
-    const size_t row = (size_t)blockIdx.z * H * W + (size_t)y * W;
-    const int* gr = g + row;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const size_t plane = (size_t)blockIdx.z * H * W;
+    const int* gp = g + plane;
+    const size_t i = (size_t)y * W + x;
     long long best;
-    int g0 = gr[x];
+    const int g0 = gp[i];
     if (g0 == 0) {
         best = 0;
     } else {
         best = g0 == G_INF ? (long long)0x7fffffffffffll : (long long)g0 * g0;
         for (long long k = 1; k * k < best; ++k) {
-            int xl = x - (int)k, xr = x + (int)k;
-            if (xl < 0 && xr >= W) break;
-            if (xl >= 0) {
-                int gv = gr[xl];
+            const int yu = y - (int)k, yd = y + (int)k;
+            if (yu < 0 && yd >= H) break;
+            if (yu >= 0) {
+                int gv = gp[(size_t)yu * W + x];
                 if (gv != G_INF) {
                     long long c = k * k + (long long)gv * gv;
                     best = c < best ? c : best;
                 }
             }
-            if (xr < W) {
-                int gv = gr[xr];
+            if (yd < H) {
+                int gv = gp[(size_t)yd * W + x];
                 if (gv != G_INF) {
                     long long c = k * k + (long long)gv * gv;
                     best = c < best ? c : best;
                 }
             }
         }
-        if (best > 0x7fffffffll) best = 0x7fffffffll;  // no zero pixel anywhere near: saturate
+        if (best > 0x7fffffffll) best = 0x7fffffffll;  // no zero pixel anywhere: saturate
     }
-    if (d2_out) d2_out[row + x] = (int)best;
-    if (edt_out) edt_out[row + x] = sqrt((double)best);
+    if (d2_out) d2_out[plane + i] = (int)best;
+    if (edt_out) edt_out[plane + i] = sqrt((double)best);
 }
 
 extern "C" int amt_edt(amt_ctx* ctx, const uint8_t* mask, int32_t* d2_out, double* edt_out, int nplanes, int H,
@@ -83,9 +81,10 @@ extern "C" int amt_edt(amt_ctx* ctx, const uint8_t* mask, int32_t* d2_out, doubl
     const size_t n = (size_t)H * W;
     AMT_TRY(amt_arena_begin(ctx, amt_align((size_t)nplanes * n * 4)));
     int* g = arena_take_t<int>(ctx, (size_t)nplanes * n);
-    hipLaunchKernelGGL(edt_cols_kernel, dim3((W + 255) / 256, nplanes), dim3(256), 0, ctx->stream, mask, g, H, W);
+    hipLaunchKernelGGL(edt_rows_kernel, dim3(H, nplanes), dim3(256), (size_t)amt_align(W, 16), ctx->stream, mask, g, H,
+                       W);
     AMT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(edt_rows_kernel, dim3((W + 255) / 256, H, nplanes), dim3(256), 0, ctx->stream, g, d2_out,
+    hipLaunchKernelGGL(edt_cols_kernel, dim3((W + 63) / 64, (H + 3) / 4, nplanes), dim3(256), 0, ctx->stream, g, d2_out,
                        edt_out, H, W);
     AMT_LAUNCH_CHECK();
     return AMT_OK;

@@ -45,39 +45,55 @@ __device__ __forceinline__ void uf_union(int* L, int a, int b) {
     }
 }
 
+// Initial labels: every foreground pixel points at the first pixel of its horizontal run of equal values
+// inside its 64-pixel wave segment (found with one ballot), so whole runs are already one tree of
+// depth 1 and the merge step only has to stitch runs.
 template <typename T>
-__global__ void __launch_bounds__(256) ccl_init_kernel(const T* __restrict__ in, int* __restrict__ L, size_t n) {
-    const size_t base = (size_t)blockIdx.y * n;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
-        L[base + i] = in[base + i] != 0 ? (int)i : -1;
+__global__ void __launch_bounds__(256) ccl_init_kernel(const T* __restrict__ in, int* __restrict__ Lall, int H, int W) {
+    const size_t n = (size_t)H * W;
+    const T* img = in + (size_t)blockIdx.z * n;
+    int* L = Lall + (size_t)blockIdx.z * n;
+    const int lane = threadIdx.x & 63;
+    const int x = blockIdx.x * 64 + lane;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (y >= H) return;
+    const int p = y * W + (x < W ? x : W - 1);
+    const long long v = x < W ? (long long)img[p] : -1;  // -1 never equals a pixel value of the lanes inside
+    const long long left = __shfl_up(v, 1);
+    const bool head = (lane == 0) || (left != v);
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long upto = heads & ((2ull << lane) - 1ull);
+    const int start_lane = 63 - __clzll((long long)upto);
+    if (x < W) L[p] = v != 0 ? p - (lane - start_lane) : -1;
 }
 
-// Merge step: every foreground pixel unions with its backward neighbours of equal value.  West and
-// north are always tested; the two diagonals only when north differs (if north matches, NW and NE are
-// already tied to it through row y-1's west unions), and NW only when west differs (otherwise west
-// reaches NW as its own north).
+// Merge step.  Runs are stitched (a) across 64-pixel segment boundaries (lane 0 with its west pixel) and
+// (b) vertically: p joins its north pixel q only when p or q starts a run -- otherwise (p-1, q-1) is the
+// same pair of runs and is handled further left.  For 8-connectivity the diagonals matter only when north
+// differs: NW unless west matches (then west reaches NW as its own north), NE unless east matches (then
+// east reaches NE as its own north).
 template <typename T>
 __global__ void __launch_bounds__(256) ccl_merge_kernel(const T* __restrict__ in, int* __restrict__ Lall, int H, int W,
                                                         int conn8) {
     const size_t n = (size_t)H * W;
     const T* img = in + (size_t)blockIdx.z * n;
     int* L = Lall + (size_t)blockIdx.z * n;
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int lane = threadIdx.x & 63;
+    const int x = blockIdx.x * 64 + lane;
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= W || y >= H) return;
     const int p = y * W + x;
     const T v = img[p];
     if (v == 0) return;
     const bool w_same = x > 0 && img[p - 1] == v;
-    if (w_same) uf_union(L, p, p - 1);
+    if (w_same && lane == 0) uf_union(L, p, p - 1);
     if (y > 0) {
         const int q = p - W;
         if (img[q] == v) {
-            uf_union(L, p, q);
+            if (!w_same || img[q - 1] != v) uf_union(L, p, q);
         } else if (conn8) {
-            // north differs: the two diagonals are not linked through row y-1, test both
-            if (x > 0 && img[q - 1] == v && !w_same) uf_union(L, p, q - 1);  // if west is same, west links to NW (its north)
-            if (x + 1 < W && img[q + 1] == v) uf_union(L, p, q + 1);
+            if (x > 0 && !w_same && img[q - 1] == v) uf_union(L, p, q - 1);
+            if (x + 1 < W && img[q + 1] == v && img[p + 1] != v) uf_union(L, p, q + 1);
         }
     }
 }
@@ -157,9 +173,9 @@ template <typename T>
 static int ccl_roots(amt_ctx* ctx, const T* in, int* L, int nplanes, int H, int W, int conn8) {
     const size_t n = (size_t)H * W;
     dim3 g1(amt_grid_for(n, 256, 4096), nplanes);
-    hipLaunchKernelGGL((ccl_init_kernel<T>), g1, dim3(256), 0, ctx->stream, in, L, n);
-    AMT_LAUNCH_CHECK();
     dim3 g2((W + 63) / 64, (H + 3) / 4, nplanes);
+    hipLaunchKernelGGL((ccl_init_kernel<T>), g2, dim3(256), 0, ctx->stream, in, L, H, W);
+    AMT_LAUNCH_CHECK();
     hipLaunchKernelGGL((ccl_merge_kernel<T>), g2, dim3(256), 0, ctx->stream, in, L, H, W, conn8);
     AMT_LAUNCH_CHECK();
     hipLaunchKernelGGL(ccl_compress_kernel, g1, dim3(256), 0, ctx->stream, L, n);
@@ -336,6 +352,66 @@ extern "C" int amt_relabel_sequential(amt_ctx* ctx, const int32_t* in, int32_t* 
         hipLaunchKernelGGL(map_labels_kernel, g1, dim3(256), 0, ctx->stream, in, P, out, n, max_label);
         AMT_LAUNCH_CHECK();
     }
+    return AMT_OK;
+}
+
+// ---- clear_border + relabel_sequential fused, for label images whose labels are each ONE component --
+// (outputs of amt_label / amt_watershed_*): a label touches the border iff one of its pixels lies on the
+// frame, so no re-labelling is needed.  present[l] = 1 if l occurs, 2 if it also touches the frame.
+__global__ void __launch_bounds__(256) frame_mark_kernel(const int* __restrict__ in, int* __restrict__ present, int H,
+                                                         int W, int max_label) {
+    const size_t n = (size_t)H * W;
+    const int* img = in + (size_t)blockIdx.y * n;
+    int* P = present + (size_t)blockIdx.y * (max_label + 1);
+    const int perim = 2 * W + 2 * H;
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < perim; k += gridDim.x * 256) {
+        int y, x;
+        if (k < W) {
+            y = 0;
+            x = k;
+        } else if (k < 2 * W) {
+            y = H - 1;
+            x = k - W;
+        } else if (k < 2 * W + H) {
+            y = k - 2 * W;
+            x = 0;
+        } else {
+            y = k - 2 * W - H;
+            x = W - 1;
+        }
+        int v = img[(size_t)y * W + x];
+        if (v > 0 && v <= max_label) P[v] = 2;
+    }
+}
+
+__global__ void __launch_bounds__(256) drop_flagged_kernel(int* __restrict__ present, int max_label) {
+    int* P = present + (size_t)blockIdx.y * (max_label + 1);
+    for (int l = blockIdx.x * 256 + threadIdx.x; l <= max_label; l += gridDim.x * 256) P[l] = (P[l] == 1) ? 1 : 0;
+}
+
+extern "C" int amt_clear_border_relabel(amt_ctx* ctx, const int32_t* in, int32_t* out, int32_t* count_dev, int nplanes,
+                                        int H, int W, int max_label) {
+    AMT_TRY(amt_set_device(ctx));
+    AMT_REQUIRE(in && out && nplanes >= 0 && H > 0 && W > 0 && max_label >= 0, "clear_border_relabel: bad arguments");
+    if (nplanes == 0) return AMT_OK;
+    const size_t n = (size_t)H * W;
+    size_t msz = (size_t)nplanes * ((size_t)max_label + 1);
+    AMT_TRY(amt_arena_begin(ctx, amt_align(msz * 4)));
+    int* P = arena_take_t<int>(ctx, msz);
+    AMT_HIP_CHECK(hipMemsetAsync(P, 0, msz * 4, ctx->stream));
+    dim3 g1(amt_grid_for(n, 256, 4096), nplanes);
+    hipLaunchKernelGGL(presence_kernel, g1, dim3(256), 0, ctx->stream, in, P, n, max_label);
+    AMT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(frame_mark_kernel, dim3(amt_grid_for((size_t)2 * W + 2 * H, 256, 64), nplanes), dim3(256), 0,
+                       ctx->stream, in, P, H, W, max_label);
+    AMT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(drop_flagged_kernel, dim3(amt_grid_for((size_t)max_label + 1, 256, 64), nplanes), dim3(256), 0,
+                       ctx->stream, P, max_label);
+    AMT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(presence_scan_kernel, dim3(nplanes), dim3(1024), 0, ctx->stream, P, max_label, count_dev);
+    AMT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(map_labels_kernel, g1, dim3(256), 0, ctx->stream, in, P, out, n, max_label);
+    AMT_LAUNCH_CHECK();
     return AMT_OK;
 }
 

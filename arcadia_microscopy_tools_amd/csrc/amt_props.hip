@@ -371,7 +371,7 @@ extern "C" int amt_regionprops(amt_ctx* ctx, const int32_t* labels, double* tabl
     if (nplanes == 0 || max_label == 0) return AMT_OK;
     const size_t n = (size_t)H * W;
     const size_t nlab = (size_t)nplanes * max_label;
-    const size_t cap = 2 * n;  // row-extent entries per plane (sum of bbox heights; <= n for connected labels)
+    const size_t cap = n;  // row-extent entries per plane (sum of bbox heights; <= n for connected labels)
     size_t need = amt_align(nlab * A_NACC * 8) + amt_align(nlab * 16) + amt_align(nlab * 4) + amt_align(nplanes * 4) +
                   amt_align((size_t)nplanes * cap * 8) + 2 * amt_align((size_t)nplanes * 3 * cap * 8);
     AMT_TRY(amt_arena_begin(ctx, need));

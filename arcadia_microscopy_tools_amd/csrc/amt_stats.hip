@@ -96,7 +96,18 @@ __global__ void __launch_bounds__(256) minmax_f64_kernel(const double* __restric
         lo = l2 < lo ? l2 : lo;
         hi = h2 > hi ? h2 : hi;
     }
+    // one pair of atomics per BLOCK (a few hundred per plane): same-address atomics serialise in L2
+    __shared__ unsigned long long s_lo[4], s_hi[4];
     if ((threadIdx.x & 63) == 0) {
+        s_lo[threadIdx.x >> 6] = lo;
+        s_hi[threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; ++k) {
+            lo = s_lo[k] < lo ? s_lo[k] : lo;
+            hi = s_hi[k] > hi ? s_hi[k] : hi;
+        }
         atomicMin(&keys[2 * plane], lo);
         atomicMax(&keys[2 * plane + 1], hi);
     }
@@ -112,7 +123,7 @@ static int minmax_f64_launch(amt_ctx* ctx, const double* in, unsigned long long*
     hipLaunchKernelGGL(minmax_init_kernel, dim3((nplanes + 63) / 64), dim3(64), 0, ctx->stream, keys, nplanes);
     AMT_LAUNCH_CHECK();
     if (n) {
-        dim3 grid(amt_grid_for(n, 256 * 8, 1024), nplanes);
+        dim3 grid(amt_grid_for(n, 256 * 16, 256), nplanes);
         hipLaunchKernelGGL(minmax_f64_kernel, grid, dim3(256), 0, ctx->stream, in, keys, n);
         AMT_LAUNCH_CHECK();
     }

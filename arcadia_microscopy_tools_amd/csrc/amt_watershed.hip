@@ -11,102 +11,194 @@
 //     raster order (a stable queue).  The config-3 recipe gives marker pixels distinct, lowest values
 //     (oracle/skops.py:seeded_flood_image; here `seeds_first`), for which both definitions coincide.
 //   * the flood never crosses between 4-connected components of the mask, and the relative order of two
-//     pixels of one component does not depend on the other components.  Each component is therefore
-//     flooded independently and sequentially by ONE LANE; thousands of components run concurrently,
-//     lanes pull components from a per-plane work counter until it is exhausted.
+//     pixels of one component does not depend on the other components.  Components are therefore
+//     independent work items:
+//       - a component whose marker pixels all carry ONE label ends up entirely with that label: it is
+//         filled by a pixel-parallel kernel, no flood at all;
+//       - otherwise the component is flooded sequentially by one lane.  If its bounding box fits an LDS
+//         tile (three size classes), a wave stages label / d2 / FIFO links in LDS, lane 0 floods at LDS
+//         latency, and the wave writes the labels back; larger components use queues in HBM.
 //
 // amt_watershed_edt: relief = -sqrt(d2) with d2 an exact non-negative integer, so the priority queue
 // is a bucket queue indexed by d2 (largest d2 = lowest relief first) with a FIFO per bucket: insertion
 // age order inside a bucket is push order.  A pixel is pushed at most once, so each FIFO is a linked
-// list threaded through one int per pixel.
+// list threaded through one link per pixel.
 // amt_watershed_f64: arbitrary float64 relief; per-component binary heap keyed (value, age, raster).
 #include "amt_internal.h"
 
-// ---- per-component bookkeeping -------------------------------------------------------------------
-// out = markers * mask ; per-root accumulators cleared
+// component classes
+enum { CLS_NONE = 0, CLS_UNIFORM = 1, CLS_S = 2, CLS_M = 3, CLS_L = 4, CLS_G = 5 };
+// LDS tile classes: max pixels of the bounding box, max d2 (bucket count - 1)
+constexpr int S_PX = 2048, S_NB = 512;
+constexpr int M_PX = 8192, M_NB = 1024;
+constexpr int L_PX = 24576, L_NB = 2048;
+
+struct comp_row {
+    int cmax;            // max d2 (bucket mode) or pixel count (heap mode)
+    int mcnt;            // marker pixels
+    int x0, y0, x1, y1;  // bounding box (inclusive)
+    int labmin, labmax;  // marker label range
+    int cls;
+    int pad;
+};
+
+// out = markers * mask
 __global__ void __launch_bounds__(256) ws_init_kernel(const int* __restrict__ markers, const uint8_t* __restrict__ mask,
-                                                      const int* __restrict__ L, int* __restrict__ out,
-                                                      int* __restrict__ rootMax, int* __restrict__ rootCnt, size_t n) {
-    const size_t base = (size_t)blockIdx.y * n;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        out[base + i] = mask[base + i] ? markers[base + i] : 0;
-        if (L[base + i] == (int)i) {
-            rootMax[base + i] = 0;
-            rootCnt[base + i] = 0;
-        }
+                                                      int* __restrict__ out, size_t total) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256)
+        out[i] = mask[i] ? markers[i] : 0;
+}
+
+__global__ void __launch_bounds__(256) ws_rows_init_kernel(comp_row* __restrict__ rows, const int* __restrict__ ncomp,
+                                                           size_t plane_stride) {
+    comp_row* r = rows + (size_t)blockIdx.y * plane_stride;
+    const int nc = ncomp[blockIdx.y];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nc; i += gridDim.x * 256) {
+        comp_row c;
+        c.cmax = 0;
+        c.mcnt = 0;
+        c.x0 = c.y0 = 0x7fffffff;
+        c.x1 = c.y1 = -1;
+        c.labmin = 0x7fffffff;
+        c.labmax = 0;
+        c.cls = CLS_NONE;
+        c.pad = 0;
+        r[i] = c;
     }
 }
 
-template <typename TV>
-__device__ __forceinline__ int bucket_of(TV v);
-template <>
-__device__ __forceinline__ int bucket_of<int>(int v) {
-    return v < 0 ? 0 : v;
-}
-
+// per-component max d2 (bucket count) or size (heap capacity), marker count, marker label range and
+// bounding box.  A wave covers 64 consecutive pixels of a row; each run of equal roots is reduced in
+// registers and costs one set of atomics.
 __global__ void __launch_bounds__(256) ws_stats_kernel(const int* __restrict__ d2, const int* __restrict__ L,
-                                                       const int* __restrict__ out, int* __restrict__ rootMax,
-                                                       int* __restrict__ rootCnt, size_t n, int use_d2) {
-    const size_t base = (size_t)blockIdx.y * n;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        int r = L[base + i];
-        if (r < 0) continue;
+                                                       const int* __restrict__ T, const int* __restrict__ out,
+                                                       comp_row* __restrict__ rows, size_t row_stride, int H, int W,
+                                                       int use_d2) {
+    const int lane = threadIdx.x & 63;
+    const int x = blockIdx.x * 64 + lane;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (y >= H) return;
+    const size_t base = (size_t)blockIdx.z * H * W;
+    const size_t i = base + (size_t)y * W + (x < W ? x : W - 1);
+    const int r = x < W ? L[i] : -1;
+    const int left = __shfl_up(r, 1);
+    const bool head = (lane == 0) || (left != r);
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long anyfg = __ballot(r >= 0);
+    if (!anyfg) return;
+    const unsigned long long later = heads & ~((2ull << lane) - 1ull);
+    const int end_lane = later ? (__ffsll((long long)later) - 2) : 63;
+    int v = 0;
+    if (r >= 0 && use_d2) {
+        v = d2[i];
+        v = v < 0 ? 0 : v;
+    }
+    const int lab = r >= 0 ? out[i] : 0;
+    int lmin = lab != 0 ? lab : 0x7fffffff, lmax = lab;
+    const unsigned long long mk = __ballot(lab != 0);
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int t = __shfl_down(v, off), t1 = __shfl_down(lmin, off), t2 = __shfl_down(lmax, off);
+        if (lane + off <= end_lane) {
+            v = t > v ? t : v;
+            lmin = t1 < lmin ? t1 : lmin;
+            lmax = t2 > lmax ? t2 : lmax;
+        }
+    }
+    if (r >= 0 && head) {
+        comp_row* c = rows + (size_t)blockIdx.z * row_stride + (T[base + r] - 1);
+        const int len = end_lane - lane + 1;
         if (use_d2) {
-            int v = d2[base + i];
-            if (v > 0) atomicMax(&rootMax[base + r], v);
+            if (v > 0) atomicMax(&c->cmax, v);
         } else {
-            atomicAdd(&rootMax[base + r], 1);  // component size (heap capacity)
+            atomicAdd(&c->cmax, len);
         }
-        if (out[base + i] != 0) atomicAdd(&rootCnt[base + r], 1);
+        atomicMin(&c->x0, x);
+        atomicMax(&c->x1, x + len - 1);
+        atomicMin(&c->y0, y);
+        atomicMax(&c->y1, y);
+        const unsigned long long run = (len == 64) ? ~0ull : (((1ull << len) - 1ull) << lane);
+        const int nmk = __popcll(mk & run);
+        if (nmk) {
+            atomicAdd(&c->mcnt, nmk);
+            atomicMin(&c->labmin, lmin);
+            atomicMax(&c->labmax, lmax);
+        }
     }
 }
 
-// roots publish their compact rows: cmax[cid], mcnt[cid], bsz[cid] (bucket count), and reset rootCnt
-__global__ void __launch_bounds__(256) ws_compact_kernel(const int* __restrict__ L, const int* __restrict__ T,
-                                                         int* __restrict__ rootMax, int* __restrict__ rootCnt,
-                                                         int* __restrict__ cmax, int* __restrict__ mcnt,
-                                                         int* __restrict__ bsz, int* __restrict__ moff, size_t n,
-                                                         int use_d2) {
+// classify components; publish marker-list sizes (moff) and queue sizes (boff) for the HBM path
+__global__ void __launch_bounds__(256) ws_classify_kernel(comp_row* __restrict__ rows, const int* __restrict__ ncomp,
+                                                          int* __restrict__ moff, int* __restrict__ boff,
+                                                          size_t row_stride, int use_d2) {
+    comp_row* r = rows + (size_t)blockIdx.y * row_stride;
+    int* mo = moff + (size_t)blockIdx.y * row_stride;
+    int* bo = boff + (size_t)blockIdx.y * row_stride;
+    const int nc = ncomp[blockIdx.y];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nc; i += gridDim.x * 256) {
+        comp_row c = r[i];
+        int cls;
+        if (c.mcnt == 0) {
+            cls = CLS_NONE;
+        } else if (c.labmin == c.labmax) {
+            cls = CLS_UNIFORM;
+        } else if (!use_d2) {
+            cls = CLS_G;
+        } else {
+            const long long area = (long long)(c.x1 - c.x0 + 3) * (c.y1 - c.y0 + 3);  // with the sentinel ring
+            if (c.labmax >= 0xFFFF) cls = CLS_G;  // labels are kept as 16-bit values in LDS
+            else if (area <= S_PX && c.cmax < S_NB) cls = CLS_S;
+            else if (area <= M_PX && c.cmax < M_NB) cls = CLS_M;
+            else if (area <= L_PX && c.cmax < L_NB) cls = CLS_L;
+            else cls = CLS_G;
+        }
+        r[i].cls = cls;
+        mo[i] = cls == CLS_G ? c.mcnt : 0;
+        bo[i] = cls == CLS_G ? (use_d2 ? c.cmax + 1 : c.cmax) : 0;
+    }
+}
+
+__global__ void __launch_bounds__(256) ws_fill_uniform_kernel(const int* __restrict__ L, const int* __restrict__ T,
+                                                              const comp_row* __restrict__ rows, size_t row_stride,
+                                                              int* __restrict__ out, size_t n) {
     const size_t base = (size_t)blockIdx.y * n;
+    const comp_row* rr = rows + (size_t)blockIdx.y * row_stride;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        if (L[base + i] == (int)i) {
-            int cid = T[base + i] - 1;
-            int mx = rootMax[base + i];
-            int mc = rootCnt[base + i];
-            cmax[base + cid] = mx;
-            mcnt[base + cid] = mc;
-            moff[base + cid] = mc;
-            // bucket queue: buckets 0..mx ; heap: capacity = component size (only needed when it has markers)
-            bsz[base + cid] = mc > 0 ? (use_d2 ? mx + 1 : mx) : 0;
-            rootCnt[base + i] = 0;  // reused as the fill cursor of the marker list
-        }
+        const int r = L[base + i];
+        if (r < 0) continue;
+        const comp_row* c = rr + (T[base + r] - 1);
+        if (c->cls == CLS_UNIFORM) out[base + i] = c->labmin;
     }
 }
 
+// marker lists of the HBM-path components (unordered fill; each lane sorts its own list)
 __global__ void __launch_bounds__(256) ws_fill_markers_kernel(const int* __restrict__ L, const int* __restrict__ T,
                                                               const int* __restrict__ out,
-                                                              const int* __restrict__ moff, int* __restrict__ rootCnt,
-                                                              int* __restrict__ mlist, size_t n) {
+                                                              const comp_row* __restrict__ rows,
+                                                              const int* __restrict__ moff, int* __restrict__ cursor,
+                                                              int* __restrict__ mlist, size_t row_stride, size_t n) {
     const size_t base = (size_t)blockIdx.y * n;
+    const size_t cb = (size_t)blockIdx.y * row_stride;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        int r = L[base + i];
+        const int r = L[base + i];
         if (r < 0 || out[base + i] == 0) continue;
-        int cid = T[base + r] - 1;
-        int pos = atomicAdd(&rootCnt[base + r], 1);
-        mlist[base + moff[base + cid] + pos] = (int)i;
+        const int cid = T[base + r] - 1;
+        if (rows[cb + cid].cls != CLS_G) continue;
+        const int pos = atomicAdd(&cursor[cb + cid], 1);
+        mlist[base + moff[cb + cid] + pos] = (int)i;
     }
 }
 
-__global__ void __launch_bounds__(256) ws_fill_neg1_kernel(int* __restrict__ buf, const int* __restrict__ total,
-                                                           size_t plane_stride) {
+__global__ void __launch_bounds__(256) ws_fill_value_kernel(int* __restrict__ buf, const int* __restrict__ total,
+                                                            size_t plane_stride, int value) {
     int* b = buf + (size_t)blockIdx.y * plane_stride;
     const int tot = total[blockIdx.y];
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < tot; i += gridDim.x * 256) b[i] = -1;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < tot; i += gridDim.x * 256) b[i] = value;
 }
 
-__global__ void ws_zero_counters_kernel(int* c, int nplanes) {
+__global__ void ws_zero_counters_kernel(int* c, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nplanes) c[i] = 0;
+    if (i < n) c[i] = 0;
 }
 
 __device__ __forceinline__ void lane_sort(int* a, int n) {
@@ -120,17 +212,135 @@ __device__ __forceinline__ void lane_sort(int* a, int n) {
     }
 }
 
-// ---- bucket-queue flood (relief = -sqrt(d2)) ------------------------------------------------------
+// ---- LDS-tile flood (bucket queue, relief = -sqrt(d2)) ----------------------------------------------
+// One wave per component.  The bounding box plus a one-pixel sentinel ring is staged in LDS:
+//   cell[i] (u32) = label (low 16 bits; 0 = unclaimed, 0xFFFF = not in this component / ring)
+//                   | d2 << 16 (15 bits) | marker flag (bit 31)
+//   nx[i]   (u16) = FIFO link
+//   ht[b]   (u32) = head (low 16) | tail (high 16) of bucket b; head 0xFFFF = empty
+// Lane 0 runs the sequential flood at LDS latency: the four neighbour cells are fetched together, a
+// claim is one cell write + one head/tail update.  The sentinel ring removes all bounds arithmetic.
+template <int TILE_PX, int NB, int CLS>
+__global__ void __launch_bounds__(64) ws_flood_lds_kernel(const int* __restrict__ d2all, const int* __restrict__ Lall,
+                                                          const int* __restrict__ Tall, int* __restrict__ outall,
+                                                          const comp_row* __restrict__ rows,
+                                                          const int* __restrict__ ncomp, int* __restrict__ counters,
+                                                          size_t row_stride, int H, int W, int seeds_first) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    unsigned* cell = reinterpret_cast<unsigned*>(smem_raw);
+    unsigned* ht = cell + TILE_PX;
+    unsigned short* nx = reinterpret_cast<unsigned short*>(ht + NB);
+    const int plane = blockIdx.y;
+    const size_t n = (size_t)H * W;
+    const int* d2 = d2all + (size_t)plane * n;
+    const int* L = Lall + (size_t)plane * n;
+    const int* T = Tall + (size_t)plane * n;
+    int* out = outall + (size_t)plane * n;
+    const comp_row* rr = rows + (size_t)plane * row_stride;
+    const int nc = ncomp[plane];
+    const int lane = threadIdx.x;
+    while (true) {
+        int c = 0;
+        if (lane == 0) c = atomicAdd(&counters[plane], 1);
+        c = __shfl(c, 0);
+        if (c >= nc) break;
+        const comp_row cr = rr[c];
+        if (cr.cls != CLS) continue;
+        const int tw = cr.x1 - cr.x0 + 3, th = cr.y1 - cr.y0 + 3;  // padded tile
+        const int npx = tw * th;
+        const int nb = cr.cmax + 1;
+        // ---- stage the bounding box + ring ----
+        for (int i = lane; i < npx; i += 64) {
+            const int ty = i / tw, tx = i - ty * tw;
+            unsigned cv = 0xFFFFu;
+            if (ty >= 1 && ty < th - 1 && tx >= 1 && tx < tw - 1) {
+                const size_t g = (size_t)(cr.y0 + ty - 1) * W + (cr.x0 + tx - 1);
+                const int r = L[g];
+                if (r >= 0 && T[r] - 1 == c) {
+                    const int o = out[g];
+                    int d = d2[g];
+                    d = d < 0 ? 0 : d;
+                    cv = ((unsigned)o & 0xFFFFu) | ((unsigned)d << 16) | (o != 0 ? 0x80000000u : 0u);
+                }
+            }
+            cell[i] = cv;
+        }
+        for (int i = lane; i < nb; i += 64) ht[i] = 0xFFFFFFFFu;
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        int cur = -1;
+        auto push = [&](int q, int b) {
+            const unsigned h = ht[b];
+            if ((h & 0xFFFFu) == 0xFFFFu) {
+                ht[b] = (unsigned)q | ((unsigned)q << 16);
+            } else {
+                nx[h >> 16] = (unsigned short)q;
+                ht[b] = (h & 0xFFFFu) | ((unsigned)q << 16);
+            }
+            cur = b > cur ? b : cur;
+        };
+        auto spread = [&](int p) {
+            const unsigned lb = cell[p] & 0xFFFFu;
+            const int q0 = p - tw, q1 = p - 1, q2 = p + 1, q3 = p + tw;
+            const unsigned c0 = cell[q0], c1 = cell[q1], c2 = cell[q2], c3 = cell[q3];
+            if ((c0 & 0xFFFFu) == 0) { cell[q0] = c0 | lb; push(q0, (c0 >> 16) & 0x7FFF); }
+            if ((c1 & 0xFFFFu) == 0) { cell[q1] = c1 | lb; push(q1, (c1 >> 16) & 0x7FFF); }
+            if ((c2 & 0xFFFFu) == 0) { cell[q2] = c2 | lb; push(q2, (c2 >> 16) & 0x7FFF); }
+            if ((c3 & 0xFFFFu) == 0) { cell[q3] = c3 | lb; push(q3, (c3 >> 16) & 0x7FFF); }
+        };
+        // ---- markers in raster order (wave ballots), then the flood, both on lane 0 ----
+        for (int i0 = 0; i0 < npx; i0 += 64) {
+            const int i = i0 + lane;
+            const bool ismk = i < npx && (cell[i] & 0x80000000u);
+            unsigned long long m = __ballot(ismk);
+            if (lane == 0) {
+                while (m) {
+                    const int b = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const int p = i0 + b;
+                    if (seeds_first) spread(p); else push(p, (cell[p] >> 16) & 0x7FFF);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (lane == 0) {
+            while (true) {
+                unsigned h = 0xFFFFu;
+                while (cur >= 0 && ((h = ht[cur]) & 0xFFFFu) == 0xFFFFu) --cur;
+                if (cur < 0) break;
+                const int p = (int)(h & 0xFFFFu);
+                if (p == (int)(h >> 16))
+                    ht[cur] = 0xFFFFFFFFu;
+                else
+                    ht[cur] = (h & 0xFFFF0000u) | nx[p];
+                spread(p);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- write back ----
+        for (int i = lane; i < npx; i += 64) {
+            const unsigned lv = cell[i] & 0xFFFFu;
+            if (lv != 0xFFFFu) {
+                const int ty = i / tw, tx = i - ty * tw;
+                out[(size_t)(cr.y0 + ty - 1) * W + (cr.x0 + tx - 1)] = (int)lv;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---- HBM bucket-queue flood (components too large for an LDS tile) ---------------------------------
 __global__ void __launch_bounds__(64) ws_flood_edt_kernel(const int* __restrict__ d2all, const uint8_t* __restrict__ maskall,
                                                           int* __restrict__ outall, int* __restrict__ nextall,
                                                           int* __restrict__ headall, int* __restrict__ tailall,
-                                                          int* __restrict__ mlistall, const int* __restrict__ cmaxall,
-                                                          const int* __restrict__ mcntall, const int* __restrict__ moffall,
-                                                          const int* __restrict__ boffall, const int* __restrict__ ncomp,
-                                                          int* __restrict__ counters, int H, int W, size_t n,
-                                                          size_t bstride, int seeds_first) {
+                                                          int* __restrict__ mlistall, const comp_row* __restrict__ rows,
+                                                          const int* __restrict__ moffall, const int* __restrict__ boffall,
+                                                          const int* __restrict__ ncomp, int* __restrict__ counters,
+                                                          size_t row_stride, int H, int W, size_t n, size_t bstride,
+                                                          int seeds_first) {
     const int plane = blockIdx.y;
     const size_t base = (size_t)plane * n;
+    const size_t cb = (size_t)plane * row_stride;
     const int* d2 = d2all + base;
     const uint8_t* mask = maskall + base;
     int* out = outall + base;
@@ -140,11 +350,11 @@ __global__ void __launch_bounds__(64) ws_flood_edt_kernel(const int* __restrict_
     while (true) {
         const int c = atomicAdd(&counters[plane], 1);
         if (c >= nc) break;
-        const int nm = mcntall[base + c];
-        if (nm == 0) continue;
-        int* ml = mlistall + base + moffall[base + c];
-        int* hd = headall + (size_t)plane * bstride + boffall[base + c];
-        int* tl = tailall + (size_t)plane * bstride + boffall[base + c];
+        if (rows[cb + c].cls != CLS_G) continue;
+        const int nm = rows[cb + c].mcnt;
+        int* ml = mlistall + base + moffall[cb + c];
+        int* hd = headall + (size_t)plane * bstride + boffall[cb + c];
+        int* tl = tailall + (size_t)plane * bstride + boffall[cb + c];
         int cur = -1;
         lane_sort(ml, nm);
 
@@ -170,7 +380,8 @@ __global__ void __launch_bounds__(64) ws_flood_edt_kernel(const int* __restrict_
                 const int q = p + nbo[k];
                 if (mask[q] && out[q] == 0) {
                     out[q] = lab;
-                    push(q, bucket_of<int>(d2[q]));
+                    int b = d2[q];
+                    push(q, b < 0 ? 0 : b);
                 }
             }
         };
@@ -178,7 +389,10 @@ __global__ void __launch_bounds__(64) ws_flood_edt_kernel(const int* __restrict_
         if (seeds_first) {
             for (int i = 0; i < nm; ++i) spread(ml[i]);
         } else {
-            for (int i = 0; i < nm; ++i) push(ml[i], bucket_of<int>(d2[ml[i]]));
+            for (int i = 0; i < nm; ++i) {
+                int b = d2[ml[i]];
+                push(ml[i], b < 0 ? 0 : b);
+            }
         }
         while (true) {
             while (cur >= 0 && hd[cur] < 0) --cur;
@@ -206,12 +420,13 @@ __device__ __forceinline__ bool hp_less(const hp_elem& a, const hp_elem& b) {
 __global__ void __launch_bounds__(64) ws_flood_heap_kernel(const double* __restrict__ relall,
                                                            const uint8_t* __restrict__ maskall, int* __restrict__ outall,
                                                            hp_elem* __restrict__ heapall, int* __restrict__ mlistall,
-                                                           const int* __restrict__ mcntall, const int* __restrict__ moffall,
-                                                           const int* __restrict__ boffall, const int* __restrict__ ncomp,
-                                                           int* __restrict__ counters, int H, int W, size_t n,
-                                                           size_t hstride) {
+                                                           const comp_row* __restrict__ rows,
+                                                           const int* __restrict__ moffall, const int* __restrict__ boffall,
+                                                           const int* __restrict__ ncomp, int* __restrict__ counters,
+                                                           size_t row_stride, int H, int W, size_t n, size_t hstride) {
     const int plane = blockIdx.y;
     const size_t base = (size_t)plane * n;
+    const size_t cb = (size_t)plane * row_stride;
     const double* rel = relall + base;
     const uint8_t* mask = maskall + base;
     int* out = outall + base;
@@ -220,10 +435,10 @@ __global__ void __launch_bounds__(64) ws_flood_heap_kernel(const double* __restr
     while (true) {
         const int c = atomicAdd(&counters[plane], 1);
         if (c >= nc) break;
-        const int nm = mcntall[base + c];
-        if (nm == 0) continue;
-        int* ml = mlistall + base + moffall[base + c];
-        hp_elem* hp = heapall + (size_t)plane * hstride + boffall[base + c];
+        if (rows[cb + c].cls != CLS_G) continue;
+        const int nm = rows[cb + c].mcnt;
+        int* ml = mlistall + base + moffall[cb + c];
+        hp_elem* hp = heapall + (size_t)plane * hstride + boffall[cb + c];
         int items = 0;
         int age = 0;
         lane_sort(ml, nm);
@@ -306,63 +521,95 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     const size_t n = (size_t)H * W;
     const size_t np = (size_t)nplanes * n;
     const int nblk = amt_i_rank_blocks(n);
-    // queue storage: bucket queue needs <= n + 2*ncomp <= 3n ints for head and tail each (only the used
-    // prefix is initialised); the heap needs <= n elements per plane.
-    const size_t bstride = use_d2 ? 3 * n : n;
-    size_t need = 9 * amt_align(np * 4) + amt_align((size_t)nplanes * nblk * 4) + 4 * amt_align(nplanes * 4);
+    // per-component rows: at most n components per plane; only the first ncomp[plane] rows are touched
+    const size_t row_stride = n;
+    // HBM queues: bucket mode needs <= n + ncomp <= 2n ints for head and tail each (only the used prefix
+    // is initialised); the heap needs <= n elements per plane.
+    const size_t bstride = use_d2 ? 2 * n : n;
+    size_t need = 7 * amt_align(np * 4) + amt_align((size_t)nplanes * row_stride * sizeof(comp_row)) +
+                  amt_align((size_t)nplanes * nblk * 4) + 8 * amt_align(nplanes * 4 * 8);
     need += use_d2 ? 2 * amt_align((size_t)nplanes * bstride * 4) : amt_align((size_t)nplanes * bstride * sizeof(hp_elem));
     AMT_TRY(amt_arena_begin(ctx, need));
     int* L = arena_take_t<int>(ctx, np);
     int* T = arena_take_t<int>(ctx, np);
-    int* rootMax = arena_take_t<int>(ctx, np);
-    int* rootCnt = arena_take_t<int>(ctx, np);
-    int* cmax = arena_take_t<int>(ctx, np);
-    int* mcnt = arena_take_t<int>(ctx, np);
     int* moff = arena_take_t<int>(ctx, np);
     int* boff = arena_take_t<int>(ctx, np);
+    int* cursor = arena_take_t<int>(ctx, np);
     int* mlist = arena_take_t<int>(ctx, np);
+    int* next = arena_take_t<int>(ctx, np);
+    comp_row* rows = arena_take_t<comp_row>(ctx, (size_t)nplanes * row_stride);
     int* blk = arena_take_t<int>(ctx, (size_t)nplanes * nblk);
     int* ncomp = arena_take_t<int>(ctx, nplanes);
     int* btot = arena_take_t<int>(ctx, nplanes);
     int* mtot = arena_take_t<int>(ctx, nplanes);
-    int* counters = arena_take_t<int>(ctx, nplanes);
-    int *head = nullptr, *tail = nullptr, *next = nullptr;
+    int* counters = arena_take_t<int>(ctx, (size_t)nplanes * 8);
+    int *head = nullptr, *tail = nullptr;
     hp_elem* heap = nullptr;
     if (use_d2) {
         head = arena_take_t<int>(ctx, (size_t)nplanes * bstride);
         tail = arena_take_t<int>(ctx, (size_t)nplanes * bstride);
-        next = T;  // T is dead once the marker lists are filled (see below): reuse as the FIFO links
     } else {
         heap = arena_take_t<hp_elem>(ctx, (size_t)nplanes * bstride);
     }
 
+    hipLaunchKernelGGL(ws_init_kernel, dim3(amt_grid_for(np, 256, 8192)), dim3(256), 0, ctx->stream, markers, mask, out,
+                       np);
+    AMT_LAUNCH_CHECK();
     AMT_TRY(amt_i_ccl_roots(ctx, mask, AMT_U8, L, nplanes, H, W, /*conn8=*/0));
     AMT_TRY(amt_i_rank_roots(ctx, L, T, blk, ncomp, nplanes, n));
+    hipLaunchKernelGGL(ws_rows_init_kernel, dim3(64, nplanes), dim3(256), 0, ctx->stream, rows, ncomp, row_stride);
+    AMT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ws_stats_kernel, dim3((W + 63) / 64, (H + 3) / 4, nplanes), dim3(256), 0, ctx->stream,
+                       use_d2 ? (const int*)relief : (const int*)nullptr, L, T, out, rows, row_stride, H, W,
+                       use_d2 ? 1 : 0);
+    AMT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ws_classify_kernel, dim3(64, nplanes), dim3(256), 0, ctx->stream, rows, ncomp, moff, boff,
+                       row_stride, use_d2 ? 1 : 0);
+    AMT_LAUNCH_CHECK();
     dim3 g1(amt_grid_for(n, 256, 4096), nplanes);
-    hipLaunchKernelGGL(ws_init_kernel, g1, dim3(256), 0, ctx->stream, markers, mask, L, out, rootMax, rootCnt, n);
+    hipLaunchKernelGGL(ws_fill_uniform_kernel, g1, dim3(256), 0, ctx->stream, L, T, rows, row_stride, out, n);
     AMT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ws_stats_kernel, g1, dim3(256), 0, ctx->stream, use_d2 ? (const int*)relief : (const int*)nullptr,
-                       L, out, rootMax, rootCnt, n, use_d2 ? 1 : 0);
+    hipLaunchKernelGGL(ws_zero_counters_kernel, dim3((nplanes * 8 + 63) / 64), dim3(64), 0, ctx->stream, counters,
+                       nplanes * 8);
     AMT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ws_compact_kernel, g1, dim3(256), 0, ctx->stream, L, T, rootMax, rootCnt, cmax, mcnt, boff, moff,
-                       n, use_d2 ? 1 : 0);
+    // ---- HBM-path bookkeeping (usually empty: only components too large for an LDS tile) ----
+    AMT_TRY(amt_scan_excl_dev(ctx, moff, ncomp, row_stride, mtot, nplanes));
+    AMT_TRY(amt_scan_excl_dev(ctx, boff, ncomp, row_stride, btot, nplanes));
+    hipLaunchKernelGGL(ws_fill_value_kernel, dim3(64, nplanes), dim3(256), 0, ctx->stream, cursor, ncomp, row_stride, 0);
     AMT_LAUNCH_CHECK();
-    // exclusive scans over the compact per-component rows (length = ncomp[plane] <= n; scan the device count)
-    hipLaunchKernelGGL(ws_zero_counters_kernel, dim3((nplanes + 63) / 64), dim3(64), 0, ctx->stream, counters, nplanes);
+    hipLaunchKernelGGL(ws_fill_markers_kernel, g1, dim3(256), 0, ctx->stream, L, T, out, rows, moff, cursor, mlist,
+                       row_stride, n);
     AMT_LAUNCH_CHECK();
-    AMT_TRY(amt_scan_excl_dev(ctx, moff, ncomp, n, mtot, nplanes));
-    AMT_TRY(amt_scan_excl_dev(ctx, boff, ncomp, n, btot, nplanes));
-    hipLaunchKernelGGL(ws_fill_markers_kernel, g1, dim3(256), 0, ctx->stream, L, T, out, moff, rootCnt, mlist, n);
-    AMT_LAUNCH_CHECK();
-    dim3 gf(64, nplanes);
     if (use_d2) {
-        hipLaunchKernelGGL(ws_fill_neg1_kernel, dim3(256, nplanes), dim3(256), 0, ctx->stream, head, btot, bstride);
+        const size_t ldsS = (size_t)S_PX * 6 + (size_t)S_NB * 4;
+        const size_t ldsM = (size_t)M_PX * 6 + (size_t)M_NB * 4;
+        const size_t ldsL = (size_t)L_PX * 6 + (size_t)L_NB * 4;
+        // the three LDS classes and the HBM path are independent, latency-bound and use few waves each:
+        // run them side by side (fork / join on the context's auxiliary streams)
+        hipLaunchKernelGGL(ws_fill_value_kernel, dim3(256, nplanes), dim3(256), 0, ctx->stream, head, btot, bstride, -1);
         AMT_LAUNCH_CHECK();
-        hipLaunchKernelGGL(ws_flood_edt_kernel, gf, dim3(64), 0, ctx->stream, (const int*)relief, mask, out, next, head,
-                           tail, mlist, cmax, mcnt, moff, boff, ncomp, counters, H, W, n, bstride, seeds_first);
+        AMT_TRY(amt_fork(ctx));
+        hipLaunchKernelGGL((ws_flood_lds_kernel<L_PX, L_NB, CLS_L>), dim3(16, nplanes), dim3(64), ldsL, ctx->stream,
+                           (const int*)relief, L, T, out, rows, ncomp, counters + 0 * nplanes, row_stride, H, W,
+                           seeds_first);
+        AMT_LAUNCH_CHECK();
+        hipLaunchKernelGGL((ws_flood_lds_kernel<M_PX, M_NB, CLS_M>), dim3(32, nplanes), dim3(64), ldsM, ctx->aux[0],
+                           (const int*)relief, L, T, out, rows, ncomp, counters + 1 * nplanes, row_stride, H, W,
+                           seeds_first);
+        AMT_LAUNCH_CHECK();
+        hipLaunchKernelGGL((ws_flood_lds_kernel<S_PX, S_NB, CLS_S>), dim3(128, nplanes), dim3(64), ldsS, ctx->aux[1],
+                           (const int*)relief, L, T, out, rows, ncomp, counters + 2 * nplanes, row_stride, H, W,
+                           seeds_first);
+        AMT_LAUNCH_CHECK();
+        hipLaunchKernelGGL(ws_flood_edt_kernel, dim3(4, nplanes), dim3(64), 0, ctx->aux[1], (const int*)relief, mask, out,
+                           next, head, tail, mlist, rows, moff, boff, ncomp, counters + 3 * nplanes, row_stride, H, W, n,
+                           bstride, seeds_first);
+        AMT_LAUNCH_CHECK();
+        AMT_TRY(amt_join(ctx));
     } else {
-        hipLaunchKernelGGL(ws_flood_heap_kernel, gf, dim3(64), 0, ctx->stream, (const double*)relief, mask, out, heap,
-                           mlist, mcnt, moff, boff, ncomp, counters, H, W, n, bstride);
+        hipLaunchKernelGGL(ws_flood_heap_kernel, dim3(64, nplanes), dim3(64), 0, ctx->stream, (const double*)relief,
+                           mask, out, heap, mlist, rows, moff, boff, ncomp, counters + 3 * nplanes, row_stride, H, W, n,
+                           bstride);
     }
     AMT_LAUNCH_CHECK();
     return AMT_OK;

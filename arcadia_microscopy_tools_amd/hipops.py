@@ -377,6 +377,18 @@ def relabel_sequential(labels: DeviceArray, max_label: int, out=None, count=None
     return o, c
 
 
+def clear_border_relabel(labels: DeviceArray, max_label: int, out=None, count=None):
+    """``relabel_sequential(clear_border(labels))`` in one pass (R/masks.py:56,65) for label images whose
+    labels are each one connected component (outputs of ``label`` / ``watershed``)."""
+    ctx = labels.ctx
+    n, H, W = _planes(labels)
+    o = _out(ctx, out, labels.shape, np.int32)
+    c = _out(ctx, count, (n,), np.int32)
+    _hip.check(_lib().amt_clear_border_relabel(ctx.handle, labels.ptr, o.ptr, c.ptr, n, H, W, int(max_label)),
+               "amt_clear_border_relabel")
+    return o, c
+
+
 def keep_labels(labels: DeviceArray, keep: DeviceArray, max_label: int, out=None) -> DeviceArray:
     """``np.where(np.isin(labels, kept), labels, 0)`` with keep = (nplanes, max_label+1) uint8 (R/masks.py:399-403)."""
     ctx = labels.ctx

@@ -127,10 +127,10 @@ class FovSegmenter:
         hipops.label(self.peaks, 1, out=self.markers, count=self.nmarkers)
         self._stage("watershed")
         hipops.watershed_edt(self.d2, self.markers, mask, seeds_first=True, out=self.ws)
+        # every watershed label is one 4-connected region grown from one marker component, so
+        # clear_border + relabel_sequential (R/masks.py:56,65) collapse into one flag-and-renumber pass
         self._stage("clear_border")
-        hipops.clear_border(self.ws, out=self.markers)  # markers buffer is free again
-        self._stage("relabel")
-        hipops.relabel_sequential(self.markers, self.max_cells, out=self.labels, count=self.ncells)
+        hipops.clear_border_relabel(self.ws, self.max_cells, out=self.labels, count=self.ncells)
         if self.props:
             self._stage("regionprops")
             hipops.regionprops(self.labels, self.max_cells, out=self.table)

@@ -28,7 +28,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (G/MI355X_MICROARCH.md: 8.0 TB/s
 # algorithmic bytes per pixel per stage: narrowest dtypes, one read + one write
 STAGE_BYTES_PER_PX = {
     "gaussian": 10, "otsu": 8, "threshold": 9, "opening": 4, "closing": 4, "label8": 5, "edt": 9, "peaks": 17,
-    "markers": 5, "watershed": 17, "clear_border": 4, "relabel": 4, "regionprops": 4, "intensity": 12,
+    "markers": 5, "watershed": 17, "clear_border": 8, "relabel": 4, "regionprops": 4, "intensity": 12,
 }
 
 

@@ -171,6 +171,11 @@ int amt_clear_border(amt_ctx* ctx, const int32_t* in, int32_t* out, int nplanes,
  * max_label = upper bound of label values in `in` (any plane). */
 int amt_relabel_sequential(amt_ctx* ctx, const int32_t* in, int32_t* out, int32_t* count_dev, int nplanes, size_t n,
                            int max_label);
+/* clear_border followed by relabel_sequential (R/masks.py:56,65) in one pass, valid when every label of
+ * `in` is a single connected component (outputs of amt_label and amt_watershed_*): a label is removed
+ * iff one of its pixels lies on the 1-px frame; survivors -> 1..K in ascending old-label order. */
+int amt_clear_border_relabel(amt_ctx* ctx, const int32_t* in, int32_t* out, int32_t* count_dev, int nplanes, int H,
+                             int W, int max_label);
 /* np.where(np.isin(labels, keep), labels, 0): keep_dev = nplanes x (max_label+1) uint8 flags */
 int amt_keep_labels(amt_ctx* ctx, const int32_t* in, const uint8_t* keep_dev, int32_t* out, int nplanes, size_t n,
                     int max_label);
