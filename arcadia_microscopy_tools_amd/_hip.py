@@ -65,11 +65,14 @@ _SIGS = {
     "amt_sub_clip0_f64": (c_int, [_P, _P, _P, _P, c_int, c_size_t]),
     "amt_rescale": (c_int, [_P, _P, c_int, _P, c_double, c_double, _P, c_int, c_size_t]),
     "amt_convert_u16_f64": (c_int, [_P, _P, c_double, _P, c_size_t]),
+    "amt_add_scalar_f64": (c_int, [_P, _P, c_double, _P, c_size_t]),
     "amt_hist_u16": (c_int, [_P, _P, _P, c_int, c_size_t]),
     "amt_minmax_f64": (c_int, [_P, _P, _P, c_int, c_size_t]),
     "amt_hist_f64": (c_int, [_P, _P, _P, _P, c_int, c_int, c_size_t]),
     "amt_percentile_u16": (c_int, [_P, _P, _P, c_int, _P, c_int, c_size_t]),
     "amt_percentile_f64": (c_int, [_P, _P, _P, c_int, _P, c_int, c_size_t]),
+    "amt_masked_sums_f64": (c_int, [_P, _P, _P, _P, c_int, c_size_t]),
+    "amt_copy_rect": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "amt_threshold_value": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, c_int, c_size_t]),
     "amt_threshold_gt": (c_int, [_P, _P, c_int, _P, _P, c_int, c_size_t]),
     "amt_threshold_gt_image": (c_int, [_P, _P, c_int, _P, _P, c_size_t]),

@@ -440,3 +440,43 @@ extern "C" int amt_deinterleave_u16(amt_ctx* ctx, const uint16_t* yxc, uint16_t*
     AMT_LAUNCH_CHECK();
     return AMT_OK;
 }
+
+__global__ void add_scalar_kernel(const double* __restrict__ in, double s, double* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = in[i] + s;
+}
+
+// out = in + s  (threshold_local's "thresh_image - offset", SK/filters/thresholding.py:236)
+extern "C" int amt_add_scalar_f64(amt_ctx* ctx, const double* in, double s, double* out, size_t n) {
+    AMT_TRY(amt_set_device(ctx));
+    AMT_REQUIRE(in && out, "add_scalar_f64: null pointer");
+    if (n == 0) return AMT_OK;
+    hipLaunchKernelGGL(add_scalar_kernel, dim3(amt_grid_for(n, 256)), dim3(256), 0, ctx->stream, in, s, out, n);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+
+// ---- rectangular copy: crop_to_center on a device-resident image (R/operations.py:100-132) ----------
+__global__ void copy_rect_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int esz, int H, int W,
+                                 int top, int left, int h, int w) {
+    const size_t row_bytes = (size_t)w * esz;
+    const uint8_t* s = src + ((size_t)blockIdx.z * H * W + (size_t)(top + blockIdx.y) * W + left) * esz;
+    uint8_t* d = dst + ((size_t)blockIdx.z * h + blockIdx.y) * row_bytes;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < row_bytes; i += (size_t)gridDim.x * blockDim.x)
+        d[i] = s[i];
+}
+
+extern "C" int amt_copy_rect(amt_ctx* ctx, const void* src, void* dst, int elem_size, int nplanes, int H, int W,
+                             int top, int left, int h, int w) {
+    AMT_TRY(amt_set_device(ctx));
+    AMT_REQUIRE(src && dst && elem_size > 0 && nplanes >= 0 && H > 0 && W > 0, "copy_rect: bad arguments");
+    AMT_REQUIRE(top >= 0 && left >= 0 && h >= 0 && w >= 0 && top + h <= H && left + w <= W,
+                "copy_rect: rectangle outside the image");
+    if (nplanes == 0 || h == 0 || w == 0) return AMT_OK;
+    dim3 grid((unsigned)(((size_t)w * elem_size + 255) / 256), h, nplanes);
+    if (grid.x > 64) grid.x = 64;
+    hipLaunchKernelGGL(copy_rect_kernel, grid, dim3(256), 0, ctx->stream, (const uint8_t*)src, (uint8_t*)dst, elem_size,
+                       H, W, top, left, h, w);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}

@@ -717,3 +717,74 @@ extern "C" int amt_percentile_f64(amt_ctx* ctx, const double* in, const double* 
     AMT_LAUNCH_CHECK();
     return AMT_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Deterministic masked sums for threshold_mean / threshold_li on float images
+// (SK/filters/thresholding.py:830, :642-707): per plane {sum(x <= t), count(x <= t), sum(x > t), count(x > t)}.
+// Fixed reduction tree (per-thread strided sum -> wave shuffle -> block -> one ordered pass over the
+// block partials), so repeated runs give identical bits; numpy's pairwise order differs in the last ulps.
+// ------------------------------------------------------------------------------------------------
+constexpr int MS_BLOCKS = 256;
+
+__global__ void __launch_bounds__(256) masked_sums_partial_kernel(const double* __restrict__ in,
+                                                                  const double* __restrict__ thr,
+                                                                  double* __restrict__ partial, size_t n) {
+    const int plane = blockIdx.y;
+    const double t = thr[plane];
+    const double* src = in + (size_t)plane * n;
+    double s_le = 0.0, s_gt = 0.0, c_le = 0.0, c_gt = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)MS_BLOCKS * 256) {
+        double v = src[i];
+        if (v > t) {
+            s_gt += v;
+            c_gt += 1.0;
+        } else {
+            s_le += v;
+            c_le += 1.0;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        s_le += __shfl_xor(s_le, off);
+        s_gt += __shfl_xor(s_gt, off);
+        c_le += __shfl_xor(c_le, off);
+        c_gt += __shfl_xor(c_gt, off);
+    }
+    __shared__ double sm[4][4];
+    if ((threadIdx.x & 63) == 0) {
+        int w = threadIdx.x >> 6;
+        sm[w][0] = s_le;
+        sm[w][1] = c_le;
+        sm[w][2] = s_gt;
+        sm[w][3] = c_gt;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        double v = ((sm[0][threadIdx.x] + sm[1][threadIdx.x]) + sm[2][threadIdx.x]) + sm[3][threadIdx.x];
+        partial[((size_t)plane * MS_BLOCKS + blockIdx.x) * 4 + threadIdx.x] = v;
+    }
+}
+
+__global__ void masked_sums_final_kernel(const double* __restrict__ partial, double* __restrict__ out) {
+    const int plane = blockIdx.x;
+    if (threadIdx.x < 4) {
+        double v = 0.0;
+        for (int b = 0; b < MS_BLOCKS; ++b) v += partial[((size_t)plane * MS_BLOCKS + b) * 4 + threadIdx.x];
+        out[plane * 4 + threadIdx.x] = v;
+    }
+}
+
+extern "C" int amt_masked_sums_f64(amt_ctx* ctx, const double* in, const double* thr_dev, double* out_dev, int nplanes,
+                                   size_t n) {
+    AMT_TRY(amt_set_device(ctx));
+    AMT_REQUIRE(in && thr_dev && out_dev && nplanes >= 0, "masked_sums_f64: bad arguments");
+    if (nplanes == 0) return AMT_OK;
+    AMT_TRY(amt_arena_begin(ctx, amt_align((size_t)nplanes * MS_BLOCKS * 4 * sizeof(double))));
+    double* partial = arena_take_t<double>(ctx, (size_t)nplanes * MS_BLOCKS * 4);
+    hipLaunchKernelGGL(masked_sums_partial_kernel, dim3(MS_BLOCKS, nplanes), dim3(256), 0, ctx->stream, in, thr_dev,
+                       partial, n);
+    AMT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(masked_sums_final_kernel, dim3(nplanes), dim3(64), 0, ctx->stream, partial, out_dev);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}

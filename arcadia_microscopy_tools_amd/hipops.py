@@ -126,6 +126,36 @@ def rescale(a: DeviceArray, in_range: DeviceArray, out_range=(0.0, 1.0), out: De
     return o
 
 
+def uniform_filter(a: DeviceArray, size: int, mode: str = "reflect", cval: float = 0.0, out=None) -> DeviceArray:
+    """``ndi.convolve1d(x, ones(size)/size)`` along axis 0 then axis 1 (threshold_local's 'mean',
+    SK/filters/thresholding.py:224-229); the image is NOT rescaled (no img_as_float)."""
+    ctx = a.ctx
+    n, H, W = _planes(a)
+    if size % 2 == 0:
+        raise ValueError("uniform_filter: size must be odd")
+    o = _out(ctx, out, a.shape, np.float64)
+    w = 1.0 / size * np.ones((size,))
+    wa, wp = _host_f64(w)
+    _hip.check(_lib().amt_gaussian(ctx.handle, a.ptr, _in_code(a), 1.0, o.ptr, n, H, W, wp, (size - 1) // 2,
+                                   _hip.MODES[mode], float(cval), 0), "amt_gaussian")
+    return o
+
+
+def to_float64(a: DeviceArray, scale: float = 1.0, out=None) -> DeviceArray:
+    """uint16 -> float64 (``x * scale``; ``img_as_float`` uses 1/65535, SK/util/dtype.py:319)."""
+    if a.dtype != np.uint16:
+        raise TypeError("to_float64 expects uint16")
+    o = _out(a.ctx, out, a.shape, np.float64)
+    _hip.check(_lib().amt_convert_u16_f64(a.ctx.handle, a.ptr, float(scale), o.ptr, a.size), "amt_convert_u16_f64")
+    return o
+
+
+def add_scalar(a: DeviceArray, s: float, out=None) -> DeviceArray:
+    o = _out(a.ctx, out, a.shape, np.float64)
+    _hip.check(_lib().amt_add_scalar_f64(a.ctx.handle, a.ptr, float(s), o.ptr, a.size), "amt_add_scalar_f64")
+    return o
+
+
 def deinterleave(yxc: DeviceArray, C: int, out: DeviceArray | None = None) -> DeviceArray:
     """(..., Y, X, C) interleaved ND2 frames -> (..., C, Y, X) (R/nikon.py:25-43)."""
     ctx = yxc.ctx
@@ -185,6 +215,28 @@ def percentile(a: DeviceArray, q, out: DeviceArray | None = None) -> DeviceArray
         _hip.check(_lib().amt_percentile_f64(ctx.handle, a.ptr, qp, len(qa), o.ptr, n, H * W), "amt_percentile_f64")
     else:
         raise TypeError(f"percentile: unsupported dtype {a.dtype}")
+    return o
+
+
+def masked_sums(a: DeviceArray, thr: DeviceArray, out: DeviceArray | None = None) -> DeviceArray:
+    """Per plane {sum(a <= t), count(a <= t), sum(a > t), count(a > t)} for float64 images (bit-reproducible)."""
+    ctx = a.ctx
+    n, H, W = _planes(a)
+    if a.dtype != np.float64:
+        raise TypeError("masked_sums expects float64")
+    o = _out(ctx, out, (n, 4), np.float64)
+    _hip.check(_lib().amt_masked_sums_f64(ctx.handle, a.ptr, thr.ptr, o.ptr, n, H * W), "amt_masked_sums_f64")
+    return o
+
+
+def crop(a: DeviceArray, top: int, left: int, h: int, w: int, out: DeviceArray | None = None) -> DeviceArray:
+    """``a[..., top:top+h, left:left+w]`` as a new device array (R/operations.py:132)."""
+    ctx = a.ctx
+    n, H, W = _planes(a)
+    o = _out(ctx, out, a.shape[:-2] + (h, w), a.dtype)
+    _hip.check(_lib().amt_copy_rect(ctx.handle, a.ptr, o.ptr, a.dtype.itemsize, n, H, W, int(top), int(left), int(h),
+                                    int(w)), "amt_copy_rect")
+    o.is_bool = a.is_bool
     return o
 
 

@@ -1,5 +1,22 @@
-"""SegmentationMask: labels -> feature table on the device (reference: R/masks.py)."""
+"""``SegmentationMask``: label image -> per-cell feature table, on the GPU (reference: R/masks.py:15-467).
+
+Same constructor, validation, error messages, immutability, property names, derived columns and key
+order as the reference.  ``label_image`` (clear_border + label / relabel_sequential) and
+``cell_properties`` (two ``regionprops_table`` passes in the reference, one per channel for intensity)
+run as HIP kernels; only the (num_cells x columns) table crosses PCIe.
+"""
 from __future__ import annotations
+
+import warnings
+from collections.abc import Mapping
+from dataclasses import dataclass, field
+from functools import cached_property
+from typing import ClassVar, Literal
+
+import numpy as np
+
+from .channels import Channel
+from .typing import BoolArray, Float64Array, Int64Array, ScalarArray, UInt16Array
 
 # property lists of the reference (R/masks.py:15-35)
 DEFAULT_CELL_PROPERTY_NAMES = [
@@ -23,3 +40,232 @@ DEFAULT_INTENSITY_PROPERTY_NAMES = [
     "intensity_min",
     "intensity_std",
 ]
+
+
+def _process_mask_device(mask_image, remove_edge_cells: bool):
+    """R/masks.py:38-65 on the device -> (int32 DeviceArray of sequential labels, count)."""
+    from . import hipops
+    from .device import get_context
+
+    ctx = get_context()
+    if mask_image.dtype == bool:
+        lab, cnt = hipops.label(ctx.asarray(mask_image), connectivity=2)
+        k = int(cnt.numpy()[0])
+        if remove_edge_cells:
+            # components of a label image are connected by construction: flag-and-renumber pass
+            lab, cnt = hipops.clear_border_relabel(lab, max(k, 1))
+            k = int(cnt.numpy()[0])
+            if k == 0:
+                raise ValueError(
+                    "No cells remain after removing edge cells. Try setting remove_edge_cells=False."
+                )
+        return lab, k
+    mx = int(mask_image.max())
+    if mx >= 2**31 - 1:
+        raise ValueError("label values above 2**31 - 2 are not supported on the device path")
+    lab = ctx.asarray(np.ascontiguousarray(mask_image, dtype=np.int32))
+    if remove_edge_cells:
+        # arbitrary label images: a label may have several pieces, only those touching the frame go
+        lab = hipops.clear_border(lab)
+        if int(hipops.max_per_plane(lab).numpy()[0]) == 0:
+            raise ValueError(
+                "No cells remain after removing edge cells. Try setting remove_edge_cells=False."
+            )
+    lab, cnt = hipops.relabel_sequential(lab, mx)
+    return lab, int(cnt.numpy()[0])
+
+
+@dataclass
+class SegmentationMask:
+    """Segmentation mask plus feature extraction (constructor contract: R/masks.py:118-143)."""
+
+    mask_image: BoolArray | Int64Array
+    intensity_image_dict: Mapping[Channel, UInt16Array] | None = None
+    remove_edge_cells: bool = True
+    outline_extractor: Literal["cellpose", "skimage"] = "cellpose"
+    property_names: list[str] | None = field(default=None)
+    intensity_property_names: list[str] | None = field(default=None)
+
+    _IMMUTABLE_FIELDS: ClassVar[frozenset[str]] = frozenset(
+        {
+            "mask_image",
+            "intensity_image_dict",
+            "remove_edge_cells",
+            "outline_extractor",
+            "property_names",
+            "intensity_property_names",
+        }
+    )
+
+    def __setattr__(self, name: str, value: object) -> None:
+        if getattr(self, "_initialized", False) and name in self._IMMUTABLE_FIELDS:
+            raise AttributeError(
+                f"Cannot modify '{name}' after SegmentationMask is initialized. "
+                "Create a new instance instead."
+            )
+        super().__setattr__(name, value)
+
+    def __post_init__(self):
+        if not isinstance(self.mask_image, np.ndarray):
+            raise TypeError("mask_image must be a numpy array")
+        if self.mask_image.ndim != 2:
+            raise ValueError("mask_image must be a 2D array")
+        if np.any(self.mask_image < 0):
+            raise ValueError("mask_image must have non-negative values")
+        if self.mask_image.max() == 0:
+            raise ValueError("mask_image contains no cells (all values are 0)")
+
+        if self.intensity_image_dict is not None:
+            if not isinstance(self.intensity_image_dict, Mapping):
+                raise TypeError("intensity_image_dict must be a Mapping of channels to 2D arrays")
+            for channel, intensities in self.intensity_image_dict.items():
+                if not isinstance(intensities, np.ndarray):
+                    raise TypeError(f"Intensity image for '{channel.name}' must be a numpy array")
+                if intensities.ndim != 2:
+                    raise ValueError(f"Intensity image for '{channel.name}' must be 2D")
+                if intensities.shape != self.mask_image.shape:
+                    raise ValueError(
+                        f"Intensity image for '{channel.name}' must have same shape as mask_image"
+                    )
+            # shallow copy of the dict; the arrays stay shared (R/masks.py:191-194)
+            self.intensity_image_dict = dict(self.intensity_image_dict)
+
+        if self.property_names is None:
+            self.property_names = DEFAULT_CELL_PROPERTY_NAMES.copy()
+        if self.intensity_property_names is None:
+            if self.intensity_image_dict:
+                self.intensity_property_names = DEFAULT_INTENSITY_PROPERTY_NAMES.copy()
+            else:
+                self.intensity_property_names = []
+        object.__setattr__(self, "_initialized", True)
+
+    # ---------------------------------------------------------------------------------------------
+    @cached_property
+    def _labels_device(self):
+        return _process_mask_device(self.mask_image, self.remove_edge_cells)
+
+    @cached_property
+    def label_image(self) -> Int64Array:
+        """Consecutive int64 labels 1..K, background 0, edge cells removed if requested (R/masks.py:210-218)."""
+        lab, _ = self._labels_device
+        return lab.numpy().astype(np.int64)
+
+    @cached_property
+    def num_cells(self) -> int:
+        return int(self._labels_device[1])
+
+    @cached_property
+    def cell_outlines(self) -> list[Float64Array]:
+        """Per-cell outline extraction (R/masks.py:68-115,229-245) is a 'next' row of the hot-path scope
+         and is not implemented on the device yet."""
+        raise NotImplementedError(
+            "cell_outlines is not implemented on the MI355X path yet (SURVEY.md section 8f, rank 2)"
+        )
+
+    @cached_property
+    def cell_properties(self) -> dict[str, ScalarArray]:
+        """Morphology + per-channel intensity features, one entry per cell ordered by label
+        (R/masks.py:247-328; columns of scikit-image's ``regionprops_table``)."""
+        from . import hipops
+        from .device import get_context
+        from .segment import assemble_cell_properties
+
+        assert self.property_names is not None
+        assert self.intensity_property_names is not None
+        lab, k = self._labels_device
+        k = int(k)
+        morph = hipops.regionprops(lab, max(k, 1)).numpy()[0][:k]
+        inten = None
+        names: list[str] = []
+        if self.intensity_image_dict and self.intensity_property_names:
+            planes = []
+            for channel, img in self.intensity_image_dict.items():
+                if img.dtype == np.uint8:
+                    img = img.astype(np.uint16)
+                if img.dtype != np.uint16:
+                    raise NotImplementedError(
+                        f"Intensity image for '{channel.name}' has dtype {img.dtype}; the device path takes "
+                        "uint8 / uint16 intensity images"
+                    )
+                planes.append(img)
+                names.append(channel.name)
+            stack = get_context().asarray(np.ascontiguousarray(np.stack(planes)))
+            inten = hipops.regionprops_intensity(lab, stack, max(k, 1)).numpy()[0][:k]
+        return assemble_cell_properties(morph, inten, names, list(self.property_names),
+                                        list(self.intensity_property_names))
+
+    @cached_property
+    def centroids_yx(self) -> Float64Array:
+        """(num_cells, 2) array of [y, x] centroids (R/masks.py:330-353)."""
+        if self.property_names is None:
+            raise ValueError("property_names cannot be None.")
+        if "centroid" not in self.property_names:
+            warnings.warn(
+                "Centroid property not available. Include 'centroid' in property_names "
+                "to get centroid coordinates. Returning empty array.",
+                UserWarning,
+                stacklevel=2,
+            )
+            return np.array([]).reshape(0, 2)
+        yc = self.cell_properties["centroid_y"]
+        xc = self.cell_properties["centroid_x"]
+        return np.array([yc, xc], dtype=float).T
+
+    def filter(self, property_name: str, min_value: float | None = None,
+               max_value: float | None = None) -> "SegmentationMask":
+        """New mask keeping the cells with ``min_value <= property <= max_value`` (R/masks.py:355-418)."""
+        from . import hipops
+        from .device import get_context
+
+        assert self.property_names is not None
+        assert self.intensity_property_names is not None
+        if min_value is None and max_value is None:
+            raise ValueError("At least one of min_value or max_value must be provided.")
+        if property_name not in self.cell_properties:
+            raise ValueError(
+                f"Property '{property_name}' not found. "
+                f"Available properties: {list(self.cell_properties.keys())}"
+            )
+        values = self.cell_properties[property_name]
+        keep = np.ones(self.num_cells, dtype=bool)
+        if min_value is not None:
+            keep &= values >= min_value
+        if max_value is not None:
+            keep &= values <= max_value
+        flags = np.zeros((1, self.num_cells + 1), dtype=np.uint8)
+        flags[0, 1:] = keep
+        lab, _ = self._labels_device
+        kept = hipops.keep_labels(lab, get_context().asarray(flags), self.num_cells)
+        new_label_image = kept.numpy().astype(np.int64)
+        if not keep.any():
+            raise ValueError(
+                f"No cells remain after filtering '{property_name}' "
+                f"with min={min_value}, max={max_value}."
+            )
+        return SegmentationMask(
+            mask_image=new_label_image,
+            intensity_image_dict=self.intensity_image_dict,
+            remove_edge_cells=False,
+            outline_extractor=self.outline_extractor,
+            property_names=list(self.property_names),
+            intensity_property_names=list(self.intensity_property_names),
+        )
+
+    def convert_properties_to_microns(self, pixel_size_um: float) -> dict[str, ScalarArray]:
+        """Scale lengths / areas / volumes to microns with ``_um`` / ``_um2`` / ``_um3`` key suffixes
+        (R/masks.py:420-467); dimensionless and intensity columns pass through."""
+        linear = {"perimeter", "axis_major_length", "axis_minor_length"}
+        area = {"area", "area_convex"}
+        volume = {"volume"}
+        tensor = {"inertia_tensor", "inertia_tensor_eigvals"}
+        out = {}
+        for name, vals in self.cell_properties.items():
+            if name in linear:
+                out[f"{name}_um"] = vals * pixel_size_um
+            elif name in area or name in tensor:
+                out[f"{name}_um2"] = vals * (pixel_size_um**2)
+            elif name in volume:
+                out[f"{name}_um3"] = vals * (pixel_size_um**3)
+            else:
+                out[name] = vals
+        return out

@@ -1,0 +1,200 @@
+"""``SegmentationModel``: the ``segment()`` / ``batch_segment()`` surface of the reference (R/model.py:28-290).
+
+The reference wraps Cellpose-SAM, whose weights are fetched from the network by name (R/model.py:160-169)
+and therefore cannot be loaded offline.  This class keeps the reference's constructor fields, parameter
+resolution / validation (same messages), return dtype (int64 labels, background 0) and per-image failure
+semantics of ``batch_segment`` (warning + ``None``), and adds a ``backend`` switch:
+
+  backend="classical" (default): the nuclei chain of BASELINE.json config 3 on the GPU -- Gaussian -> Otsu ->
+      opening/closing -> EDT -> peak markers -> watershed -> sequential labels (``segment.FovSegmenter``).
+      ``cell_diameter_px`` sets the marker spacing (min_distance = round(diameter / 6), 5 px for the default
+      30 px); the Cellpose-specific thresholds are validated for API parity but do not apply.
+  backend="cellpose": delegates to ``cellpose.models.CellposeModel`` exactly like the reference when that
+      package and its weights are available (PyTorch-ROCm device selection is unchanged: ``torch.cuda`` is
+      the ROCm device); raises ``RuntimeError`` otherwise.
+"""
+from __future__ import annotations
+
+import logging
+import warnings
+from collections.abc import Sequence
+from dataclasses import dataclass, field
+from typing import Any, TypedDict
+
+import numpy as np
+
+from .exceptions import SegmentationWarning
+from .typing import Float64Array, Int64Array
+
+logger = logging.getLogger(__name__)
+
+
+class CellposeParams(TypedDict):
+    """Resolved parameters in ``CellposeModel.eval`` naming (R/model.py:18-25)."""
+
+    diameter: float
+    flow_threshold: float
+    cellprob_threshold: float
+    niter: int | None
+    batch_size: int
+
+
+@dataclass
+class SegmentationModel:
+    """High-throughput cell segmentation (defaults: R/model.py:67-72)."""
+
+    default_cell_diameter_px: float = 30
+    default_flow_threshold: float = 0.4
+    default_cellprob_threshold: float = 0
+    default_num_iterations: int | None = None
+    default_batch_size: int = 8
+    device: Any = field(default=None)
+    backend: str = "classical"
+    sigma: float = 2.0
+    opening_radius: int = 2
+    _model: Any = field(default=None, init=False, repr=False)
+
+    def __post_init__(self) -> None:
+        if self.backend not in ("classical", "cellpose"):
+            raise ValueError(f"backend must be 'classical' or 'cellpose', got '{self.backend}'")
+        if self.device is None and self.backend == "cellpose":
+            self.device = self.find_best_available_device()
+
+    # -- parameters (R/model.py:80-132) ---------------------------------------------------------------
+    def _resolve_and_validate_parameters(self, cell_diameter_px, flow_threshold, cellprob_threshold,
+                                         num_iterations, batch_size) -> CellposeParams:
+        p: CellposeParams = {
+            "diameter": cell_diameter_px if cell_diameter_px is not None else self.default_cell_diameter_px,
+            "flow_threshold": flow_threshold if flow_threshold is not None else self.default_flow_threshold,
+            "cellprob_threshold": cellprob_threshold
+            if cellprob_threshold is not None
+            else self.default_cellprob_threshold,
+            "niter": num_iterations if num_iterations is not None else self.default_num_iterations,
+            "batch_size": batch_size if batch_size is not None else self.default_batch_size,
+        }
+        if p["diameter"] <= 0:
+            raise ValueError(f"Cell diameter [px] must be positive, got {p['diameter']}")
+        if p["flow_threshold"] < 0:
+            raise ValueError(f"Flow threshold must be non-negative, got {p['flow_threshold']}")
+        if not (-10 <= p["cellprob_threshold"] <= 10):
+            raise ValueError(
+                f"Cell probability threshold must be between -10 and 10, got {p['cellprob_threshold']}"
+            )
+        return p
+
+    @staticmethod
+    def find_best_available_device():
+        """CUDA/ROCm GPU > MPS > CPU, as a ``torch.device`` (R/model.py:134-158); on ROCm ``torch.cuda`` IS the
+        MI355X."""
+        import torch
+
+        if torch.cuda.is_available():
+            device = torch.device("cuda")
+            name = torch.cuda.get_device_name(0)
+            mem = torch.cuda.get_device_properties(0).total_memory / (1024**3)
+            logger.info(f"Using CUDA GPU: {name} with {mem:.1f} GB memory")
+        elif torch.backends.mps.is_available():
+            device = torch.device("mps")
+            logger.info("Using Apple Metal Performance Shaders (MPS) for acceleration.")
+        else:
+            device = torch.device("cpu")
+            logger.info(f"No GPU acceleration available. Using CPU with {torch.get_num_threads()} threads.")
+        return device
+
+    @property
+    def cellpose_model(self):
+        """Lazy Cellpose model (R/model.py:160-169); only for backend='cellpose'."""
+        if self._model is None:
+            logger.info(f"Loading Cellpose-SAM model on {self.device}")
+            try:
+                from cellpose.models import CellposeModel
+
+                self._model = CellposeModel(device=self.device)
+            except Exception as e:
+                raise RuntimeError(f"Failed to load Cellpose model: {e}") from e
+        return self._model
+
+    # -- classical backend ------------------------------------------------------------------------------
+    def _segment_classical(self, intensities: np.ndarray, params: CellposeParams) -> Int64Array:
+        from . import hipops
+        from .device import get_context
+
+        a = np.asarray(intensities)
+        if a.ndim == 3:
+            a = a[0]  # ([channel], height, width): the nuclear channel comes first
+        if a.ndim != 2:
+            raise ValueError(f"expected an image of shape ([channel], height, width), got {np.shape(intensities)}")
+        if a.dtype == np.uint8:
+            a = a.astype(np.uint16)
+        if a.dtype not in (np.uint16, np.float64):
+            a = a.astype(np.float64)
+        ctx = get_context()
+        d = ctx.asarray(np.ascontiguousarray(a))
+        g = hipops.gaussian(d, self.sigma)
+        thr = hipops.threshold_otsu(g)
+        m0 = hipops.greater_than(g, thr)
+        fp = hipops.disk(self.opening_radius)
+        m1 = hipops.binary_closing(hipops.binary_opening(m0, fp), fp)
+        d2, _ = hipops.edt(m1, want_edt=False)
+        min_distance = max(1, int(round(params["diameter"] / 6.0)))
+        peaks = hipops.peak_mask(d2, m1, min_distance)
+        markers, nmark = hipops.label(peaks, connectivity=1)
+        ws = hipops.watershed_edt(d2, markers, m1, seeds_first=True)
+        k = int(nmark.numpy()[0])
+        labels, _ = hipops.relabel_sequential(ws, max(k, 1))
+        return labels.numpy().astype(np.int64)
+
+    # -- public API (R/model.py:171-290) ----------------------------------------------------------------
+    def segment(self, intensities: Float64Array, cell_diameter_px: float | None = None,
+                flow_threshold: float | None = None, cellprob_threshold: float | None = None,
+                num_iterations: int | None = None, batch_size: int | None = None,
+                **cellpose_kwargs: Any) -> Int64Array:
+        """Segment one image -> int64 label image (background 0).
+
+        Raises ``ValueError`` for out-of-range parameters and ``RuntimeError`` when the backend fails
+        (R/model.py:206-215)."""
+        params = self._resolve_and_validate_parameters(
+            cell_diameter_px, flow_threshold, cellprob_threshold, num_iterations, batch_size
+        )
+        try:
+            if self.backend == "cellpose":
+                mask, *_ = self.cellpose_model.eval(x=intensities, **params, **cellpose_kwargs)
+            else:
+                mask = self._segment_classical(intensities, params)
+        except Exception as e:
+            raise RuntimeError(f"Cellpose segmentation failed: {e}") from e
+        return mask.astype(np.int64)
+
+    def batch_segment(self, intensities_batch: Sequence[Float64Array], cell_diameter_px: float | None = None,
+                      flow_threshold: float | None = None, cellprob_threshold: float | None = None,
+                      num_iterations: int | None = None, batch_size: int | None = None,
+                      show_progress: bool = True, **cellpose_kwargs: Any) -> list[Int64Array | None]:
+        """Segment several images with one parameter set; a failing image yields a ``SegmentationWarning`` and
+        ``None`` at its index, the rest continue (R/model.py:217-290)."""
+        params = self._resolve_and_validate_parameters(
+            cell_diameter_px, flow_threshold, cellprob_threshold, num_iterations, batch_size
+        )
+        masks: list[Int64Array | None] = []
+        iterator = enumerate(intensities_batch)
+        if show_progress:
+            try:
+                from tqdm import tqdm
+
+                iterator = tqdm(iterator, total=len(intensities_batch), desc="Segmenting")
+            except Exception:
+                pass
+        for i, intensities in iterator:
+            try:
+                if self.backend == "cellpose":
+                    mask, *_ = self.cellpose_model.eval(x=intensities, **params, **cellpose_kwargs)
+                else:
+                    mask = self._segment_classical(intensities, params)
+                masks.append(mask.astype(np.int64))
+            except Exception as e:
+                warnings.warn(
+                    f"Cellpose segmentation failed on image {i}: {e}",
+                    SegmentationWarning,
+                    stacklevel=2,
+                )
+                masks.append(None)
+        return masks

@@ -1,0 +1,216 @@
+"""Minimal reader for uncompressed modern ND2 files: pixel blocks + channel names, no third-party package.
+
+The reference loads ND2 through the ``nd2`` package (R/nikon.py:25-43: ``nd2.ND2File.asarray()`` plus a
+large metadata parser).  The hot path only needs the pixels and the channel list, so this module walks the
+chunk map itself (layout: SURVEY.md A.10), decodes the "lite variant" attribute blocks far enough to get
+width / height / component count / frame count and the optical-configuration names, and de-interleaves the
+(Y, X, C) frames into (C, Y, X) on the GPU (``hipops.deinterleave``) or, for plumbing without a GPU, with a
+numpy transpose.  Compressed frames, montages and multi-loop experiments are out of scope (row "next 1").
+"""
+from __future__ import annotations
+
+import struct
+from pathlib import Path
+
+import numpy as np
+
+from .channels import BRIGHTFIELD, CHANNELS, FITC, Channel
+from .metadata_structures import ChannelMetadata, DimensionFlags
+
+_MAGIC = 0x0ABECEDA
+_MAP_SIG = b"ND2 CHUNK MAP SIGNATURE 0000001!"
+
+_ALIASES = {"MONO": BRIGHTFIELD, "GFP": FITC}
+
+
+def resolve_optical_config(name: str) -> Channel | None:
+    """Optical-configuration name -> predefined channel (same matching order as R/nikon.py:52-76)."""
+    key = name.upper()
+    if key in CHANNELS:
+        return CHANNELS[key]
+    for alias, ch in _ALIASES.items():
+        if alias in key:
+            return ch
+    matches = [n for n in CHANNELS if n in key]
+    if matches:
+        return CHANNELS[max(matches, key=len)]
+    return None
+
+
+def read_chunk_map(data: bytes) -> dict[bytes, tuple[int, int]]:
+    """{chunk name: (file offset of the chunk header, payload size)} from the map at the end of the file."""
+    (map_off,) = struct.unpack("<Q", data[-8:])
+    magic, name_len, data_len = struct.unpack("<IIQ", data[map_off:map_off + 16])
+    if magic != _MAGIC:
+        raise ValueError("not a modern ND2 file (bad chunk-map magic)")
+    payload = data[map_off + 16 + name_len: map_off + 16 + name_len + data_len]
+    out: dict[bytes, tuple[int, int]] = {}
+    pos = 0
+    while pos < len(payload):
+        end = payload.find(b"!", pos)
+        if end < 0:
+            break
+        name = payload[pos:end + 1]
+        if name == _MAP_SIG:
+            break
+        off, size = struct.unpack("<QQ", payload[end + 1:end + 17])
+        out[name] = (off, size)
+        pos = end + 17
+    return out
+
+
+def chunk_payload(data: bytes, entry: tuple[int, int]) -> bytes:
+    off, _ = entry
+    magic, name_len, data_len = struct.unpack("<IIQ", data[off:off + 16])
+    if magic != _MAGIC:
+        raise ValueError("corrupt ND2 chunk header")
+    start = off + 16 + name_len
+    return data[start:start + data_len]
+
+
+def parse_lite_variant(buf: bytes, count: int | None = None, pos: int = 0):
+    """Decode a CLxLiteVariant block into nested dicts (types: 1 bool, 2 i32, 3 u32, 4 i64, 5 u64, 6 f64,
+    7 pointer, 8 utf-16 string, 9 byte array, 11 level)."""
+    out: dict[str, object] = {}
+    n = 0
+    while pos < len(buf) and (count is None or n < count):
+        if pos + 2 > len(buf):
+            break
+        typ, nlen = buf[pos], buf[pos + 1]
+        pos += 2
+        name = buf[pos:pos + 2 * nlen].decode("utf-16-le", "replace").rstrip("\x00")
+        pos += 2 * nlen
+        if typ == 1:
+            val = bool(buf[pos])
+            pos += 1
+        elif typ in (2, 3):
+            val = struct.unpack("<i" if typ == 2 else "<I", buf[pos:pos + 4])[0]
+            pos += 4
+        elif typ in (4, 5, 7):
+            val = struct.unpack("<q" if typ == 4 else "<Q", buf[pos:pos + 8])[0]
+            pos += 8
+        elif typ == 6:
+            val = struct.unpack("<d", buf[pos:pos + 8])[0]
+            pos += 8
+        elif typ == 8:
+            end = pos
+            while end + 1 < len(buf) and buf[end:end + 2] != b"\x00\x00":
+                end += 2
+            val = buf[pos:end].decode("utf-16-le", "replace")
+            pos = end + 2
+        elif typ == 9:
+            (blen,) = struct.unpack("<Q", buf[pos:pos + 8])
+            val = buf[pos + 8:pos + 8 + blen]
+            pos += 8 + blen
+        elif typ == 11:
+            item_count, length = struct.unpack("<IQ", buf[pos:pos + 12])
+            # `length` counts from the start of this entry's header to the end of its items; a table of
+            # item_count 8-byte offsets follows the items
+            header = 2 + 2 * nlen
+            start = pos + 12
+            val, _ = parse_lite_variant(buf, item_count, start)
+            pos = pos - header + length + 8 * item_count
+        else:
+            raise ValueError(f"unknown lite-variant type {typ}")
+        if name in out:
+            if not isinstance(out[name], list):
+                out[name] = [out[name]]
+            out[name].append(val)
+        else:
+            out[name] = val
+        n += 1
+    return out, pos
+
+
+def read_attributes(data: bytes, cmap) -> dict[str, int]:
+    attrs, _ = parse_lite_variant(chunk_payload(data, cmap[b"ImageAttributesLV!"]))
+    a = attrs.get("SLxImageAttributes", attrs)
+    return {
+        "width": int(a["uiWidth"]),
+        "height": int(a["uiHeight"]),
+        "components": int(a["uiComp"]),
+        "bits": int(a["uiBpcInMemory"]),
+        "frames": int(a["uiSequenceCount"]),
+        "width_bytes": int(a.get("uiWidthBytes", 0)),
+        "compression": int(a.get("eCompression", 2)),
+    }
+
+
+def read_channel_names(data: bytes, cmap, n_components: int) -> list[str]:
+    """Optical-configuration names of the planes, in component order (best effort)."""
+    key = b"ImageMetadataSeqLV|0!"
+    if key not in cmap:
+        return []
+    try:
+        meta, _ = parse_lite_variant(chunk_payload(data, cmap[key]))
+        planes = meta["SLxPictureMetadata"]["sPicturePlanes"]["sPlaneNew"]
+        names = []
+        for k in sorted(planes, key=lambda s: int("".join(c for c in s if c.isdigit()) or 0)):
+            p = planes[k]
+            names.append(str(p.get("sOpticalConfigName") or p.get("sDescription") or k))
+        return names[:n_components]
+    except Exception:
+        return []
+
+
+def read_frames_interleaved(path: Path):
+    """-> (frames (N, Y, X, C) uint16 little-endian, attributes, channel names)."""
+    data = Path(path).read_bytes()
+    cmap = read_chunk_map(data)
+    at = read_attributes(data, cmap)
+    if at["bits"] != 16:
+        raise NotImplementedError(f"only 16-bit ND2 frames are supported (got {at['bits']} bits)")
+    W, H, C, N = at["width"], at["height"], at["components"], at["frames"]
+    frame_bytes = W * H * C * 2
+    frames = np.empty((N, H, W, C), dtype="<u2")
+    for i in range(N):
+        key = b"ImageDataSeq|%d!" % i
+        if key not in cmap:
+            raise ValueError(f"ND2 file has no chunk {key!r}")
+        payload = chunk_payload(data, cmap[key])
+        if len(payload) < 8 + frame_bytes:
+            raise NotImplementedError("compressed or padded ND2 frames are not supported")
+        frames[i] = np.frombuffer(payload, dtype="<u2", count=W * H * C, offset=8).reshape(H, W, C)
+    return frames, at, read_channel_names(data, cmap, C)
+
+
+def load_nd2(nd2_path: Path, channels: list[Channel] | None = None, use_device: bool | None = None):
+    """-> (intensities uint16, InstrumentMetadata) like R/nikon.py:25-43.
+
+    Shapes follow ``nd2.ND2File.asarray()`` for the supported cases: (Y, X), (C, Y, X), (N, Y, X) or
+    (N, C, Y, X) with size-1 axes dropped.  The loop axis of multi-frame files is named 'T' (the chunk map
+    alone does not say whether it is a time or a z loop).
+    """
+    from .microscopy import InstrumentMetadata
+
+    frames, at, names = read_frames_interleaved(Path(nd2_path))
+    N, H, W, C = frames.shape
+    if use_device is None:
+        from . import _hip
+
+        try:
+            use_device = _hip.load_library().amt_device_count() > 0
+        except Exception:
+            use_device = False
+    if C > 1 and use_device:
+        from . import hipops
+        from .device import get_context
+
+        cyx = hipops.deinterleave(get_context().asarray(frames), C).numpy()
+    else:
+        cyx = np.ascontiguousarray(frames.transpose(0, 3, 1, 2))
+    sizes: dict[str, int] = {}
+    if N > 1:
+        sizes["T"] = N
+    if C > 1:
+        sizes["C"] = C
+    sizes["Y"], sizes["X"] = H, W
+    out = cyx.reshape(tuple(sizes.values())).astype(np.uint16, copy=False)
+    if channels is None:
+        channels = []
+        for i in range(C):
+            ch = resolve_optical_config(names[i]) if i < len(names) else None
+            channels.append(ch or Channel(names[i] if i < len(names) else f"CH{i}", "#FFFFFF"))
+    flags = DimensionFlags.TIMELAPSE if N > 1 else DimensionFlags(0)
+    meta = InstrumentMetadata(sizes, [ChannelMetadata(ch, flags) for ch in channels])
+    return out, meta

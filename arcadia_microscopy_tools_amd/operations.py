@@ -1,0 +1,241 @@
+"""Image operations of the reference (R/operations.py:10-216) on the GPU.
+
+``rescale_by_percentile``, ``subtract_background_dog``, ``crop_to_center`` and ``apply_threshold`` keep the
+reference's signatures, validation, error messages and edge-case results.  Each accepts a numpy array
+(uploaded, processed, downloaded: a drop-in call) or a ``DeviceArray`` (stays in HBM, so a ``Pipeline``
+of these functions makes one upload and one download).  All pixel-sized arithmetic runs in HIP kernels
+behind the C ABI; there is no CPU fallback.
+
+The device path processes 2-D images.  The reference calls scikit-image with whatever array it is given
+(an n-D array is filtered along ALL axes); to treat a (T, Y, X) / (Z, Y, X) stack plane by plane use
+``Pipeline(parallel=True)``, which maps the operations over axis 0 as the reference does (R/pipeline.py:139-149).
+"""
+from __future__ import annotations
+
+from typing import Literal
+
+import numpy as np
+
+from . import _thresholds, hipops
+from .device import DeviceArray, get_context
+from .pipeline import device_operator
+from .typing import BoolArray, Float64Array, ScalarArray
+
+_SUPPORTED_METHODS = ("otsu", "li", "yen", "isodata", "mean", "minimum", "triangle", "local", "niblack", "sauvola")
+
+
+def _to_device(intensities, what: str):
+    """-> (DeviceArray, was_numpy).  uint8 is widened to uint16 (exact); other dtypes are refused loudly."""
+    if isinstance(intensities, DeviceArray):
+        d = intensities
+        was_numpy = False
+    else:
+        a = np.asarray(intensities)
+        if a.dtype == np.uint8:
+            a = a.astype(np.uint16)
+        elif a.dtype not in (np.uint16, np.float64):
+            raise TypeError(
+                f"{what}: dtype {a.dtype} is not supported on the MI355X path (uint8, uint16 and float64 are)"
+            )
+        d = get_context().asarray(a)
+        was_numpy = True
+    if d.ndim != 2:
+        raise NotImplementedError(
+            f"{what}: the device path filters 2-D images, got {d.ndim}-D; map a stack over its first axis with "
+            "Pipeline(parallel=True)"
+        )
+    return d, was_numpy
+
+
+def _result(d: DeviceArray, was_numpy: bool):
+    return d.numpy() if was_numpy else d
+
+
+def _min_max(d: DeviceArray):
+    mm = hipops.percentile(d, (0.0, 100.0)).numpy()[0]
+    return mm[0], mm[1]
+
+
+@device_operator
+def rescale_by_percentile(
+    intensities: ScalarArray,
+    percentile_range: tuple[float, float] = (0, 100),
+    out_range: tuple[float, float] = (0, 1),
+) -> ScalarArray:
+    """Percentile-based contrast stretching (R/operations.py:10-54): ``np.percentile`` then
+    ``skimage.exposure.rescale_intensity(in_range=(p1, p2), out_range=out_range)``; float64 result."""
+    if not (0 <= percentile_range[0] < percentile_range[1] <= 100):
+        raise ValueError(
+            f"Invalid percentile range: {percentile_range}. "
+            f"Values must be in ascending order between 0 and 100."
+        )
+    if not isinstance(intensities, DeviceArray) and np.asarray(intensities).size == 0:
+        return np.zeros_like(intensities, dtype=float)
+    d, was_numpy = _to_device(intensities, "rescale_by_percentile")
+    lo, hi = _min_max(d)
+    if lo == hi:  # constant image (R/operations.py:43-44)
+        const = np.full(d.shape, out_range[0], dtype=float)
+        return const if was_numpy else d.ctx.asarray(const)
+    p = hipops.percentile(d, percentile_range)
+    return _result(hipops.rescale(d, p, out_range), was_numpy)
+
+
+@device_operator
+def subtract_background_dog(
+    intensities: ScalarArray,
+    low_sigma: float = 0.6,
+    high_sigma: float = 16.0,
+    percentile: float = 0,
+) -> Float64Array:
+    """Difference-of-Gaussians background subtraction (R/operations.py:57-97):
+    ``clip(dog - np.percentile(dog, percentile), 0, None)`` with ``dog = difference_of_gaussians(x, low, high)``."""
+    if not (0 <= percentile <= 100):
+        raise ValueError(f"Percentile must be between 0 and 100, got {percentile}")
+    if low_sigma >= high_sigma:
+        raise ValueError(f"low_sigma ({low_sigma}) must be smaller than high_sigma ({high_sigma})")
+    d, was_numpy = _to_device(intensities, "subtract_background_dog")
+    dog = hipops.difference_of_gaussians(d, low_sigma, high_sigma)
+    level = hipops.percentile(dog, percentile)
+    return _result(hipops.sub_clip0(dog, level, out=dog), was_numpy)
+
+
+@device_operator
+def crop_to_center(intensities: ScalarArray, output_shape: tuple[int, int]) -> ScalarArray:
+    """Centre crop on the last two axes, clamped to the image size (R/operations.py:100-132).
+    numpy input -> a view, as in the reference; DeviceArray input -> a cropped device copy."""
+    height, width = intensities.shape[-2:]
+    crop_height, crop_width = output_shape
+    crop_width = min(width, crop_width)
+    crop_height = min(height, crop_height)
+    left = (width - crop_width) // 2
+    top = (height - crop_height) // 2
+    if isinstance(intensities, DeviceArray):
+        return hipops.crop(intensities, top, left, crop_height, crop_width)
+    return intensities[..., top: top + crop_height, left: left + crop_width]
+
+
+def _global_threshold(d: DeviceArray, method: str, kwargs: dict) -> float:
+    """Threshold VALUE for the histogram-based methods: histogram on the device, selection on <= 65,536 counts."""
+    nbins = int(kwargs.pop("nbins", 256))
+    if d.dtype == np.uint16:
+        hist = hipops.histogram_u16(d).numpy()[0]
+        counts, centers = _thresholds.counts_centers_u16(hist)
+    else:
+        h, mm = hipops.histogram_f64(d, nbins)
+        mmv = mm.numpy()[0]
+        counts, centers = _thresholds.counts_centers_f64(h.numpy()[0], mmv[0], mmv[1])
+    if method == "yen":
+        return _thresholds.yen(counts, centers)
+    if method == "isodata":
+        return _thresholds.isodata(counts, centers)
+    if method == "triangle":
+        return _thresholds.triangle(counts, centers)
+    if method == "minimum":
+        return _thresholds.minimum(counts, centers, **kwargs)
+    raise AssertionError(method)
+
+
+def _mean_threshold(d: DeviceArray) -> float:
+    if d.dtype == np.uint16:
+        hist = hipops.histogram_u16(d).numpy()[0]
+        counts, centers = _thresholds.counts_centers_u16(hist)
+        return _thresholds.mean_from_hist(counts, centers)
+    inf = d.ctx.asarray(np.array([np.inf]))
+    s = hipops.masked_sums(d, inf).numpy()[0]
+    return s[0] / s[1]
+
+
+def _li_threshold(d: DeviceArray, tolerance=None, initial_guess=None) -> float:
+    """``skimage.filters.threshold_li`` (SK thresholding.py:642-707).  Integer images: exact, from the
+    histogram.  Float images: every iteration's two class means come from one device reduction."""
+    if d.dtype == np.uint16:
+        hist = hipops.histogram_u16(d).numpy()[0]
+        counts, centers = _thresholds.counts_centers_u16(hist)
+        return _thresholds.li_from_hist(counts, centers, tolerance, initial_guess)
+    ctx = d.ctx
+    image_min, image_max = _min_max(d)
+    if tolerance is None:
+        # smallest gap between distinct values / 2: for float images take it from the data's own resolution
+        # (scikit-image sorts the unique values; any tolerance below the true gap yields the same fixed point)
+        tolerance = np.spacing(max(abs(image_min), abs(image_max))) / 2
+    tot = hipops.masked_sums(d, ctx.asarray(np.array([np.inf]))).numpy()[0]
+    t_next = (tot[0] / tot[1]) if initial_guess is None else float(initial_guess)
+    t_curr = t_next - 2 * tolerance - 1.0
+    # work in the original value space: means shift by image_min exactly as scikit-image's (image - min)
+    for _ in range(10000):
+        if abs(t_next - t_curr) <= tolerance:
+            break
+        t_curr = t_next
+        s = hipops.masked_sums(d, ctx.asarray(np.array([t_curr]))).numpy()[0]
+        mean_back = s[0] / s[1] - image_min
+        mean_fore = s[2] / s[3] - image_min
+        t_next = (mean_back - mean_fore) / (np.log(mean_back) - np.log(mean_fore)) + image_min
+    return t_next
+
+
+def _local_threshold(d: DeviceArray, block_size, method="gaussian", offset=0, mode="reflect", param=None, cval=0):
+    """``skimage.filters.threshold_local`` (SK thresholding.py:206-236) -> float64 threshold image on the device."""
+    if block_size % 2 == 0:
+        raise ValueError(
+            "The kwarg ``block_size`` must be odd! Given ``block_size`` {0} is even.".format(block_size)
+        )
+    if method == "gaussian":
+        sigma = (block_size - 1) / 6.0 if param is None else param
+        t = hipops.gaussian(d, sigma, mode=mode, cval=cval, scale=1.0)
+    elif method == "mean":
+        t = hipops.uniform_filter(d, block_size, mode=mode, cval=cval)
+    elif method == "median":
+        t = hipops.median(d, np.ones((block_size, block_size), np.uint8), mode=mode, cval=cval)
+        if t.dtype != np.float64:
+            t = hipops.to_float64(t)
+    else:
+        raise ValueError(f"threshold_local method '{method}' is not supported on the device path")
+    if offset:
+        t = hipops.add_scalar(t, -float(offset))
+    return t
+
+
+@device_operator
+def apply_threshold(
+    intensities: ScalarArray,
+    method: Literal[
+        "otsu", "li", "yen", "isodata", "mean", "minimum", "triangle", "local", "niblack", "sauvola"
+    ] = "otsu",
+    **kwargs,
+) -> BoolArray:
+    """``intensities > threshold_<method>(intensities, **kwargs)`` (R/operations.py:135-216); boolean result."""
+    if not isinstance(intensities, DeviceArray) and np.asarray(intensities).size == 0:
+        return np.zeros_like(intensities, dtype=bool)
+    method_lower = method.lower()
+    if method_lower not in _SUPPORTED_METHODS:
+        raise ValueError(
+            f"Unsupported thresholding method: '{method}'. "
+            f"Supported methods: {', '.join(_SUPPORTED_METHODS)}"
+        )
+    d, was_numpy = _to_device(intensities, "apply_threshold")
+    ctx = d.ctx
+    lo, hi = _min_max(d)
+    if lo == hi:  # constant image (R/operations.py:201-202)
+        z = np.zeros(d.shape, dtype=bool)
+        return z if was_numpy else ctx.asarray(z)
+    kw = dict(kwargs)
+    if method_lower == "otsu":
+        thr = hipops.threshold_otsu(d, nbins=int(kw.pop("nbins", 256)))
+        mask = hipops.greater_than(d, thr)
+    elif method_lower in ("yen", "isodata", "triangle", "minimum"):
+        t = _global_threshold(d, method_lower, kw)
+        mask = hipops.greater_than(d, ctx.asarray(np.array([float(t)])))
+    elif method_lower == "mean":
+        mask = hipops.greater_than(d, ctx.asarray(np.array([float(_mean_threshold(d))])))
+    elif method_lower == "li":
+        mask = hipops.greater_than(d, ctx.asarray(np.array([float(_li_threshold(d, **kw))])))
+    elif method_lower == "local":
+        if "block_size" not in kw:
+            raise TypeError("threshold_local() missing 1 required positional argument: 'block_size'")
+        mask = hipops.greater_than_image(d, _local_threshold(d, **kw))
+    else:
+        raise NotImplementedError(
+            f"apply_threshold(method='{method_lower}') is not implemented on the MI355X path yet "
+            "(integral-image window statistics); see DESIGN.md 'Out of scope / next'"
+        )
+    return _result(mask, was_numpy)

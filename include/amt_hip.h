@@ -104,6 +104,8 @@ int amt_sub_clip0_f64(amt_ctx* ctx, const double* in, const double* level_dev, d
 int amt_rescale(amt_ctx* ctx, const void* in, int in_dtype, const double* range_dev, double omin, double omax,
                 double* out, int nplanes, size_t n);
 int amt_convert_u16_f64(amt_ctx* ctx, const uint16_t* in, double scale, double* out, size_t n);
+/* out = in + s (threshold_local subtracts its offset this way, SK/filters/thresholding.py:236) */
+int amt_add_scalar_f64(amt_ctx* ctx, const double* in, double s, double* out, size_t n);
 
 /* ---- statistics: np.percentile (R/operations.py:47,94), histogram (SK/exposure/exposure.py) -- */
 /* One 65536-bin histogram per plane (uint32 counts), bin = pixel value. */
@@ -119,6 +121,14 @@ int amt_percentile_u16(amt_ctx* ctx, const uint16_t* in, const double* q_host, i
                        size_t n);
 int amt_percentile_f64(amt_ctx* ctx, const double* in, const double* q_host, int nq, double* out_dev, int nplanes,
                        size_t n);
+
+/* out_dev[plane] = {sum(x <= t), count(x <= t), sum(x > t), count(x > t)} with t = thr_dev[plane]; a fixed
+ * reduction tree (bit-reproducible).  Feeds threshold_mean / threshold_li on float images
+ * (SK/filters/thresholding.py:830, :642-707). */
+int amt_masked_sums_f64(amt_ctx* ctx, const double* in, const double* thr_dev, double* out_dev, int nplanes, size_t n);
+/* dst[plane] (h x w) = src[plane][top:top+h, left:left+w]; crop_to_center (R/operations.py:100-132). */
+int amt_copy_rect(amt_ctx* ctx, const void* src, void* dst, int elem_size, int nplanes, int H, int W, int top,
+                  int left, int h, int w);
 
 /* ---- thresholds: R/operations.py:186-216 (apply_threshold), SK/filters/thresholding.py ------- */
 #define AMT_THR_OTSU 0

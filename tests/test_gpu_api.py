@@ -1,0 +1,237 @@
+"""GPU parity of the reference-level API (operations, Pipeline, SegmentationMask, SegmentationModel,
+MicroscopyImage.to_device).  The mask tests mirror RT/test_masks.py (disks from ski.draw.disk; the shapes
+are stored in tests/golden/disks_80.npz); everything is also compared with the CPU oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from arcadia_microscopy_tools_amd.channels import BRIGHTFIELD, DAPI, FITC, TRITC  # noqa: E402
+from arcadia_microscopy_tools_amd.masks import SegmentationMask  # noqa: E402
+from arcadia_microscopy_tools_amd.operations import (apply_threshold, crop_to_center,  # noqa: E402
+                                                     rescale_by_percentile, subtract_background_dog)
+from arcadia_microscopy_tools_amd.pipeline import ImageOperation, Pipeline  # noqa: E402
+
+
+def test_operations_on_fixture(golden):
+    from oracle import skops
+
+    g = golden("nd2_multichannel")
+    fitc = g["pixels"][2]
+    out = rescale_by_percentile(fitc, percentile_range=(1, 99))
+    assert out.dtype == np.float64 and np.array_equal(out, g["rescale_fitc_1_99"])
+    bg = subtract_background_dog(fitc, 0.6, 16.0, percentile=90)
+    dog = skops.difference_of_gaussians(fitc, 0.6, 16.0)
+    assert np.array_equal(bg, np.clip(dog - np.percentile(dog, 90), 0, None))
+    np.testing.assert_allclose(bg, g["bgsub_fitc_p90"], rtol=0, atol=1e-15)
+    # defaults: percentile 0 = minimum
+    assert np.array_equal(subtract_background_dog(fitc), np.clip(dog - np.percentile(dog, 0), 0, None))
+    # constant images (R/operations.py:43-44, 201-202)
+    const = np.full((32, 32), 9, np.uint16)
+    assert np.array_equal(rescale_by_percentile(const, out_range=(0.25, 1)), np.full((32, 32), 0.25))
+    assert not apply_threshold(const).any()
+    # the reference's own range test (RT/test_pipeline.py:267-328): 0 <= result <= 1
+    r = rescale_by_percentile(fitc, (2, 98), (0, 1))
+    assert r.min() == 0.0 and r.max() == 1.0
+    with pytest.raises(NotImplementedError, match="2-D"):
+        rescale_by_percentile(g["pixels"])
+    with pytest.raises(TypeError, match="float32"):
+        rescale_by_percentile(fitc.astype(np.float32))
+
+
+def test_apply_threshold_methods(golden):
+    from oracle import skops
+
+    g = golden("ops_192")
+    u = g["u16"]
+    gz = skops.gaussian(u, 2.0)
+    for method in ("otsu", "yen", "isodata", "triangle", "mean", "li"):
+        f = getattr(skops, "threshold_" + method)
+        m = apply_threshold(u, method=method)
+        assert m.dtype == bool and np.array_equal(m, u > f(u)), method
+        mf = apply_threshold(gz, method=method.upper())
+        assert np.array_equal(mf, gz > f(gz)), method + " f64"
+    assert np.array_equal(apply_threshold(u, "local", block_size=35), u > skops.threshold_local(u, 35))
+    assert np.array_equal(apply_threshold(u, "local", block_size=35, offset=3.0),
+                          u > skops.threshold_local(u, 35, offset=3.0))
+    # threshold_local's own `method` cannot pass through apply_threshold(**kwargs) in the reference either
+    # (it collides with apply_threshold's `method`); the other local methods are checked on the helper
+    from arcadia_microscopy_tools_amd.device import get_context
+    from arcadia_microscopy_tools_amd.operations import _local_threshold
+
+    du = get_context().asarray(u)
+    assert np.array_equal(_local_threshold(du, 35, method="mean", offset=3.0).numpy(),
+                          skops.threshold_local(u, 35, method="mean", offset=3.0))
+    assert np.array_equal(_local_threshold(du, 5, method="median").numpy(),
+                          skops.threshold_local(u, 5, method="median"))
+    with pytest.raises(ValueError, match="must be odd"):
+        apply_threshold(u, "local", block_size=34)
+    with pytest.raises(ValueError, match="Unsupported thresholding method: 'foo'"):
+        apply_threshold(u, method="foo")
+    dapi = golden("nd2_multichannel")["pixels"][1]
+    with pytest.raises(RuntimeError, match="two maxima"):
+        apply_threshold(dapi, method="minimum")
+    assert int(apply_threshold(dapi).sum()) == 1297  # BASELINE configs[0]
+    with pytest.raises(NotImplementedError):
+        apply_threshold(u, method="sauvola")
+
+
+def test_pipeline_device_chain(golden):
+    from oracle import skops
+
+    px = golden("nd2_multichannel")["pixels"]
+    fluor = Pipeline([ImageOperation(subtract_background_dog, percentile=90),
+                      ImageOperation(rescale_by_percentile, percentile_range=(1, 99))])
+
+    def ref(plane):
+        dog = skops.difference_of_gaussians(plane, 0.6, 16.0)
+        x = np.clip(dog - np.percentile(dog, 90), 0, None)
+        p1, p2 = np.percentile(x, (1, 99))
+        return skops.rescale_intensity(x, (p1, p2), (0, 1))
+
+    out = fluor(px[2])
+    assert out.dtype == np.float64 and np.array_equal(out, ref(px[2]))
+    # mixed pipeline: a plain numpy callable between device operators
+    mixed = Pipeline([ImageOperation(subtract_background_dog), ImageOperation(lambda x: x * 2.0),
+                      ImageOperation(rescale_by_percentile)])
+    dog = skops.difference_of_gaussians(px[1], 0.6, 16.0)
+    x2 = np.clip(dog - np.percentile(dog, 0), 0, None) * 2.0
+    assert np.array_equal(mixed(px[1]), skops.rescale_intensity(x2, (x2.min(), x2.max()), (0, 1)))
+    # parallel mode maps the chain over axis 0 from worker threads (one context / stream per thread)
+    par = Pipeline(fluor.operations, parallel=True, max_workers=4)
+    outs = par(px)
+    assert outs.shape == px.shape
+    for c in range(4):
+        assert np.array_equal(outs[c], ref(px[c])), c
+    pd = Pipeline([ImageOperation(rescale_by_percentile, out_range=(0, 65535))], preserve_dtype=True)
+    assert pd(px[1]).dtype == np.uint16
+    # crop on the device
+    from arcadia_microscopy_tools_amd.device import get_context
+
+    d = get_context().asarray(px[1])
+    assert np.array_equal(crop_to_center(d, (100, 50)).numpy(), crop_to_center(px[1], (100, 50)))
+
+
+def test_segmentation_mask_disks(golden):
+    """RT/test_masks.py:155-295 on the device."""
+    g = golden("disks_80")
+    labels = g["labels"]
+    rng = np.random.default_rng(0)
+    dapi = rng.integers(100, 4000, labels.shape).astype(np.uint16)
+    fitc = rng.integers(100, 4000, labels.shape).astype(np.uint16)
+    sm = SegmentationMask(mask_image=labels, intensity_image_dict={DAPI: dapi, FITC: fitc})
+    assert sm.num_cells == 3 and sm.label_image.dtype == np.int64 and np.array_equal(sm.label_image, labels)
+    props = sm.cell_properties
+    assert all(len(v) == 3 for v in props.values())
+    for k in ("label", "volume", "area", "area_convex", "perimeter", "eccentricity", "circularity", "solidity",
+              "axis_major_length", "axis_minor_length", "orientation", "centroid_y", "centroid_x"):
+        assert k in props, k
+    for k in ("intensity_mean_dapi", "intensity_max_fitc", "intensity_min_dapi", "intensity_std_fitc"):
+        assert k in props, k
+    assert "centroid-0" not in props and "centroid" not in props
+    assert props["area"].tolist() == [69, 193, 373] and props["area_convex"].tolist() == [69, 201, 381]
+    np.testing.assert_allclose(props["perimeter"], [27.313708, 48.970563, 68.284271], atol=1e-6)
+    np.testing.assert_allclose(sm.centroids_yx, [[15, 15], [40, 40], [62, 60]], atol=1e-9)
+    assert np.all((props["circularity"] > 0.85) & (props["circularity"] <= 1.2))
+    assert np.all(props["volume"] > 0)
+    for lab in (1, 2, 3):
+        sel = labels == lab
+        np.testing.assert_allclose(props["intensity_mean_dapi"][lab - 1], dapi[sel].mean(), rtol=1e-12)
+        np.testing.assert_allclose(props["intensity_std_fitc"][lab - 1], fitc[sel].std(), rtol=1e-10)
+        assert props["intensity_max_dapi"][lab - 1] == dapi[sel].max()
+    # filter (RT/test_masks.py:263-295)
+    big = sm.filter("area", min_value=150)
+    assert big.num_cells == 2 and big.remove_edge_cells is False and set(np.unique(big.label_image)) == {0, 1, 2}
+    mid = sm.filter("area", min_value=100, max_value=250)
+    assert mid.num_cells == 1 and int((mid.label_image > 0).sum()) == 193
+    assert mid.cell_properties["area"].tolist() == [193]
+    with pytest.raises(ValueError, match="At least one of min_value or max_value"):
+        sm.filter("area")
+    with pytest.raises(ValueError, match="Property 'nope' not found"):
+        sm.filter("nope", min_value=1)
+    with pytest.raises(ValueError, match="No cells remain after filtering 'area'"):
+        sm.filter("area", min_value=1e9)
+    um = sm.convert_properties_to_microns(0.5)
+    np.testing.assert_allclose(um["area_um2"], props["area"] * 0.25)
+    np.testing.assert_allclose(um["perimeter_um"], props["perimeter"] * 0.5)
+    np.testing.assert_allclose(um["volume_um3"], props["volume"] * 0.125)
+    assert np.array_equal(um["circularity"], props["circularity"]) and "area" not in um
+    with pytest.warns(UserWarning, match="Centroid property not available"):
+        assert SegmentationMask(labels, property_names=["label", "area"]).centroids_yx.shape == (0, 2)
+    sub = SegmentationMask(labels, property_names=["label", "circularity"]).cell_properties
+    assert list(sub.keys()) == ["label", "circularity"]
+    with pytest.raises(NotImplementedError):
+        sm.cell_outlines
+
+
+def test_segmentation_mask_edges_and_bool(golden):
+    from oracle import regionprops as rp
+    from oracle import skops
+
+    g = golden("c2c3_256")
+    ws = g["watershed"].astype(np.int64)
+    fov = g["fov"]
+    sm = SegmentationMask(ws, {BRIGHTFIELD: fov[0], DAPI: fov[1], FITC: fov[2], TRITC: fov[3]})
+    assert np.array_equal(sm.label_image, g["labels"])
+    ref = rp.cell_properties(g["labels"], {"BRIGHTFIELD": fov[0], "DAPI": fov[1], "FITC": fov[2], "TRITC": fov[3]})
+    props = sm.cell_properties
+    assert list(props.keys()) == list(ref.keys())
+    for k in ref:
+        if k in ("orientation", "eccentricity"):
+            continue
+        np.testing.assert_allclose(props[k], ref[k], rtol=1e-9, err_msg=k)
+    # boolean mask: label (8-conn) after clear_border; edge-touching blobs removed
+    m = np.zeros((40, 50), bool)
+    m[0:5, 0:5] = True
+    m[10:20, 10:20] = True
+    m[25:30, 30:45] = True
+    m[35:40, 45:50] = True
+    sb = SegmentationMask(m)
+    ref_lab = skops.label(skops.clear_border(skops.label(m)) > 0)
+    assert sb.num_cells == 2 and np.array_equal(sb.label_image, ref_lab)
+    assert SegmentationMask(m, remove_edge_cells=False).num_cells == 4
+    edge_only = np.zeros((20, 20), bool)
+    edge_only[0:4, 3:8] = True
+    with pytest.raises(ValueError, match="No cells remain after removing edge cells"):
+        SegmentationMask(edge_only).label_image
+    # integer mask whose labels are not consecutive and one label in two pieces (one piece on the border)
+    im = np.zeros((30, 30), np.int64)
+    im[0:3, 0:3] = 7
+    im[10:14, 10:14] = 7
+    im[20:24, 5:9] = 3
+    si = SegmentationMask(im)
+    assert np.array_equal(si.label_image, skops.relabel_sequential(skops.clear_border(im)))
+
+
+def test_segmentation_model_classical():
+    from arcadia_microscopy_tools_amd import synth
+    from arcadia_microscopy_tools_amd.model import SegmentationModel
+    from oracle import chains, skops
+
+    fov = synth.synth_fov(4, size=320)
+    model = SegmentationModel()
+    mask = model.segment(fov[1])
+    assert mask.dtype == np.int64 and mask.shape == (320, 320)
+    _, inter = chains.c3_labels(fov[1])
+    assert np.array_equal(mask, skops.relabel_sequential(inter["watershed"]))
+    assert np.array_equal(model.segment(fov[1:2]), mask)  # ([channel], H, W)
+    out = model.batch_segment([fov[1], np.zeros((4,)), fov[1]], show_progress=False)
+    assert out[1] is None and np.array_equal(out[0], mask) and np.array_equal(out[2], mask)
+    # larger diameter -> larger marker spacing -> no more cells than before
+    assert model.segment(fov[1], cell_diameter_px=60).max() <= mask.max()
+
+
+def test_microscopy_image_to_device(golden):
+    from arcadia_microscopy_tools_amd import hipops
+    from arcadia_microscopy_tools_amd.microscopy import MicroscopyImage
+
+    px = golden("nd2_multichannel")["pixels"]
+    im = MicroscopyImage.from_array(px, [BRIGHTFIELD, DAPI, FITC, TRITC])
+    dev = im.to_device()
+    d = dev.get_channel_intensities(DAPI)
+    assert d.shape == (256, 256) and np.array_equal(d.numpy(), px[1])
+    assert hipops.threshold_otsu(d).numpy()[0] == 2742
+    with pytest.raises(ValueError, match="Channel 'CY5' not found"):
+        dev.get_channel_intensities("CY5")
+    out = im.apply_pipeline(Pipeline([ImageOperation(apply_threshold)]), DAPI)
+    assert out.dtype == bool and int(out.sum()) == 1297

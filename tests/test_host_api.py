@@ -1,0 +1,299 @@
+"""Host-side logic of the drop-in boundary (no GPU): construction rules, validation and error messages of
+ImageOperation / Pipeline / MicroscopyImage / SegmentationMask / SegmentationModel mirror the reference's own
+tests (RT/test_pipeline.py, RT/test_microscopy.py, RT/test_masks.py, RT/test_model.py); the C ABI library
+loads and exports every symbol include/amt_hip.h declares; the product fails loudly without a GPU."""
+import os
+import re
+import warnings
+
+import numpy as np
+import pytest
+
+import arcadia_microscopy_tools_amd as amt
+from arcadia_microscopy_tools_amd import _hip
+from arcadia_microscopy_tools_amd.channels import BRIGHTFIELD, CHANNELS, DAPI, FITC, TRITC, Channel
+from arcadia_microscopy_tools_amd.masks import DEFAULT_CELL_PROPERTY_NAMES, SegmentationMask
+from arcadia_microscopy_tools_amd.microscopy import MicroscopyImage
+from arcadia_microscopy_tools_amd.model import SegmentationModel
+from arcadia_microscopy_tools_amd.operations import (apply_threshold, crop_to_center, rescale_by_percentile,
+                                                     subtract_background_dog)
+from arcadia_microscopy_tools_amd.pipeline import ImageOperation, Pipeline
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def double_intensity(x):
+    return x * 2
+
+
+def add_ten(x):
+    return x + 10
+
+
+# ---- C ABI ------------------------------------------------------------------------------------------
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "amt_hip.h")).read()
+    declared = set(re.findall(r"\b(amt_[a-z0-9_]+)\s*\(", header))
+    declared -= {"amt_ctx"}
+    lib = _hip.load_library()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"libamt_hip.so does not export {name}"
+    assert declared == set(_hip.exported_names()), declared ^ set(_hip.exported_names())
+    assert b"gfx950" in lib.amt_version()
+
+
+def test_no_gpu_fails_loudly():
+    lib = _hip.load_library()
+    if lib.amt_device_count() > 0:
+        pytest.skip("a GPU is present")
+    from arcadia_microscopy_tools_amd.device import Context
+
+    with pytest.raises(amt.HipUnavailableError, match="MI355X"):
+        Context(0)
+    with pytest.raises(amt.HipUnavailableError):
+        rescale_by_percentile(np.arange(16, dtype=np.uint16).reshape(4, 4))
+
+
+# ---- ImageOperation / Pipeline (RT/test_pipeline.py) ----------------------------------------------------
+def test_image_operation_contract():
+    op = ImageOperation(np.add, 5)
+    assert op.func == np.add and op.args == (5,) and op.kwargs == {}
+    np.testing.assert_array_equal(op(np.array([1, 2, 3])), [6, 7, 8])
+    assert ImageOperation(np.clip, a_min=0, a_max=100).kwargs == {"a_min": 0, "a_max": 100}
+    assert "double_intensity" in repr(ImageOperation(double_intensity))
+    with pytest.raises(AttributeError):
+        op.func = add_ten
+    with pytest.raises(AttributeError):
+        del op.func
+    assert ImageOperation(np.add, 5) == ImageOperation(np.add, 5) != ImageOperation(np.add, 10)
+    assert hash(ImageOperation(np.add, 5, k=1)) == hash(ImageOperation(np.add, 5, k=1))
+    assert ImageOperation(rescale_by_percentile).on_device and not ImageOperation(double_intensity).on_device
+
+
+def test_pipeline_contract():
+    with pytest.raises(ValueError, match="at least one operation"):
+        Pipeline(operations=[])
+    with pytest.raises(TypeError, match="callable"):
+        Pipeline(operations=[1])
+    with pytest.raises(ValueError, match="max_workers must be at least 1"):
+        Pipeline(operations=[ImageOperation(add_ten)], max_workers=0)
+    with pytest.warns(UserWarning, match="copy=True has no effect"):
+        Pipeline(operations=[ImageOperation(add_ten)], copy=True, parallel=True)
+    p = Pipeline(operations=(ImageOperation(double_intensity), ImageOperation(add_ten)))
+    assert len(p) == 2 and p.copy is False and p.preserve_dtype is False and p.parallel is False
+    img = np.array([1, 2, 3], dtype=np.uint16)
+    out = p(img)
+    np.testing.assert_array_equal(out, [12, 14, 16])
+    assert out.dtype == np.uint16
+    pf = Pipeline([ImageOperation(lambda x: x.astype(float) / x.max())], preserve_dtype=True)
+    assert pf(img).dtype == np.uint16
+    assert "Pipeline([" in repr(p) and "preserve_dtype=True" in repr(pf)
+    # copy=True protects the input from in-place operations
+    def inplace(x):
+        x += 1
+        return x
+    src = np.zeros(3, np.uint16)
+    Pipeline([ImageOperation(inplace)], copy=True)(src)
+    assert src.sum() == 0
+    # parallel mode
+    stack = np.arange(24, dtype=np.uint16).reshape(3, 2, 4)
+    pp = Pipeline([ImageOperation(double_intensity)], parallel=True, max_workers=2)
+    np.testing.assert_array_equal(pp(stack), stack * 2)
+    with pytest.raises(ValueError, match="Parallel mode requires at least 3D input"):
+        pp(np.zeros((4, 4), np.uint16))
+    ppd = Pipeline([ImageOperation(lambda x: x / 2.0)], parallel=True, preserve_dtype=True)
+    assert ppd(stack).dtype == np.uint16
+
+
+# ---- operations: validation that must not need a GPU (R/operations.py:34-38,85-88,122-132,199-211) -------
+def test_operations_validation():
+    img = np.arange(64, dtype=np.uint16).reshape(8, 8)
+    with pytest.raises(ValueError, match="Invalid percentile range"):
+        rescale_by_percentile(img, percentile_range=(50, 10))
+    with pytest.raises(ValueError, match="Percentile must be between 0 and 100"):
+        subtract_background_dog(img, percentile=101)
+    with pytest.raises(ValueError, match="must be smaller than high_sigma"):
+        subtract_background_dog(img, low_sigma=5, high_sigma=2)
+    empty = np.zeros((0, 4), np.uint16)
+    assert rescale_by_percentile(empty).dtype == float and rescale_by_percentile(empty).shape == (0, 4)
+    assert apply_threshold(empty).dtype == bool
+    # crop_to_center is pure slicing on numpy input (a view, as in the reference)
+    big = np.arange(100).reshape(10, 10)
+    c = crop_to_center(big, (4, 6))
+    assert c.shape == (4, 6) and c.base is not None and c[0, 0] == big[3, 2]
+    assert crop_to_center(big, (50, 50)).shape == (10, 10)
+    assert crop_to_center(np.zeros((3, 9, 9)), (5, 3)).shape == (3, 5, 3)
+
+
+# ---- MicroscopyImage (RT/test_microscopy.py + R/microscopy.py:115-131,241-282) ---------------------------
+def _image(arr, chans, axes=None):
+    return MicroscopyImage.from_array(arr, chans, axes)
+
+
+def test_microscopy_image_contract():
+    arr = np.arange(4 * 6 * 5, dtype=np.uint16).reshape(4, 6, 5)
+    im = _image(arr, [BRIGHTFIELD, DAPI, FITC, TRITC])
+    assert im.shape == (4, 6, 5) and im.sizes == {"C": 4, "Y": 6, "X": 5}
+    assert im.num_channels == 4 and im.channel_axis == 0 and [c.name for c in im.channels][1] == "DAPI"
+    d = im.get_channel_intensities(DAPI)
+    assert d.shape == (6, 5) and np.shares_memory(d, arr) and np.array_equal(d, arr[1])
+    assert np.array_equal(im.get_channel_intensities("FITC"), arr[2])
+    with pytest.raises(ValueError, match="Channel 'CY5' not found in image"):
+        im.get_channel_intensities("CY5")
+    assert "MicroscopyImage" in repr(im) and "DAPI" in repr(im)
+    # (T, C, Y, X): channel axis 1, temporal axis preserved
+    t = np.zeros((3, 2, 4, 4), np.uint16)
+    t[:, 1] = 7
+    im4 = _image(t, [DAPI, FITC], "TCYX")
+    assert im4.channel_axis == 1 and im4.get_channel_intensities(FITC).shape == (3, 4, 4)
+    assert im4.get_channel_intensities(FITC).min() == 7
+    # single channel returns everything
+    s = _image(np.zeros((5, 4, 4), np.uint16), [DAPI], "TYX")
+    assert s.get_channel_intensities(DAPI).shape == (5, 4, 4) and s.channel_axis is None
+    with pytest.raises(ValueError, match="does not match metadata sizes"):
+        MicroscopyImage(np.zeros((2, 2), np.uint16), im.metadata)
+    with pytest.warns(amt.MetadataWarning, match="Expected uint16"):
+        _image(np.zeros((4, 4), np.float32), [DAPI])
+    with pytest.raises(ValueError, match="Number of channel metadata entries"):
+        _image(np.zeros((2, 4, 4), np.uint16), [DAPI])
+    out = im.apply_pipeline(Pipeline([ImageOperation(double_intensity)]), DAPI)
+    assert np.array_equal(out, arr[1] * 2)
+
+
+def test_channels():
+    assert CHANNELS["DAPI"] is DAPI and DAPI.excitation_nm == 405
+    with pytest.raises(ValueError, match="hex code"):
+        Channel("X", "red")
+    with pytest.raises(ValueError, match="excitation_nm must be positive"):
+        Channel("X", "#FFF", excitation_nm=-1)
+    assert hash(Channel("A", "#FFFFFF")) == hash(Channel("A", "#FFFFFF"))
+
+
+def test_nd2lite_reads_golden_fixture(golden, tmp_path):
+    """The ND2 chunk walk + lite-variant attributes, on a synthetic file written here (the reference's
+    fixture itself is not available on the GPU box; its pixels are pinned in tests/golden)."""
+    import struct
+
+    from arcadia_microscopy_tools_amd import nd2lite
+
+    px = golden("nd2_multichannel")["pixels"]  # (4, 256, 256)
+    frame = np.ascontiguousarray(px.transpose(1, 2, 0)).astype("<u2").tobytes()
+
+    def lv(typ, name, payload):
+        n = (name + "\x00").encode("utf-16-le")
+        return bytes([typ, len(n) // 2]) + n + payload
+
+    items = b"".join([
+        lv(3, "uiWidth", struct.pack("<I", 256)), lv(3, "uiWidthBytes", struct.pack("<I", 2048)),
+        lv(3, "uiHeight", struct.pack("<I", 256)), lv(3, "uiComp", struct.pack("<I", 4)),
+        lv(2, "uiBpcInMemory", struct.pack("<i", 16)), lv(3, "uiSequenceCount", struct.pack("<I", 1)),
+    ])
+    name = ("SLxImageAttributes" + "\x00").encode("utf-16-le")
+    head = bytes([11, len(name) // 2]) + name
+    attrs = head + struct.pack("<IQ", 6, len(head) + 12 + len(items)) + items + b"\x00" * (6 * 8)
+
+    def chunk(cname, payload):
+        nm = cname + b"\x00" * (32 - len(cname))
+        return struct.pack("<IIQ", 0x0ABECEDA, len(nm), len(payload)) + nm + payload
+
+    blob = b""
+    entries = []
+    for cname, payload in ((b"ImageAttributesLV!", attrs), (b"ImageDataSeq|0!", b"\x00" * 8 + frame)):
+        entries.append((cname, len(blob), len(payload)))
+        blob += chunk(cname, payload)
+    mp = b"".join(c + struct.pack("<QQ", off, size) for c, off, size in entries)
+    mp += b"ND2 CHUNK MAP SIGNATURE 0000001!" + struct.pack("<Q", len(blob))
+    map_off = len(blob)
+    blob += chunk(b"ND2 FILEMAP SIGNATURE NAME 0001!", mp)
+    blob += struct.pack("<Q", map_off)
+    f = tmp_path / "synthetic.nd2"
+    f.write_bytes(blob)
+    arr, meta = nd2lite.load_nd2(f, channels=[BRIGHTFIELD, DAPI, FITC, TRITC], use_device=False)
+    assert arr.shape == (4, 256, 256) and arr.dtype == np.uint16 and np.array_equal(arr, px)
+    assert meta.sizes == {"C": 4, "Y": 256, "X": 256}
+    im = MicroscopyImage.from_nd2_path(f, channels=[BRIGHTFIELD, DAPI, FITC, TRITC]) if False else None
+    assert nd2lite.resolve_optical_config("Mono") is BRIGHTFIELD
+    assert nd2lite.resolve_optical_config("GFP 488 nm") is FITC
+    assert nd2lite.resolve_optical_config("FITC BP") is FITC and nd2lite.resolve_optical_config("zzz") is None
+
+
+# ---- SegmentationMask validation (RT/test_masks.py:297-349) -----------------------------------------------
+def test_segmentation_mask_validation():
+    m = np.zeros((8, 8), np.int64)
+    m[2:5, 2:5] = 1
+    with pytest.raises(TypeError, match="mask_image must be a numpy array"):
+        SegmentationMask(mask_image=[[0, 1]])
+    with pytest.raises(ValueError, match="must be a 2D array"):
+        SegmentationMask(mask_image=np.zeros((2, 2, 2), np.int64))
+    with pytest.raises(ValueError, match="non-negative"):
+        SegmentationMask(mask_image=-m)
+    with pytest.raises(ValueError, match="contains no cells"):
+        SegmentationMask(mask_image=np.zeros((4, 4), np.int64))
+    with pytest.raises(TypeError, match="must be a Mapping"):
+        SegmentationMask(mask_image=m, intensity_image_dict=[m])
+    with pytest.raises(TypeError, match="Intensity image for 'DAPI' must be a numpy array"):
+        SegmentationMask(mask_image=m, intensity_image_dict={DAPI: [[1]]})
+    with pytest.raises(ValueError, match="must be 2D"):
+        SegmentationMask(mask_image=m, intensity_image_dict={DAPI: np.zeros((2, 8, 8))})
+    with pytest.raises(ValueError, match="same shape as mask_image"):
+        SegmentationMask(mask_image=m, intensity_image_dict={DAPI: np.zeros((4, 4))})
+    d = {DAPI: np.zeros((8, 8), np.uint16)}
+    sm = SegmentationMask(mask_image=m, intensity_image_dict=d)
+    assert sm.property_names == DEFAULT_CELL_PROPERTY_NAMES and sm.property_names is not DEFAULT_CELL_PROPERTY_NAMES
+    assert sm.intensity_property_names == ["intensity_mean", "intensity_max", "intensity_min", "intensity_std"]
+    assert sm.intensity_image_dict is not d and sm.intensity_image_dict[DAPI] is d[DAPI]
+    assert SegmentationMask(mask_image=m).intensity_property_names == []
+    with pytest.raises(AttributeError, match="Cannot modify 'mask_image'"):
+        sm.mask_image = m
+    with pytest.raises(AttributeError, match="Cannot modify 'remove_edge_cells'"):
+        sm.remove_edge_cells = False
+
+
+# ---- SegmentationModel parameter handling (RT/test_model.py:40-80,453-490) ----------------------------------
+def test_segmentation_model_parameters():
+    model = SegmentationModel()
+    assert (model.default_cell_diameter_px, model.default_flow_threshold, model.default_cellprob_threshold,
+            model.default_num_iterations, model.default_batch_size) == (30, 0.4, 0, None, 8)
+    p = model._resolve_and_validate_parameters(None, None, None, None, None)
+    assert p == {"diameter": 30, "flow_threshold": 0.4, "cellprob_threshold": 0, "niter": None, "batch_size": 8}
+    p = model._resolve_and_validate_parameters(50, 0.6, 1.0, 200, 16)
+    assert p == {"diameter": 50, "flow_threshold": 0.6, "cellprob_threshold": 1.0, "niter": 200, "batch_size": 16}
+    img = np.zeros((8, 8))
+    with pytest.raises(ValueError, match="Cell diameter .* must be positive"):
+        model.segment(img, cell_diameter_px=-5)
+    with pytest.raises(ValueError, match="Flow threshold must be non-negative"):
+        model.segment(img, flow_threshold=-0.1)
+    with pytest.raises(ValueError, match="between -10 and 10"):
+        model.segment(img, cellprob_threshold=11)
+    with pytest.raises(ValueError, match="between -10 and 10"):
+        model.batch_segment([img], cellprob_threshold=-11, show_progress=False)
+    with pytest.raises(ValueError, match="backend must be"):
+        SegmentationModel(backend="nope")
+    # a failing backend surfaces as RuntimeError from segment() and as warning + None from batch_segment()
+    lib = _hip.load_library()
+    if lib.amt_device_count() == 0:
+        with pytest.raises(RuntimeError, match="Cellpose segmentation failed"):
+            model.segment(img)
+        with pytest.warns(amt.SegmentationWarning, match="failed on image 0"):
+            out = model.batch_segment([img, img], show_progress=False)
+        assert out == [None, None]
+    cp = SegmentationModel(backend="cellpose", device="cpu")
+    with pytest.raises(RuntimeError, match="Failed to load Cellpose model|Cellpose segmentation failed"):
+        cp.segment(img)
+
+
+def test_plate_sharding_and_packing():
+    from arcadia_microscopy_tools_amd import plate, synth
+
+    parts = [plate.shard_indices(384, r, 8) for r in range(8)]
+    assert sorted(sum(parts, [])) == list(range(384)) and all(len(p) == 48 for p in parts)
+    parts = [plate.shard_indices(10, r, 4) for r in range(4)]
+    assert [len(p) for p in parts] == [3, 3, 2, 2] and sorted(sum(parts, [])) == list(range(10))
+    with pytest.raises(ValueError):
+        plate.shard_indices(4, 4, 4)
+    assert synth.well_id(0) == "A01" and synth.well_id(24) == "B01" and synth.well_id(383) == "P24"
+    cols = plate.table_columns(("DAPI", "FITC"))
+    assert cols[:2] == ["fov_index", "label"] and cols[-1] == "intensity_std_fitc" and len(cols) == 2 + 12 + 8
+    t = {c: np.arange(3, dtype=float) for c in cols[1:]}
+    rows = plate.pack_rows([5], [t], ("DAPI", "FITC"))
+    assert rows.shape == (3, len(cols)) and (rows[:, 0] == 5).all() and rows[2, 1] == 2
