@@ -92,78 +92,72 @@ __global__ void __launch_bounds__(256) conv_axis1_kernel(const double* __restric
 
 // ------------------------------------------------------------------------------------------------
 // Fused single-kernel path for small radii (r <= 12): one HBM read of the input, one write of the
-// result; the axis-0 intermediate lives in LDS only.  Tile 32 rows x 64 cols per 256-thread block.
-//   stage 1: load (32 + 2r) x (64 + 2r) samples (converted to f64) into LDS  [src]
-//   stage 2: axis-0 pass for 32 rows x (64 + 2r) columns                    [mid]
-//   stage 3: axis-1 pass for 32 x 64 outputs, written straight to HBM.
-// Each thread keeps a sliding register window along the filter axis so every LDS value is read once
-// per 8 outputs instead of once per tap.
+// result, no intermediate in HBM.
+//   * a 256-thread block owns 256 - 2R output columns (+ R halo columns each side) and a chunk of rows;
+//     thread t owns input column x0 - R + t and slides DOWN it: a register window of 2R+1 converted
+//     samples gives the axis-0 result of one row per step (one new load per row, every load coalesced
+//     across the wave);
+//   * that axis-0 row goes to a double-buffered LDS row; after one barrier the inner threads read
+//     their 2R+1 neighbours from LDS, finish the axis-1 pass and store one float64 each -- a wave writes
+//     512 contiguous bytes;
+//   * both passes use scipy's order: centre tap first, then pairs outermost -> innermost.
+// ~4 KB of LDS and ~64 VGPRs per block: 8 waves per SIMD hide the load latency.
 // ------------------------------------------------------------------------------------------------
-constexpr int FT_H = 32;
-constexpr int FT_W = 64;
 constexpr int FR_MAX = 12;
 
 template <typename TIn, int R>
 __global__ void __launch_bounds__(256) gauss_fused_kernel(const TIn* __restrict__ in, double scale,
                                                           double* __restrict__ out, int H, int W,
                                                           const double* __restrict__ wts, int mode, double cval,
-                                                          size_t in_stride) {
-    constexpr int SW = FT_W + 2 * R;      // staged width
-    constexpr int SH = FT_H + 2 * R;      // staged height
-    constexpr int SWP = SW + 1;           // +1 double of padding against bank conflicts on column walks
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    double* src = reinterpret_cast<double*>(smem_raw);  // SH x SWP
-    double* mid = src + (size_t)SH * SWP;               // FT_H x SWP
-    double* w = mid + (size_t)FT_H * SWP;               // 2R + 1 (kept in the dynamic region: G17)
-    const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H;
+                                                          size_t in_stride, int TH) {
+    constexpr int K = 2 * R + 1;
+    constexpr int OUTW = 256 - 2 * R;
+    __shared__ double rowbuf[2][256];
+    __shared__ double wsh[K];
+    const int t = threadIdx.x;
+    const int x0 = blockIdx.x * OUTW;
+    const int y0 = blockIdx.y * TH;
     const size_t plane = (size_t)blockIdx.z * H * W;
-    const size_t iplane = (size_t)blockIdx.z * in_stride;
-    if (tid < 2 * R + 1) w[tid] = wts[tid];
-    for (int i = tid; i < SH * SW; i += 256) {
-        int ky = i / SW, kx = i - ky * SW;
-        int yy = amt_map_index(y0 - R + ky, H, mode);
-        int xx = amt_map_index(x0 - R + kx, W, mode);
-        double v = cval;
-        if (yy >= 0 && xx >= 0) v = load_as_f64<TIn>(in, iplane + (size_t)yy * W + xx, scale);
-        src[ky * SWP + kx] = v;
-    }
+    const TIn* src = in + (size_t)blockIdx.z * in_stride;
+    if (t < K) wsh[t] = wts[t];
     __syncthreads();
-    // stage 2: SW columns, FT_H rows; a thread owns one column and a strip of 8 rows.
-    // work items = SW * (FT_H / 8)
-    for (int item = tid; item < SW * (FT_H / 8); item += 256) {
-        int col = item % SW;
-        int strip = item / SW;
-        const double* c = src + (size_t)(strip * 8) * SWP + col;  // row (strip*8) of src == y0 - R + strip*8
-        double win[8 + 2 * R];
+    double w[R + 1];  // w[j] = weight at distance j from the centre
 #pragma unroll
-        for (int k = 0; k < 8 + 2 * R; ++k) win[k] = c[(size_t)k * SWP];
+    for (int j = 0; j <= R; ++j) w[j] = wsh[R - j];
+    const int xg = x0 - R + t;
+    const int xm = amt_map_index(xg, W, mode);  // -1: outside in 'constant' mode
+    const bool out_thread = (t >= R) && (t < 256 - R) && (xg < W);
+    auto load_row = [&](int y) -> double {
+        const int yy = amt_map_index(y, H, mode);
+        if (yy < 0 || xm < 0) return cval;
+        return load_as_f64<TIn>(src, (size_t)yy * W + xm, scale);
+    };
+    double win[K];
 #pragma unroll
-        for (int o = 0; o < 8; ++o) {
-            double acc = win[o + R] * w[R];
+    for (int k = 0; k < K - 1; ++k) win[k + 1] = load_row(y0 - R + k);
+    const int rows = (y0 + TH <= H) ? TH : (H - y0);
+    for (int r0 = 0; r0 < rows; r0 += K) {
 #pragma unroll
-            for (int j = R; j >= 1; --j) acc += (win[o + R - j] + win[o + R + j]) * w[R - j];
-            mid[(size_t)(strip * 8 + o) * SWP + col] = acc;
-        }
-    }
-    __syncthreads();
-    // stage 3: FT_H rows x FT_W outputs; a thread owns one row and a strip of 8 consecutive columns.
-    {
-        int row = tid / 8;        // 0..31
-        int strip = tid % 8;      // 0..7 -> columns strip*8 .. strip*8+7
-        const double* c = mid + (size_t)row * SWP + strip * 8;
-        double win[8 + 2 * R];
+        for (int ph = 0; ph < K; ++ph) {
+            const int r = r0 + ph;
+            if (r < rows) {  // uniform across the block
+                // rotate: logical win[i] lives in register (i + ph + 1) % K; the newest sample lands in (ph) % K
+                win[ph % K] = load_row(y0 + r + R);
+                // logical index i -> physical (i + ph + 1) % K
+                double acc = win[(R + ph + 1) % K] * w[0];
 #pragma unroll
-        for (int k = 0; k < 8 + 2 * R; ++k) win[k] = c[k];
-        int y = y0 + row;
-        if (y < H) {
+                for (int j = R; j >= 1; --j) acc += (win[(R - j + ph + 1) % K] + win[(R + j + ph + 1) % K]) * w[j];
+                // scipy extends the axis-0 RESULT with cval along axis 1 in 'constant' mode
+                if (xm < 0) acc = cval;
+                rowbuf[r & 1][t] = acc;
+                __syncthreads();
+                if (out_thread) {
+                    const double* c = &rowbuf[r & 1][t];
+                    double a2 = c[0] * w[0];
 #pragma unroll
-            for (int o = 0; o < 8; ++o) {
-                double acc = win[o + R] * w[R];
-#pragma unroll
-                for (int j = R; j >= 1; --j) acc += (win[o + R - j] + win[o + R + j]) * w[R - j];
-                int x = x0 + strip * 8 + o;
-                if (x < W) out[plane + (size_t)y * W + x] = acc;
+                    for (int j = R; j >= 1; --j) a2 += (c[-j] + c[j]) * w[j];
+                    out[plane + (size_t)(y0 + r) * W + xg] = a2;
+                }
             }
         }
     }
@@ -172,11 +166,14 @@ __global__ void __launch_bounds__(256) gauss_fused_kernel(const TIn* __restrict_
 template <typename TIn, int R>
 static int launch_fused(amt_ctx* ctx, const TIn* in, double scale, double* out, int nplanes, int H, int W,
                         const double* wdev, int mode, double cval, size_t in_stride) {
-    constexpr int SW = FT_W + 2 * R, SH = FT_H + 2 * R, SWP = SW + 1;
-    size_t smem = ((size_t)(SH + FT_H) * SWP + 2 * R + 1) * sizeof(double);
-    dim3 grid((W + FT_W - 1) / FT_W, (H + FT_H - 1) / FT_H, nplanes);
-    hipLaunchKernelGGL((gauss_fused_kernel<TIn, R>), grid, dim3(256), smem, ctx->stream, in, scale, out, H, W, wdev,
-                       mode, cval, in_stride);
+    constexpr int OUTW = 256 - 2 * R;
+    const int gx = (W + OUTW - 1) / OUTW;
+    // rows per block: long chunks amortise the 2R warm-up rows, but keep >= ~4 blocks per CU in flight
+    int TH = 256;
+    while (TH > 32 && (long long)gx * ((H + TH - 1) / TH) * nplanes < 4LL * ctx->num_cus) TH >>= 1;
+    dim3 grid(gx, (H + TH - 1) / TH, nplanes);
+    hipLaunchKernelGGL((gauss_fused_kernel<TIn, R>), grid, dim3(256), 0, ctx->stream, in, scale, out, H, W, wdev,
+                       mode, cval, in_stride, TH);
     AMT_LAUNCH_CHECK();
     return AMT_OK;
 }

@@ -6,135 +6,122 @@
 //   dilation: out[p] = OR_{s in S}  in[p - s]   (outside counts as `border_value`, 0 in skimage)
 // S = the non-zero footprint cells as offsets from the centre.
 //
-// Layout: one 256-thread workgroup produces a 32 x 64 output tile from an LDS-staged input tile with
-// halo; the fused open/close kernels keep the intermediate (tile + one halo) in LDS as well, so a
-// pair of primitives costs one HBM read and one HBM write of the mask.
+// Layout: the mask is packed to one BIT per pixel (a wave ballot turns 64 consecutive pixels into one
+// 64-bit word), the primitives run on the packed rows -- a footprint offset (dy, dx) is one funnel shift
+// of (previous | current | next) word of row y + dy followed by an AND / OR, i.e. |S| word operations
+// per 64 pixels -- and the result is unpacked to bytes.  The packed plane (H * ceil(W / 64) words; 512 KB
+// at 2048^2) lives in L2, so an opening or closing costs one HBM read and one HBM write of the byte mask.
 #include "amt_common.h"
 
-constexpr int MT_H = 32;
-constexpr int MT_W = 64;
+typedef unsigned long long u64;
 constexpr int MAX_OFFS = 1024;
 
-struct offs_t {
-    int n;
-    int ry, rx;  // half extents
-    // dy, dx pairs follow in device memory
-};
+constexpr int PACK_WORDS_PER_WAVE = 16;
 
-// stage `in` (image coords y0-hy .. , x0-hx ..) into LDS; outside image -> `outside`
-__device__ __forceinline__ void stage_tile(const uint8_t* __restrict__ in, size_t plane, int H, int W, int y0, int x0,
-                                           int hy, int hx, int th, int tw, uint8_t* __restrict__ lds, int pitch,
-                                           uint8_t outside) {
-    const int rows = th + 2 * hy, cols = tw + 2 * hx;
-    for (int i = threadIdx.x; i < rows * cols; i += 256) {
-        int ky = i / cols, kx = i - ky * cols;
-        int y = y0 - hy + ky, x = x0 - hx + kx;
-        uint8_t v = outside;
-        if (y >= 0 && y < H && x >= 0 && x < W) v = in[plane + (size_t)y * W + x] ? 1 : 0;
-        lds[ky * pitch + kx] = v;
+__global__ void __launch_bounds__(256) pack_kernel(const uint8_t* __restrict__ in, u64* __restrict__ packed, int H,
+                                                   int W, int WW) {
+    // a wave packs PACK_WORDS_PER_WAVE consecutive words of the (row-major) packed plane: lane i tests
+    // pixel word*64 + i of the word's row; the loads of all iterations are independent
+    const int lane = threadIdx.x & 63;
+    const size_t plane = blockIdx.y;
+    const size_t nwords = (size_t)H * WW;
+    const size_t w0 = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * PACK_WORDS_PER_WAVE;
+    const uint8_t* src = in + plane * (size_t)H * W;
+    bool v[PACK_WORDS_PER_WAVE];
+#pragma unroll
+    for (int k = 0; k < PACK_WORDS_PER_WAVE; ++k) {
+        const size_t wi = w0 + k;
+        v[k] = false;
+        if (wi < nwords) {
+            const int y = (int)(wi / WW), wx = (int)(wi - (size_t)y * WW);
+            const int x = wx * 64 + lane;
+            v[k] = x < W && src[(size_t)y * W + x] != 0;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < PACK_WORDS_PER_WAVE; ++k) {
+        const u64 m = __ballot(v[k]);
+        if (lane == 0 && w0 + k < nwords) packed[plane * nwords + w0 + k] = m;
     }
 }
 
-// one primitive over an LDS region: dst (rows x cols, origin = image (oy, ox)) from src whose origin is
-// (oy - ry, ox - rx).  ERODE: AND over +offsets; DILATE: OR over -offsets.
-// positions of dst outside the image are set to `dst_outside` (border value seen by the NEXT primitive).
+__device__ __forceinline__ unsigned spread4(unsigned nib) {
+    return (nib & 1u) | ((nib & 2u) << 7) | ((nib & 4u) << 14) | ((nib & 8u) << 21);
+}
+
+__global__ void __launch_bounds__(256) unpack_kernel(const u64* __restrict__ packed, uint8_t* __restrict__ out, int H,
+                                                     int W, int WW) {
+    // one thread per 16 pixels of a row (one 16-byte store when W % 16 == 0)
+    const size_t plane = blockIdx.y;
+    const int per_row = (W + 15) / 16;
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= (size_t)H * per_row) return;
+    const int y = (int)(q / per_row);
+    const int x = (int)(q - (size_t)y * per_row) * 16;
+    const u64 w = packed[(plane * H + y) * WW + (x >> 6)];
+    const unsigned bits = (unsigned)(w >> (x & 63)) & 0xFFFFu;
+    uint8_t* o = out + (plane * H + y) * W + x;
+    if ((W & 15) == 0) {
+        uint4 r;
+        r.x = spread4(bits & 0xFu);
+        r.y = spread4((bits >> 4) & 0xFu);
+        r.z = spread4((bits >> 8) & 0xFu);
+        r.w = spread4((bits >> 12) & 0xFu);
+        *reinterpret_cast<uint4*>(o) = r;
+    } else {
+        for (int k = 0; k < 16 && x + k < W; ++k) o[k] = (bits >> k) & 1u;
+    }
+}
+
+// bits of word `wx` of row y as the primitive sees them: outside the image = border (all ones / zeros),
+// and the bits of the last word beyond W also read as border
+__device__ __forceinline__ u64 row_word(const u64* __restrict__ rows, int y, int wx, int H, int WW, int W,
+                                        u64 border) {
+    if (y < 0 || y >= H || wx < 0 || wx >= WW) return border;
+    u64 v = rows[(size_t)y * WW + wx];
+    if (wx == WW - 1 && (W & 63)) {
+        const u64 valid = (1ull << (W & 63)) - 1ull;
+        v = (v & valid) | (border & ~valid);
+    }
+    return v;
+}
+
+// offsets are sorted by dy (row-major footprint scan), so the three words of a source row are loaded once
 template <bool ERODE>
-__device__ __forceinline__ void lds_primitive(const uint8_t* __restrict__ src, int spitch, uint8_t* __restrict__ dst,
-                                              int dpitch, int rows, int cols, int oy, int ox, int H, int W, int ry,
-                                              int rx, const int2* __restrict__ offs, int noffs, uint8_t dst_outside) {
-    for (int i = threadIdx.x; i < rows * cols; i += 256) {
-        int ky = i / cols, kx = i - ky * cols;
-        int y = oy + ky, x = ox + kx;
-        uint8_t r;
-        if (y < 0 || y >= H || x < 0 || x >= W) {
-            r = dst_outside;
-        } else {
-            const uint8_t* c = src + (ky + ry) * spitch + (kx + rx);
-            if (ERODE) {
-                r = 1;
-                for (int k = 0; k < noffs; ++k) r &= c[offs[k].y * spitch + offs[k].x];
-            } else {
-                r = 0;
-                for (int k = 0; k < noffs; ++k) r |= c[-offs[k].y * spitch - offs[k].x];
-            }
-        }
-        dst[ky * dpitch + kx] = r;
-    }
-}
-
-template <bool ERODE>
-__global__ void __launch_bounds__(256) morph1_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int H,
-                                                     int W, const int2* __restrict__ offs_g, int noffs, int ry, int rx,
-                                                     int border_value) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int pitch = MT_W + 2 * rx;
-    uint8_t* tile = reinterpret_cast<uint8_t*>(smem_raw);
-    int2* offs = reinterpret_cast<int2*>(smem_raw + amt_align((size_t)(MT_H + 2 * ry) * pitch, 16));
-    const int x0 = blockIdx.x * MT_W, y0 = blockIdx.y * MT_H;
-    const size_t plane = (size_t)blockIdx.z * H * W;
+__global__ void __launch_bounds__(256) packed_prim_kernel(const u64* __restrict__ in, u64* __restrict__ out, int H,
+                                                          int W, int WW, const int2* __restrict__ offs_g, int noffs,
+                                                          int border_value) {
+    __shared__ int2 offs[MAX_OFFS];
     for (int i = threadIdx.x; i < noffs; i += 256) offs[i] = offs_g[i];
-    stage_tile(in, plane, H, W, y0, x0, ry, rx, MT_H, MT_W, tile, pitch, (uint8_t)(border_value ? 1 : 0));
     __syncthreads();
-    for (int i = threadIdx.x; i < MT_H * MT_W; i += 256) {
-        int ky = i / MT_W, kx = i - ky * MT_W;
-        int y = y0 + ky, x = x0 + kx;
-        if (y >= H || x >= W) continue;
-        const uint8_t* c = tile + (ky + ry) * pitch + (kx + rx);
-        uint8_t r;
-        if (ERODE) {
-            r = 1;
-            for (int k = 0; k < noffs; ++k) r &= c[offs[k].y * pitch + offs[k].x];
-        } else {
-            r = 0;
-            for (int k = 0; k < noffs; ++k) r |= c[-offs[k].y * pitch - offs[k].x];
+    const int wx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (wx >= WW || y >= H) return;
+    const u64* rows = in + (size_t)blockIdx.z * H * WW;
+    const u64 border = border_value ? ~0ull : 0ull;
+    u64 acc = ERODE ? ~0ull : 0ull;
+    int cur_dy = 0x7fffffff;
+    u64 p = 0, c = 0, nx = 0;
+    for (int k = 0; k < noffs; ++k) {
+        // erosion reads in[p + s]; dilation reads in[p - s]
+        const int dy = ERODE ? offs[k].y : -offs[k].y;
+        const int dx = ERODE ? offs[k].x : -offs[k].x;
+        if (dy != cur_dy) {
+            cur_dy = dy;
+            p = row_word(rows, y + dy, wx - 1, H, WW, W, border);
+            c = row_word(rows, y + dy, wx, H, WW, W, border);
+            nx = row_word(rows, y + dy, wx + 1, H, WW, W, border);
         }
-        out[plane + (size_t)y * W + x] = r;
+        u64 v;
+        if (dx == 0)
+            v = c;
+        else if (dx > 0)
+            v = (c >> dx) | (nx << (64 - dx));  // pixel x + dx
+        else
+            v = (c << (-dx)) | (p >> (64 + dx));  // pixel x - |dx|
+        acc = ERODE ? (acc & v) : (acc | v);
     }
-}
-
-// fused pair: OPEN = dilate(erode(x)) ; CLOSE = erode(dilate(x)) with skimage's border rules
-// (erosion sees outside = 1, dilation sees outside = 0).
-template <bool OPEN>
-__global__ void __launch_bounds__(256) morph2_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int H,
-                                                     int W, const int2* __restrict__ offs_g, int noffs, int ry,
-                                                     int rx) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int p0 = MT_W + 4 * rx;  // input tile pitch (halo 2r)
-    const int p1 = MT_W + 2 * rx;  // intermediate pitch (halo r)
-    uint8_t* t0 = reinterpret_cast<uint8_t*>(smem_raw);
-    size_t o1 = amt_align((size_t)(MT_H + 4 * ry) * p0, 16);
-    uint8_t* t1 = t0 + o1;
-    size_t o2 = o1 + amt_align((size_t)(MT_H + 2 * ry) * p1, 16);
-    int2* offs = reinterpret_cast<int2*>(smem_raw + o2);
-    const int x0 = blockIdx.x * MT_W, y0 = blockIdx.y * MT_H;
-    const size_t plane = (size_t)blockIdx.z * H * W;
-    for (int i = threadIdx.x; i < noffs; i += 256) offs[i] = offs_g[i];
-    // first primitive's view of the outside: erosion 1, dilation 0
-    stage_tile(in, plane, H, W, y0, x0, 2 * ry, 2 * rx, MT_H, MT_W, t0, p0, (uint8_t)(OPEN ? 1 : 0));
-    __syncthreads();
-    // intermediate on tile + halo r; outside positions as the SECOND primitive sees them
-    if (OPEN)
-        lds_primitive<true>(t0, p0, t1, p1, MT_H + 2 * ry, MT_W + 2 * rx, y0 - ry, x0 - rx, H, W, ry, rx, offs, noffs,
-                            (uint8_t)0);
-    else
-        lds_primitive<false>(t0, p0, t1, p1, MT_H + 2 * ry, MT_W + 2 * rx, y0 - ry, x0 - rx, H, W, ry, rx, offs, noffs,
-                             (uint8_t)1);
-    __syncthreads();
-    for (int i = threadIdx.x; i < MT_H * MT_W; i += 256) {
-        int ky = i / MT_W, kx = i - ky * MT_W;
-        int y = y0 + ky, x = x0 + kx;
-        if (y >= H || x >= W) continue;
-        const uint8_t* c = t1 + (ky + ry) * p1 + (kx + rx);
-        uint8_t r;
-        if (OPEN) {
-            r = 0;
-            for (int k = 0; k < noffs; ++k) r |= c[-offs[k].y * p1 - offs[k].x];
-        } else {
-            r = 1;
-            for (int k = 0; k < noffs; ++k) r &= c[offs[k].y * p1 + offs[k].x];
-        }
-        out[plane + (size_t)y * W + x] = r;
-    }
+    out[((size_t)blockIdx.z * H + y) * WW + wx] = acc;
 }
 
 static int build_offsets(const uint8_t* fp, int fh, int fw, int2* host, int* n) {
@@ -155,39 +142,56 @@ static int build_offsets(const uint8_t* fp, int fh, int fw, int2* host, int* n) 
     return AMT_OK;
 }
 
+// which: 0 erode, 1 dilate, 2 open (erode then dilate), 3 close (dilate then erode)
 static int morph_common(amt_ctx* ctx, const uint8_t* in, uint8_t* out, int nplanes, int H, int W,
                         const uint8_t* footprint, int fh, int fw, int which, int border_value) {
     AMT_TRY(amt_set_device(ctx));
     AMT_REQUIRE(in && out && nplanes >= 0 && H > 0 && W > 0, "binary morphology: bad arguments");
-    AMT_REQUIRE(in != out, "binary morphology: in-place operation is not supported");
-    int2 host[MAX_OFFS];
+    static thread_local int2 host[MAX_OFFS];
     int noffs = 0;
     AMT_TRY(build_offsets(footprint, fh, fw, host, &noffs));
     if (nplanes == 0) return AMT_OK;
-    const int ry = fh / 2, rx = fw / 2;
-    AMT_TRY(amt_arena_begin(ctx, amt_align(sizeof(int2) * noffs)));
+    const int WW = (W + 63) / 64;
+    const size_t words = (size_t)nplanes * H * WW;
+    AMT_TRY(amt_arena_begin(ctx, amt_align(sizeof(int2) * noffs) + 2 * amt_align(words * 8)));
     int2* offs = arena_take_t<int2>(ctx, noffs);
+    u64* pa = arena_take_t<u64>(ctx, words);
+    u64* pb = arena_take_t<u64>(ctx, words);
     AMT_TRY(amt_param_upload(ctx, offs, host, sizeof(int2) * noffs));
-    dim3 grid((W + MT_W - 1) / MT_W, (H + MT_H - 1) / MT_H, nplanes);
-    if (which <= 1) {
-        size_t smem = amt_align((size_t)(MT_H + 2 * ry) * (MT_W + 2 * rx), 16) + sizeof(int2) * noffs;
-        if (which == 0)
-            hipLaunchKernelGGL((morph1_kernel<true>), grid, dim3(256), smem, ctx->stream, in, out, H, W, offs, noffs, ry,
-                               rx, border_value);
-        else
-            hipLaunchKernelGGL((morph1_kernel<false>), grid, dim3(256), smem, ctx->stream, in, out, H, W, offs, noffs,
-                               ry, rx, border_value);
-    } else {
-        size_t smem = amt_align((size_t)(MT_H + 4 * ry) * (MT_W + 4 * rx), 16) +
-                      amt_align((size_t)(MT_H + 2 * ry) * (MT_W + 2 * rx), 16) + sizeof(int2) * noffs;
-        AMT_REQUIRE(smem <= 160 * 1024, "footprint %d x %d too large for the fused open/close kernel", fh, fw);
-        if (which == 2)
-            hipLaunchKernelGGL((morph2_kernel<true>), grid, dim3(256), smem, ctx->stream, in, out, H, W, offs, noffs, ry,
-                               rx);
-        else
-            hipLaunchKernelGGL((morph2_kernel<false>), grid, dim3(256), smem, ctx->stream, in, out, H, W, offs, noffs,
-                               ry, rx);
+    const size_t nwords = (size_t)H * WW;
+    const unsigned gpack = (unsigned)((nwords + 4 * PACK_WORDS_PER_WAVE - 1) / (4 * PACK_WORDS_PER_WAVE));
+    hipLaunchKernelGGL(pack_kernel, dim3(gpack, nplanes), dim3(256), 0, ctx->stream, in, pa, H, W, WW);
+    AMT_LAUNCH_CHECK();
+    dim3 gp((WW + 63) / 64, (H + 3) / 4, nplanes);
+    u64* result = pb;
+    switch (which) {
+        case 0:
+            hipLaunchKernelGGL((packed_prim_kernel<true>), gp, dim3(256), 0, ctx->stream, pa, pb, H, W, WW, offs, noffs,
+                               border_value);
+            break;
+        case 1:
+            hipLaunchKernelGGL((packed_prim_kernel<false>), gp, dim3(256), 0, ctx->stream, pa, pb, H, W, WW, offs, noffs,
+                               border_value);
+            break;
+        case 2:  // skimage: erosion sees outside = 1, dilation sees outside = 0
+            hipLaunchKernelGGL((packed_prim_kernel<true>), gp, dim3(256), 0, ctx->stream, pa, pb, H, W, WW, offs, noffs, 1);
+            AMT_LAUNCH_CHECK();
+            hipLaunchKernelGGL((packed_prim_kernel<false>), gp, dim3(256), 0, ctx->stream, pb, pa, H, W, WW, offs, noffs,
+                               0);
+            result = pa;
+            break;
+        default:
+            hipLaunchKernelGGL((packed_prim_kernel<false>), gp, dim3(256), 0, ctx->stream, pa, pb, H, W, WW, offs, noffs,
+                               0);
+            AMT_LAUNCH_CHECK();
+            hipLaunchKernelGGL((packed_prim_kernel<true>), gp, dim3(256), 0, ctx->stream, pb, pa, H, W, WW, offs, noffs, 1);
+            result = pa;
+            break;
     }
+    AMT_LAUNCH_CHECK();
+    const size_t nq = (size_t)H * ((W + 15) / 16);
+    hipLaunchKernelGGL(unpack_kernel, dim3((unsigned)((nq + 255) / 256), nplanes), dim3(256), 0, ctx->stream, result, out,
+                       H, W, WW);
     AMT_LAUNCH_CHECK();
     return AMT_OK;
 }
