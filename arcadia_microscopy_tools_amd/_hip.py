@@ -94,6 +94,7 @@ _SIGS = {
     "amt_watershed_f64": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int]),
     "amt_regionprops": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int]),
     "amt_regionprops_intensity_u16": (c_int, [_P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int]),
+    "amt_regionprops_full_u16": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int]),
     "amt_max_i32": (c_int, [_P, _P, _P, c_int, c_size_t]),
 }
 

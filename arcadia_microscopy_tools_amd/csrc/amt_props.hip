@@ -29,41 +29,189 @@ __global__ void __launch_bounds__(256) rp_init_kernel(u64* __restrict__ acc, int
 
 __device__ __forceinline__ u64 sum_sq_upto(u64 m) { return m * (m + 1) * (2 * m + 1) / 6; }  // 0^2 + ... + m^2
 
-// moments + bbox + (optionally) per-row extents for the convex hull
-__global__ void __launch_bounds__(256) rp_moments_kernel(const int* __restrict__ labels, u64* __restrict__ acc,
-                                                         int* __restrict__ bbox, int H, int W, int max_label) {
+// exact a*b - c*d for 64-bit operands, as a double (the difference itself must fit in 127 bits)
+__device__ __forceinline__ double diff_of_products(u64 a, u64 b, u64 c, u64 d) {
+    u64 lo1 = a * b, hi1 = __umul64hi(a, b);
+    u64 lo2 = c * d, hi2 = __umul64hi(c, d);
+    // (hi1:lo1) - (hi2:lo2), signed
+    bool neg = (hi1 < hi2) || (hi1 == hi2 && lo1 < lo2);
+    u64 hi, lo;
+    if (!neg) {
+        lo = lo1 - lo2;
+        hi = hi1 - hi2 - (lo1 < lo2 ? 1 : 0);
+    } else {
+        lo = lo2 - lo1;
+        hi = hi2 - hi1 - (lo2 < lo1 ? 1 : 0);
+    }
+    double v = (double)hi * 18446744073709551616.0 + (double)lo;
+    return neg ? -v : v;
+}
+
+// bounding boxes: a wave covers 64 consecutive pixels of 8 rows (all 8 loads issued up front); every
+// run of equal labels costs one set of min/max atomics.
+__global__ void __launch_bounds__(256) rp_bbox_kernel(const int* __restrict__ labels, int* __restrict__ bbox, int H,
+                                                      int W, int max_label) {
     const int lane = threadIdx.x & 63;
     const int x = blockIdx.x * 64 + lane;
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (y >= H) return;
+    const int yb = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 8;
+    if (yb >= H) return;
     const size_t n = (size_t)H * W;
     const int plane = blockIdx.z;
-    int lab = 0;
-    if (x < W) lab = labels[(size_t)plane * n + (size_t)y * W + x];
-    if (lab < 0 || lab > max_label) lab = 0;
-    const int left = __shfl_up(lab, 1);
-    const bool head = (lane == 0) || (left != lab);
-    const u64 heads = __ballot(head);
-    if (lab != 0 && head) {
-        // run end = lane before the next head
-        u64 later = heads & ~((2ull << lane) - 1ull);
-        int end_lane = later ? (__ffsll((long long)later) - 2) : 63;
-        u64 a = (u64)x, b = (u64)(x + (end_lane - lane));
-        u64 len = b - a + 1;
-        u64 sx = (a + b) * len / 2;
-        u64 sxx = sum_sq_upto(b) - (a ? sum_sq_upto(a - 1) : 0);
-        u64* A = acc + ((size_t)plane * max_label + (lab - 1)) * A_NACC;
-        atomicAdd(&A[A_N], len);
-        atomicAdd(&A[A_SY], (u64)y * len);
-        atomicAdd(&A[A_SX], sx);
-        atomicAdd(&A[A_SYY], (u64)y * (u64)y * len);
-        atomicAdd(&A[A_SXX], sxx);
-        atomicAdd(&A[A_SXY], (u64)y * sx);
-        int* B = bbox + ((size_t)plane * max_label + (lab - 1)) * 4;
-        atomicMin(&B[0], y);
-        atomicMin(&B[1], (int)a);
-        atomicMax(&B[2], y);
-        atomicMax(&B[3], (int)b);
+    int labs[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int y = yb + k;
+        int v = 0;
+        if (x < W && y < H) v = labels[(size_t)plane * n + (size_t)y * W + x];
+        labs[k] = (v < 0 || v > max_label) ? 0 : v;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int lab = labs[k];
+        const int left = __shfl_up(lab, 1);
+        const bool head = (lane == 0) || (left != lab);
+        const u64 heads = __ballot(head);
+        if (lab != 0 && head) {
+            const u64 later = heads & ~((2ull << lane) - 1ull);
+            const int end_lane = later ? (__ffsll((long long)later) - 2) : 63;
+            int* B = bbox + ((size_t)plane * max_label + (lab - 1)) * 4;
+            atomicMin(&B[0], yb + k);
+            atomicMin(&B[1], x);
+            atomicMax(&B[2], yb + k);
+            atomicMax(&B[3], x + (end_lane - lane));
+        }
+    }
+}
+
+__device__ __forceinline__ u64 wave_sum_u64(u64 v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        unsigned t = __shfl_xor(v, off);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        unsigned t = __shfl_xor(v, off);
+        v = t > v ? t : v;
+    }
+    return v;
+}
+
+// One wave per label scans the label's bounding box (and nothing else): exact integer moment sums,
+// per-row extents for the convex hull, and {sum, sum of squares, min, max} of up to 4 intensity channels
+// per call, all accumulated privately per lane and reduced once -- no atomics, run-to-run identical.
+constexpr int RP_MAXC = 4;
+__global__ void __launch_bounds__(64) rp_label_kernel(const int* __restrict__ labels, const int* __restrict__ bbox,
+                                                      const int* __restrict__ hoff, const int* __restrict__ htot,
+                                                      int2* __restrict__ rows, size_t cap, u64* __restrict__ acc,
+                                                      const uint16_t* __restrict__ inten, int C, int c0, int nc,
+                                                      double* __restrict__ itable, int H, int W, int max_label,
+                                                      int want_morph) {
+    const int plane = blockIdx.y;
+    const int l = blockIdx.x;
+    const int lane = threadIdx.x;
+    const size_t li = (size_t)plane * max_label + l;
+    const int y0 = bbox[li * 4 + 0], x0 = bbox[li * 4 + 1], y1 = bbox[li * 4 + 2], x1 = bbox[li * 4 + 3];
+    if (y1 < y0) {  // label absent from this plane
+        if (itable && lane < 4 * nc) itable[(li * C + c0) * 4 + lane] = 0.0;
+        return;
+    }
+    const size_t n = (size_t)H * W;
+    const int* L = labels + (size_t)plane * n;
+    const uint16_t* I = inten ? inten + ((size_t)plane * C + c0) * n : nullptr;
+    const int want = l + 1;
+    const bool rows_ok = want_morph && (size_t)htot[plane] <= cap;
+    int2* myrows = rows + (size_t)plane * cap + (size_t)hoff[li];
+    u64 cnt = 0, sy = 0, sx = 0, syy = 0, sxx = 0, sxy = 0;
+    u64 s[RP_MAXC], q[RP_MAXC];
+    unsigned mn[RP_MAXC], mx[RP_MAXC];
+#pragma unroll
+    for (int c = 0; c < RP_MAXC; ++c) {
+        s[c] = 0;
+        q[c] = 0;
+        mn[c] = 0xffffffffu;
+        mx[c] = 0;
+    }
+    for (int y = y0; y <= y1; ++y) {
+        int rmin = 0x7fffffff, rmax = -1;
+        for (int xb = x0; xb <= x1; xb += 64) {
+            const int x = xb + lane;
+            const bool m = x <= x1 && L[(size_t)y * W + x] == want;
+            if (m) {
+                cnt += 1;
+                sy += (u64)y;
+                sx += (u64)x;
+                syy += (u64)y * (u64)y;
+                sxx += (u64)x * (u64)x;
+                sxy += (u64)y * (u64)x;
+                if (I) {
+#pragma unroll
+                    for (int c = 0; c < RP_MAXC; ++c)
+                        if (c < nc) {
+                            const unsigned v = I[(size_t)c * n + (size_t)y * W + x];
+                            s[c] += v;
+                            q[c] += (u64)v * v;
+                            mn[c] = v < mn[c] ? v : mn[c];
+                            mx[c] = v > mx[c] ? v : mx[c];
+                        }
+                }
+            }
+            const u64 bal = __ballot(m);
+            if (bal) {
+                const int first = xb + __ffsll((long long)bal) - 1;
+                const int last = xb + 63 - __clzll((long long)bal);
+                rmin = first < rmin ? first : rmin;
+                rmax = last > rmax ? last : rmax;
+            }
+        }
+        if (rows_ok && lane == 0) myrows[y - y0] = make_int2(rmin, rmax);
+    }
+    cnt = wave_sum_u64(cnt);
+    if (want_morph) {
+        sy = wave_sum_u64(sy);
+        sx = wave_sum_u64(sx);
+        syy = wave_sum_u64(syy);
+        sxx = wave_sum_u64(sxx);
+        sxy = wave_sum_u64(sxy);
+        if (lane == 0) {
+            u64* A = acc + li * A_NACC;
+            A[A_N] = cnt;
+            A[A_SY] = sy;
+            A[A_SX] = sx;
+            A[A_SYY] = syy;
+            A[A_SXX] = sxx;
+            A[A_SXY] = sxy;
+        }
+    }
+    if (itable) {
+#pragma unroll
+        for (int c = 0; c < RP_MAXC; ++c)
+            if (c < nc) {
+                const u64 S = wave_sum_u64(s[c]), Q = wave_sum_u64(q[c]);
+                const unsigned lo = wave_min_u32(mn[c]), hi = wave_max_u32(mx[c]);
+                if (lane == 0) {
+                    double* t = itable + (li * C + c0 + c) * 4;
+                    if (cnt == 0) {
+                        t[0] = t[1] = t[2] = t[3] = 0.0;
+                    } else {
+                        const double dn = (double)cnt;
+                        t[0] = (double)S / dn;
+                        t[1] = (double)hi;
+                        t[2] = (double)lo;
+                        const double nv = diff_of_products(cnt, Q, S, S);  // n*Sxx - Sx^2 = n^2 * var
+                        const double var = nv / (dn * dn);
+                        t[3] = sqrt(var < 0.0 ? 0.0 : var);
+                    }
+                }
+            }
     }
 }
 
@@ -127,43 +275,6 @@ __global__ void __launch_bounds__(256) rp_heights_kernel(const int* __restrict__
     for (int l = blockIdx.x * 256 + threadIdx.x; l < max_label; l += gridDim.x * 256) {
         const int* B = bbox + ((size_t)plane * max_label + l) * 4;
         hoff[(size_t)plane * max_label + l] = B[2] >= B[0] ? B[2] - B[0] + 1 : 0;
-    }
-}
-
-__global__ void __launch_bounds__(256) rp_rows_init_kernel(int2* __restrict__ rows, const int* __restrict__ total,
-                                                           size_t cap) {
-    int2* r = rows + (size_t)blockIdx.y * cap;
-    size_t tot = (size_t)total[blockIdx.y];
-    if (tot > cap) tot = cap;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (size_t)gridDim.x * 256)
-        r[i] = make_int2(0x7fffffff, -1);
-}
-
-__global__ void __launch_bounds__(256) rp_rows_fill_kernel(const int* __restrict__ labels, const int* __restrict__ bbox,
-                                                           const int* __restrict__ hoff, int2* __restrict__ rows,
-                                                           size_t cap, int H, int W, int max_label) {
-    const int lane = threadIdx.x & 63;
-    const int x = blockIdx.x * 64 + lane;
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (y >= H) return;
-    const size_t n = (size_t)H * W;
-    const int plane = blockIdx.z;
-    int lab = 0;
-    if (x < W) lab = labels[(size_t)plane * n + (size_t)y * W + x];
-    if (lab < 0 || lab > max_label) lab = 0;
-    const int left = __shfl_up(lab, 1);
-    const bool head = (lane == 0) || (left != lab);
-    const u64 heads = __ballot(head);
-    if (lab != 0 && head) {
-        u64 later = heads & ~((2ull << lane) - 1ull);
-        int end_lane = later ? (__ffsll((long long)later) - 2) : 63;
-        const size_t li = (size_t)plane * max_label + (lab - 1);
-        size_t idx = (size_t)hoff[li] + (size_t)(y - bbox[li * 4 + 0]);
-        if (idx < cap) {
-            int2* r = rows + (size_t)plane * cap + idx;
-            atomicMin(&r->x, x);
-            atomicMax(&r->y, x + (end_lane - lane));
-        }
     }
 }
 
@@ -290,24 +401,6 @@ __global__ void __launch_bounds__(64) rp_hull_kernel(const int* __restrict__ bbo
 }
 
 // ---- final per-label columns ------------------------------------------------------------------------
-// exact a*b - c*d for 64-bit operands, as a double (the difference itself must fit in 127 bits)
-__device__ __forceinline__ double diff_of_products(u64 a, u64 b, u64 c, u64 d) {
-    u64 lo1 = a * b, hi1 = __umul64hi(a, b);
-    u64 lo2 = c * d, hi2 = __umul64hi(c, d);
-    // (hi1:lo1) - (hi2:lo2), signed
-    bool neg = (hi1 < hi2) || (hi1 == hi2 && lo1 < lo2);
-    u64 hi, lo;
-    if (!neg) {
-        lo = lo1 - lo2;
-        hi = hi1 - hi2 - (lo1 < lo2 ? 1 : 0);
-    } else {
-        lo = lo2 - lo1;
-        hi = hi2 - hi1 - (lo2 < lo1 ? 1 : 0);
-    }
-    double v = (double)hi * 18446744073709551616.0 + (double)lo;
-    return neg ? -v : v;
-}
-
 __global__ void __launch_bounds__(256) rp_final_kernel(const u64* __restrict__ acc, const int* __restrict__ bbox,
                                                        double* __restrict__ table, size_t nlab) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nlab; i += (size_t)gridDim.x * 256) {
@@ -364,14 +457,15 @@ __global__ void __launch_bounds__(256) rp_solidity_kernel(double* __restrict__ t
     }
 }
 
-extern "C" int amt_regionprops(amt_ctx* ctx, const int32_t* labels, double* table_dev, int nplanes, int H, int W,
-                               int max_label) {
+// want_morph: fill the AMT_RP_* table; itable != NULL: fill {mean, max, min, std} per label and channel
+static int regionprops_common(amt_ctx* ctx, const int32_t* labels, const uint16_t* intensity, int C, double* table_dev,
+                              double* itable_dev, int nplanes, int H, int W, int max_label) {
     AMT_TRY(amt_set_device(ctx));
-    AMT_REQUIRE(labels && table_dev && nplanes >= 0 && H > 0 && W > 0 && max_label >= 0, "regionprops: bad arguments");
+    const bool want_morph = table_dev != nullptr;
     if (nplanes == 0 || max_label == 0) return AMT_OK;
     const size_t n = (size_t)H * W;
     const size_t nlab = (size_t)nplanes * max_label;
-    const size_t cap = n;  // row-extent entries per plane (sum of bbox heights; <= n for connected labels)
+    const size_t cap = want_morph ? n : 1;  // row-extent entries per plane (sum of bbox heights)
     size_t need = amt_align(nlab * A_NACC * 8) + amt_align(nlab * 16) + amt_align(nlab * 4) + amt_align(nplanes * 4) +
                   amt_align((size_t)nplanes * cap * 8) + 2 * amt_align((size_t)nplanes * 3 * cap * 8);
     AMT_TRY(amt_arena_begin(ctx, need));
@@ -384,153 +478,60 @@ extern "C" int amt_regionprops(amt_ctx* ctx, const int32_t* labels, double* tabl
     int2* chainR = arena_take_t<int2>(ctx, (size_t)nplanes * 3 * cap);
     hipLaunchKernelGGL(rp_init_kernel, dim3(amt_grid_for(nlab, 256, 1024)), dim3(256), 0, ctx->stream, acc, bbox, nlab);
     AMT_LAUNCH_CHECK();
-    dim3 gpix((W + 63) / 64, (H + 3) / 4, nplanes);
-    hipLaunchKernelGGL(rp_moments_kernel, gpix, dim3(256), 0, ctx->stream, labels, acc, bbox, H, W, max_label);
+    hipLaunchKernelGGL(rp_bbox_kernel, dim3((W + 63) / 64, (H + 31) / 32, nplanes), dim3(256), 0, ctx->stream, labels,
+                       bbox, H, W, max_label);
     AMT_LAUNCH_CHECK();
-    dim3 gper((W + PT_W - 1) / PT_W, (H + PT_H - 1) / PT_H, nplanes);
-    hipLaunchKernelGGL(rp_perimeter_kernel, gper, dim3(256), 0, ctx->stream, labels, acc, H, W, max_label);
-    AMT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(rp_final_kernel, dim3(amt_grid_for(nlab, 256, 1024)), dim3(256), 0, ctx->stream, acc, bbox,
-                       table_dev, nlab);
-    AMT_LAUNCH_CHECK();
-    // convex area
     hipLaunchKernelGGL(rp_heights_kernel, dim3(amt_grid_for(max_label, 256, 256), nplanes), dim3(256), 0, ctx->stream,
                        bbox, hoff, max_label);
     AMT_LAUNCH_CHECK();
     AMT_TRY(amt_scan_excl(ctx, hoff, max_label, (size_t)max_label, htot, nplanes));
-    hipLaunchKernelGGL(rp_rows_init_kernel, dim3(512, nplanes), dim3(256), 0, ctx->stream, rows, htot, cap);
-    AMT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(rp_rows_fill_kernel, gpix, dim3(256), 0, ctx->stream, labels, bbox, hoff, rows, cap, H, W,
-                       max_label);
-    AMT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(rp_hull_kernel, dim3((max_label + 63) / 64, nplanes), dim3(64), 0, ctx->stream, bbox, hoff, htot,
-                       rows, chainL, chainR, cap, table_dev, max_label);
-    AMT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(rp_solidity_kernel, dim3(amt_grid_for(nlab, 256, 1024)), dim3(256), 0, ctx->stream, table_dev,
-                       nlab);
-    AMT_LAUNCH_CHECK();
+    if (want_morph) {
+        dim3 gper((W + PT_W - 1) / PT_W, (H + PT_H - 1) / PT_H, nplanes);
+        hipLaunchKernelGGL(rp_perimeter_kernel, gper, dim3(256), 0, ctx->stream, labels, acc, H, W, max_label);
+        AMT_LAUNCH_CHECK();
+    }
+    // per-label scan: moments + row extents on the first call, intensity channels in groups of RP_MAXC
+    const int groups = intensity ? (C + RP_MAXC - 1) / RP_MAXC : 1;
+    for (int g = 0; g < groups; ++g) {
+        const int c0 = g * RP_MAXC;
+        const int nc = intensity ? ((C - c0) < RP_MAXC ? (C - c0) : RP_MAXC) : 0;
+        hipLaunchKernelGGL(rp_label_kernel, dim3(max_label, nplanes), dim3(64), 0, ctx->stream, labels, bbox, hoff, htot,
+                           rows, cap, acc, intensity, C, c0, nc, intensity ? itable_dev : (double*)nullptr, H, W,
+                           max_label, (want_morph && g == 0) ? 1 : 0);
+        AMT_LAUNCH_CHECK();
+    }
+    if (want_morph) {
+        hipLaunchKernelGGL(rp_final_kernel, dim3(amt_grid_for(nlab, 256, 1024)), dim3(256), 0, ctx->stream, acc, bbox,
+                           table_dev, nlab);
+        AMT_LAUNCH_CHECK();
+        hipLaunchKernelGGL(rp_hull_kernel, dim3((max_label + 63) / 64, nplanes), dim3(64), 0, ctx->stream, bbox, hoff,
+                           htot, rows, chainL, chainR, cap, table_dev, max_label);
+        AMT_LAUNCH_CHECK();
+        hipLaunchKernelGGL(rp_solidity_kernel, dim3(amt_grid_for(nlab, 256, 1024)), dim3(256), 0, ctx->stream,
+                           table_dev, nlab);
+        AMT_LAUNCH_CHECK();
+    }
     return AMT_OK;
 }
 
-// ---- intensity statistics ----------------------------------------------------------------------------
-// per (plane, label, channel): sum, sum of squares (u64), min, max (u32)
-__global__ void __launch_bounds__(256) rpi_init_kernel(u64* __restrict__ s, unsigned* __restrict__ mm, size_t cnt) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < cnt; i += (size_t)gridDim.x * 256) {
-        s[2 * i] = 0;
-        s[2 * i + 1] = 0;
-        mm[2 * i] = 0xffffffffu;
-        mm[2 * i + 1] = 0;
-    }
-}
-
-__global__ void __launch_bounds__(256) rpi_accum_kernel(const int* __restrict__ labels,
-                                                        const uint16_t* __restrict__ inten, int C, u64* __restrict__ s,
-                                                        unsigned* __restrict__ mm, u64* __restrict__ cnt, int H, int W,
-                                                        int max_label) {
-    const int lane = threadIdx.x & 63;
-    const int x = blockIdx.x * 64 + lane;
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (y >= H) return;
-    const size_t n = (size_t)H * W;
-    const int plane = blockIdx.z;
-    int lab = 0;
-    if (x < W) lab = labels[(size_t)plane * n + (size_t)y * W + x];
-    if (lab < 0 || lab > max_label) lab = 0;
-    const int left = __shfl_up(lab, 1);
-    const bool head = (lane == 0) || (left != lab);
-    const u64 heads = __ballot(head);
-    const u64 any = __ballot(lab != 0);
-    if (!any) return;
-    // start lane of my run = highest head at or before me ; end lane = lane before next head
-    const u64 upto = heads & ((2ull << lane) - 1ull);
-    const int start_lane = 63 - __clzll((long long)upto);
-    const u64 later = heads & ~((2ull << lane) - 1ull);
-    const int end_lane = later ? (__ffsll((long long)later) - 2) : 63;
-    const size_t pix = (size_t)y * W + (x < W ? x : W - 1);
-    if (cnt && lab != 0 && head) atomicAdd(&cnt[(size_t)plane * max_label + (lab - 1)], (u64)(end_lane - lane + 1));
-    for (int c = 0; c < C; ++c) {
-        unsigned v = (x < W) ? inten[((size_t)plane * C + c) * n + pix] : 0u;
-        // wave inclusive prefix sums of v and v^2
-        unsigned ps = v;
-        u64 pq = (u64)v * v;
-        unsigned mn = v, mx = v;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            unsigned t = __shfl_up(ps, off);
-            u64 tq = __shfl_up(pq, off);
-            if (lane >= off) {
-                ps += t;
-                pq += tq;
-            }
-            // segmented min/max: combine with lane+off while it stays inside the run
-            unsigned tmn = __shfl_down(mn, off), tmx = __shfl_down(mx, off);
-            if (lane + off <= end_lane) {
-                mn = tmn < mn ? tmn : mn;
-                mx = tmx > mx ? tmx : mx;
-            }
-        }
-        // run totals at the head lane: prefix[end] - prefix[start-1]
-        unsigned pe = __shfl(ps, end_lane);
-        u64 qe = __shfl(pq, end_lane);
-        unsigned pb = __shfl(ps, start_lane > 0 ? start_lane - 1 : 0);
-        u64 qb = __shfl(pq, start_lane > 0 ? start_lane - 1 : 0);
-        if (start_lane == 0) {
-            pb = 0;
-            qb = 0;
-        }
-        if (lab != 0 && head) {
-            size_t k = ((size_t)plane * max_label + (lab - 1)) * C + c;
-            atomicAdd(&s[2 * k], (u64)(pe - pb));
-            atomicAdd(&s[2 * k + 1], qe - qb);
-            atomicMin(&mm[2 * k], mn);
-            atomicMax(&mm[2 * k + 1], mx);
-        }
-    }
-}
-
-__global__ void __launch_bounds__(256) rpi_final_kernel(const u64* __restrict__ s, const unsigned* __restrict__ mm,
-                                                        const u64* __restrict__ cnt, double* __restrict__ table, int C,
-                                                        size_t nlab) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nlab * C; i += (size_t)gridDim.x * 256) {
-        const size_t li = i / C;
-        const u64 n = cnt[li];
-        double* t = table + i * 4;
-        if (n == 0) {
-            t[0] = t[1] = t[2] = t[3] = 0.0;
-            continue;
-        }
-        const double dn = (double)n;
-        t[0] = (double)s[2 * i] / dn;
-        t[1] = (double)mm[2 * i + 1];
-        t[2] = (double)mm[2 * i];
-        double nv = diff_of_products(n, s[2 * i + 1], s[2 * i], s[2 * i]);  // n*Sxx - Sx^2 = n^2 * var
-        double var = nv / (dn * dn);
-        t[3] = sqrt(var < 0.0 ? 0.0 : var);
-    }
+extern "C" int amt_regionprops(amt_ctx* ctx, const int32_t* labels, double* table_dev, int nplanes, int H, int W,
+                               int max_label) {
+    AMT_REQUIRE(labels && table_dev && nplanes >= 0 && H > 0 && W > 0 && max_label >= 0, "regionprops: bad arguments");
+    return regionprops_common(ctx, labels, nullptr, 0, table_dev, nullptr, nplanes, H, W, max_label);
 }
 
 extern "C" int amt_regionprops_intensity_u16(amt_ctx* ctx, const int32_t* labels, const uint16_t* intensity, int C,
                                              double* table_dev, int nplanes, int H, int W, int max_label) {
-    AMT_TRY(amt_set_device(ctx));
     AMT_REQUIRE(labels && intensity && table_dev && nplanes >= 0 && H > 0 && W > 0 && max_label >= 0 && C >= 1,
                 "regionprops_intensity: bad arguments");
-    if (nplanes == 0 || max_label == 0) return AMT_OK;
-    const size_t nlab = (size_t)nplanes * max_label;
-    size_t need = amt_align(nlab * C * 16) + amt_align(nlab * C * 8) + amt_align(nlab * 8);
-    AMT_TRY(amt_arena_begin(ctx, need));
-    u64* s = arena_take_t<u64>(ctx, nlab * C * 2);
-    unsigned* mm = arena_take_t<unsigned>(ctx, nlab * C * 2);
-    u64* cnt = arena_take_t<u64>(ctx, nlab);
-    AMT_HIP_CHECK(hipMemsetAsync(cnt, 0, nlab * 8, ctx->stream));
-    hipLaunchKernelGGL(rpi_init_kernel, dim3(amt_grid_for(nlab * C, 256, 1024)), dim3(256), 0, ctx->stream, s, mm,
-                       nlab * C);
-    AMT_LAUNCH_CHECK();
-    dim3 gpix((W + 63) / 64, (H + 3) / 4, nplanes);
-    hipLaunchKernelGGL(rpi_accum_kernel, gpix, dim3(256), 0, ctx->stream, labels, intensity, C, s, mm, cnt, H, W,
-                       max_label);
-    AMT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(rpi_final_kernel, dim3(amt_grid_for(nlab * C, 256, 1024)), dim3(256), 0, ctx->stream, s, mm, cnt,
-                       table_dev, C, nlab);
-    AMT_LAUNCH_CHECK();
-    return AMT_OK;
+    return regionprops_common(ctx, labels, intensity, C, nullptr, table_dev, nplanes, H, W, max_label);
+}
+
+extern "C" int amt_regionprops_full_u16(amt_ctx* ctx, const int32_t* labels, const uint16_t* intensity, int C,
+                                        double* table_dev, double* itable_dev, int nplanes, int H, int W,
+                                        int max_label) {
+    AMT_REQUIRE(labels && intensity && table_dev && itable_dev && nplanes >= 0 && H > 0 && W > 0 && max_label >= 0 &&
+                    C >= 1,
+                "regionprops_full: bad arguments");
+    return regionprops_common(ctx, labels, intensity, C, table_dev, itable_dev, nplanes, H, W, max_label);
 }

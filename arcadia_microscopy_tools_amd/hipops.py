@@ -521,6 +521,24 @@ def regionprops(labels: DeviceArray, max_label: int, out=None) -> DeviceArray:
     return o
 
 
+def regionprops_full(labels: DeviceArray, intensity: DeviceArray, max_label: int, out=None, iout=None):
+    """Morphology table + intensity table in one call (shared bounding-box pass and per-label scan)."""
+    ctx = labels.ctx
+    n, H, W = _planes(labels)
+    if intensity.dtype != np.uint16:
+        raise TypeError("intensity images must be uint16 on the device path")
+    if intensity.ndim < 3 or intensity.shape[-2:] != labels.shape[-2:]:
+        raise ValueError("intensity must be (..., C, Y, X) matching the label planes")
+    C = int(intensity.shape[-3])
+    if intensity.size != n * C * H * W:
+        raise ValueError("intensity / labels plane count mismatch")
+    o = _out(ctx, out, (n, max_label, _hip.RP_NCOLS), np.float64)
+    io = _out(ctx, iout, (n, max_label, C, 4), np.float64)
+    _hip.check(_lib().amt_regionprops_full_u16(ctx.handle, labels.ptr, intensity.ptr, C, o.ptr, io.ptr, n, H, W,
+                                               int(max_label)), "amt_regionprops_full_u16")
+    return o, io
+
+
 def regionprops_intensity(labels: DeviceArray, intensity: DeviceArray, max_label: int, out=None) -> DeviceArray:
     """Intensity table (nplanes, max_label, C, 4) = {mean, max, min, std}; ``intensity`` is (..., C, Y, X)
     uint16 with one (C, Y, X) stack per label plane."""

@@ -133,9 +133,7 @@ class FovSegmenter:
         hipops.clear_border_relabel(self.ws, self.max_cells, out=self.labels, count=self.ncells)
         if self.props:
             self._stage("regionprops")
-            hipops.regionprops(self.labels, self.max_cells, out=self.table)
-            self._stage("intensity")
-            hipops.regionprops_intensity(self.labels, fovs, self.max_cells, out=self.itable)
+            hipops.regionprops_full(self.labels, fovs, self.max_cells, out=self.table, iout=self.itable)
         self._end()
         self._ran = "c3"
         return self.labels

@@ -28,7 +28,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (G/MI355X_MICROARCH.md: 8.0 TB/s
 # algorithmic bytes per pixel per stage: narrowest dtypes, one read + one write
 STAGE_BYTES_PER_PX = {
     "gaussian": 10, "otsu": 8, "threshold": 9, "opening": 4, "closing": 4, "label8": 5, "edt": 9, "peaks": 17,
-    "markers": 5, "watershed": 17, "clear_border": 8, "relabel": 4, "regionprops": 4, "intensity": 12,
+    "markers": 5, "watershed": 17, "clear_border": 8, "relabel": 4, "regionprops": 16, "intensity": 12,
 }
 
 
@@ -44,7 +44,10 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=8, help="fields of view per GPU per step")
+    ap.add_argument("--batch", type=int, default=32, help="fields of view per GPU per step")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="HIP streams per GPU; the batch is split over them so that the latency-bound flood of one "
+                         "part overlaps the bandwidth-bound stages of the other")
     ap.add_argument("--size", type=int, default=2048)
     ap.add_argument("--workload", choices=["c3", "c2"], default="c3")
     ap.add_argument("--cpu-fovs", type=int, default=2, help="FOVs timed through the single-thread CPU oracle")
@@ -121,7 +124,15 @@ def main():
     gen_s = time.perf_counter() - t0
     log(f"rank {rank}: generated {B} synthetic FOVs in {gen_s:.1f}s; device = {ctx.device_name()}")
     d_fovs = ctx.asarray(fovs)
-    seg = FovSegmenter(B, 4, S, S, ctx=ctx)
+    # split the batch over `streams` contexts (each = one HIP stream + arena); parts run concurrently
+    nstreams = max(1, min(args.streams, B))
+    if distributed:
+        nstreams = 1  # RCCL is ordered on torch's current stream, which the single context shares
+    bounds = [round(i * B / nstreams) for i in range(nstreams + 1)]
+    ctxs = [ctx] + [Context(local_rank) for _ in range(nstreams - 1)]
+    parts = [d_fovs[bounds[i]:bounds[i + 1]] for i in range(nstreams)]
+    segs = [FovSegmenter(bounds[i + 1] - bounds[i], 4, S, S, ctx=ctxs[i]) for i in range(nstreams)]
+    seg = segs[0]
     packed = None
     if distributed:
         from arcadia_microscopy_tools_amd.plate import DevicePackedTables
@@ -130,18 +141,20 @@ def main():
         packed.adopt()
 
     def step():
-        if args.workload == "c3":
-            seg.run_c3(d_fovs)
-            if packed is not None:
-                packed.all_gather()
-        else:
-            seg.run_c2(d_fovs)
+        for sg, part in zip(segs, parts):
+            if args.workload == "c3":
+                sg.run_c3(part)
+            else:
+                sg.run_c2(part)
+        if packed is not None and args.workload == "c3":
+            packed.all_gather()
 
     def sync():
         if distributed:
             torch.cuda.synchronize()
         else:
-            ctx.synchronize()
+            for c in ctxs:
+                c.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -215,7 +228,8 @@ def main():
                              "watershed nuclei + morphology and 4-channel intensity regionprops"
                              if args.workload == "c3" else
                              "configs[1]: synthetic 2048x2048 uint16 DAPI plane, Gaussian(2)+Otsu+open/close+CCL"),
-                "fovs_per_gpu_per_step": B, "fov_shape": [4, S, S], "resident_in_hbm": True,
+                "fovs_per_gpu_per_step": B, "streams_per_gpu": nstreams, "fov_shape": [4, S, S],
+                "resident_in_hbm": True,
                 "cells_per_fov_mean": float(np.mean(ncells)),
                 "feature_table_all_gather": bool(distributed and args.workload == "c3"),
             },

@@ -235,6 +235,10 @@ int amt_regionprops(amt_ctx* ctx, const int32_t* labels, double* table_dev, int 
  * table_dev = nplanes x max_label x C x 4 doubles. */
 int amt_regionprops_intensity_u16(amt_ctx* ctx, const int32_t* labels, const uint16_t* intensity, int C,
                                   double* table_dev, int nplanes, int H, int W, int max_label);
+/* Both tables in one call (the bounding-box pass and the per-label scan are shared): what
+ * SegmentationMask.cell_properties needs for a (C,Y,X) field of view (R/masks.py:286-326). */
+int amt_regionprops_full_u16(amt_ctx* ctx, const int32_t* labels, const uint16_t* intensity, int C, double* table_dev,
+                             double* itable_dev, int nplanes, int H, int W, int max_label);
 int amt_max_i32(amt_ctx* ctx, const int32_t* in, int32_t* max_dev, int nplanes, size_t n);
 
 #ifdef __cplusplus
