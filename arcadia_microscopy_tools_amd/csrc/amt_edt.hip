@@ -93,56 +93,76 @@ extern "C" int amt_edt(amt_ctx* ctx, const uint8_t* mask, int32_t* d2_out, doubl
 // ---- peak mask ---------------------------------------------------------------------------------
 // peaks = (d2 == maximum_filter(d2, size=2m+1, mode='constant' (0))) & mask & (d2 > 0), border m cleared
 // (comparing the integer d2 is equivalent to comparing sqrt(d2)).
-__global__ void __launch_bounds__(256) rowmax_kernel(const int* __restrict__ d2, int* __restrict__ out, int H, int W,
-                                                     int m) {
-    const int x = blockIdx.x * 256 + threadIdx.x;
-    const int y = blockIdx.y;
-    if (x >= W) return;
-    const size_t row = (size_t)blockIdx.z * H * W + (size_t)y * W;
-    int best = 0;  // constant 0 outside
-    int x0 = x - m < 0 ? 0 : x - m, x1 = x + m >= W ? W - 1 : x + m;
-    for (int k = x0; k <= x1; ++k) {
-        int v = d2[row + k];
-        best = v > best ? v : best;
-    }
-    out[row + x] = best;
-}
-
-__global__ void __launch_bounds__(256) colmax_peaks_kernel(const int* __restrict__ d2, const int* __restrict__ rmax,
-                                                           const uint8_t* __restrict__ mask,
-                                                           uint8_t* __restrict__ peaks, int H, int W, int m) {
-    const int x = blockIdx.x * 256 + threadIdx.x;
-    const int y = blockIdx.y;
-    if (x >= W) return;
+// One 256-thread block per 32 x 64 tile: d2 tile + halo m staged in LDS, separable maximum (rows, then
+// columns) in LDS, compare.  Tiles without any masked pixel with d2 > 0 exit after the staging pass.
+constexpr int PK_H = 32, PK_W = 64, PK_MAXM = 16;
+__global__ void __launch_bounds__(256) peaks_tile_kernel(const int* __restrict__ d2, const uint8_t* __restrict__ mask,
+                                                         uint8_t* __restrict__ peaks, int H, int W, int m) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int TW = PK_W + 2 * m, TH = PK_H + 2 * m;
+    int* tile = reinterpret_cast<int*>(smem_raw);  // TH x TW
+    int* rmax = tile + TH * TW;                    // TH x PK_W
+    __shared__ int any_fg;
+    const int x0 = blockIdx.x * PK_W, y0 = blockIdx.y * PK_H;
     const size_t base = (size_t)blockIdx.z * H * W;
-    const size_t i = base + (size_t)y * W + x;
-    uint8_t r = 0;
-    const int v = d2[i];
-    if (v > 0 && mask[i] && y >= m && y < H - m && x >= m && x < W - m) {
-        int best = 0;
-        int y0 = y - m < 0 ? 0 : y - m, y1 = y + m >= H ? H - 1 : y + m;
-        for (int k = y0; k <= y1; ++k) {
-            int t = rmax[base + (size_t)k * W + x];
-            best = t > best ? t : best;
-        }
-        r = (v == best) ? 1 : 0;
+    if (threadIdx.x == 0) any_fg = 0;
+    __syncthreads();
+    int local_any = 0;
+    for (int i = threadIdx.x; i < TH * TW; i += 256) {
+        const int ky = i / TW, kx = i - ky * TW;
+        const int y = y0 - m + ky, x = x0 - m + kx;
+        int v = 0;  // constant 0 outside the image
+        if (y >= 0 && y < H && x >= 0 && x < W) v = d2[base + (size_t)y * W + x];
+        tile[i] = v;
+        if (v > 0 && ky >= m && ky < TH - m && kx >= m && kx < TW - m) local_any = 1;
     }
-    peaks[i] = r;
+    if (local_any) any_fg = 1;
+    __syncthreads();
+    if (!any_fg) {  // nothing can be a peak here
+        for (int i = threadIdx.x; i < PK_H * PK_W; i += 256) {
+            const int ky = i / PK_W, kx = i - ky * PK_W;
+            const int y = y0 + ky, x = x0 + kx;
+            if (y < H && x < W) peaks[base + (size_t)y * W + x] = 0;
+        }
+        return;
+    }
+    for (int i = threadIdx.x; i < TH * PK_W; i += 256) {
+        const int ky = i / PK_W, kx = i - ky * PK_W;
+        const int* c = tile + ky * TW + kx;  // window kx .. kx + 2m of the padded row
+        int best = 0;
+        for (int k = 0; k <= 2 * m; ++k) best = c[k] > best ? c[k] : best;
+        rmax[i] = best;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < PK_H * PK_W; i += 256) {
+        const int ky = i / PK_W, kx = i - ky * PK_W;
+        const int y = y0 + ky, x = x0 + kx;
+        if (y >= H || x >= W) continue;
+        const int v = tile[(ky + m) * TW + (kx + m)];
+        uint8_t r = 0;
+        if (v > 0 && y >= m && y < H - m && x >= m && x < W - m && mask[base + (size_t)y * W + x]) {
+            int best = 0;
+            for (int k = 0; k <= 2 * m; ++k) {
+                const int t = rmax[(ky + k) * PK_W + kx];
+                best = t > best ? t : best;
+            }
+            r = (v == best) ? 1 : 0;
+        }
+        peaks[base + (size_t)y * W + x] = r;
+    }
 }
 
 extern "C" int amt_peak_mask(amt_ctx* ctx, const int32_t* d2, const uint8_t* mask, uint8_t* peaks, int nplanes, int H,
                              int W, int min_distance) {
     AMT_TRY(amt_set_device(ctx));
     AMT_REQUIRE(d2 && mask && peaks && nplanes >= 0 && H > 0 && W > 0, "peak_mask: bad arguments");
-    AMT_REQUIRE(min_distance >= 0 && min_distance <= 64, "peak_mask: min_distance %d out of range 0..64", min_distance);
+    AMT_REQUIRE(min_distance >= 0 && min_distance <= PK_MAXM, "peak_mask: min_distance %d out of range 0..%d",
+                min_distance, PK_MAXM);
     if (nplanes == 0) return AMT_OK;
-    const size_t n = (size_t)H * W;
-    AMT_TRY(amt_arena_begin(ctx, amt_align((size_t)nplanes * n * 4)));
-    int* rmax = arena_take_t<int>(ctx, (size_t)nplanes * n);
-    dim3 grid((W + 255) / 256, H, nplanes);
-    hipLaunchKernelGGL(rowmax_kernel, grid, dim3(256), 0, ctx->stream, d2, rmax, H, W, min_distance);
-    AMT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colmax_peaks_kernel, grid, dim3(256), 0, ctx->stream, d2, rmax, mask, peaks, H, W, min_distance);
+    const int m = min_distance;
+    const size_t smem = ((size_t)(PK_H + 2 * m) * (PK_W + 2 * m) + (size_t)(PK_H + 2 * m) * PK_W) * sizeof(int);
+    dim3 grid((W + PK_W - 1) / PK_W, (H + PK_H - 1) / PK_H, nplanes);
+    hipLaunchKernelGGL(peaks_tile_kernel, grid, dim3(256), smem, ctx->stream, d2, mask, peaks, H, W, m);
     AMT_LAUNCH_CHECK();
     return AMT_OK;
 }

@@ -68,7 +68,9 @@ static inline int amt_scan_excl_dev(amt_ctx* ctx, int* data, const int* len_dev,
 // ---- connected components (amt_label.hip) -------------------------------------------------------
 // L[plane][p] = flat index of the component's first pixel (its union-find root), -1 for background.
 // Components are sets of equal-valued non-zero pixels; conn8 selects 8- vs 4-connectivity.
-int amt_i_ccl_roots(amt_ctx* ctx, const void* in, int in_dtype, int* L, int nplanes, int H, int W, int conn8);
+// blk (nullable) = nplanes * amt_i_rank_blocks(n) ints receiving the per-block root counts for amt_i_rank_roots.
+int amt_i_ccl_roots(amt_ctx* ctx, const void* in, int in_dtype, int* L, int* blk, int nplanes, int H, int W,
+                    int conn8);
 // T[plane][root] = 1-based rank of the root in raster order; count_dev[plane] = number of roots.
 // blk = scratch of nplanes * amt_i_rank_blocks(n) ints.
 int amt_i_rank_blocks(size_t n);

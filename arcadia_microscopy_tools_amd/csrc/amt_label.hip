@@ -98,39 +98,38 @@ __global__ void __launch_bounds__(256) ccl_merge_kernel(const T* __restrict__ in
     }
 }
 
-__global__ void __launch_bounds__(256) ccl_compress_kernel(int* __restrict__ L, size_t n) {
-    const size_t base = (size_t)blockIdx.y * n;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        int l = L[base + i];
-        if (l >= 0) {
-            int r = l;
-            int p = L[base + r];
-            while (p != r) {
-                r = p;
-                p = L[base + r];
-            }
-            L[base + i] = r;
-        }
-    }
-}
-
 // ---- raster renumbering: exclusive prefix sum over root flags ----------------------------------
-constexpr int RN_CHUNK = 2048;  // pixels per block in the count / rank passes (256 threads x 8)
+constexpr int RN_CHUNK = 2048;  // pixels per block in the compress / rank passes (256 threads x 8)
 
-__global__ void __launch_bounds__(256) root_count_kernel(const int* __restrict__ L, int* __restrict__ blockcnt, size_t n,
-                                                         int nblk) {
+// Path compression (every pixel points at its root afterwards) fused with the per-block root count that
+// the renumbering needs: a pixel is a root iff L[p] == p, which compression never changes.
+__global__ void __launch_bounds__(256) ccl_compress_count_kernel(int* __restrict__ L, int* __restrict__ blockcnt,
+                                                                 size_t n, int nblk) {
     const size_t base = (size_t)blockIdx.y * n;
     const size_t start = (size_t)blockIdx.x * RN_CHUNK;
     int c = 0;
+#pragma unroll
     for (int k = 0; k < 8; ++k) {
-        size_t i = start + (size_t)k * 256 + threadIdx.x;
-        if (i < n) c += (L[base + i] == (int)i) ? 1 : 0;
+        const size_t i = start + (size_t)k * 256 + threadIdx.x;
+        if (i < n) {
+            const int l = L[base + i];
+            if (l >= 0) {
+                int r = l;
+                int p = L[base + r];
+                while (p != r) {
+                    r = p;
+                    p = L[base + r];
+                }
+                if (r != l) L[base + i] = r;
+                c += (r == (int)i) ? 1 : 0;
+            }
+        }
     }
     for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off);
     __shared__ int s[4];
     if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = c;
     __syncthreads();
-    if (threadIdx.x == 0) blockcnt[(size_t)blockIdx.y * nblk + blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+    if (threadIdx.x == 0 && blockcnt) blockcnt[(size_t)blockIdx.y * nblk + blockIdx.x] = s[0] + s[1] + s[2] + s[3];
 }
 
 // rank of every root (1-based) written at the root's own position of T
@@ -170,30 +169,29 @@ __global__ void __launch_bounds__(256) apply_rank_kernel(const int* __restrict__
 }
 
 template <typename T>
-static int ccl_roots(amt_ctx* ctx, const T* in, int* L, int nplanes, int H, int W, int conn8) {
+static int ccl_roots(amt_ctx* ctx, const T* in, int* L, int* blk, int nplanes, int H, int W, int conn8) {
     const size_t n = (size_t)H * W;
-    dim3 g1(amt_grid_for(n, 256, 4096), nplanes);
+    const int nblk = amt_i_rank_blocks(n);
     dim3 g2((W + 63) / 64, (H + 3) / 4, nplanes);
     hipLaunchKernelGGL((ccl_init_kernel<T>), g2, dim3(256), 0, ctx->stream, in, L, H, W);
     AMT_LAUNCH_CHECK();
     hipLaunchKernelGGL((ccl_merge_kernel<T>), g2, dim3(256), 0, ctx->stream, in, L, H, W, conn8);
     AMT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ccl_compress_kernel, g1, dim3(256), 0, ctx->stream, L, n);
+    hipLaunchKernelGGL(ccl_compress_count_kernel, dim3(nblk, nplanes), dim3(256), 0, ctx->stream, L, blk, n, nblk);
     AMT_LAUNCH_CHECK();
     return AMT_OK;
 }
 
-int amt_i_ccl_roots(amt_ctx* ctx, const void* in, int in_dtype, int* L, int nplanes, int H, int W, int conn8) {
-    if (in_dtype == AMT_U8) return ccl_roots<uint8_t>(ctx, (const uint8_t*)in, L, nplanes, H, W, conn8);
-    return ccl_roots<int32_t>(ctx, (const int32_t*)in, L, nplanes, H, W, conn8);
+int amt_i_ccl_roots(amt_ctx* ctx, const void* in, int in_dtype, int* L, int* blk, int nplanes, int H, int W,
+                    int conn8) {
+    if (in_dtype == AMT_U8) return ccl_roots<uint8_t>(ctx, (const uint8_t*)in, L, blk, nplanes, H, W, conn8);
+    return ccl_roots<int32_t>(ctx, (const int32_t*)in, L, blk, nplanes, H, W, conn8);
 }
 
 int amt_i_rank_blocks(size_t n) { return (int)((n + RN_CHUNK - 1) / RN_CHUNK); }
 
 int amt_i_rank_roots(amt_ctx* ctx, const int* L, int* T, int* blk, int* count_dev, int nplanes, size_t n) {
-    const int nblk = amt_i_rank_blocks(n);
-    hipLaunchKernelGGL(root_count_kernel, dim3(nblk, nplanes), dim3(256), 0, ctx->stream, L, blk, n, nblk);
-    AMT_LAUNCH_CHECK();
+    const int nblk = amt_i_rank_blocks(n);  // blk holds the per-block root counts written by amt_i_ccl_roots
     AMT_TRY(amt_scan_excl(ctx, blk, nblk, (size_t)nblk, count_dev, nplanes));
     hipLaunchKernelGGL(root_rank_kernel, dim3(nblk, nplanes), dim3(256), 0, ctx->stream, L, blk, T, n, nblk);
     AMT_LAUNCH_CHECK();
@@ -215,7 +213,7 @@ extern "C" int amt_label(amt_ctx* ctx, const void* in, int in_dtype, int32_t* ou
     int* T = arena_take_t<int>(ctx, (size_t)nplanes * n);
     int* blk = arena_take_t<int>(ctx, (size_t)nplanes * nblk);
     int* L = out;
-    AMT_TRY(amt_i_ccl_roots(ctx, in, in_dtype, L, nplanes, H, W, connectivity == 2));
+    AMT_TRY(amt_i_ccl_roots(ctx, in, in_dtype, L, blk, nplanes, H, W, connectivity == 2));
     AMT_TRY(amt_i_rank_roots(ctx, L, T, blk, count_dev, nplanes, n));
     dim3 g1(amt_grid_for(n, 256, 4096), nplanes);
     hipLaunchKernelGGL(apply_rank_kernel, g1, dim3(256), 0, ctx->stream, L, T, out, n);
@@ -269,7 +267,7 @@ extern "C" int amt_clear_border(amt_ctx* ctx, const int32_t* in, int32_t* out, i
     int* L = arena_take_t<int>(ctx, (size_t)nplanes * n);
     int* T = arena_take_t<int>(ctx, (size_t)nplanes * n);
     AMT_HIP_CHECK(hipMemsetAsync(T, 0, (size_t)nplanes * n * 4, ctx->stream));
-    AMT_TRY(ccl_roots<int32_t>(ctx, in, L, nplanes, H, W, 1));
+    AMT_TRY(ccl_roots<int32_t>(ctx, in, L, nullptr, nplanes, H, W, 1));
     dim3 gf(amt_grid_for((size_t)2 * W + 2 * H, 256, 64), nplanes);
     hipLaunchKernelGGL(frame_flag_kernel, gf, dim3(256), 0, ctx->stream, L, T, H, W);
     AMT_LAUNCH_CHECK();

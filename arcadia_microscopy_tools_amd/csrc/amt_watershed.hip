@@ -42,11 +42,21 @@ struct comp_row {
     int pad;
 };
 
-// out = markers * mask
-__global__ void __launch_bounds__(256) ws_init_kernel(const int* __restrict__ markers, const uint8_t* __restrict__ mask,
-                                                      int* __restrict__ out, size_t total) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256)
-        out[i] = mask[i] ? markers[i] : 0;
+// out = label of the component for single-label components, markers * mask elsewhere
+__global__ void __launch_bounds__(256) ws_seed_kernel(const int* __restrict__ markers, const int* __restrict__ L,
+                                                      const int* __restrict__ T, const comp_row* __restrict__ rows,
+                                                      size_t row_stride, int* __restrict__ out, size_t n) {
+    const size_t base = (size_t)blockIdx.y * n;
+    const comp_row* rr = rows + (size_t)blockIdx.y * row_stride;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int r = L[base + i];
+        int v = 0;
+        if (r >= 0) {
+            const comp_row* c = rr + (T[base + r] - 1);
+            v = (c->cls == CLS_UNIFORM) ? c->labmin : markers[base + i];
+        }
+        out[base + i] = v;
+    }
 }
 
 __global__ void __launch_bounds__(256) ws_rows_init_kernel(comp_row* __restrict__ rows, const int* __restrict__ ncomp,
@@ -68,61 +78,78 @@ __global__ void __launch_bounds__(256) ws_rows_init_kernel(comp_row* __restrict_
 }
 
 // per-component max d2 (bucket count) or size (heap capacity), marker count, marker label range and
-// bounding box.  A wave covers 64 consecutive pixels of a row; each run of equal roots is reduced in
-// registers and costs one set of atomics.
+// bounding box.  A wave covers 64 consecutive pixels of 8 rows (loads issued up front); each run of equal
+// roots is reduced in registers and costs one set of atomics.
 __global__ void __launch_bounds__(256) ws_stats_kernel(const int* __restrict__ d2, const int* __restrict__ L,
-                                                       const int* __restrict__ T, const int* __restrict__ out,
+                                                       const int* __restrict__ T, const int* __restrict__ markers,
                                                        comp_row* __restrict__ rows, size_t row_stride, int H, int W,
                                                        int use_d2) {
     const int lane = threadIdx.x & 63;
     const int x = blockIdx.x * 64 + lane;
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (y >= H) return;
+    const int yb = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 8;
+    if (yb >= H) return;
     const size_t base = (size_t)blockIdx.z * H * W;
-    const size_t i = base + (size_t)y * W + (x < W ? x : W - 1);
-    const int r = x < W ? L[i] : -1;
-    const int left = __shfl_up(r, 1);
-    const bool head = (lane == 0) || (left != r);
-    const unsigned long long heads = __ballot(head);
-    const unsigned long long anyfg = __ballot(r >= 0);
-    if (!anyfg) return;
-    const unsigned long long later = heads & ~((2ull << lane) - 1ull);
-    const int end_lane = later ? (__ffsll((long long)later) - 2) : 63;
-    int v = 0;
-    if (r >= 0 && use_d2) {
-        v = d2[i];
-        v = v < 0 ? 0 : v;
-    }
-    const int lab = r >= 0 ? out[i] : 0;
-    int lmin = lab != 0 ? lab : 0x7fffffff, lmax = lab;
-    const unsigned long long mk = __ballot(lab != 0);
+    int rs[8], vs[8], ms[8];
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        int t = __shfl_down(v, off), t1 = __shfl_down(lmin, off), t2 = __shfl_down(lmax, off);
-        if (lane + off <= end_lane) {
-            v = t > v ? t : v;
-            lmin = t1 < lmin ? t1 : lmin;
-            lmax = t2 > lmax ? t2 : lmax;
+    for (int k = 0; k < 8; ++k) {
+        const int y = yb + k;
+        rs[k] = -1;
+        vs[k] = 0;
+        ms[k] = 0;
+        if (x < W && y < H) {
+            const size_t i = base + (size_t)y * W + x;
+            rs[k] = L[i];
+            if (rs[k] >= 0) {
+                ms[k] = markers[i];
+                if (use_d2) {
+                    const int d = d2[i];
+                    vs[k] = d < 0 ? 0 : d;
+                }
+            }
         }
     }
-    if (r >= 0 && head) {
-        comp_row* c = rows + (size_t)blockIdx.z * row_stride + (T[base + r] - 1);
-        const int len = end_lane - lane + 1;
-        if (use_d2) {
-            if (v > 0) atomicMax(&c->cmax, v);
-        } else {
-            atomicAdd(&c->cmax, len);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int r = rs[k];
+        const unsigned long long anyfg = __ballot(r >= 0);
+        if (!anyfg) continue;
+        const int left = __shfl_up(r, 1);
+        const bool head = (lane == 0) || (left != r);
+        const unsigned long long heads = __ballot(head);
+        const unsigned long long later = heads & ~((2ull << lane) - 1ull);
+        const int end_lane = later ? (__ffsll((long long)later) - 2) : 63;
+        int v = vs[k];
+        const int lab = ms[k];
+        int lmin = lab != 0 ? lab : 0x7fffffff, lmax = lab;
+        const unsigned long long mk = __ballot(lab != 0);
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            int t = __shfl_down(v, off), t1 = __shfl_down(lmin, off), t2 = __shfl_down(lmax, off);
+            if (lane + off <= end_lane) {
+                v = t > v ? t : v;
+                lmin = t1 < lmin ? t1 : lmin;
+                lmax = t2 > lmax ? t2 : lmax;
+            }
         }
-        atomicMin(&c->x0, x);
-        atomicMax(&c->x1, x + len - 1);
-        atomicMin(&c->y0, y);
-        atomicMax(&c->y1, y);
-        const unsigned long long run = (len == 64) ? ~0ull : (((1ull << len) - 1ull) << lane);
-        const int nmk = __popcll(mk & run);
-        if (nmk) {
-            atomicAdd(&c->mcnt, nmk);
-            atomicMin(&c->labmin, lmin);
-            atomicMax(&c->labmax, lmax);
+        if (r >= 0 && head) {
+            comp_row* c = rows + (size_t)blockIdx.z * row_stride + (T[base + r] - 1);
+            const int len = end_lane - lane + 1;
+            if (use_d2) {
+                if (v > 0) atomicMax(&c->cmax, v);
+            } else {
+                atomicAdd(&c->cmax, len);
+            }
+            atomicMin(&c->x0, x);
+            atomicMax(&c->x1, x + len - 1);
+            atomicMin(&c->y0, yb + k);
+            atomicMax(&c->y1, yb + k);
+            const unsigned long long run = (len == 64) ? ~0ull : (((1ull << len) - 1ull) << lane);
+            const int nmk = __popcll(mk & run);
+            if (nmk) {
+                atomicAdd(&c->mcnt, nmk);
+                atomicMin(&c->labmin, lmin);
+                atomicMax(&c->labmax, lmax);
+            }
         }
     }
 }
@@ -130,7 +157,7 @@ __global__ void __launch_bounds__(256) ws_stats_kernel(const int* __restrict__ d
 // classify components; publish marker-list sizes (moff) and queue sizes (boff) for the HBM path
 __global__ void __launch_bounds__(256) ws_classify_kernel(comp_row* __restrict__ rows, const int* __restrict__ ncomp,
                                                           int* __restrict__ moff, int* __restrict__ boff,
-                                                          size_t row_stride, int use_d2) {
+                                                          int* __restrict__ has_g, size_t row_stride, int use_d2) {
     comp_row* r = rows + (size_t)blockIdx.y * row_stride;
     int* mo = moff + (size_t)blockIdx.y * row_stride;
     int* bo = boff + (size_t)blockIdx.y * row_stride;
@@ -153,21 +180,9 @@ __global__ void __launch_bounds__(256) ws_classify_kernel(comp_row* __restrict__
             else cls = CLS_G;
         }
         r[i].cls = cls;
+        if (cls == CLS_G) has_g[blockIdx.y] = 1;
         mo[i] = cls == CLS_G ? c.mcnt : 0;
         bo[i] = cls == CLS_G ? (use_d2 ? c.cmax + 1 : c.cmax) : 0;
-    }
-}
-
-__global__ void __launch_bounds__(256) ws_fill_uniform_kernel(const int* __restrict__ L, const int* __restrict__ T,
-                                                              const comp_row* __restrict__ rows, size_t row_stride,
-                                                              int* __restrict__ out, size_t n) {
-    const size_t base = (size_t)blockIdx.y * n;
-    const comp_row* rr = rows + (size_t)blockIdx.y * row_stride;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const int r = L[base + i];
-        if (r < 0) continue;
-        const comp_row* c = rr + (T[base + r] - 1);
-        if (c->cls == CLS_UNIFORM) out[base + i] = c->labmin;
     }
 }
 
@@ -176,7 +191,9 @@ __global__ void __launch_bounds__(256) ws_fill_markers_kernel(const int* __restr
                                                               const int* __restrict__ out,
                                                               const comp_row* __restrict__ rows,
                                                               const int* __restrict__ moff, int* __restrict__ cursor,
-                                                              int* __restrict__ mlist, size_t row_stride, size_t n) {
+                                                              int* __restrict__ mlist, const int* __restrict__ has_g,
+                                                              size_t row_stride, size_t n) {
+    if (!has_g[blockIdx.y]) return;  // the common case: every component fitted an LDS tile
     const size_t base = (size_t)blockIdx.y * n;
     const size_t cb = (size_t)blockIdx.y * row_stride;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
@@ -552,25 +569,23 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
         heap = arena_take_t<hp_elem>(ctx, (size_t)nplanes * bstride);
     }
 
-    hipLaunchKernelGGL(ws_init_kernel, dim3(amt_grid_for(np, 256, 8192)), dim3(256), 0, ctx->stream, markers, mask, out,
-                       np);
-    AMT_LAUNCH_CHECK();
-    AMT_TRY(amt_i_ccl_roots(ctx, mask, AMT_U8, L, nplanes, H, W, /*conn8=*/0));
+    AMT_TRY(amt_i_ccl_roots(ctx, mask, AMT_U8, L, blk, nplanes, H, W, /*conn8=*/0));
     AMT_TRY(amt_i_rank_roots(ctx, L, T, blk, ncomp, nplanes, n));
     hipLaunchKernelGGL(ws_rows_init_kernel, dim3(64, nplanes), dim3(256), 0, ctx->stream, rows, ncomp, row_stride);
     AMT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ws_stats_kernel, dim3((W + 63) / 64, (H + 3) / 4, nplanes), dim3(256), 0, ctx->stream,
-                       use_d2 ? (const int*)relief : (const int*)nullptr, L, T, out, rows, row_stride, H, W,
+    hipLaunchKernelGGL(ws_zero_counters_kernel, dim3((nplanes * 8 + 63) / 64), dim3(64), 0, ctx->stream, counters,
+                       nplanes * 8);
+    AMT_LAUNCH_CHECK();
+    int* has_g = counters + 4 * nplanes;
+    hipLaunchKernelGGL(ws_stats_kernel, dim3((W + 63) / 64, (H + 31) / 32, nplanes), dim3(256), 0, ctx->stream,
+                       use_d2 ? (const int*)relief : (const int*)nullptr, L, T, markers, rows, row_stride, H, W,
                        use_d2 ? 1 : 0);
     AMT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ws_classify_kernel, dim3(64, nplanes), dim3(256), 0, ctx->stream, rows, ncomp, moff, boff,
+    hipLaunchKernelGGL(ws_classify_kernel, dim3(64, nplanes), dim3(256), 0, ctx->stream, rows, ncomp, moff, boff, has_g,
                        row_stride, use_d2 ? 1 : 0);
     AMT_LAUNCH_CHECK();
     dim3 g1(amt_grid_for(n, 256, 4096), nplanes);
-    hipLaunchKernelGGL(ws_fill_uniform_kernel, g1, dim3(256), 0, ctx->stream, L, T, rows, row_stride, out, n);
-    AMT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ws_zero_counters_kernel, dim3((nplanes * 8 + 63) / 64), dim3(64), 0, ctx->stream, counters,
-                       nplanes * 8);
+    hipLaunchKernelGGL(ws_seed_kernel, g1, dim3(256), 0, ctx->stream, markers, L, T, rows, row_stride, out, n);
     AMT_LAUNCH_CHECK();
     // ---- HBM-path bookkeeping (usually empty: only components too large for an LDS tile) ----
     AMT_TRY(amt_scan_excl_dev(ctx, moff, ncomp, row_stride, mtot, nplanes));
@@ -578,7 +593,7 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     hipLaunchKernelGGL(ws_fill_value_kernel, dim3(64, nplanes), dim3(256), 0, ctx->stream, cursor, ncomp, row_stride, 0);
     AMT_LAUNCH_CHECK();
     hipLaunchKernelGGL(ws_fill_markers_kernel, g1, dim3(256), 0, ctx->stream, L, T, out, rows, moff, cursor, mlist,
-                       row_stride, n);
+                       has_g, row_stride, n);
     AMT_LAUNCH_CHECK();
     if (use_d2) {
         const size_t ldsS = (size_t)S_PX * 6 + (size_t)S_NB * 4;
