@@ -157,7 +157,9 @@ __global__ void __launch_bounds__(256) ws_stats_kernel(const int* __restrict__ d
 // classify components; publish marker-list sizes (moff) and queue sizes (boff) for the HBM path
 __global__ void __launch_bounds__(256) ws_classify_kernel(comp_row* __restrict__ rows, const int* __restrict__ ncomp,
                                                           int* __restrict__ moff, int* __restrict__ boff,
-                                                          int* __restrict__ has_g, size_t row_stride, int use_d2) {
+                                                          int* __restrict__ has_g, int* __restrict__ wl,
+                                                          int* __restrict__ wl_count, int nplanes, size_t row_stride,
+                                                          int use_d2) {
     comp_row* r = rows + (size_t)blockIdx.y * row_stride;
     int* mo = moff + (size_t)blockIdx.y * row_stride;
     int* bo = boff + (size_t)blockIdx.y * row_stride;
@@ -181,6 +183,12 @@ __global__ void __launch_bounds__(256) ws_classify_kernel(comp_row* __restrict__
         }
         r[i].cls = cls;
         if (cls == CLS_G) has_g[blockIdx.y] = 1;
+        if (cls == CLS_S || cls == CLS_M || cls == CLS_L) {
+            // per-class worklist of this plane (order is irrelevant: components are independent)
+            const int k = cls - CLS_S;
+            const int pos = atomicAdd(&wl_count[k * nplanes + blockIdx.y], 1);
+            wl[((size_t)k * nplanes + blockIdx.y) * row_stride + pos] = i;
+        }
         mo[i] = cls == CLS_G ? c.mcnt : 0;
         bo[i] = cls == CLS_G ? (use_d2 ? c.cmax + 1 : c.cmax) : 0;
     }
@@ -241,8 +249,9 @@ template <int TILE_PX, int NB, int CLS>
 __global__ void __launch_bounds__(64) ws_flood_lds_kernel(const int* __restrict__ d2all, const int* __restrict__ Lall,
                                                           const int* __restrict__ Tall, int* __restrict__ outall,
                                                           const comp_row* __restrict__ rows,
-                                                          const int* __restrict__ ncomp, int* __restrict__ counters,
-                                                          size_t row_stride, int H, int W, int seeds_first) {
+                                                          const int* __restrict__ wl, const int* __restrict__ wl_count,
+                                                          int* __restrict__ counters, size_t row_stride, int H, int W,
+                                                          int seeds_first) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     unsigned* cell = reinterpret_cast<unsigned*>(smem_raw);
     unsigned* ht = cell + TILE_PX;
@@ -254,40 +263,68 @@ __global__ void __launch_bounds__(64) ws_flood_lds_kernel(const int* __restrict_
     const int* T = Tall + (size_t)plane * n;
     int* out = outall + (size_t)plane * n;
     const comp_row* rr = rows + (size_t)plane * row_stride;
-    const int nc = ncomp[plane];
+    const int* mylist = wl + (size_t)plane * row_stride;
+    const int nwork = wl_count[plane];
     const int lane = threadIdx.x;
     while (true) {
-        int c = 0;
-        if (lane == 0) c = atomicAdd(&counters[plane], 1);
-        c = __shfl(c, 0);
-        if (c >= nc) break;
+        int k = 0;
+        if (lane == 0) k = atomicAdd(&counters[plane], 1);
+        k = __shfl(k, 0);
+        if (k >= nwork) break;
+        const int c = mylist[k];
         const comp_row cr = rr[c];
-        if (cr.cls != CLS) continue;
         const int tw = cr.x1 - cr.x0 + 3, th = cr.y1 - cr.y0 + 3;  // padded tile
         const int npx = tw * th;
         const int nb = cr.cmax + 1;
-        // ---- stage the bounding box + ring ----
-        for (int i = lane; i < npx; i += 64) {
-            const int ty = i / tw, tx = i - ty * tw;
-            unsigned cv = 0xFFFFu;
-            if (ty >= 1 && ty < th - 1 && tx >= 1 && tx < tw - 1) {
-                const size_t g = (size_t)(cr.y0 + ty - 1) * W + (cr.x0 + tx - 1);
-                const int r = L[g];
-                if (r >= 0 && T[r] - 1 == c) {
-                    const int o = out[g];
-                    int d = d2[g];
-                    d = d < 0 ? 0 : d;
-                    cv = ((unsigned)o & 0xFFFFu) | ((unsigned)d << 16) | (o != 0 ? 0x80000000u : 0u);
+        const unsigned inv_tw = 0xFFFFFFFFu / (unsigned)tw + 1u;  // i / tw == (i * inv_tw) >> 32 for i < 65536
+        // ---- stage the bounding box + ring: 4 independent elements per lane in flight ----
+        for (int i0 = 0; i0 < npx; i0 += 256) {
+            int rr4[4];
+            size_t g4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * 64 + lane;
+                const int ty = (int)(((unsigned long long)(unsigned)i * inv_tw) >> 32), tx = i - ty * tw;
+                rr4[u] = -1;
+                g4[u] = 0;
+                if (i < npx && ty >= 1 && ty < th - 1 && tx >= 1 && tx < tw - 1) {
+                    g4[u] = (size_t)(cr.y0 + ty - 1) * W + (cr.x0 + tx - 1);
+                    rr4[u] = L[g4[u]];
                 }
             }
-            cell[i] = cv;
+            int t4[4], o4[4], d4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                t4[u] = rr4[u] >= 0 ? T[rr4[u]] : 0;
+                o4[u] = rr4[u] >= 0 ? out[g4[u]] : 0;
+                d4[u] = rr4[u] >= 0 ? d2[g4[u]] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * 64 + lane;
+                if (i < npx) {
+                    unsigned cv = 0xFFFFu;
+                    if (rr4[u] >= 0 && t4[u] - 1 == c) {
+                        const int d = d4[u] < 0 ? 0 : d4[u];
+                        cv = ((unsigned)o4[u] & 0xFFFFu) | ((unsigned)d << 16) | (o4[u] != 0 ? 0x80000000u : 0u);
+                    }
+                    cell[i] = cv;
+                }
+            }
         }
         for (int i = lane; i < nb; i += 64) ht[i] = 0xFFFFFFFFu;
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
+        // The flood is one sequential thread of control.  Every value it computes is wave-uniform, so each
+        // LDS load is passed through readfirstlane: indices, labels, bucket numbers and all branches then
+        // live on the scalar unit; only the LDS instructions themselves (address + data) touch VGPRs.
+        auto ld32 = [&](const unsigned* a, int i) -> unsigned { return __builtin_amdgcn_readfirstlane(a[i]); };
+        auto ld16 = [&](const unsigned short* a, int i) -> unsigned {
+            return __builtin_amdgcn_readfirstlane((unsigned)a[i]);
+        };
         int cur = -1;
         auto push = [&](int q, int b) {
-            const unsigned h = ht[b];
+            const unsigned h = ld32(ht, b);
             if ((h & 0xFFFFu) == 0xFFFFu) {
                 ht[b] = (unsigned)q | ((unsigned)q << 16);
             } else {
@@ -297,13 +334,13 @@ __global__ void __launch_bounds__(64) ws_flood_lds_kernel(const int* __restrict_
             cur = b > cur ? b : cur;
         };
         auto spread = [&](int p) {
-            const unsigned lb = cell[p] & 0xFFFFu;
+            const unsigned lb = ld32(cell, p) & 0xFFFFu;
             const int q0 = p - tw, q1 = p - 1, q2 = p + 1, q3 = p + tw;
-            const unsigned c0 = cell[q0], c1 = cell[q1], c2 = cell[q2], c3 = cell[q3];
-            if ((c0 & 0xFFFFu) == 0) { cell[q0] = c0 | lb; push(q0, (c0 >> 16) & 0x7FFF); }
-            if ((c1 & 0xFFFFu) == 0) { cell[q1] = c1 | lb; push(q1, (c1 >> 16) & 0x7FFF); }
-            if ((c2 & 0xFFFFu) == 0) { cell[q2] = c2 | lb; push(q2, (c2 >> 16) & 0x7FFF); }
-            if ((c3 & 0xFFFFu) == 0) { cell[q3] = c3 | lb; push(q3, (c3 >> 16) & 0x7FFF); }
+            const unsigned c0 = ld32(cell, q0), c1 = ld32(cell, q1), c2 = ld32(cell, q2), c3 = ld32(cell, q3);
+            if ((c0 & 0xFFFFu) == 0) { cell[q0] = c0 | lb; push(q0, (int)((c0 >> 16) & 0x7FFF)); }
+            if ((c1 & 0xFFFFu) == 0) { cell[q1] = c1 | lb; push(q1, (int)((c1 >> 16) & 0x7FFF)); }
+            if ((c2 & 0xFFFFu) == 0) { cell[q2] = c2 | lb; push(q2, (int)((c2 >> 16) & 0x7FFF)); }
+            if ((c3 & 0xFFFFu) == 0) { cell[q3] = c3 | lb; push(q3, (int)((c3 >> 16) & 0x7FFF)); }
         };
         // ---- markers in raster order (wave ballots), then the flood, both on lane 0 ----
         for (int i0 = 0; i0 < npx; i0 += 64) {
@@ -315,7 +352,7 @@ __global__ void __launch_bounds__(64) ws_flood_lds_kernel(const int* __restrict_
                     const int b = __ffsll((long long)m) - 1;
                     m &= m - 1;
                     const int p = i0 + b;
-                    if (seeds_first) spread(p); else push(p, (cell[p] >> 16) & 0x7FFF);
+                    if (seeds_first) spread(p); else push(p, (int)((ld32(cell, p) >> 16) & 0x7FFF));
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -323,13 +360,13 @@ __global__ void __launch_bounds__(64) ws_flood_lds_kernel(const int* __restrict_
         if (lane == 0) {
             while (true) {
                 unsigned h = 0xFFFFu;
-                while (cur >= 0 && ((h = ht[cur]) & 0xFFFFu) == 0xFFFFu) --cur;
+                while (cur >= 0 && ((h = ld32(ht, cur)) & 0xFFFFu) == 0xFFFFu) --cur;
                 if (cur < 0) break;
                 const int p = (int)(h & 0xFFFFu);
                 if (p == (int)(h >> 16))
                     ht[cur] = 0xFFFFFFFFu;
                 else
-                    ht[cur] = (h & 0xFFFF0000u) | nx[p];
+                    ht[cur] = (h & 0xFFFF0000u) | ld16(nx, p);
                 spread(p);
             }
         }
@@ -338,7 +375,7 @@ __global__ void __launch_bounds__(64) ws_flood_lds_kernel(const int* __restrict_
         for (int i = lane; i < npx; i += 64) {
             const unsigned lv = cell[i] & 0xFFFFu;
             if (lv != 0xFFFFu) {
-                const int ty = i / tw, tx = i - ty * tw;
+                const int ty = (int)(((unsigned long long)(unsigned)i * inv_tw) >> 32), tx = i - ty * tw;
                 out[(size_t)(cr.y0 + ty - 1) * W + (cr.x0 + tx - 1)] = (int)lv;
             }
         }
@@ -543,7 +580,7 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     // HBM queues: bucket mode needs <= n + ncomp <= 2n ints for head and tail each (only the used prefix
     // is initialised); the heap needs <= n elements per plane.
     const size_t bstride = use_d2 ? 2 * n : n;
-    size_t need = 7 * amt_align(np * 4) + amt_align((size_t)nplanes * row_stride * sizeof(comp_row)) +
+    size_t need = 10 * amt_align(np * 4) + amt_align((size_t)nplanes * row_stride * sizeof(comp_row)) +
                   amt_align((size_t)nplanes * nblk * 4) + 8 * amt_align(nplanes * 4 * 8);
     need += use_d2 ? 2 * amt_align((size_t)nplanes * bstride * 4) : amt_align((size_t)nplanes * bstride * sizeof(hp_elem));
     AMT_TRY(amt_arena_begin(ctx, need));
@@ -560,6 +597,7 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     int* btot = arena_take_t<int>(ctx, nplanes);
     int* mtot = arena_take_t<int>(ctx, nplanes);
     int* counters = arena_take_t<int>(ctx, (size_t)nplanes * 8);
+    int* wl = arena_take_t<int>(ctx, 3 * (size_t)nplanes * row_stride);  // worklists of the three LDS classes
     int *head = nullptr, *tail = nullptr;
     hp_elem* heap = nullptr;
     if (use_d2) {
@@ -577,12 +615,13 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
                        nplanes * 8);
     AMT_LAUNCH_CHECK();
     int* has_g = counters + 4 * nplanes;
+    int* wl_count = counters + 5 * nplanes;  // [3][nplanes]
     hipLaunchKernelGGL(ws_stats_kernel, dim3((W + 63) / 64, (H + 31) / 32, nplanes), dim3(256), 0, ctx->stream,
                        use_d2 ? (const int*)relief : (const int*)nullptr, L, T, markers, rows, row_stride, H, W,
                        use_d2 ? 1 : 0);
     AMT_LAUNCH_CHECK();
     hipLaunchKernelGGL(ws_classify_kernel, dim3(64, nplanes), dim3(256), 0, ctx->stream, rows, ncomp, moff, boff, has_g,
-                       row_stride, use_d2 ? 1 : 0);
+                       wl, wl_count, nplanes, row_stride, use_d2 ? 1 : 0);
     AMT_LAUNCH_CHECK();
     dim3 g1(amt_grid_for(n, 256, 4096), nplanes);
     hipLaunchKernelGGL(ws_seed_kernel, g1, dim3(256), 0, ctx->stream, markers, L, T, rows, row_stride, out, n);
@@ -605,16 +644,16 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
         AMT_LAUNCH_CHECK();
         AMT_TRY(amt_fork(ctx));
         hipLaunchKernelGGL((ws_flood_lds_kernel<L_PX, L_NB, CLS_L>), dim3(16, nplanes), dim3(64), ldsL, ctx->stream,
-                           (const int*)relief, L, T, out, rows, ncomp, counters + 0 * nplanes, row_stride, H, W,
-                           seeds_first);
+                           (const int*)relief, L, T, out, rows, wl + 2 * (size_t)nplanes * row_stride,
+                           wl_count + 2 * nplanes, counters + 0 * nplanes, row_stride, H, W, seeds_first);
         AMT_LAUNCH_CHECK();
-        hipLaunchKernelGGL((ws_flood_lds_kernel<M_PX, M_NB, CLS_M>), dim3(32, nplanes), dim3(64), ldsM, ctx->aux[0],
-                           (const int*)relief, L, T, out, rows, ncomp, counters + 1 * nplanes, row_stride, H, W,
-                           seeds_first);
+        hipLaunchKernelGGL((ws_flood_lds_kernel<M_PX, M_NB, CLS_M>), dim3(64, nplanes), dim3(64), ldsM, ctx->aux[0],
+                           (const int*)relief, L, T, out, rows, wl + 1 * (size_t)nplanes * row_stride,
+                           wl_count + 1 * nplanes, counters + 1 * nplanes, row_stride, H, W, seeds_first);
         AMT_LAUNCH_CHECK();
         hipLaunchKernelGGL((ws_flood_lds_kernel<S_PX, S_NB, CLS_S>), dim3(128, nplanes), dim3(64), ldsS, ctx->aux[1],
-                           (const int*)relief, L, T, out, rows, ncomp, counters + 2 * nplanes, row_stride, H, W,
-                           seeds_first);
+                           (const int*)relief, L, T, out, rows, wl + 0 * (size_t)nplanes * row_stride,
+                           wl_count + 0 * nplanes, counters + 2 * nplanes, row_stride, H, W, seeds_first);
         AMT_LAUNCH_CHECK();
         hipLaunchKernelGGL(ws_flood_edt_kernel, dim3(4, nplanes), dim3(64), 0, ctx->aux[1], (const int*)relief, mask, out,
                            next, head, tail, mlist, rows, moff, boff, ncomp, counters + 3 * nplanes, row_stride, H, W, n,

@@ -233,9 +233,8 @@ def apply_threshold(
         if "block_size" not in kw:
             raise TypeError("threshold_local() missing 1 required positional argument: 'block_size'")
         mask = hipops.greater_than_image(d, _local_threshold(d, **kw))
-    else:
-        raise NotImplementedError(
-            f"apply_threshold(method='{method_lower}') is not implemented on the MI355X path yet "
-            "(integral-image window statistics); see DESIGN.md 'Out of scope / next'"
-        )
+    else:  # niblack / sauvola (SK/filters/thresholding.py:967-1087)
+        if isinstance(kw.get("window_size", 15), (tuple, list, np.ndarray)):
+            raise NotImplementedError("per-axis window sizes are not supported on the device path")
+        mask = hipops.greater_than_image(d, hipops.window_threshold(d, method=method_lower, **kw))
     return _result(mask, was_numpy)

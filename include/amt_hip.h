@@ -145,6 +145,11 @@ int amt_threshold_value(amt_ctx* ctx, const void* in, int in_dtype, int method, 
 /* out = in > thr[plane] (uint8 0/1) */
 int amt_threshold_gt(amt_ctx* ctx, const void* in, int in_dtype, const double* thr_dev, uint8_t* out, int nplanes,
                      size_t n);
+/* Niblack (method 0: m - k*s) / Sauvola (method 1: m*(1 + k*(s/r - 1))) threshold image from the mean m and
+ * standard deviation s of the window_size^2 square around each pixel, mirror padding
+ * (SK/filters/thresholding.py:910-964,1026-1027,1083-1087).  uint16 window sums are exact integers. */
+int amt_window_threshold(amt_ctx* ctx, const void* in, int in_dtype, double* thr_image, int nplanes, int H, int W,
+                         int window_size, int method, double k, double r);
 /* out = in > thr_image (per-pixel thresholds: local / niblack / sauvola) */
 int amt_threshold_gt_image(amt_ctx* ctx, const void* in, int in_dtype, const double* thr_image, uint8_t* out,
                            size_t n);

@@ -72,8 +72,22 @@ def test_apply_threshold_methods(golden):
     with pytest.raises(RuntimeError, match="two maxima"):
         apply_threshold(dapi, method="minimum")
     assert int(apply_threshold(dapi).sum()) == 1297  # BASELINE configs[0]
-    with pytest.raises(NotImplementedError):
-        apply_threshold(u, method="sauvola")
+    # niblack / sauvola: window mean and std (uint16 window sums are exact integers on the device)
+    from arcadia_microscopy_tools_amd import hipops
+
+    for ws in (15, 25):
+        np.testing.assert_allclose(hipops.window_threshold(du, ws, "niblack", 0.2).numpy(),
+                                   skops.threshold_niblack(u, ws, 0.2), rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(hipops.window_threshold(du, ws, "sauvola", 0.2).numpy(),
+                                   skops.threshold_sauvola(u, ws, 0.2), rtol=1e-9, atol=1e-9)
+    assert np.array_equal(apply_threshold(u, "sauvola", window_size=25), u > skops.threshold_sauvola(u, 25))
+    assert np.array_equal(apply_threshold(u, "niblack"), u > skops.threshold_niblack(u))
+    np.testing.assert_allclose(hipops.window_threshold(get_context().asarray(gz), 15, "sauvola", 0.2).numpy(),
+                               skops.threshold_sauvola(gz, 15, 0.2), rtol=1e-7, atol=1e-12)
+    assert np.array_equal(apply_threshold(gz, "niblack", window_size=15, k=0.1),
+                          gz > skops.threshold_niblack(gz, 15, 0.1))
+    with pytest.raises(ValueError, match="is even"):
+        apply_threshold(u, "sauvola", window_size=14)
 
 
 def test_pipeline_device_chain(golden):
