@@ -41,6 +41,7 @@ _SIGS = {
     "amt_ctx_create": (c_int, [c_int, POINTER(c_void_p)]),
     "amt_ctx_create_on_stream": (c_int, [c_int, c_void_p, POINTER(c_void_p)]),
     "amt_ctx_destroy": (c_int, [_P]),
+    "amt_ctx_stream": (c_int, [_P, POINTER(c_void_p)]),
     "amt_last_error": (c_char_p, []),
     "amt_version": (c_char_p, []),
     "amt_device_name": (c_int, [_P, c_char_p, c_int]),
@@ -51,6 +52,7 @@ _SIGS = {
     "amt_memcpy_d2d": (c_int, [_P, _P, _P, c_size_t]),
     "amt_memset": (c_int, [_P, _P, c_int, c_size_t]),
     "amt_sync": (c_int, [_P]),
+    "amt_stream_wait": (c_int, [_P, _P]),
     "amt_host_alloc": (c_int, [c_size_t, POINTER(c_void_p)]),
     "amt_host_free": (c_int, [_P]),
     "amt_timer_create": (c_int, [_P, POINTER(c_void_p)]),

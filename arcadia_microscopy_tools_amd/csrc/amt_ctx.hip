@@ -1,6 +1,8 @@
 // Context, memory, timers and error plumbing of libamt_hip.so.
 #include "amt_common.h"
 
+#include <cstdlib>
+
 static thread_local char g_err[1024] = "";
 
 void amt_set_error(const char* fmt, ...) {
@@ -113,7 +115,22 @@ int amt_arena_begin(amt_ctx* ctx, size_t total_bytes) {
     return AMT_OK;
 }
 
+// AMT_FORK=0 keeps every kernel of an op on the context's single stream (no auxiliary streams): useful
+// when several contexts already provide the overlap and hardware queues are scarce.
+static bool fork_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("AMT_FORK");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
+}
+
 int amt_fork(amt_ctx* ctx) {
+    if (!fork_enabled()) {
+        ctx->aux[0] = ctx->aux[1] = ctx->stream;
+        return AMT_OK;
+    }
     if (!ctx->aux_ready) {
         for (int i = 0; i < 2; ++i) AMT_HIP_CHECK(hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking));
         for (int i = 0; i < 3; ++i) AMT_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev[i], hipEventDisableTiming));
@@ -125,6 +142,7 @@ int amt_fork(amt_ctx* ctx) {
 }
 
 int amt_join(amt_ctx* ctx) {
+    if (!fork_enabled()) return AMT_OK;
     for (int i = 0; i < 2; ++i) {
         AMT_HIP_CHECK(hipEventRecord(ctx->ev[1 + i], ctx->aux[i]));
         AMT_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev[1 + i], 0));
@@ -201,6 +219,25 @@ extern "C" int amt_memset(amt_ctx* ctx, void* dst, int value, size_t bytes) {
 extern "C" int amt_sync(amt_ctx* ctx) {
     AMT_TRY(amt_set_device(ctx));
     AMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return AMT_OK;
+}
+
+extern "C" int amt_ctx_stream(amt_ctx* ctx, void** hip_stream) {
+    AMT_REQUIRE(ctx && hip_stream, "amt_ctx_stream: null argument");
+    *hip_stream = (void*)ctx->stream;
+    return AMT_OK;
+}
+
+extern "C" int amt_stream_wait(amt_ctx* ctx, amt_ctx* other) {
+    // everything enqueued so far on `other`'s stream happens-before what is enqueued next on `ctx`'s stream
+    AMT_TRY(amt_set_device(ctx));
+    AMT_REQUIRE(other != nullptr, "amt_stream_wait: other is null");
+    AMT_REQUIRE(other->device == ctx->device, "amt_stream_wait: contexts on different devices");
+    hipEvent_t ev;
+    AMT_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    AMT_HIP_CHECK(hipEventRecord(ev, other->stream));
+    AMT_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ev, 0));
+    AMT_HIP_CHECK(hipEventDestroy(ev));  // destruction is deferred until the event has completed
     return AMT_OK;
 }
 

@@ -92,6 +92,17 @@ class Context:
     def synchronize(self):
         _hip.check(self._lib.amt_sync(self.handle), "amt_sync")
 
+    @property
+    def stream_ptr(self) -> int:
+        """The context's hipStream_t as an integer (0 = the null stream)."""
+        p = ctypes.c_void_p()
+        _hip.check(self._lib.amt_ctx_stream(self.handle, ctypes.byref(p)), "amt_ctx_stream")
+        return int(p.value or 0)
+
+    def wait_for(self, other: "Context"):
+        """Order this context's stream after the work enqueued so far on ``other``'s stream (no host sync)."""
+        _hip.check(self._lib.amt_stream_wait(self.handle, other.handle), "amt_stream_wait")
+
     def device_name(self) -> str:
         buf = ctypes.create_string_buffer(256)
         _hip.check(self._lib.amt_device_name(self.handle, buf, 256), "amt_device_name")

@@ -80,29 +80,106 @@ def all_gather_rows(local_rows, group=None):
     return torch.cat(parts, dim=0), counts
 
 
+class PlateTables:
+    """The per-rank block of the per-plate feature table, and its ONE all-gather.
+
+    A rank processes its shard of the plate in `steps` batches.  Each batch's segmenters write their
+    morphology table, intensity table and cell counts straight into this rank's slice of one torch-allocated
+    byte buffer (no copies, no per-step collective); when the rank's shard is done a single
+    ``all_gather_into_tensor`` over RCCL exchanges the blocks (BASELINE.json north_star: "RCCL all-gather over
+    xGMI only for the final per-plate label/feature table").  Layout of a rank's block (bytes):
+    [S*B*K*14 float64 | S*B*K*C*4 float64 | S*B int32 (padded to 8 bytes)], S = steps, B = FOVs per step."""
+
+    def __init__(self, segs, steps, torch_device, group=None):
+        import torch
+        import torch.distributed as dist
+
+        from .device import Context
+
+        self.torch, self.dist, self.group = torch, dist, group
+        self.segs = list(segs)
+        self.steps = int(steps)
+        B = sum(s.B for s in self.segs)
+        K, C = self.segs[0].max_cells, self.segs[0].C
+        self.B, self.K, self.C = B, K, C
+        n = self.steps * B
+        self.n_table = n * K * _hip.RP_NCOLS * 8
+        self.n_itable = n * K * C * 4 * 8
+        self.n_cells = (n * 4 + 7) // 8 * 8
+        self.local = torch.zeros(self.n_table + self.n_itable + self.n_cells, dtype=torch.uint8, device=torch_device)
+        self.gathered = None
+        # the collective's stream is one of the library's own HIP streams handed to torch as an external stream
+        self.gctx = Context(self.segs[0].ctx.device)
+        self.stream = torch.cuda.ExternalStream(self.gctx.stream_ptr, device=torch_device)
+
+    def point(self, step: int):
+        """Make the segmenters write the tables of batch `step` (0-based, modulo `steps`) into the plate block."""
+        from .device import DeviceArray
+
+        base = self.local.data_ptr()
+        K, C = self.K, self.C
+        b0 = (step % self.steps) * self.B
+        for s in self.segs:
+            s.table = DeviceArray(s.ctx, base + b0 * K * _hip.RP_NCOLS * 8, (s.B, K, _hip.RP_NCOLS), np.float64)
+            s.itable = DeviceArray(s.ctx, base + self.n_table + b0 * K * C * 4 * 8, (s.B, K, C, 4), np.float64)
+            s.ncells = DeviceArray(s.ctx, base + self.n_table + self.n_itable + b0 * 4, (s.B,), np.int32)
+            b0 += s.B
+
+    def all_gather(self):
+        """Enqueue the plate's single all-gather after everything the compute streams have been given."""
+        torch, dist = self.torch, self.dist
+        world = dist.get_world_size(self.group)
+        if self.gathered is None:
+            self.gathered = torch.empty(world * self.local.numel(), dtype=torch.uint8, device=self.local.device)
+        for s in self.segs:
+            self.gctx.wait_for(s.ctx)
+        with torch.cuda.stream(self.stream):
+            dist.all_gather_into_tensor(self.gathered, self.local, group=self.group)
+        return self.gathered
+
+    def result(self):
+        """(table, itable, ncells) of the whole plate: leading axes (rank, step * B + fov)."""
+        torch = self.torch
+        world = self.dist.get_world_size(self.group)
+        self.stream.synchronize()
+        n = self.steps * self.B
+        g = self.gathered.view(world, -1)
+        t = g[:, : self.n_table].contiguous().view(torch.float64).view(world, n, self.K, _hip.RP_NCOLS)
+        it = g[:, self.n_table: self.n_table + self.n_itable].contiguous().view(torch.float64).view(
+            world, n, self.K, self.C, 4)
+        nc = g[:, self.n_table + self.n_itable: self.n_table + self.n_itable + n * 4].contiguous().view(
+            torch.int32).view(world, n)
+        return t, it, nc
+
+
 class DevicePackedTables:
     """Device-resident packed blocks for the bench / plate loop: the segmenter's raw tables
     (B, max_cells, 14) + (B, max_cells, C, 4) + counts are gathered as they are (fixed shape, so a single
     all_gather_into_tensor per array and no host round trip inside the timed region)."""
 
-    def __init__(self, seg, torch_device):
+    def __init__(self, segs, torch_device):
         import torch
 
-        self.seg = seg
+        self.segs = list(segs) if isinstance(segs, (list, tuple)) else [segs]
         self.torch = torch
-        B, K, C = seg.B, seg.max_cells, seg.C
+        B = sum(s.B for s in self.segs)
+        K, C = self.segs[0].max_cells, self.segs[0].C
         self.table = torch.empty((B, K, _hip.RP_NCOLS), dtype=torch.float64, device=torch_device)
         self.itable = torch.empty((B, K, C, 4), dtype=torch.float64, device=torch_device)
         self.ncells = torch.empty((B,), dtype=torch.int32, device=torch_device)
 
     def adopt(self):
-        """Point the segmenter's output tables at the torch allocations (so RCCL can send them)."""
+        """Point every segmenter's output tables at its slice of the torch allocations (so RCCL can send
+        the whole rank's block in one call)."""
         from .device import DeviceArray
 
-        s = self.seg
-        s.table = DeviceArray(s.ctx, self.table.data_ptr(), tuple(self.table.shape), np.float64)
-        s.itable = DeviceArray(s.ctx, self.itable.data_ptr(), tuple(self.itable.shape), np.float64)
-        s.ncells = DeviceArray(s.ctx, self.ncells.data_ptr(), tuple(self.ncells.shape), np.int32)
+        b0 = 0
+        for s in self.segs:
+            t, it, nc = self.table[b0:b0 + s.B], self.itable[b0:b0 + s.B], self.ncells[b0:b0 + s.B]
+            s.table = DeviceArray(s.ctx, t.data_ptr(), tuple(t.shape), np.float64)
+            s.itable = DeviceArray(s.ctx, it.data_ptr(), tuple(it.shape), np.float64)
+            s.ncells = DeviceArray(s.ctx, nc.data_ptr(), tuple(nc.shape), np.int32)
+            b0 += s.B
 
     def all_gather(self, group=None):
         import torch.distributed as dist

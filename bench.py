@@ -18,7 +18,12 @@ import os
 import sys
 import time
 
-import numpy as np
+# Each context owns up to three HIP streams (main + two fork/join streams for the flood classes) and the
+# batch is split over several contexts; ROCm's default of 4 hardware queues per process would multiplex them.
+# Must be set before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -45,10 +50,13 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=32, help="fields of view per GPU per step")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=4,
                     help="HIP streams per GPU; the batch is split over them so that the latency-bound flood of one "
                          "part overlaps the bandwidth-bound stages of the other")
     ap.add_argument("--size", type=int, default=2048)
+    ap.add_argument("--unique", type=int, default=8,
+                    help="distinct synthetic FOVs generated per GPU (host-side generation costs ~0.5 s each); the "
+                         "batch cycles through them")
     ap.add_argument("--workload", choices=["c3", "c2"], default="c3")
     ap.add_argument("--cpu-fovs", type=int, default=2, help="FOVs timed through the single-thread CPU oracle")
     ap.add_argument("--no-cpu", action="store_true")
@@ -94,10 +102,16 @@ def cpu_baseline(fovs: np.ndarray, workload: str, n_single: int):
 
 def main():
     args = parse_args()
+    # stdout must carry exactly ONE JSON line: RCCL / HIP runtime banners written to fd 1 by native code are
+    # sent to stderr instead, and the JSON goes to the saved descriptor at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    distributed = world > 1
+    # AMT_BENCH_FORCE_DIST=1 exercises the RCCL path with a single rank (used to rehearse the N > 1 code)
+    distributed = world > 1 or os.environ.get("AMT_BENCH_FORCE_DIST") == "1"
 
     from arcadia_microscopy_tools_amd import synth
     from arcadia_microscopy_tools_amd.device import Context, set_default_device
@@ -110,9 +124,11 @@ def main():
 
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        stream = torch.cuda.current_stream().cuda_stream
+        # compute runs on the library's own HIP streams (measured: compute placed on a torch-created stream
+        # ran ~30 % slower next to a second stream); only the collective uses a torch (side) stream,
+        # ordered against the compute streams with amt_stream_wait (plate.PlateGatherer)
         set_default_device(local_rank)
-        ctx = Context(local_rank, stream=stream)
+        ctx = Context(local_rank)
     else:
         set_default_device(local_rank)
         ctx = Context(local_rank)
@@ -120,14 +136,15 @@ def main():
     B, S = args.batch, args.size
     # every rank owns B distinct FOV indices of the plate (weak scaling)
     t0 = time.perf_counter()
-    fovs = np.stack([synth.synth_fov(rank * B + i, size=S) for i in range(B)])
+    nuniq = max(1, min(args.unique, B))
+    uniq = [synth.synth_fov(rank * B + i, size=S) for i in range(nuniq)]
+    fovs = np.stack([uniq[i % nuniq] for i in range(B)])
     gen_s = time.perf_counter() - t0
-    log(f"rank {rank}: generated {B} synthetic FOVs in {gen_s:.1f}s; device = {ctx.device_name()}")
+    log(f"rank {rank}: generated {nuniq} distinct synthetic FOVs (batch {B}) in {gen_s:.1f}s; "
+        f"device = {ctx.device_name()}")
     d_fovs = ctx.asarray(fovs)
     # split the batch over `streams` contexts (each = one HIP stream + arena); parts run concurrently
     nstreams = max(1, min(args.streams, B))
-    if distributed:
-        nstreams = 1  # RCCL is ordered on torch's current stream, which the single context shares
     bounds = [round(i * B / nstreams) for i in range(nstreams + 1)]
     ctxs = [ctx] + [Context(local_rank) for _ in range(nstreams - 1)]
     parts = [d_fovs[bounds[i]:bounds[i + 1]] for i in range(nstreams)]
@@ -135,19 +152,21 @@ def main():
     seg = segs[0]
     packed = None
     if distributed:
-        from arcadia_microscopy_tools_amd.plate import DevicePackedTables
+        from arcadia_microscopy_tools_amd.plate import PlateTables
 
-        packed = DevicePackedTables(seg, torch.device("cuda", local_rank))
-        packed.adopt()
+        # this rank's block of the per-plate feature table: every step writes its slice, ONE all-gather at the end
+        packed = PlateTables(segs, args.steps, torch.device("cuda", local_rank))
 
-    def step():
+    gather = packed is not None and args.workload == "c3"
+
+    def step(i=0):
+        if gather:
+            packed.point(i)
         for sg, part in zip(segs, parts):
             if args.workload == "c3":
                 sg.run_c3(part)
             else:
                 sg.run_c2(part)
-        if packed is not None and args.workload == "c3":
-            packed.all_gather()
 
     def sync():
         if distributed:
@@ -164,8 +183,10 @@ def main():
         dist.barrier()
         sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        step(i)
+    if gather:
+        packed.all_gather()  # the plate's single RCCL all-gather, inside the timed region
     sync()
     if distributed:
         dist.barrier()
@@ -239,7 +260,7 @@ def main():
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(fovs, args.workload, args.cpu_fovs)
             out["gpu_over_cpu_1thread"] = out["value"] / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

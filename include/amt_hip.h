@@ -57,6 +57,8 @@ int amt_ctx_create(int device, amt_ctx** out);
 /* Share an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); 0 = null stream. */
 int amt_ctx_create_on_stream(int device, void* hip_stream, amt_ctx** out);
 int amt_ctx_destroy(amt_ctx* ctx);
+/* The context's hipStream_t (e.g. to wrap it in torch.cuda.ExternalStream for an RCCL collective). */
+int amt_ctx_stream(amt_ctx* ctx, void** hip_stream);
 const char* amt_last_error(void);
 const char* amt_version(void);
 int amt_device_name(amt_ctx* ctx, char* buf, int buflen);
@@ -67,6 +69,9 @@ int amt_memcpy_d2h(amt_ctx* ctx, void* dst, const void* src, size_t bytes); /* a
 int amt_memcpy_d2d(amt_ctx* ctx, void* dst, const void* src, size_t bytes);
 int amt_memset(amt_ctx* ctx, void* dst, int value, size_t bytes);
 int amt_sync(amt_ctx* ctx);
+/* Order `ctx`'s stream after everything enqueued so far on `other`'s stream (same device), without
+ * blocking the host: joins batch parts processed on separate streams before a collective. */
+int amt_stream_wait(amt_ctx* ctx, amt_ctx* other);
 /* pinned host staging buffers for the FOV feeder */
 int amt_host_alloc(size_t bytes, void** hptr);
 int amt_host_free(void* hptr);
