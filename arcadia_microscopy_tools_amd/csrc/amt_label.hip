@@ -482,3 +482,164 @@ extern "C" int amt_max_i32(amt_ctx* ctx, const int32_t* in, int32_t* max_dev, in
     }
     return AMT_OK;
 }
+
+// ---- sparse labelling ---------------------------------------------------------------------------------
+// For masks with few foreground pixels (the EDT peak markers: a few thousand pixels in 4 Mpx) the dense
+// passes above mostly stream background.  Here the foreground pixels are compacted IN RASTER ORDER into a
+// list (ballot ranks + block prefix), `out` doubles as the pixel -> list-index map, union-find runs on the
+// list only (root = smallest list index = first raster pixel of the component), roots are ranked by a scan
+// over the list and the labels are scattered back.  Same numbering as amt_label by construction.
+__global__ void __launch_bounds__(256) sp_count_kernel(const uint8_t* __restrict__ in, int* __restrict__ blockcnt,
+                                                       size_t n, int nblk) {
+    const size_t base = (size_t)blockIdx.y * n;
+    const size_t start = (size_t)blockIdx.x * RN_CHUNK;
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const size_t i = start + (size_t)k * 256 + threadIdx.x;
+        if (i < n) c += in[base + i] != 0 ? 1 : 0;
+    }
+    for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off);
+    __shared__ int s[4];
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) blockcnt[(size_t)blockIdx.y * nblk + blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
+__global__ void __launch_bounds__(256) sp_compact_kernel(const uint8_t* __restrict__ in, const int* __restrict__ blockoff,
+                                                         int* __restrict__ list, int* __restrict__ parent,
+                                                         int* __restrict__ out, size_t n, int nblk, int cap) {
+    const size_t base = (size_t)blockIdx.y * n;
+    const size_t start = (size_t)blockIdx.x * RN_CHUNK;
+    int* lst = list + (size_t)blockIdx.y * cap;
+    int* par = parent + (size_t)blockIdx.y * cap;
+    __shared__ int wave_tot[4];
+    __shared__ int running;
+    if (threadIdx.x == 0) running = blockoff[(size_t)blockIdx.y * nblk + blockIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = 0; k < 8; ++k) {
+        const size_t i = start + (size_t)k * 256 + threadIdx.x;
+        const bool fg = i < n && in[base + i] != 0;
+        const unsigned long long m = __ballot(fg);
+        const int before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_tot[wave] = __popcll(m);
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wave_tot[w];
+        const int run = running;
+        if (fg) {
+            const int idx = run + woff + before;
+            if (idx < cap) {
+                lst[idx] = (int)i;
+                par[idx] = idx;
+                out[base + i] = idx + 1;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) running = run + wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256) sp_merge_kernel(const int* __restrict__ list, int* __restrict__ parent,
+                                                       const int* __restrict__ out, const int* __restrict__ total,
+                                                       int H, int W, int cap, int conn8) {
+    const size_t n = (size_t)H * W;
+    const int K = total[blockIdx.y] < cap ? total[blockIdx.y] : cap;
+    const int* lst = list + (size_t)blockIdx.y * cap;
+    int* par = parent + (size_t)blockIdx.y * cap;
+    const int* o = out + (size_t)blockIdx.y * n;
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < K; k += gridDim.x * 256) {
+        const int p = lst[k];
+        const int y = p / W, x = p - y * W;
+        if (x > 0 && o[p - 1] > 0) uf_union(par, k, o[p - 1] - 1);
+        if (y > 0) {
+            if (o[p - W] > 0) uf_union(par, k, o[p - W] - 1);
+            if (conn8) {
+                if (x > 0 && o[p - W - 1] > 0) uf_union(par, k, o[p - W - 1] - 1);
+                if (x + 1 < W && o[p - W + 1] > 0) uf_union(par, k, o[p - W + 1] - 1);
+            }
+        }
+    }
+}
+
+// flags[k] = 1 for roots (after full compression of parent[k])
+__global__ void __launch_bounds__(256) sp_compress_kernel(int* __restrict__ parent, int* __restrict__ flags,
+                                                          const int* __restrict__ total, int cap) {
+    const int K = total[blockIdx.y] < cap ? total[blockIdx.y] : cap;
+    int* par = parent + (size_t)blockIdx.y * cap;
+    int* fl = flags + (size_t)blockIdx.y * cap;
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < K; k += gridDim.x * 256) {
+        int r = par[k];
+        int q = par[r];
+        while (q != r) {
+            r = q;
+            q = par[r];
+        }
+        par[k] = r;
+        fl[k] = (r == k) ? 1 : 0;
+    }
+}
+
+__global__ void __launch_bounds__(256) sp_write_kernel(const int* __restrict__ list, const int* __restrict__ parent,
+                                                       const int* __restrict__ rank, const int* __restrict__ total,
+                                                       const int* __restrict__ nroots, int* __restrict__ out,
+                                                       int* __restrict__ count_dev, size_t n, int cap) {
+    const int tot = total[blockIdx.y];
+    const int K = tot < cap ? tot : cap;
+    const int* lst = list + (size_t)blockIdx.y * cap;
+    const int* par = parent + (size_t)blockIdx.y * cap;
+    const int* rk = rank + (size_t)blockIdx.y * cap;
+    int* o = out + (size_t)blockIdx.y * n;
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < K; k += gridDim.x * 256) o[lst[k]] = rk[par[k]] + 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && count_dev) count_dev[blockIdx.y] = tot > cap ? -1 : nroots[blockIdx.y];
+}
+
+__global__ void sp_clamp_kernel(int* total_clamped, const int* total, int cap, int nplanes) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nplanes) total_clamped[i] = total[i] < cap ? total[i] : cap;
+}
+
+extern "C" int amt_label_sparse(amt_ctx* ctx, const uint8_t* in, int32_t* out, int32_t* count_dev, int nplanes, int H,
+                                int W, int connectivity, int capacity) {
+    AMT_TRY(amt_set_device(ctx));
+    AMT_REQUIRE(in && out && nplanes >= 0 && H > 0 && W > 0, "label_sparse: bad arguments");
+    AMT_REQUIRE(connectivity == 1 || connectivity == 2, "label_sparse: connectivity must be 1 or 2");
+    AMT_REQUIRE(capacity >= 1, "label_sparse: capacity must be positive");
+    AMT_REQUIRE((size_t)H * W < 0x7fffffffull, "label_sparse: plane too large");
+    if (nplanes == 0) return AMT_OK;
+    const size_t n = (size_t)H * W;
+    const int nblk = amt_i_rank_blocks(n);
+    const size_t capn = (size_t)nplanes * capacity;
+    AMT_TRY(amt_arena_begin(ctx, 3 * amt_align(capn * 4) + amt_align((size_t)nplanes * nblk * 4) +
+                                     3 * amt_align(nplanes * 4)));
+    int* list = arena_take_t<int>(ctx, capn);
+    int* parent = arena_take_t<int>(ctx, capn);
+    int* flags = arena_take_t<int>(ctx, capn);
+    int* blk = arena_take_t<int>(ctx, (size_t)nplanes * nblk);
+    int* total = arena_take_t<int>(ctx, nplanes);
+    int* total_c = arena_take_t<int>(ctx, nplanes);
+    int* nroots = arena_take_t<int>(ctx, nplanes);
+    AMT_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)nplanes * n * sizeof(int32_t), ctx->stream));
+    hipLaunchKernelGGL(sp_count_kernel, dim3(nblk, nplanes), dim3(256), 0, ctx->stream, in, blk, n, nblk);
+    AMT_LAUNCH_CHECK();
+    AMT_TRY(amt_scan_excl(ctx, blk, nblk, (size_t)nblk, total, nplanes));
+    hipLaunchKernelGGL(sp_compact_kernel, dim3(nblk, nplanes), dim3(256), 0, ctx->stream, in, blk, list, parent, out, n,
+                       nblk, capacity);
+    AMT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sp_clamp_kernel, dim3((nplanes + 63) / 64), dim3(64), 0, ctx->stream, total_c, total, capacity,
+                       nplanes);
+    AMT_LAUNCH_CHECK();
+    const unsigned gk = amt_grid_for((size_t)capacity, 256, 64);
+    hipLaunchKernelGGL(sp_merge_kernel, dim3(gk, nplanes), dim3(256), 0, ctx->stream, list, parent, out, total, H, W,
+                       capacity, connectivity == 2 ? 1 : 0);
+    AMT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sp_compress_kernel, dim3(gk, nplanes), dim3(256), 0, ctx->stream, parent, flags, total, capacity);
+    AMT_LAUNCH_CHECK();
+    AMT_TRY(amt_scan_excl_dev(ctx, flags, total_c, (size_t)capacity, nroots, nplanes));
+    hipLaunchKernelGGL(sp_write_kernel, dim3(gk, nplanes), dim3(256), 0, ctx->stream, list, parent, flags, total, nroots,
+                       out, count_dev, n, capacity);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}

@@ -45,6 +45,35 @@ __global__ void __launch_bounds__(256) pack_kernel(const uint8_t* __restrict__ i
     }
 }
 
+// same packing, fused with the comparison `in > thr[plane]` (R/operations.py:216): the byte mask of the
+// threshold never exists
+template <typename T>
+__global__ void __launch_bounds__(256) pack_gt_kernel(const T* __restrict__ in, const double* __restrict__ thr,
+                                                      u64* __restrict__ packed, int H, int W, int WW) {
+    const int lane = threadIdx.x & 63;
+    const size_t plane = blockIdx.y;
+    const size_t nwords = (size_t)H * WW;
+    const size_t w0 = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * PACK_WORDS_PER_WAVE;
+    const T* src = in + plane * (size_t)H * W;
+    const double t = thr[plane];
+    bool v[PACK_WORDS_PER_WAVE];
+#pragma unroll
+    for (int k = 0; k < PACK_WORDS_PER_WAVE; ++k) {
+        const size_t wi = w0 + k;
+        v[k] = false;
+        if (wi < nwords) {
+            const int y = (int)(wi / WW), wx = (int)(wi - (size_t)y * WW);
+            const int x = wx * 64 + lane;
+            v[k] = x < W && (double)src[(size_t)y * W + x] > t;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < PACK_WORDS_PER_WAVE; ++k) {
+        const u64 m = __ballot(v[k]);
+        if (lane == 0 && w0 + k < nwords) packed[plane * nwords + w0 + k] = m;
+    }
+}
+
 __device__ __forceinline__ unsigned spread4(unsigned nib) {
     return (nib & 1u) | ((nib & 2u) << 7) | ((nib & 4u) << 14) | ((nib & 8u) << 21);
 }
@@ -211,4 +240,49 @@ extern "C" int amt_binary_open(amt_ctx* ctx, const uint8_t* in, uint8_t* out, in
 extern "C" int amt_binary_close(amt_ctx* ctx, const uint8_t* in, uint8_t* out, int nplanes, int H, int W,
                                 const uint8_t* footprint, int fh, int fw) {
     return morph_common(ctx, in, out, nplanes, H, W, footprint, fh, fw, 3, 0);
+}
+
+// `binary_closing(binary_opening(in > thr))` in one packed chain: compare -> 4 word-level primitives ->
+// unpack (the Gaussian -> Otsu -> '>' -> open -> close mask chain of BASELINE configs[1]/[2]).
+extern "C" int amt_threshold_open_close(amt_ctx* ctx, const void* in, int in_dtype, const double* thr_dev,
+                                        uint8_t* out, int nplanes, int H, int W, const uint8_t* footprint, int fh,
+                                        int fw) {
+    AMT_TRY(amt_set_device(ctx));
+    AMT_REQUIRE(in && thr_dev && out && nplanes >= 0 && H > 0 && W > 0, "threshold_open_close: bad arguments");
+    AMT_REQUIRE(in_dtype == AMT_U16 || in_dtype == AMT_F64, "threshold_open_close: dtype must be AMT_U16 or AMT_F64");
+    static thread_local int2 host[MAX_OFFS];
+    int noffs = 0;
+    AMT_TRY(build_offsets(footprint, fh, fw, host, &noffs));
+    if (nplanes == 0) return AMT_OK;
+    const int WW = (W + 63) / 64;
+    const size_t words = (size_t)nplanes * H * WW;
+    AMT_TRY(amt_arena_begin(ctx, amt_align(sizeof(int2) * noffs) + 2 * amt_align(words * 8)));
+    int2* offs = arena_take_t<int2>(ctx, noffs);
+    u64* pa = arena_take_t<u64>(ctx, words);
+    u64* pb = arena_take_t<u64>(ctx, words);
+    AMT_TRY(amt_param_upload(ctx, offs, host, sizeof(int2) * noffs));
+    const size_t nwords = (size_t)H * WW;
+    const unsigned gpack = (unsigned)((nwords + 4 * PACK_WORDS_PER_WAVE - 1) / (4 * PACK_WORDS_PER_WAVE));
+    if (in_dtype == AMT_F64)
+        hipLaunchKernelGGL((pack_gt_kernel<double>), dim3(gpack, nplanes), dim3(256), 0, ctx->stream, (const double*)in,
+                           thr_dev, pa, H, W, WW);
+    else
+        hipLaunchKernelGGL((pack_gt_kernel<uint16_t>), dim3(gpack, nplanes), dim3(256), 0, ctx->stream,
+                           (const uint16_t*)in, thr_dev, pa, H, W, WW);
+    AMT_LAUNCH_CHECK();
+    dim3 gp((WW + 63) / 64, (H + 3) / 4, nplanes);
+    // opening: erosion (outside = 1) then dilation (outside = 0); closing: dilation then erosion
+    hipLaunchKernelGGL((packed_prim_kernel<true>), gp, dim3(256), 0, ctx->stream, pa, pb, H, W, WW, offs, noffs, 1);
+    AMT_LAUNCH_CHECK();
+    hipLaunchKernelGGL((packed_prim_kernel<false>), gp, dim3(256), 0, ctx->stream, pb, pa, H, W, WW, offs, noffs, 0);
+    AMT_LAUNCH_CHECK();
+    hipLaunchKernelGGL((packed_prim_kernel<false>), gp, dim3(256), 0, ctx->stream, pa, pb, H, W, WW, offs, noffs, 0);
+    AMT_LAUNCH_CHECK();
+    hipLaunchKernelGGL((packed_prim_kernel<true>), gp, dim3(256), 0, ctx->stream, pb, pa, H, W, WW, offs, noffs, 1);
+    AMT_LAUNCH_CHECK();
+    const size_t nq = (size_t)H * ((W + 15) / 16);
+    hipLaunchKernelGGL(unpack_kernel, dim3((unsigned)((nq + 255) / 256), nplanes), dim3(256), 0, ctx->stream, pa, out, H,
+                       W, WW);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
 }

@@ -354,6 +354,19 @@ def binary_closing(a, footprint=None, out=None):
     return _binary("close", a, footprint, out)
 
 
+def threshold_open_close(a: DeviceArray, thr: DeviceArray, footprint=None, out=None) -> DeviceArray:
+    """``binary_closing(binary_opening(a > thr[plane], fp), fp)`` as one packed chain (no intermediate masks)."""
+    ctx = a.ctx
+    n, H, W = _planes(a)
+    fp = _fp(footprint)
+    o = _out(ctx, out, a.shape, np.uint8)
+    _hip.check(_lib().amt_threshold_open_close(ctx.handle, a.ptr, _in_code(a), thr.ptr, o.ptr, n, H, W,
+                                               fp.ctypes.data_as(ctypes.c_void_p), fp.shape[0], fp.shape[1]),
+               "amt_threshold_open_close")
+    o.is_bool = True
+    return o
+
+
 def _rank(a: DeviceArray, footprint, op: int, mode: str, cval: float, out):
     ctx = a.ctx
     n, H, W = _planes(a)
@@ -421,6 +434,22 @@ def label(a: DeviceArray, connectivity: int = 2, out: DeviceArray | None = None,
     o = _out(ctx, out, a.shape, np.int32)
     c = _out(ctx, count, (n,), np.int32)
     _hip.check(_lib().amt_label(ctx.handle, a.ptr, code, o.ptr, c.ptr, n, H, W, int(connectivity)), "amt_label")
+    return o, c
+
+
+def label_sparse(a: DeviceArray, connectivity: int = 2, capacity: int | None = None, out=None, count=None):
+    """``label`` for sparse uint8 masks (at most ``capacity`` foreground pixels per plane, default max(65536,
+    plane size / 16)); a plane that overflows reports count -1."""
+    ctx = a.ctx
+    n, H, W = _planes(a)
+    if a.dtype != np.uint8:
+        raise TypeError("label_sparse expects a uint8 / bool mask")
+    if capacity is None:
+        capacity = max(65536, (H * W) // 16)
+    o = _out(ctx, out, a.shape, np.int32)
+    c = _out(ctx, count, (n,), np.int32)
+    _hip.check(_lib().amt_label_sparse(ctx.handle, a.ptr, o.ptr, c.ptr, n, H, W, int(connectivity), int(capacity)),
+               "amt_label_sparse")
     return o, c
 
 

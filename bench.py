@@ -32,7 +32,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (G/MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
 # algorithmic bytes per pixel per stage: narrowest dtypes, one read + one write
 STAGE_BYTES_PER_PX = {
-    "gaussian": 10, "otsu": 8, "threshold": 9, "opening": 4, "closing": 4, "label8": 5, "edt": 9, "peaks": 17,
+    "gaussian": 10, "otsu": 8, "threshold": 9, "opening": 4, "closing": 4, "threshold_open_close": 17, "label8": 5, "edt": 9, "peaks": 17,
     "markers": 5, "watershed": 17, "clear_border": 8, "relabel": 4, "regionprops": 16, "intensity": 12,
 }
 
@@ -217,8 +217,11 @@ def main():
         achieved = dom_bytes / (stage_avg[dom] * 1e-3) / 1e9
         chain_bytes = sum(STAGE_BYTES_PER_PX[k] for k in stage_avg) * npx
         chain_ms = sum(stage_avg.values())
-        fm = [k for k in ("gaussian", "opening", "closing") if k in stage_avg]
-        fm_bytes = sum(STAGE_BYTES_PER_PX[k] for k in fm) * npx
+        # filter + morphology chain of the north_star: Gaussian (10 B/px) + open + close (8 B/px).  The '>' is
+        # fused into the packed open/close chain, so that stage's time is charged in full while only the
+        # morphology's 8 B/px are credited (conservative).
+        fm = [k for k in ("gaussian", "opening", "closing", "threshold_open_close") if k in stage_avg]
+        fm_bytes = sum(8 if k == "threshold_open_close" else STAGE_BYTES_PER_PX[k] for k in fm) * npx
         fm_ms = sum(stage_avg[k] for k in fm)
         roofline = {
             "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

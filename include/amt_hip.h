@@ -171,6 +171,10 @@ int amt_binary_open(amt_ctx* ctx, const uint8_t* in, uint8_t* out, int nplanes, 
                     const uint8_t* footprint, int fh, int fw);
 int amt_binary_close(amt_ctx* ctx, const uint8_t* in, uint8_t* out, int nplanes, int H, int W,
                      const uint8_t* footprint, int fh, int fw);
+/* out = binary_closing(binary_opening(in > thr[plane])) in one packed chain (the mask chain of BASELINE
+ * configs[1]/[2]: R/operations.py:216 followed by SK/morphology/binary.py:82-147). */
+int amt_threshold_open_close(amt_ctx* ctx, const void* in, int in_dtype, const double* thr_dev, uint8_t* out,
+                             int nplanes, int H, int W, const uint8_t* footprint, int fh, int fw);
 /* grey erosion / dilation / median over a footprint (uint16 or float64 images), scipy boundary `mode`.
  * op: 0 = erosion (min), 1 = dilation (max, footprint already mirrored by the caller), 2 = median */
 int amt_rank_filter(amt_ctx* ctx, const void* in, void* out, int dtype, int nplanes, int H, int W,
@@ -184,6 +188,11 @@ int amt_subtract(amt_ctx* ctx, const void* a, const void* b, void* out, int dtyp
  * order of each component's first pixel; count_dev[plane] = K. */
 int amt_label(amt_ctx* ctx, const void* in, int in_dtype, int32_t* out, int32_t* count_dev, int nplanes, int H, int W,
               int connectivity);
+/* Same result as amt_label for uint8 masks with at most `capacity` foreground pixels per plane (e.g. the EDT
+ * peak markers): foreground is compacted in raster order and labelled on the compact list.  If a plane has
+ * more foreground pixels than `capacity`, count_dev[plane] = -1 and that plane's labels are invalid. */
+int amt_label_sparse(amt_ctx* ctx, const uint8_t* in, int32_t* out, int32_t* count_dev, int nplanes, int H, int W,
+                     int connectivity, int capacity);
 /* skimage.segmentation.clear_border(labels) with buffer_size=0: zero every 8-connected component of
  * equal-valued pixels that touches the 1-px frame; other pixels keep their value. */
 int amt_clear_border(amt_ctx* ctx, const int32_t* in, int32_t* out, int nplanes, int H, int W);

@@ -122,3 +122,63 @@ def test_c2_full_size_vs_oracle(ctx):
     seg = FovSegmenter(1, 4, 2048, 2048, ctx=ctx)
     lab = seg.run_c2(ctx.asarray(fov[None])).numpy()[0]
     assert np.array_equal(lab, chains.c2_chain(fov[1]))
+
+
+def test_degenerate_fovs(ctx):
+    """Empty / constant / saturated / tiny fields of view must not crash or hang, and must match the oracle."""
+    from arcadia_microscopy_tools_amd import synth
+    from arcadia_microscopy_tools_amd.segment import FovSegmenter
+    from oracle import chains, skops
+
+    S = 192
+    base = synth.synth_fov(11, size=S)
+    fovs = np.stack([base, base, base, base, base])
+    fovs[1] = 0                                   # all dark: constant image, empty mask
+    fovs[2, 1] = 65535                            # saturated DAPI: constant
+    fovs[3, 1, :, :] = 300
+    fovs[3, 1, 60:130, 50:150] = 9000             # one big rectangle (single component, plateau peaks)
+    fovs[4, 1, :8, :] = 60000                     # bright band touching the border + nuclei
+    seg = FovSegmenter(5, 4, S, S, ctx=ctx, max_cells=256)
+    labels = seg.run_c3(ctx.asarray(fovs)).numpy()
+    res = seg.result()
+    tables = res.feature_tables()
+    for b in range(5):
+        mask, _, _ = chains.c2_mask(fovs[b, 1])
+        if mask.any():
+            edt = skops.distance_transform_edt(mask)
+            markers, _ = skops.peak_markers(edt, mask, 5)
+            from oracle.watershed import watershed
+
+            ws = watershed(skops.seeded_flood_image(edt, markers), markers, mask=mask)
+            cleared = skops.clear_border(ws)
+            ref = skops.relabel_sequential(cleared) if cleared.max() > 0 else cleared
+        else:
+            ref = np.zeros((S, S), np.int64)
+        assert np.array_equal(labels[b], ref), f"fov {b}"
+        assert res.ncells[b] == ref.max()
+        assert len(tables[b]["area"]) == ref.max()
+    assert res.ncells[1] == 0 and res.ncells[2] == 0
+    # config 2 on the same inputs
+    lab8 = seg.run_c2(ctx.asarray(fovs)).numpy()
+    for b in range(5):
+        assert np.array_equal(lab8[b], chains.c2_chain(fovs[b, 1])), f"c2 fov {b}"
+
+
+def test_tiny_and_odd_shapes(ctx):
+    from arcadia_microscopy_tools_amd import hipops
+    from oracle import skops
+
+    rng = np.random.default_rng(21)
+    for shape in ((1, 1), (1, 7), (9, 1), (3, 3), (17, 65), (65, 129)):
+        m = rng.random(shape) < 0.6
+        d = ctx.asarray(m)
+        assert np.array_equal(hipops.label(d)[0].numpy(), skops.label(m)), shape
+        if min(shape) >= 3:
+            assert np.array_equal(hipops.binary_opening(d, skops.disk(1)).numpy(),
+                                  skops.binary_opening(m, skops.disk(1))), shape
+        u = rng.integers(0, 60000, shape).astype(np.uint16)
+        du = ctx.asarray(u)
+        assert np.array_equal(hipops.gaussian(du, 1.0).numpy(), skops.gaussian(u, 1.0)), shape
+        assert hipops.threshold_otsu(du).numpy()[0] == skops.threshold_otsu(u) or u.size == 1, shape
+        if m.any() and not m.all():
+            assert np.array_equal(hipops.edt(d)[1].numpy(), skops.distance_transform_edt(m)), shape

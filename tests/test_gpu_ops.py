@@ -279,3 +279,25 @@ def test_regionprops_intensity(ctx, ops, golden):
     for ci, name in enumerate(("brightfield", "dapi", "fitc", "tritc")):
         for j, k in enumerate(("intensity_mean", "intensity_max", "intensity_min", "intensity_std")):
             np.testing.assert_allclose(t[:, ci, j], g[f"rp_{k}_{name}"], rtol=1e-10, err_msg=f"{k}_{name}")
+
+
+def test_label_sparse(ctx, ops, golden):
+    from oracle import skops
+
+    rng = np.random.default_rng(31)
+    for shape, p in (((64, 64), 0.05), ((130, 257), 0.02), ((300, 301), 0.1), ((40, 40), 0.0)):
+        m = rng.random(shape) < p
+        m2 = np.stack([m, np.roll(m, 3, axis=1)])
+        for conn in (1, 2):
+            lab, cnt = ops.label_sparse(ctx.asarray(m2), connectivity=conn)
+            for b in range(2):
+                ref = skops.label(m2[b], conn)
+                assert cnt.numpy()[b] == ref.max()
+                assert np.array_equal(lab.numpy()[b], ref), (shape, conn, b)
+    g = golden("c2c3_256")
+    pk = ops.peak_mask(ops.edt(ctx.asarray(g["mask"]))[0], ctx.asarray(g["mask"]), 5)
+    assert np.array_equal(ops.label_sparse(pk, 1)[0].numpy(), g["markers"])
+    # overflow is reported, not silently wrong
+    dense = np.ones((64, 64), bool)
+    _, cnt = ops.label_sparse(ctx.asarray(dense), capacity=100)
+    assert cnt.numpy()[0] == -1
