@@ -31,7 +31,7 @@ enum { CLS_NONE = 0, CLS_UNIFORM = 1, CLS_S = 2, CLS_M = 3, CLS_L = 4, CLS_G = 5
 // LDS tile classes: max pixels of the bounding box, max d2 (bucket count - 1)
 constexpr int S_PX = 2048, S_NB = 512;
 constexpr int M_PX = 8192, M_NB = 1024;
-constexpr int L_PX = 24576, L_NB = 2048;
+constexpr int L_PX = 32512, L_NB = 2048;  // pixel indices must fit the 15-bit link field
 
 struct comp_row {
     int cmax;            // max d2 (bucket mode) or pixel count (heap mode)
@@ -240,11 +240,16 @@ __device__ __forceinline__ void lane_sort(int* a, int n) {
 // ---- LDS-tile flood (bucket queue, relief = -sqrt(d2)) ----------------------------------------------
 // One wave per component.  The bounding box plus a one-pixel sentinel ring is staged in LDS:
 //   cell[i] (u32) = label (low 16 bits; 0 = unclaimed, 0xFFFF = not in this component / ring)
-//                   | d2 << 16 (15 bits) | marker flag (bit 31)
-//   nx[i]   (u16) = FIFO link
+//                   | field << 16 (15 bits) | marker flag (bit 31)
+//                   field = d2 while the pixel is unclaimed; once the pixel has been pushed its d2 is dead
+//                   and the field becomes the FIFO link to the pixel pushed after it into the same bucket
 //   ht[b]   (u32) = head (low 16) | tail (high 16) of bucket b; head 0xFFFF = empty
-// Lane 0 runs the sequential flood at LDS latency: the four neighbour cells are fetched together, a
-// claim is one cell write + one head/tail update.  The sentinel ring removes all bounds arithmetic.
+// A single wave issues about one instruction every four clocks, so the flood is bound by the number of
+// instructions per pop, not by LDS latency.  Per pop: lanes 0..3 fetch the four neighbour cells and lane 4
+// the popped cell (label + link) in ONE ds_read; the claim test and the label write are one vector
+// compare / one masked ds_write; only the claimed neighbours (one per pop on average) go through the
+// scalar FIFO append.  The current bucket's head/tail live in scalar registers.  The sentinel ring
+// removes all bounds arithmetic.
 template <int TILE_PX, int NB, int CLS>
 __global__ void __launch_bounds__(64) ws_flood_lds_kernel(const int* __restrict__ d2all, const int* __restrict__ Lall,
                                                           const int* __restrict__ Tall, int* __restrict__ outall,
@@ -255,7 +260,7 @@ __global__ void __launch_bounds__(64) ws_flood_lds_kernel(const int* __restrict_
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     unsigned* cell = reinterpret_cast<unsigned*>(smem_raw);
     unsigned* ht = cell + TILE_PX;
-    unsigned short* nx = reinterpret_cast<unsigned short*>(ht + NB);
+    unsigned short* half = reinterpret_cast<unsigned short*>(cell);  // half[2 * i + 1] = field of cell i
     const int plane = blockIdx.y;
     const size_t n = (size_t)H * W;
     const int* d2 = d2all + (size_t)plane * n;
@@ -315,59 +320,91 @@ __global__ void __launch_bounds__(64) ws_flood_lds_kernel(const int* __restrict_
         for (int i = lane; i < nb; i += 64) ht[i] = 0xFFFFFFFFu;
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
-        // The flood is one sequential thread of control.  Every value it computes is wave-uniform, so each
-        // LDS load is passed through readfirstlane: indices, labels, bucket numbers and all branches then
-        // live on the scalar unit; only the LDS instructions themselves (address + data) touch VGPRs.
-        auto ld32 = [&](const unsigned* a, int i) -> unsigned { return __builtin_amdgcn_readfirstlane(a[i]); };
-        auto ld16 = [&](const unsigned short* a, int i) -> unsigned {
-            return __builtin_amdgcn_readfirstlane((unsigned)a[i]);
-        };
-        int cur = -1;
+        // ---- the flood: one sequential thread of control executed by lanes 0..15 in lock step ----
+        constexpr unsigned NONE = 0xFFFFu;
+        int cur = -1;                   // current bucket, -1 = none yet
+        unsigned head = NONE, tail = 0; // FIFO of the current bucket (register copy; ht[cur] is stale)
+        int raise = -1;                 // highest bucket above `cur` that received a push since the last switch
+        const int offk = lane == 0 ? -tw : lane == 1 ? -1 : lane == 2 ? 1 : lane == 3 ? tw : 0;
+        auto uni = [&](unsigned v) -> unsigned { return __builtin_amdgcn_readfirstlane(v); };
         auto push = [&](int q, int b) {
-            const unsigned h = ld32(ht, b);
-            if ((h & 0xFFFFu) == 0xFFFFu) {
-                ht[b] = (unsigned)q | ((unsigned)q << 16);
+            if (b == cur) {
+                if (head == NONE) head = (unsigned)q; else half[2 * tail + 1] = (unsigned short)q;
+                tail = (unsigned)q;
             } else {
-                nx[h >> 16] = (unsigned short)q;
-                ht[b] = (h & 0xFFFFu) | ((unsigned)q << 16);
+                const unsigned h = uni(ht[b]);
+                if ((h & 0xFFFFu) == NONE) {
+                    ht[b] = (unsigned)q | ((unsigned)q << 16);
+                } else {
+                    half[2 * (h >> 16) + 1] = (unsigned short)q;
+                    ht[b] = (h & 0xFFFFu) | ((unsigned)q << 16);
+                }
+                raise = b > raise ? b : raise;
             }
-            cur = b > cur ? b : cur;
         };
-        auto spread = [&](int p) {
-            const unsigned lb = ld32(cell, p) & 0xFFFFu;
-            const int q0 = p - tw, q1 = p - 1, q2 = p + 1, q3 = p + tw;
-            const unsigned c0 = ld32(cell, q0), c1 = ld32(cell, q1), c2 = ld32(cell, q2), c3 = ld32(cell, q3);
-            if ((c0 & 0xFFFFu) == 0) { cell[q0] = c0 | lb; push(q0, (int)((c0 >> 16) & 0x7FFF)); }
-            if ((c1 & 0xFFFFu) == 0) { cell[q1] = c1 | lb; push(q1, (int)((c1 >> 16) & 0x7FFF)); }
-            if ((c2 & 0xFFFFu) == 0) { cell[q2] = c2 | lb; push(q2, (int)((c2 >> 16) & 0x7FFF)); }
-            if ((c3 & 0xFFFFu) == 0) { cell[q3] = c3 | lb; push(q3, (int)((c3 >> 16) & 0x7FFF)); }
+        // claim the unlabelled neighbours of p in the order N, W, E, S (lanes 0..3; lane 4 fetches cell[p]).
+        // With `pop`, p is the head of the current bucket and is unlinked BEFORE its neighbours are pushed.
+        auto spread = [&](int p, bool pop) {
+            const int q = p + offk;
+            const unsigned c = cell[q];
+            const unsigned cp = (unsigned)__builtin_amdgcn_readlane((int)c, 4);
+            if (pop) head = (head == tail) ? NONE : (cp >> 16);  // the field of a linked cell is its successor
+            const bool claim = (c & 0xFFFFu) == 0;
+            unsigned m = (unsigned)__ballot(claim);
+            if (m) {
+                if (claim) cell[q] = c | (cp & 0xFFFFu);
+                do {
+                    const int k = __ffs((int)m) - 1;
+                    m &= m - 1;
+                    const unsigned ck = (unsigned)__builtin_amdgcn_readlane((int)c, k);
+                    push(__builtin_amdgcn_readlane(q, k), (int)((ck >> 16) & 0x7FFF));
+                } while (m);
+            }
         };
-        // ---- markers in raster order (wave ballots), then the flood, both on lane 0 ----
+        // ---- markers in raster order (wave ballots) ----
         for (int i0 = 0; i0 < npx; i0 += 64) {
             const int i = i0 + lane;
             const bool ismk = i < npx && (cell[i] & 0x80000000u);
             unsigned long long m = __ballot(ismk);
-            if (lane == 0) {
+            if (lane < 16) {
                 while (m) {
                     const int b = __ffsll((long long)m) - 1;
                     m &= m - 1;
                     const int p = i0 + b;
-                    if (seeds_first) spread(p); else push(p, (int)((ld32(cell, p) >> 16) & 0x7FFF));
+                    if (seeds_first) spread(p, false); else push(p, (int)((uni(cell[p]) >> 16) & 0x7FFF));
                 }
             }
             __builtin_amdgcn_wave_barrier();
         }
-        if (lane == 0) {
+        if (lane < 16) {
             while (true) {
-                unsigned h = 0xFFFFu;
-                while (cur >= 0 && ((h = ld32(ht, cur)) & 0xFFFFu) == 0xFFFFu) --cur;
-                if (cur < 0) break;
-                const int p = (int)(h & 0xFFFFu);
-                if (p == (int)(h >> 16))
-                    ht[cur] = 0xFFFFFFFFu;
-                else
-                    ht[cur] = (h & 0xFFFF0000u) | ld16(nx, p);
-                spread(p);
+                if (raise > cur) {  // a push landed above the current bucket: switch to it
+                    if (cur >= 0) ht[cur] = head == NONE ? 0xFFFFFFFFu : (head | (tail << 16));
+                    cur = raise;
+                    const unsigned h = uni(ht[cur]);
+                    head = h & 0xFFFFu;
+                    tail = h >> 16;
+                }
+                raise = -1;
+                if (head == NONE) {  // current bucket exhausted: walk down, 16 buckets per LDS round trip
+                    if (cur >= 0) ht[cur] = 0xFFFFFFFFu;
+                    while (cur >= 0) {
+                        const int bi = cur - 1 - lane;
+                        const unsigned h = bi >= 0 ? ht[bi] : 0xFFFFFFFFu;
+                        const unsigned m = (unsigned)__ballot((h & 0xFFFFu) != NONE);
+                        if (m) {
+                            const int k = __ffs((int)m) - 1;
+                            cur = cur - 1 - k;
+                            const unsigned hk = (unsigned)__builtin_amdgcn_readlane((int)h, k);
+                            head = hk & 0xFFFFu;
+                            tail = hk >> 16;
+                            break;
+                        }
+                        cur -= 16;
+                    }
+                    if (cur < 0) break;
+                }
+                spread((int)head, true);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -635,9 +672,9 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
                        has_g, row_stride, n);
     AMT_LAUNCH_CHECK();
     if (use_d2) {
-        const size_t ldsS = (size_t)S_PX * 6 + (size_t)S_NB * 4;
-        const size_t ldsM = (size_t)M_PX * 6 + (size_t)M_NB * 4;
-        const size_t ldsL = (size_t)L_PX * 6 + (size_t)L_NB * 4;
+        const size_t ldsS = (size_t)S_PX * 4 + (size_t)S_NB * 4;
+        const size_t ldsM = (size_t)M_PX * 4 + (size_t)M_NB * 4;
+        const size_t ldsL = (size_t)L_PX * 4 + (size_t)L_NB * 4;
         // the three LDS classes and the HBM path are independent, latency-bound and use few waves each:
         // run them side by side (fork / join on the context's auxiliary streams)
         hipLaunchKernelGGL(ws_fill_value_kernel, dim3(256, nplanes), dim3(256), 0, ctx->stream, head, btot, bstride, -1);
