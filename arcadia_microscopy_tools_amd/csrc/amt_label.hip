@@ -45,55 +45,153 @@ __device__ __forceinline__ void uf_union(int* L, int a, int b) {
     }
 }
 
-// Initial labels: every foreground pixel points at the first pixel of its horizontal run of equal values
-// inside its 64-pixel wave segment (found with one ballot), so whole runs are already one tree of
-// depth 1 and the merge step only has to stitch runs.
-template <typename T>
-__global__ void __launch_bounds__(256) ccl_init_kernel(const T* __restrict__ in, int* __restrict__ Lall, int H, int W) {
-    const size_t n = (size_t)H * W;
-    const T* img = in + (size_t)blockIdx.z * n;
-    int* L = Lall + (size_t)blockIdx.z * n;
-    const int lane = threadIdx.x & 63;
-    const int x = blockIdx.x * 64 + lane;
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (y >= H) return;
-    const int p = y * W + (x < W ? x : W - 1);
-    const long long v = x < W ? (long long)img[p] : -1;  // -1 never equals a pixel value of the lanes inside
-    const long long left = __shfl_up(v, 1);
-    const bool head = (lane == 0) || (left != v);
-    const unsigned long long heads = __ballot(head);
-    const unsigned long long upto = heads & ((2ull << lane) - 1ull);
-    const int start_lane = 63 - __clzll((long long)upto);
-    if (x < W) L[p] = v != 0 ? p - (lane - start_lane) : -1;
+// ---- run-based, tile-local union-find -------------------------------------------------------------
+// Runs: maximal horizontal stretches of equal non-zero values inside one 64-pixel wave segment (found with
+// one ballot).  Every pixel initially points at the first pixel of its run, so whole runs are trees of depth 1
+// and only RUN PAIRS have to be stitched.
+//   ccl_tile_kernel    one block per 64 x 64 tile: each wave loads 16 rows (all in flight), the tile's
+//                      union-find lives in LDS (unions at LDS latency, no global atomics), and every pixel
+//                      is written ONCE, already pointing at the tile-local root (as a global flat index);
+//   ccl_border_kernel  stitches tiles in HBM: the row pair across each tile boundary and the column pair
+//                      across each 64-pixel segment boundary.
+// Vertical rule: p joins its north pixel q only when p or q starts a run -- otherwise (p-1, q-1) is the same
+// pair of runs and is handled further left.  For 8-connectivity the diagonals matter only when north differs:
+// NW unless west matches (then west reaches NW as its own north), NE unless east matches.
+constexpr int STRIP_R = 16;            // rows per wave
+constexpr int TILE_R = 4 * STRIP_R;    // rows per block
+constexpr long long CCL_NOVAL = -(1ll << 40);  // outside the image: equals no pixel value
+
+__device__ __forceinline__ int lds_find(int* S, int a) {
+    int p = __hip_atomic_load(&S[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (p != a) {
+        a = p;
+        p = __hip_atomic_load(&S[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    return a;
 }
 
-// Merge step.  Runs are stitched (a) across 64-pixel segment boundaries (lane 0 with its west pixel) and
-// (b) vertically: p joins its north pixel q only when p or q starts a run -- otherwise (p-1, q-1) is the
-// same pair of runs and is handled further left.  For 8-connectivity the diagonals matter only when north
-// differs: NW unless west matches (then west reaches NW as its own north), NE unless east matches (then
-// east reaches NE as its own north).
-template <typename T>
-__global__ void __launch_bounds__(256) ccl_merge_kernel(const T* __restrict__ in, int* __restrict__ Lall, int H, int W,
-                                                        int conn8) {
+__device__ __forceinline__ void lds_union(int* S, int a, int b) {
+    while (true) {
+        a = lds_find(S, a);
+        b = lds_find(S, b);
+        if (a == b) return;
+        if (a < b) {
+            const int t = a;
+            a = b;
+            b = t;
+        }
+        const int old = atomicMin(&S[a], b);
+        if (old == a) return;
+        a = old;
+    }
+}
+
+// stitch row y (values v, index p) to row y-1 (values up) inside one 64-lane segment; executed by all lanes.
+// LDS = true: L is the tile's LDS array and `pitch` = 64; otherwise L is the plane in HBM and pitch = W.
+template <bool CONN8, bool LDS>
+__device__ __forceinline__ void ccl_stitch_rows(int* L, int p, int pitch, int lane, long long v, long long up) {
+    const long long w = __shfl_up(v, 1), upw = __shfl_up(up, 1);
+    const bool head = lane == 0 || w != v;
+    const bool up_head = lane == 0 || upw != up;
+    long long e = 0, upe = 0;
+    if (CONN8) {
+        e = __shfl_down(v, 1);
+        upe = __shfl_down(up, 1);
+    }
+    if (v == 0 || v == CCL_NOVAL) return;
+    int q = -1;
+    if (up == v) {
+        if (head || up_head) q = p - pitch;
+    } else if (CONN8) {
+        if (lane > 0 && w != v && upw == v) q = p - pitch - 1;
+        if (lane < 63 && upe == v && e != v) {
+            if (q >= 0) {  // both diagonals: two unions
+                if (LDS) lds_union(L, p, q); else uf_union(L, p, q);
+            }
+            q = p - pitch + 1;
+        }
+    }
+    if (q >= 0) {
+        if (LDS) lds_union(L, p, q); else uf_union(L, p, q);
+    }
+}
+
+template <typename T, bool CONN8>
+__global__ void __launch_bounds__(256) ccl_tile_kernel(const T* __restrict__ in, int* __restrict__ Lall, int H, int W) {
+    __shared__ int S[TILE_R * 64];
+    __shared__ long long vlast[4][64];
     const size_t n = (size_t)H * W;
     const T* img = in + (size_t)blockIdx.z * n;
     int* L = Lall + (size_t)blockIdx.z * n;
-    const int lane = threadIdx.x & 63;
-    const int x = blockIdx.x * 64 + lane;
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= W || y >= H) return;
-    const int p = y * W + x;
-    const T v = img[p];
-    if (v == 0) return;
-    const bool w_same = x > 0 && img[p - 1] == v;
-    if (w_same && lane == 0) uf_union(L, p, p - 1);
-    if (y > 0) {
-        const int q = p - W;
-        if (img[q] == v) {
-            if (!w_same || img[q - 1] != v) uf_union(L, p, q);
-        } else if (conn8) {
-            if (x > 0 && !w_same && img[q - 1] == v) uf_union(L, p, q - 1);
-            if (x + 1 < W && img[q + 1] == v && img[p + 1] != v) uf_union(L, p, q + 1);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x0 = blockIdx.x * 64, ty0 = blockIdx.y * TILE_R;
+    const int x = x0 + lane;
+    const int xc = x < W ? x : W - 1;
+    const int r0 = wave * STRIP_R;  // first tile row of this wave
+    long long v[STRIP_R];
+#pragma unroll
+    for (int k = 0; k < STRIP_R; ++k) {
+        const int y = ty0 + r0 + k;
+        v[k] = (x < W && y < H) ? (long long)img[(size_t)y * W + xc] : CCL_NOVAL;
+    }
+#pragma unroll
+    for (int k = 0; k < STRIP_R; ++k) {
+        const long long left = __shfl_up(v[k], 1);
+        const bool head = (lane == 0) || (left != v[k]);
+        const unsigned long long heads = __ballot(head);
+        const unsigned long long upto = heads & ((2ull << lane) - 1ull);
+        const int start_lane = 63 - __clzll((long long)upto);
+        S[(r0 + k) * 64 + lane] = (r0 + k) * 64 + start_lane;
+    }
+    vlast[wave][lane] = v[STRIP_R - 1];
+    __syncthreads();
+#pragma unroll
+    for (int k = 1; k < STRIP_R; ++k) ccl_stitch_rows<CONN8, true>(S, (r0 + k) * 64 + lane, 64, lane, v[k], v[k - 1]);
+    if (wave > 0) ccl_stitch_rows<CONN8, true>(S, r0 * 64 + lane, 64, lane, v[0], vlast[wave - 1][lane]);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < STRIP_R; ++k) {
+        const int y = ty0 + r0 + k;
+        if (x < W && y < H) {
+            int out = -1;
+            if (v[k] != 0) {
+                const int r = lds_find(S, (r0 + k) * 64 + lane);
+                out = (ty0 + (r >> 6)) * W + x0 + (r & 63);
+            }
+            L[(size_t)y * W + x] = out;
+        }
+    }
+}
+
+// blockIdx.y selects the job: [0, nrow_jobs) = strip-boundary rows, the rest = segment-boundary columns
+template <typename T, bool CONN8>
+__global__ void __launch_bounds__(256) ccl_border_kernel(const T* __restrict__ in, int* __restrict__ Lall, int H, int W,
+                                                         int nrow_blocks) {
+    const size_t n = (size_t)H * W;
+    const T* img = in + (size_t)blockIdx.z * n;
+    int* L = Lall + (size_t)blockIdx.z * n;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if ((int)blockIdx.y < nrow_blocks) {
+        // row pairs (y-1, y) with y a multiple of TILE_R; one wave per 64-pixel segment
+        const int y = ((int)blockIdx.y * 4 + wave + 1) * TILE_R;
+        if (y >= H) return;
+        const int x = blockIdx.x * 64 + lane;
+        const int xc = x < W ? x : W - 1;
+        const long long v = x < W ? (long long)img[(size_t)y * W + xc] : CCL_NOVAL;
+        const long long up = x < W ? (long long)img[(size_t)(y - 1) * W + xc] : CCL_NOVAL;
+        ccl_stitch_rows<CONN8, false>(L, y * W + xc, W, lane, v, up);
+    } else {
+        // column pairs (x-1, x) with x a multiple of 64; one thread per (row, boundary)
+        const int nbound = (W - 1) / 64;  // boundaries at x = 64, 128, ...
+        const int t = (((int)blockIdx.y - nrow_blocks) * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+        if (nbound == 0 || t >= H * nbound) return;
+        const int y = t / nbound, x = (t % nbound + 1) * 64;
+        const int pb = y * W + x, pa = pb - 1;
+        const T vb = img[pb], va = img[pa];
+        if (vb != 0 && va == vb) uf_union(L, pb, pa);
+        if (CONN8 && y > 0) {
+            if (vb != 0 && img[pa - W] == vb) uf_union(L, pb, pa - W);  // NW of b
+            if (va != 0 && img[pb - W] == va) uf_union(L, pa, pb - W);  // NE of a
         }
     }
 }
@@ -102,34 +200,57 @@ __global__ void __launch_bounds__(256) ccl_merge_kernel(const T* __restrict__ in
 constexpr int RN_CHUNK = 2048;  // pixels per block in the compress / rank passes (256 threads x 8)
 
 // Path compression (every pixel points at its root afterwards) fused with the per-block root count that
-// the renumbering needs: a pixel is a root iff L[p] == p, which compression never changes.
+// the raster renumbering needs: a pixel is a root iff L[p] == p, which compression never changes.
+// The first two hops of all eight pixels of a thread are issued as independent loads; only deeper chains loop.
+// With `ids` the roots additionally receive dense 1-based component ids in arbitrary order (one atomic per
+// wave), for callers that need a component index but not the raster numbering.
 __global__ void __launch_bounds__(256) ccl_compress_count_kernel(int* __restrict__ L, int* __restrict__ blockcnt,
-                                                                 size_t n, int nblk) {
+                                                                 size_t n, int nblk, int* __restrict__ ids,
+                                                                 int* __restrict__ nids) {
     const size_t base = (size_t)blockIdx.y * n;
     const size_t start = (size_t)blockIdx.x * RN_CHUNK;
-    int c = 0;
+    int l[8], r[8], r2[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const size_t i = start + (size_t)k * 256 + threadIdx.x;
-        if (i < n) {
-            const int l = L[base + i];
-            if (l >= 0) {
-                int r = l;
-                int p = L[base + r];
-                while (p != r) {
-                    r = p;
-                    p = L[base + r];
-                }
-                if (r != l) L[base + i] = r;
-                c += (r == (int)i) ? 1 : 0;
+        l[k] = i < n ? L[base + i] : -1;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r[k] = l[k] >= 0 ? L[base + l[k]] : -1;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r2[k] = (r[k] >= 0 && r[k] != l[k]) ? L[base + r[k]] : r[k];
+    int c = 0;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const size_t i = start + (size_t)k * 256 + threadIdx.x;
+        bool is_root = false;
+        if (l[k] >= 0) {
+            int root = r[k], p = r2[k];
+            while (p != root) {
+                root = p;
+                p = L[base + root];
+            }
+            if (root != l[k]) L[base + i] = root;
+            is_root = root == (int)i;
+            c += is_root ? 1 : 0;
+        }
+        if (ids) {
+            const unsigned long long m = __ballot(is_root);
+            if (m) {
+                int first = 0;
+                if (lane == 0) first = atomicAdd(&nids[blockIdx.y], __popcll(m));
+                first = __shfl(first, 0);
+                if (is_root) ids[base + i] = first + __popcll(m & ((1ull << lane) - 1ull)) + 1;
             }
         }
     }
+    if (!blockcnt) return;
     for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off);
     __shared__ int s[4];
     if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = c;
     __syncthreads();
-    if (threadIdx.x == 0 && blockcnt) blockcnt[(size_t)blockIdx.y * nblk + blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+    if (threadIdx.x == 0) blockcnt[(size_t)blockIdx.y * nblk + blockIdx.x] = s[0] + s[1] + s[2] + s[3];
 }
 
 // rank of every root (1-based) written at the root's own position of T
@@ -169,23 +290,45 @@ __global__ void __launch_bounds__(256) apply_rank_kernel(const int* __restrict__
 }
 
 template <typename T>
-static int ccl_roots(amt_ctx* ctx, const T* in, int* L, int* blk, int nplanes, int H, int W, int conn8) {
+static int ccl_roots(amt_ctx* ctx, const T* in, int* L, int* blk, int nplanes, int H, int W, int conn8, int* ids,
+                     int* nids) {
     const size_t n = (size_t)H * W;
     const int nblk = amt_i_rank_blocks(n);
-    dim3 g2((W + 63) / 64, (H + 3) / 4, nplanes);
-    hipLaunchKernelGGL((ccl_init_kernel<T>), g2, dim3(256), 0, ctx->stream, in, L, H, W);
+    const int segs = (W + 63) / 64;
+    dim3 gs(segs, (H + TILE_R - 1) / TILE_R, nplanes);
+    const int nrow_jobs = (H - 1) / TILE_R;               // tile boundaries
+    const int nrow_blocks = (nrow_jobs + 3) / 4;
+    const int ncol_jobs = H * ((W - 1) / 64);             // (row, segment boundary) pairs
+    const int ncol_blocks = (ncol_jobs + 256 * segs - 1) / (256 * segs);
+    dim3 gb(segs, nrow_blocks + ncol_blocks, nplanes);
+    if (conn8) {
+        hipLaunchKernelGGL((ccl_tile_kernel<T, true>), gs, dim3(256), 0, ctx->stream, in, L, H, W);
+        AMT_LAUNCH_CHECK();
+        if (gb.y > 0) hipLaunchKernelGGL((ccl_border_kernel<T, true>), gb, dim3(256), 0, ctx->stream, in, L, H, W, nrow_blocks);
+    } else {
+        hipLaunchKernelGGL((ccl_tile_kernel<T, false>), gs, dim3(256), 0, ctx->stream, in, L, H, W);
+        AMT_LAUNCH_CHECK();
+        if (gb.y > 0) hipLaunchKernelGGL((ccl_border_kernel<T, false>), gb, dim3(256), 0, ctx->stream, in, L, H, W, nrow_blocks);
+    }
     AMT_LAUNCH_CHECK();
-    hipLaunchKernelGGL((ccl_merge_kernel<T>), g2, dim3(256), 0, ctx->stream, in, L, H, W, conn8);
-    AMT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ccl_compress_count_kernel, dim3(nblk, nplanes), dim3(256), 0, ctx->stream, L, blk, n, nblk);
+    hipLaunchKernelGGL(ccl_compress_count_kernel, dim3(nblk, nplanes), dim3(256), 0, ctx->stream, L, blk, n, nblk, ids,
+                       nids);
     AMT_LAUNCH_CHECK();
     return AMT_OK;
 }
 
 int amt_i_ccl_roots(amt_ctx* ctx, const void* in, int in_dtype, int* L, int* blk, int nplanes, int H, int W,
                     int conn8) {
-    if (in_dtype == AMT_U8) return ccl_roots<uint8_t>(ctx, (const uint8_t*)in, L, blk, nplanes, H, W, conn8);
-    return ccl_roots<int32_t>(ctx, (const int32_t*)in, L, blk, nplanes, H, W, conn8);
+    if (in_dtype == AMT_U8)
+        return ccl_roots<uint8_t>(ctx, (const uint8_t*)in, L, blk, nplanes, H, W, conn8, nullptr, nullptr);
+    return ccl_roots<int32_t>(ctx, (const int32_t*)in, L, blk, nplanes, H, W, conn8, nullptr, nullptr);
+}
+
+// Components of a uint8 mask with dense (unordered) 1-based ids written at the roots of `ids`; `nids[plane]`
+// must be zero on entry and holds the component count afterwards.
+int amt_i_ccl_ids_u8(amt_ctx* ctx, const uint8_t* in, int* L, int* ids, int* nids, int nplanes, int H, int W,
+                     int conn8) {
+    return ccl_roots<uint8_t>(ctx, in, L, nullptr, nplanes, H, W, conn8, ids, nids);
 }
 
 int amt_i_rank_blocks(size_t n) { return (int)((n + RN_CHUNK - 1) / RN_CHUNK); }
@@ -267,7 +410,7 @@ extern "C" int amt_clear_border(amt_ctx* ctx, const int32_t* in, int32_t* out, i
     int* L = arena_take_t<int>(ctx, (size_t)nplanes * n);
     int* T = arena_take_t<int>(ctx, (size_t)nplanes * n);
     AMT_HIP_CHECK(hipMemsetAsync(T, 0, (size_t)nplanes * n * 4, ctx->stream));
-    AMT_TRY(ccl_roots<int32_t>(ctx, in, L, nullptr, nplanes, H, W, 1));
+    AMT_TRY(ccl_roots<int32_t>(ctx, in, L, nullptr, nplanes, H, W, 1, nullptr, nullptr));
     dim3 gf(amt_grid_for((size_t)2 * W + 2 * H, 256, 64), nplanes);
     hipLaunchKernelGGL(frame_flag_kernel, gf, dim3(256), 0, ctx->stream, L, T, H, W);
     AMT_LAUNCH_CHECK();

@@ -274,7 +274,7 @@ __global__ void __launch_bounds__(64) ws_flood_lds_kernel(const int* __restrict_
     while (true) {
         int k = 0;
         if (lane == 0) k = atomicAdd(&counters[plane], 1);
-        k = __shfl(k, 0);
+        k = __builtin_amdgcn_readfirstlane(k);  // uniform: the component row and all flood state stay scalar
         if (k >= nwork) break;
         const int c = mylist[k];
         const comp_row cr = rr[c];
@@ -320,7 +320,8 @@ __global__ void __launch_bounds__(64) ws_flood_lds_kernel(const int* __restrict_
         for (int i = lane; i < nb; i += 64) ht[i] = 0xFFFFFFFFu;
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
-        // ---- the flood: one sequential thread of control executed by lanes 0..15 in lock step ----
+        // ---- the flood: one sequential thread of control; the WHOLE wave executes it in lock step so that
+        // all state is provably uniform (SGPRs, scalar branches); lanes >= 5 just mirror lane 4 ----
         constexpr unsigned NONE = 0xFFFFu;
         int cur = -1;                   // current bucket, -1 = none yet
         unsigned head = NONE, tail = 0; // FIFO of the current bucket (register copy; ht[cur] is stale)
@@ -366,17 +367,14 @@ __global__ void __launch_bounds__(64) ws_flood_lds_kernel(const int* __restrict_
             const int i = i0 + lane;
             const bool ismk = i < npx && (cell[i] & 0x80000000u);
             unsigned long long m = __ballot(ismk);
-            if (lane < 16) {
-                while (m) {
-                    const int b = __ffsll((long long)m) - 1;
-                    m &= m - 1;
-                    const int p = i0 + b;
-                    if (seeds_first) spread(p, false); else push(p, (int)((uni(cell[p]) >> 16) & 0x7FFF));
-                }
+            while (m) {
+                const int b = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const int p = i0 + b;
+                if (seeds_first) spread(p, false); else push(p, (int)((uni(cell[p]) >> 16) & 0x7FFF));
             }
-            __builtin_amdgcn_wave_barrier();
         }
-        if (lane < 16) {
+        {
             while (true) {
                 if (raise > cur) {  // a push landed above the current bucket: switch to it
                     if (cur >= 0) ht[cur] = head == NONE ? 0xFFFFFFFFu : (head | (tail << 16));
@@ -386,21 +384,21 @@ __global__ void __launch_bounds__(64) ws_flood_lds_kernel(const int* __restrict_
                     tail = h >> 16;
                 }
                 raise = -1;
-                if (head == NONE) {  // current bucket exhausted: walk down, 16 buckets per LDS round trip
+                if (head == NONE) {  // current bucket exhausted: walk down, 64 buckets per LDS round trip
                     if (cur >= 0) ht[cur] = 0xFFFFFFFFu;
                     while (cur >= 0) {
                         const int bi = cur - 1 - lane;
                         const unsigned h = bi >= 0 ? ht[bi] : 0xFFFFFFFFu;
-                        const unsigned m = (unsigned)__ballot((h & 0xFFFFu) != NONE);
+                        const unsigned long long m = __ballot((h & 0xFFFFu) != NONE);
                         if (m) {
-                            const int k = __ffs((int)m) - 1;
+                            const int k = __ffsll((long long)m) - 1;
                             cur = cur - 1 - k;
                             const unsigned hk = (unsigned)__builtin_amdgcn_readlane((int)h, k);
                             head = hk & 0xFFFFu;
                             tail = hk >> 16;
                             break;
                         }
-                        cur -= 16;
+                        cur -= 64;
                     }
                     if (cur < 0) break;
                 }
@@ -611,14 +609,13 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     if (nplanes == 0) return AMT_OK;
     const size_t n = (size_t)H * W;
     const size_t np = (size_t)nplanes * n;
-    const int nblk = amt_i_rank_blocks(n);
     // per-component rows: at most n components per plane; only the first ncomp[plane] rows are touched
     const size_t row_stride = n;
     // HBM queues: bucket mode needs <= n + ncomp <= 2n ints for head and tail each (only the used prefix
     // is initialised); the heap needs <= n elements per plane.
     const size_t bstride = use_d2 ? 2 * n : n;
     size_t need = 10 * amt_align(np * 4) + amt_align((size_t)nplanes * row_stride * sizeof(comp_row)) +
-                  amt_align((size_t)nplanes * nblk * 4) + 8 * amt_align(nplanes * 4 * 8);
+                  9 * amt_align(nplanes * 4 * 9);
     need += use_d2 ? 2 * amt_align((size_t)nplanes * bstride * 4) : amt_align((size_t)nplanes * bstride * sizeof(hp_elem));
     AMT_TRY(amt_arena_begin(ctx, need));
     int* L = arena_take_t<int>(ctx, np);
@@ -629,11 +626,9 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     int* mlist = arena_take_t<int>(ctx, np);
     int* next = arena_take_t<int>(ctx, np);
     comp_row* rows = arena_take_t<comp_row>(ctx, (size_t)nplanes * row_stride);
-    int* blk = arena_take_t<int>(ctx, (size_t)nplanes * nblk);
-    int* ncomp = arena_take_t<int>(ctx, nplanes);
     int* btot = arena_take_t<int>(ctx, nplanes);
     int* mtot = arena_take_t<int>(ctx, nplanes);
-    int* counters = arena_take_t<int>(ctx, (size_t)nplanes * 8);
+    int* counters = arena_take_t<int>(ctx, (size_t)nplanes * 9);
     int* wl = arena_take_t<int>(ctx, 3 * (size_t)nplanes * row_stride);  // worklists of the three LDS classes
     int *head = nullptr, *tail = nullptr;
     hp_elem* heap = nullptr;
@@ -644,12 +639,14 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
         heap = arena_take_t<hp_elem>(ctx, (size_t)nplanes * bstride);
     }
 
-    AMT_TRY(amt_i_ccl_roots(ctx, mask, AMT_U8, L, blk, nplanes, H, W, /*conn8=*/0));
-    AMT_TRY(amt_i_rank_roots(ctx, L, T, blk, ncomp, nplanes, n));
-    hipLaunchKernelGGL(ws_rows_init_kernel, dim3(64, nplanes), dim3(256), 0, ctx->stream, rows, ncomp, row_stride);
+    int* ncomp = counters + 8 * (size_t)nplanes;
+    hipLaunchKernelGGL(ws_zero_counters_kernel, dim3((nplanes * 9 + 63) / 64), dim3(64), 0, ctx->stream, counters,
+                       nplanes * 9);
     AMT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ws_zero_counters_kernel, dim3((nplanes * 8 + 63) / 64), dim3(64), 0, ctx->stream, counters,
-                       nplanes * 8);
+    // components of the mask with dense ids in T (the order of the ids is irrelevant: components are
+    // independent work items and nothing in the output depends on their numbering)
+    AMT_TRY(amt_i_ccl_ids_u8(ctx, mask, L, T, ncomp, nplanes, H, W, /*conn8=*/0));
+    hipLaunchKernelGGL(ws_rows_init_kernel, dim3(64, nplanes), dim3(256), 0, ctx->stream, rows, ncomp, row_stride);
     AMT_LAUNCH_CHECK();
     int* has_g = counters + 4 * nplanes;
     int* wl_count = counters + 5 * nplanes;  // [3][nplanes]
