@@ -2,74 +2,108 @@
 //
 // scipy.ndimage.distance_transform_edt(mask) == sqrt(float64(d2)) bitwise, with d2 the exact integer
 // squared distance to the nearest zero pixel.  d2 is computed separably:
-//   pass 1 (rows)   : g(y,x) = distance to the nearest zero pixel in row y (G_INF if none), found by an
-//                     outward search in an LDS copy of the row;
-//   pass 2 (columns): d2(y,x) = min_k (k^2 + g(y+-k,x)^2), scanning k outward while k^2 < best; a wave
-//                     reads 64 consecutive x of row y+-k, so every access is coalesced.
+//   pass 1 (rows)   : g(y,x) = distance to the nearest zero pixel in row y (G_INF if none).  The row is
+//                     turned into 64-pixel bit words of "zero" flags (one ballot each); the nearest zero on
+//                     either side of a pixel is a clz / ffs on its own word, walking to further words only
+//                     across solid 64-pixel stretches.  g is stored as uint16 (sides are <= 32768).
+//   pass 2 (columns): d2(y,x) = min_k (k^2 + g(y+-k,x)^2), scanning k outward while k^2 < best.  A block
+//                     stages 64 columns x (32 + 2*24) rows of g in LDS; only searches deeper than the halo
+//                     continue in HBM (coalesced: a wave reads 64 consecutive x of row y+-k).
 // Both searches are exact and cost O(distance) per pixel, which is what nuclei-sized objects need; they
 // degrade (never fail) on very large solid regions.
 #include "amt_internal.h"
 
-constexpr int G_INF = 0x3fffffff;
+constexpr unsigned G_INF = 0xFFFFu;  // no zero pixel in this row
+constexpr int EC_ROWS = 32, EC_HALO = 24, EC_TROWS = EC_ROWS + 2 * EC_HALO;
 
-__global__ void __launch_bounds__(256) edt_rows_kernel(const uint8_t* __restrict__ mask, int* __restrict__ g, int H,
-                                                       int W) {
+__global__ void __launch_bounds__(256) edt_rows_kernel(const uint8_t* __restrict__ mask, unsigned short* __restrict__ g,
+                                                       int H, int W) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    uint8_t* row = reinterpret_cast<uint8_t*>(smem_raw);
+    unsigned long long* zw = reinterpret_cast<unsigned long long*>(smem_raw);  // zero flags, 64 pixels per word
     const size_t base = ((size_t)blockIdx.y * H + blockIdx.x) * W;
-    for (int x = threadIdx.x; x < W; x += 256) row[x] = mask[base + x];
+    const int nw = (W + 63) / 64;
+    const int lane = threadIdx.x & 63;
+    for (int x0 = (threadIdx.x >> 6) * 64; x0 < W; x0 += 256) {
+        const int x = x0 + lane;
+        const unsigned long long z = __ballot(x < W && mask[base + x] == 0);  // beyond W: "not zero"
+        if (lane == 0) zw[x0 >> 6] = z;
+    }
     __syncthreads();
     for (int x = threadIdx.x; x < W; x += 256) {
-        int d = 0;
-        if (row[x]) {
-            d = G_INF;
-            for (int k = 1; x - k >= 0 || x + k < W; ++k) {
-                if ((x - k >= 0 && row[x - k] == 0) || (x + k < W && row[x + k] == 0)) {
-                    d = k;
-                    break;
-                }
-            }
+        const int wi = x >> 6, bit = x & 63;
+        const unsigned long long own = zw[wi];
+        unsigned d = 0;
+        if (!((own >> bit) & 1ull)) {
+            // nearest zero to the left
+            unsigned dl = G_INF, dr = G_INF;
+            unsigned long long m = own & ((1ull << bit) - 1ull);
+            int w = wi;
+            while (m == 0 && w > 0) m = zw[--w];
+            if (m) dl = (unsigned)(x - (w * 64 + 63 - __clzll((long long)m)));
+            // nearest zero to the right
+            m = bit == 63 ? 0ull : (own >> (bit + 1)) << (bit + 1);
+            w = wi;
+            while (m == 0 && w + 1 < nw) m = zw[++w];
+            if (m) dr = (unsigned)(w * 64 + __ffsll((long long)m) - 1 - x);
+            d = dl < dr ? dl : dr;
         }
-        g[base + x] = d;
+        g[base + x] = (unsigned short)d;
     }
 }
 
-__global__ void __launch_bounds__(256) edt_cols_kernel(const int* __restrict__ g, int* __restrict__ d2_out,
+__global__ void __launch_bounds__(256) edt_cols_kernel(const unsigned short* __restrict__ g, int* __restrict__ d2_out,
                                                        double* __restrict__ edt_out, int H, int W) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= W || y >= H) return;
+    __shared__ unsigned short tile[EC_TROWS][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = blockIdx.x * 64 + lane;
+    const int y0 = blockIdx.y * EC_ROWS;
     const size_t plane = (size_t)blockIdx.z * H * W;
-    const int* gp = g + plane;
-    const size_t i = (size_t)y * W + x;
-    long long best;
-    const int g0 = gp[i];
-    if (g0 == 0) {
-        best = 0;
-    } else {
-        best = g0 == G_INF ? (long long)0x7fffffffffffll : (long long)g0 * g0;
-        for (long long k = 1; k * k < best; ++k) {
-            const int yu = y - (int)k, yd = y + (int)k;
-            if (yu < 0 && yd >= H) break;
-            if (yu >= 0) {
-                int gv = gp[(size_t)yu * W + x];
-                if (gv != G_INF) {
-                    long long c = k * k + (long long)gv * gv;
-                    best = c < best ? c : best;
-                }
-            }
-            if (yd < H) {
-                int gv = gp[(size_t)yd * W + x];
-                if (gv != G_INF) {
-                    long long c = k * k + (long long)gv * gv;
-                    best = c < best ? c : best;
-                }
-            }
-        }
-        if (best > 0x7fffffffll) best = 0x7fffffffll;  // no zero pixel anywhere: saturate
+    const unsigned short* gp = g + plane;
+    const int xc = x < W ? x : W - 1;
+    for (int r = wave; r < EC_TROWS; r += 4) {
+        const int y = y0 - EC_HALO + r;
+        tile[r][lane] = (y >= 0 && y < H && x < W) ? gp[(size_t)y * W + xc] : (unsigned short)G_INF;
     }
-    if (d2_out) d2_out[plane + i] = (int)best;
-    if (edt_out) edt_out[plane + i] = sqrt((double)best);
+    __syncthreads();
+    if (x >= W) return;
+#pragma unroll 1
+    for (int j = 0; j < EC_ROWS / 4; ++j) {
+        const int ly = EC_HALO + wave * (EC_ROWS / 4) + j;
+        const int y = y0 - EC_HALO + ly;
+        if (y >= H) break;
+        const unsigned g0 = tile[ly][lane];
+        unsigned best = 0;
+        if (g0 != 0) {
+            best = g0 == G_INF ? 0xFFFFFFFFu : g0 * g0;
+            unsigned k = 1;
+            for (; k <= (unsigned)EC_HALO && k * k < best; ++k) {
+                const unsigned gu = tile[ly - (int)k][lane], gd = tile[ly + (int)k][lane];
+                const unsigned gm = gu < gd ? gu : gd;
+                if (gm != G_INF) {
+                    const unsigned c = k * k + gm * gm;
+                    best = c < best ? c : best;
+                }
+            }
+            for (; k < 65536u && (unsigned long long)k * k < best; ++k) {  // beyond the LDS halo
+                const int yu = y - (int)k, yd = y + (int)k;
+                if (yu < 0 && yd >= H) break;
+                unsigned gm = G_INF;
+                if (yu >= 0) gm = gp[(size_t)yu * W + x];
+                if (yd < H) {
+                    const unsigned gd = gp[(size_t)yd * W + x];
+                    gm = gd < gm ? gd : gm;
+                }
+                if (gm != G_INF) {
+                    const unsigned c = k * k + gm * gm;  // < 2^31: both terms < 2^30
+                    best = c < best ? c : best;
+                }
+            }
+            if (best > 0x7fffffffu) best = 0x7fffffffu;  // no zero pixel anywhere: saturate
+        }
+        const size_t i = plane + (size_t)y * W + x;
+        if (d2_out) d2_out[i] = (int)best;
+        if (edt_out) edt_out[i] = sqrt((double)best);
+    }
 }
 
 extern "C" int amt_edt(amt_ctx* ctx, const uint8_t* mask, int32_t* d2_out, double* edt_out, int nplanes, int H,
@@ -79,13 +113,13 @@ extern "C" int amt_edt(amt_ctx* ctx, const uint8_t* mask, int32_t* d2_out, doubl
     AMT_REQUIRE(H <= 32768 && W <= 32768, "edt: image larger than 32768 pixels per side");
     if (nplanes == 0) return AMT_OK;
     const size_t n = (size_t)H * W;
-    AMT_TRY(amt_arena_begin(ctx, amt_align((size_t)nplanes * n * 4)));
-    int* g = arena_take_t<int>(ctx, (size_t)nplanes * n);
-    hipLaunchKernelGGL(edt_rows_kernel, dim3(H, nplanes), dim3(256), (size_t)amt_align(W, 16), ctx->stream, mask, g, H,
-                       W);
+    AMT_TRY(amt_arena_begin(ctx, amt_align((size_t)nplanes * n * 2)));
+    unsigned short* g = arena_take_t<unsigned short>(ctx, (size_t)nplanes * n);
+    hipLaunchKernelGGL(edt_rows_kernel, dim3(H, nplanes), dim3(256), (size_t)((W + 63) / 64) * 8, ctx->stream, mask, g,
+                       H, W);
     AMT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(edt_cols_kernel, dim3((W + 63) / 64, (H + 3) / 4, nplanes), dim3(256), 0, ctx->stream, g, d2_out,
-                       edt_out, H, W);
+    hipLaunchKernelGGL(edt_cols_kernel, dim3((W + 63) / 64, (H + EC_ROWS - 1) / EC_ROWS, nplanes), dim3(256), 0,
+                       ctx->stream, g, d2_out, edt_out, H, W);
     AMT_LAUNCH_CHECK();
     return AMT_OK;
 }
