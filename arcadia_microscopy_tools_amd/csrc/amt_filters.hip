@@ -94,14 +94,19 @@ __global__ void __launch_bounds__(256) conv_axis1_kernel(const double* __restric
 // Fused single-kernel path for small radii (r <= 12): one HBM read of the input, one write of the
 // result, no intermediate in HBM.
 //   * a 256-thread block owns 256 - 2R output columns (+ R halo columns each side) and a chunk of rows;
-//     thread t owns input column x0 - R + t and slides DOWN it: a register window of 2R+1 converted
-//     samples gives the axis-0 result of one row per step (one new load per row, every load coalesced
-//     across the wave);
-//   * that axis-0 row goes to a double-buffered LDS row; after one barrier the inner threads read
-//     their 2R+1 neighbours from LDS, finish the axis-1 pass and store one float64 each -- a wave writes
-//     512 contiguous bytes;
-//   * both passes use scipy's order: centre tap first, then pairs outermost -> innermost.
-// ~4 KB of LDS and ~64 VGPRs per block: 8 waves per SIMD hide the load latency.
+//     thread t owns input column x0 - R + t and slides DOWN it four rows at a time: a register window of
+//     2R+4 converted samples gives the axis-0 results of four rows per step (four new loads in flight,
+//     every load coalesced across the wave);
+//   * the axis-0 rows are collected four at a time in a double-buffered LDS group; after ONE barrier per
+//     group, wave q finishes row q of the group: each lane reads 2R+4 neighbours (128-bit LDS reads) and
+//     produces four adjacent outputs -- 5 LDS values per output instead of 2R+1, 32 contiguous bytes per
+//     lane on the store side;
+//   * both passes use scipy's order: centre tap first, then pairs outermost -> innermost;
+//   * the weights are wave-uniform and stay in scalar registers; the boundary-mapped source rows are
+//     computed once per block (one call site of the general index mapping keeps the code small enough
+//     for the instruction cache);
+//   * optionally the block folds min / max of its outputs into per-plane ordered keys (what Otsu's
+//     histogram range needs), which saves a full re-read of the result.
 // ------------------------------------------------------------------------------------------------
 constexpr int FR_MAX = 12;
 
@@ -109,63 +114,115 @@ template <typename TIn, int R>
 __global__ void __launch_bounds__(256) gauss_fused_kernel(const TIn* __restrict__ in, double scale,
                                                           double* __restrict__ out, int H, int W,
                                                           const double* __restrict__ wts, int mode, double cval,
-                                                          size_t in_stride, int TH) {
+                                                          size_t in_stride, int TH,
+                                                          unsigned long long* __restrict__ keys) {
     constexpr int K = 2 * R + 1;
     constexpr int OUTW = 256 - 2 * R;
-    __shared__ double rowbuf[2][256];
-    __shared__ double wsh[K];
+    constexpr int NSEG = (OUTW + 3) / 4;
+    __shared__ __attribute__((aligned(16))) double rowbuf[2][4][256 + 4];
+    __shared__ int ymap[256 + 2 * FR_MAX + 4];
     const int t = threadIdx.x;
     const int x0 = blockIdx.x * OUTW;
     const int y0 = blockIdx.y * TH;
     const size_t plane = (size_t)blockIdx.z * H * W;
     const TIn* src = in + (size_t)blockIdx.z * in_stride;
-    if (t < K) wsh[t] = wts[t];
-    __syncthreads();
-    double w[R + 1];  // w[j] = weight at distance j from the centre
+    double w[R + 1];  // w[j] = weight at distance j from the centre (uniform -> scalar loads)
 #pragma unroll
-    for (int j = 0; j <= R; ++j) w[j] = wsh[R - j];
+    for (int j = 0; j <= R; ++j) w[j] = wts[R - j];
     const int xg = x0 - R + t;
     const int xm = amt_map_index(xg, W, mode);  // -1: outside in 'constant' mode
-    const bool out_thread = (t >= R) && (t < 256 - R) && (xg < W);
-    auto load_row = [&](int y) -> double {
-        const int yy = amt_map_index(y, H, mode);
+    for (int k = t; k < TH + 2 * R + 4; k += 256) ymap[k] = amt_map_index(y0 - R + k, H, mode);
+    __syncthreads();
+    auto load_row = [&](int k) -> double {  // k = window row: image row y0 - R + k
+        const int yy = ymap[k];
         if (yy < 0 || xm < 0) return cval;
         return load_as_f64<TIn>(src, (size_t)yy * W + xm, scale);
     };
-    double win[K];
+    // axis-1 role of this thread: row q of a group, outputs 4 * seg .. 4 * seg + 3 of the block
+    const int q = t >> 6, seg = t & 63;
+    const int xo = x0 + 4 * seg;
+    unsigned long long klo = ~0ull, khi = 0ull;
+    auto finish_group = [&](int buf, int rg, int nrows) {  // rg = first row (relative to y0) of the group
+        if (q < nrows && seg < NSEG) {
+            const double* c0 = &rowbuf[buf][q][4 * seg];
+            double c[2 * R + 4];
 #pragma unroll
-    for (int k = 0; k < K - 1; ++k) win[k + 1] = load_row(y0 - R + k);
-    const int rows = (y0 + TH <= H) ? TH : (H - y0);
-    for (int r0 = 0; r0 < rows; r0 += K) {
+            for (int i = 0; i < 2 * R + 4; ++i) c[i] = c0[i];
+            double a[4];
 #pragma unroll
-        for (int ph = 0; ph < K; ++ph) {
-            const int r = r0 + ph;
-            if (r < rows) {  // uniform across the block
-                // rotate: logical win[i] lives in register (i + ph + 1) % K; the newest sample lands in (ph) % K
-                win[ph % K] = load_row(y0 + r + R);
-                // logical index i -> physical (i + ph + 1) % K
-                double acc = win[(R + ph + 1) % K] * w[0];
+            for (int i = 0; i < 4; ++i) {
+                double a2 = c[i + R] * w[0];
 #pragma unroll
-                for (int j = R; j >= 1; --j) acc += (win[(R - j + ph + 1) % K] + win[(R + j + ph + 1) % K]) * w[j];
-                // scipy extends the axis-0 RESULT with cval along axis 1 in 'constant' mode
-                if (xm < 0) acc = cval;
-                rowbuf[r & 1][t] = acc;
-                __syncthreads();
-                if (out_thread) {
-                    const double* c = &rowbuf[r & 1][t];
-                    double a2 = c[0] * w[0];
+                for (int j = R; j >= 1; --j) a2 += (c[i + R - j] + c[i + R + j]) * w[j];
+                a[i] = a2;
+            }
+            double* dst = out + plane + (size_t)(y0 + rg + q) * W + xo;
+            if (4 * seg + 3 < OUTW && xo + 3 < W && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
+                reinterpret_cast<double2*>(dst)[0] = make_double2(a[0], a[1]);
+                reinterpret_cast<double2*>(dst)[1] = make_double2(a[2], a[3]);
+                if (keys) {
 #pragma unroll
-                    for (int j = R; j >= 1; --j) a2 += (c[-j] + c[j]) * w[j];
-                    out[plane + (size_t)(y0 + r) * W + xg] = a2;
+                    for (int i = 0; i < 4; ++i) {
+                        const unsigned long long k = amt_f64_key(a[i]);
+                        klo = k < klo ? k : klo;
+                        khi = k > khi ? k : khi;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (4 * seg + i < OUTW && xo + i < W) {
+                        dst[i] = a[i];
+                        if (keys) {
+                            const unsigned long long k = amt_f64_key(a[i]);
+                            klo = k < klo ? k : klo;
+                            khi = k > khi ? k : khi;
+                        }
+                    }
                 }
             }
+        }
+    };
+    // window of K + 3 samples: rows rg - R .. rg + R + 3 of the current group of four output rows
+    double win[K + 3];
+#pragma unroll
+    for (int k = 0; k < K - 1; ++k) win[k] = load_row(k);
+    const int rows = (y0 + TH <= H) ? TH : (H - y0);
+    for (int rg = 0; rg < rows; rg += 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) win[K - 1 + i] = load_row(rg + 2 * R + i);  // four loads in flight
+        const int buf = (rg >> 2) & 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            double acc = win[R + i] * w[0];
+#pragma unroll
+            for (int j = R; j >= 1; --j) acc += (win[R + i - j] + win[R + i + j]) * w[j];
+            // scipy extends the axis-0 RESULT with cval along axis 1 in 'constant' mode
+            if (xm < 0) acc = cval;
+            rowbuf[buf][i][t] = acc;
+        }
+        __syncthreads();
+        finish_group(buf, rg, rows - rg < 4 ? rows - rg : 4);
+#pragma unroll
+        for (int k = 0; k < K - 1; ++k) win[k] = win[k + 4];
+    }
+    if (keys) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const unsigned long long l2 = __shfl_xor(klo, off), h2 = __shfl_xor(khi, off);
+            klo = l2 < klo ? l2 : klo;
+            khi = h2 > khi ? h2 : khi;
+        }
+        if ((t & 63) == 0) {  // four pairs of atomics per block
+            atomicMin(&keys[2 * blockIdx.z], klo);
+            atomicMax(&keys[2 * blockIdx.z + 1], khi);
         }
     }
 }
 
 template <typename TIn, int R>
 static int launch_fused(amt_ctx* ctx, const TIn* in, double scale, double* out, int nplanes, int H, int W,
-                        const double* wdev, int mode, double cval, size_t in_stride) {
+                        const double* wdev, int mode, double cval, size_t in_stride, unsigned long long* keys) {
     constexpr int OUTW = 256 - 2 * R;
     const int gx = (W + OUTW - 1) / OUTW;
     // rows per block: long chunks amortise the 2R warm-up rows, but keep >= ~4 blocks per CU in flight
@@ -173,18 +230,19 @@ static int launch_fused(amt_ctx* ctx, const TIn* in, double scale, double* out, 
     while (TH > 32 && (long long)gx * ((H + TH - 1) / TH) * nplanes < 4LL * ctx->num_cus) TH >>= 1;
     dim3 grid(gx, (H + TH - 1) / TH, nplanes);
     hipLaunchKernelGGL((gauss_fused_kernel<TIn, R>), grid, dim3(256), 0, ctx->stream, in, scale, out, H, W, wdev,
-                       mode, cval, in_stride, TH);
+                       mode, cval, in_stride, TH, keys);
     AMT_LAUNCH_CHECK();
     return AMT_OK;
 }
 
 template <typename TIn>
 static int gaussian_typed(amt_ctx* ctx, const TIn* in, double scale, double* out, double* tmp, int nplanes, int H,
-                          int W, const double* wdev, int r, int mode, double cval, size_t in_stride) {
+                          int W, const double* wdev, int r, int mode, double cval, size_t in_stride,
+                          unsigned long long* keys) {
     switch (r) {
 #define AMT_FUSED_CASE(RR) \
     case RR:               \
-        return launch_fused<TIn, RR>(ctx, in, scale, out, nplanes, H, W, wdev, mode, cval, in_stride);
+        return launch_fused<TIn, RR>(ctx, in, scale, out, nplanes, H, W, wdev, mode, cval, in_stride, keys);
         AMT_FUSED_CASE(1)
         AMT_FUSED_CASE(2)
         AMT_FUSED_CASE(3)
@@ -226,12 +284,13 @@ static int check_gauss_args(const void* in, int in_dtype, double* out, int nplan
 
 static int gaussian_dispatch(amt_ctx* ctx, const void* in, int in_dtype, double scale, double* out, double* tmp,
                              int nplanes, int H, int W, const double* wdev, int r, int mode, double cval,
-                             size_t in_stride = 0) {
+                             size_t in_stride = 0, unsigned long long* keys = nullptr) {
     if (in_stride == 0) in_stride = (size_t)H * W;
     if (in_dtype == AMT_U16)
         return gaussian_typed<uint16_t>(ctx, (const uint16_t*)in, scale, out, tmp, nplanes, H, W, wdev, r, mode, cval,
-                                        in_stride);
-    return gaussian_typed<double>(ctx, (const double*)in, 1.0, out, tmp, nplanes, H, W, wdev, r, mode, cval, in_stride);
+                                        in_stride, keys);
+    return gaussian_typed<double>(ctx, (const double*)in, 1.0, out, tmp, nplanes, H, W, wdev, r, mode, cval, in_stride,
+                                  keys);
 }
 
 __global__ void convert_u16_f64_kernel(const uint16_t* __restrict__ in, double scale, double* __restrict__ out,
