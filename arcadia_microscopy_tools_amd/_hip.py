@@ -62,7 +62,7 @@ _SIGS = {
     "amt_timer_destroy": (c_int, [_P, _P]),
     "amt_deinterleave_u16": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int]),
     "amt_gaussian": (c_int, [_P, _P, c_int, c_double, _P, c_int, c_int, c_int, _P, c_int, c_int, c_double,
-                             c_size_t]),
+                             c_size_t, _P]),
     "amt_dog": (c_int, [_P, _P, c_int, c_double, _P, c_int, c_int, c_int, _P, c_int, _P, c_int, c_int, c_double]),
     "amt_sub_clip0_f64": (c_int, [_P, _P, _P, _P, c_int, c_size_t]),
     "amt_rescale": (c_int, [_P, _P, c_int, _P, c_double, c_double, _P, c_int, c_size_t]),
@@ -75,7 +75,7 @@ _SIGS = {
     "amt_percentile_f64": (c_int, [_P, _P, _P, c_int, _P, c_int, c_size_t]),
     "amt_masked_sums_f64": (c_int, [_P, _P, _P, _P, c_int, c_size_t]),
     "amt_copy_rect": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
-    "amt_threshold_value": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, c_int, c_size_t]),
+    "amt_threshold_value": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, c_int, c_size_t, _P]),
     "amt_threshold_gt": (c_int, [_P, _P, c_int, _P, _P, c_int, c_size_t]),
     "amt_window_threshold": (c_int, [_P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_double, c_double]),
     "amt_threshold_gt_image": (c_int, [_P, _P, c_int, _P, _P, c_size_t]),

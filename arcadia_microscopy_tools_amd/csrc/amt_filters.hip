@@ -5,7 +5,7 @@
 //     acc = x[i]*w[c];  for j = r, r-1, ..., 1:  acc += (x[i-j] + x[i+j]) * w[c-j]
 // axis 0 first, its float64 result is the input of axis 1.  The weights arrive from the host
 // (numpy), so np.exp rounding is shared with the CPU path.
-#include "amt_common.h"
+#include "amt_internal.h"
 
 // ------------------------------------------------------------------------------------------------
 // Generic two-pass path (any radius up to 128): each pass stages a tile plus halo in LDS.
@@ -141,7 +141,7 @@ __global__ void __launch_bounds__(256) gauss_fused_kernel(const TIn* __restrict_
     // axis-1 role of this thread: row q of a group, outputs 4 * seg .. 4 * seg + 3 of the block
     const int q = t >> 6, seg = t & 63;
     const int xo = x0 + 4 * seg;
-    unsigned long long klo = ~0ull, khi = 0ull;
+    double vlo = __builtin_huge_val(), vhi = -__builtin_huge_val();  // folded to ordered keys at the end
     auto finish_group = [&](int buf, int rg, int nrows) {  // rg = first row (relative to y0) of the group
         if (q < nrows && seg < NSEG) {
             const double* c0 = &rowbuf[buf][q][4 * seg];
@@ -163,9 +163,8 @@ __global__ void __launch_bounds__(256) gauss_fused_kernel(const TIn* __restrict_
                 if (keys) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const unsigned long long k = amt_f64_key(a[i]);
-                        klo = k < klo ? k : klo;
-                        khi = k > khi ? k : khi;
+                        vlo = fmin(vlo, a[i]);
+                        vhi = fmax(vhi, a[i]);
                     }
                 }
             } else {
@@ -174,9 +173,8 @@ __global__ void __launch_bounds__(256) gauss_fused_kernel(const TIn* __restrict_
                     if (4 * seg + i < OUTW && xo + i < W) {
                         dst[i] = a[i];
                         if (keys) {
-                            const unsigned long long k = amt_f64_key(a[i]);
-                            klo = k < klo ? k : klo;
-                            khi = k > khi ? k : khi;
+                            vlo = fmin(vlo, a[i]);
+                            vhi = fmax(vhi, a[i]);
                         }
                     }
                 }
@@ -207,6 +205,11 @@ __global__ void __launch_bounds__(256) gauss_fused_kernel(const TIn* __restrict_
         for (int k = 0; k < K - 1; ++k) win[k] = win[k + 4];
     }
     if (keys) {
+        unsigned long long klo = amt_f64_key(vlo), khi = amt_f64_key(vhi);
+        if (vlo > vhi) {  // this thread stored nothing
+            klo = ~0ull;
+            khi = 0ull;
+        }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
             const unsigned long long l2 = __shfl_xor(klo, off), h2 = __shfl_xor(khi, off);
@@ -317,7 +320,8 @@ extern "C" int amt_convert_u16_f64(amt_ctx* ctx, const uint16_t* in, double scal
 }
 
 extern "C" int amt_gaussian(amt_ctx* ctx, const void* in, int in_dtype, double scale, double* out, int nplanes, int H,
-                            int W, const double* weights, int radius, int mode, double cval, size_t in_plane_stride) {
+                            int W, const double* weights, int radius, int mode, double cval, size_t in_plane_stride,
+                            double* minmax_dev) {
     AMT_TRY(amt_set_device(ctx));
     AMT_TRY(check_gauss_args(in, in_dtype, out, nplanes, H, W, weights, radius));
     AMT_REQUIRE(in_plane_stride == 0 || in_plane_stride >= (size_t)H * W, "gaussian: in_plane_stride smaller than a plane");
@@ -325,21 +329,41 @@ extern "C" int amt_gaussian(amt_ctx* ctx, const void* in, int in_dtype, double s
                 "gaussian: strided input needs radius >= 1");
     if (nplanes == 0) return AMT_OK;
     size_t n = (size_t)nplanes * H * W;
+    const size_t kbytes = minmax_dev ? amt_align((size_t)2 * nplanes * 8) : 0;
     if (radius == 0) {  // sigma too small: scipy's kernel is the single weight 1.0
-        if (in_dtype == AMT_U16) return amt_convert_u16_f64(ctx, (const uint16_t*)in, scale, out, n);
-        hipLaunchKernelGGL(copy_f64_kernel, dim3(amt_grid_for(n, 256)), dim3(256), 0, ctx->stream, (const double*)in,
-                           out, n);
-        AMT_LAUNCH_CHECK();
+        if (in_dtype == AMT_U16) {
+            AMT_TRY(amt_convert_u16_f64(ctx, (const uint16_t*)in, scale, out, n));
+        } else {
+            hipLaunchKernelGGL(copy_f64_kernel, dim3(amt_grid_for(n, 256)), dim3(256), 0, ctx->stream,
+                               (const double*)in, out, n);
+            AMT_LAUNCH_CHECK();
+        }
+        if (minmax_dev) {
+            AMT_TRY(amt_arena_begin(ctx, kbytes));
+            unsigned long long* keys = (unsigned long long*)amt_arena_take(ctx, kbytes);
+            AMT_TRY(amt_i_minmax_f64(ctx, out, keys, minmax_dev, nplanes, (size_t)H * W));
+        }
         return AMT_OK;
     }
     size_t wbytes = amt_align((2 * radius + 1) * sizeof(double));
     size_t tmpbytes = radius > FR_MAX ? amt_align(n * sizeof(double)) : 0;
-    AMT_TRY(amt_arena_begin(ctx, wbytes + tmpbytes));
+    AMT_TRY(amt_arena_begin(ctx, wbytes + tmpbytes + kbytes));
     double* wdev = (double*)amt_arena_take(ctx, wbytes);
     double* tmp = tmpbytes ? (double*)amt_arena_take(ctx, tmpbytes) : nullptr;
+    unsigned long long* keys = kbytes ? (unsigned long long*)amt_arena_take(ctx, kbytes) : nullptr;
     AMT_TRY(amt_param_upload(ctx, wdev, weights, (2 * radius + 1) * sizeof(double)));
-    return gaussian_dispatch(ctx, in, in_dtype, scale, out, tmp, nplanes, H, W, wdev, radius, mode, cval,
-                             in_plane_stride);
+    if (!minmax_dev)
+        return gaussian_dispatch(ctx, in, in_dtype, scale, out, tmp, nplanes, H, W, wdev, radius, mode, cval,
+                                 in_plane_stride);
+    if (radius > FR_MAX) {  // two-pass path: min / max in a pass of their own
+        AMT_TRY(gaussian_dispatch(ctx, in, in_dtype, scale, out, tmp, nplanes, H, W, wdev, radius, mode, cval,
+                                  in_plane_stride));
+        return amt_i_minmax_f64(ctx, out, keys, minmax_dev, nplanes, (size_t)H * W);
+    }
+    AMT_TRY(amt_i_minmax_init(ctx, keys, nplanes));
+    AMT_TRY(gaussian_dispatch(ctx, in, in_dtype, scale, out, tmp, nplanes, H, W, wdev, radius, mode, cval,
+                              in_plane_stride, keys));
+    return amt_i_minmax_finish(ctx, keys, minmax_dev, nplanes);
 }
 
 __global__ void sub_inplace_kernel(double* __restrict__ a, const double* __restrict__ b, size_t n) {

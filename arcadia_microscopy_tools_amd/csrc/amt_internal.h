@@ -65,6 +65,12 @@ static inline int amt_scan_excl_dev(amt_ctx* ctx, int* data, const int* len_dev,
     return AMT_OK;
 }
 
+// ---- float64 min / max per plane on ordered 64-bit keys (amt_stats.hip) ---------------------------
+// keys = 2 * nplanes scratch words; init -> (producers fold with atomicMin / atomicMax on amt_f64_key) -> finish
+int amt_i_minmax_init(amt_ctx* ctx, unsigned long long* keys, int nplanes);
+int amt_i_minmax_finish(amt_ctx* ctx, const unsigned long long* keys, double* out, int nplanes);
+int amt_i_minmax_f64(amt_ctx* ctx, const double* in, unsigned long long* keys, double* out, int nplanes, size_t n);
+
 // ---- connected components (amt_label.hip) -------------------------------------------------------
 // L[plane][p] = flat index of the component's first pixel (its union-find root), -1 for background.
 // Components are sets of equal-valued non-zero pixels; conn8 selects 8- vs 4-connectivity.

@@ -118,6 +118,19 @@ __global__ void minmax_finish_kernel(const unsigned long long* keys, double* out
     if (i < 2 * nplanes) out[i] = amt_key_f64(keys[i]);
 }
 
+int amt_i_minmax_init(amt_ctx* ctx, unsigned long long* keys, int nplanes) {
+    hipLaunchKernelGGL(minmax_init_kernel, dim3((nplanes + 63) / 64), dim3(64), 0, ctx->stream, keys, nplanes);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+
+int amt_i_minmax_finish(amt_ctx* ctx, const unsigned long long* keys, double* out, int nplanes) {
+    hipLaunchKernelGGL(minmax_finish_kernel, dim3((2 * nplanes + 63) / 64), dim3(64), 0, ctx->stream, keys, out,
+                       nplanes);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+
 static int minmax_f64_launch(amt_ctx* ctx, const double* in, unsigned long long* keys, double* out, int nplanes,
                              size_t n) {
     hipLaunchKernelGGL(minmax_init_kernel, dim3((nplanes + 63) / 64), dim3(64), 0, ctx->stream, keys, nplanes);
@@ -131,6 +144,10 @@ static int minmax_f64_launch(amt_ctx* ctx, const double* in, unsigned long long*
                        nplanes);
     AMT_LAUNCH_CHECK();
     return AMT_OK;
+}
+
+int amt_i_minmax_f64(amt_ctx* ctx, const double* in, unsigned long long* keys, double* out, int nplanes, size_t n) {
+    return minmax_f64_launch(ctx, in, keys, out, nplanes, n);
 }
 
 extern "C" int amt_minmax_f64(amt_ctx* ctx, const double* in, double* minmax_dev, int nplanes, size_t n) {
@@ -386,9 +403,10 @@ __global__ void __launch_bounds__(256) otsu_f64_kernel(const uint32_t* __restric
 }
 
 extern "C" int amt_threshold_value(amt_ctx* ctx, const void* in, int in_dtype, int method, int nbins, double* thr_dev,
-                                   int32_t* status_dev, int nplanes, size_t n) {
+                                   int32_t* status_dev, int nplanes, size_t n, const double* minmax_dev) {
     AMT_TRY(amt_set_device(ctx));
     AMT_REQUIRE(in && thr_dev && nplanes >= 0, "threshold_value: bad arguments");
+    AMT_REQUIRE(!minmax_dev || in_dtype == AMT_F64, "threshold_value: minmax_dev applies to float64 input only");
     AMT_REQUIRE(method == AMT_THR_OTSU,
                 "threshold_value: only AMT_THR_OTSU runs fully on the device; other methods are evaluated by the "
                 "host layer on amt_hist_* output");
@@ -408,7 +426,10 @@ extern "C" int amt_threshold_value(amt_ctx* ctx, const void* in, int in_dtype, i
     unsigned long long* keys = arena_take_t<unsigned long long>(ctx, 2 * nplanes);
     double* mm = arena_take_t<double>(ctx, 2 * nplanes);
     uint32_t* hist = arena_take_t<uint32_t>(ctx, (size_t)nplanes * nbins);
-    AMT_TRY(minmax_f64_launch(ctx, (const double*)in, keys, mm, nplanes, n));
+    if (minmax_dev)
+        mm = const_cast<double*>(minmax_dev);
+    else
+        AMT_TRY(minmax_f64_launch(ctx, (const double*)in, keys, mm, nplanes, n));
     AMT_TRY(hist_f64_launch(ctx, (const double*)in, mm, hist, nbins, nplanes, n));
     hipLaunchKernelGGL(otsu_f64_kernel, dim3(nplanes), dim3(256), (size_t)5 * nbins * sizeof(double), ctx->stream, hist,
                        mm, nbins, thr_dev);

@@ -65,7 +65,8 @@ def gaussian_weights(sigma: float, truncate: float = 4.0) -> np.ndarray:
 
 
 def gaussian(a: DeviceArray, sigma: float, mode: str = "nearest", cval: float = 0.0, truncate: float = 4.0,
-             scale: float | None = None, out: DeviceArray | None = None, channel: int | None = None) -> DeviceArray:
+             scale: float | None = None, out: DeviceArray | None = None, channel: int | None = None,
+             minmax_out: DeviceArray | None = None) -> DeviceArray:
     """``skimage.filters.gaussian`` per plane (SK/filters/_gaussian.py:119-126): uint16 input is first
     converted like ``img_as_float`` (x * (1/65535), SK/util/dtype.py:319) unless ``scale`` is given."""
     ctx = a.ctx
@@ -86,8 +87,11 @@ def gaussian(a: DeviceArray, sigma: float, mode: str = "nearest", cval: float = 
     wa, wp = _host_f64(w)
     if scale is None:
         scale = 1.0 / 65535 if a.dtype == np.uint16 else 1.0
+    if minmax_out is not None and (minmax_out.dtype != np.float64 or minmax_out.size != 2 * n):
+        raise ValueError("minmax_out must be a float64 DeviceArray with 2 values per output plane")
     _hip.check(_lib().amt_gaussian(ctx.handle, ptr, _in_code(a), float(scale), o.ptr, n, H, W, wp, r,
-                                   _hip.MODES[mode], float(cval), stride), "amt_gaussian")
+                                   _hip.MODES[mode], float(cval), stride,
+                                   minmax_out.ptr if minmax_out is not None else None), "amt_gaussian")
     return o
 
 
@@ -137,7 +141,7 @@ def uniform_filter(a: DeviceArray, size: int, mode: str = "reflect", cval: float
     w = 1.0 / size * np.ones((size,))
     wa, wp = _host_f64(w)
     _hip.check(_lib().amt_gaussian(ctx.handle, a.ptr, _in_code(a), 1.0, o.ptr, n, H, W, wp, (size - 1) // 2,
-                                   _hip.MODES[mode], float(cval), 0), "amt_gaussian")
+                                   _hip.MODES[mode], float(cval), 0, None), "amt_gaussian")
     return o
 
 
@@ -240,13 +244,17 @@ def crop(a: DeviceArray, top: int, left: int, h: int, w: int, out: DeviceArray |
     return o
 
 
-def threshold_otsu(a: DeviceArray, nbins: int = 256, out: DeviceArray | None = None) -> DeviceArray:
-    """``skimage.filters.threshold_otsu`` per plane, value stays on the device (SK/filters/thresholding.py:321-350)."""
+def threshold_otsu(a: DeviceArray, nbins: int = 256, out: DeviceArray | None = None,
+                   minmax: DeviceArray | None = None) -> DeviceArray:
+    """``skimage.filters.threshold_otsu`` per plane, value stays on the device (SK/filters/thresholding.py:321-350).
+    ``minmax`` = per-plane [min, max] already known for a float64 image (``gaussian(..., minmax_out=)``)."""
     ctx = a.ctx
     n, H, W = _planes(a)
     o = _out(ctx, out, (n,), np.float64)
-    _hip.check(_lib().amt_threshold_value(ctx.handle, a.ptr, _in_code(a), _hip.THR_OTSU, nbins, o.ptr, None, n, H * W),
-               "amt_threshold_value")
+    if minmax is not None and (a.dtype != np.float64 or minmax.dtype != np.float64 or minmax.size != 2 * n):
+        raise ValueError("minmax needs a float64 image and 2 float64 values per plane")
+    _hip.check(_lib().amt_threshold_value(ctx.handle, a.ptr, _in_code(a), _hip.THR_OTSU, nbins, o.ptr, None, n, H * W,
+                                          minmax.ptr if minmax is not None else None), "amt_threshold_value")
     return o
 
 

@@ -56,6 +56,7 @@ class FovSegmenter:
         shp = (B, self.H, self.W)
         self.gauss = c.empty(shp, np.float64)
         self.thr = c.empty((B,), np.float64)
+        self.gmm = c.empty((B, 2), np.float64)  # [min, max] of the smoothed image, folded in by the Gaussian
         self.mask_a = c.empty(shp, np.uint8)
         self.mask_b = c.empty(shp, np.uint8)
         self.labels8 = None  # config 2 only, allocated on demand
@@ -92,9 +93,9 @@ class FovSegmenter:
     def mask_chain(self, fovs: DeviceArray) -> DeviceArray:
         """Gaussian -> Otsu -> '>' -> opening -> closing on the DAPI channel of every FOV."""
         self._stage("gaussian")
-        hipops.gaussian(fovs, self.sigma, channel=self.dapi_index, out=self.gauss)
+        hipops.gaussian(fovs, self.sigma, channel=self.dapi_index, out=self.gauss, minmax_out=self.gmm)
         self._stage("otsu")
-        hipops.threshold_otsu(self.gauss, out=self.thr)
+        hipops.threshold_otsu(self.gauss, out=self.thr, minmax=self.gmm)
         # '>' + opening + closing as one bit-packed chain (identical to the three separate operators)
         self._stage("threshold_open_close")
         hipops.threshold_open_close(self.gauss, self.thr, self.footprint, out=self.mask_a)

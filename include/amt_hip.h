@@ -94,9 +94,12 @@ int amt_deinterleave_u16(amt_ctx* ctx, const uint16_t* yxc, uint16_t* cyx, int n
  * scipy builds them (computed by the caller with numpy so that np.exp rounding is shared).
  * in_dtype AMT_U16 (scaled by `scale`, 1/65535 for img_as_float) or AMT_F64 (scale ignored if 1).
  * in_plane_stride = elements between consecutive INPUT planes (0 = H*W); C*H*W filters one channel of
- * every (C,Y,X) field of view of a batch in a single launch.  Output planes are always contiguous. */
+ * every (C,Y,X) field of view of a batch in a single launch.  Output planes are always contiguous.
+ * minmax_dev (nullable) receives [min, max] of every OUTPUT plane (2 doubles per plane), folded in while the
+ * result is written -- hand it to amt_threshold_value to spare Otsu a full re-read of the image. */
 int amt_gaussian(amt_ctx* ctx, const void* in, int in_dtype, double scale, double* out, int nplanes, int H, int W,
-                 const double* weights, int radius, int mode, double cval, size_t in_plane_stride);
+                 const double* weights, int radius, int mode, double cval, size_t in_plane_stride,
+                 double* minmax_dev);
 /* out = G(w_lo) - G(w_hi) of the same converted input (SK/filters/_gaussian.py:284-290). */
 int amt_dog(amt_ctx* ctx, const void* in, int in_dtype, double scale, double* out, int nplanes, int H, int W,
             const double* w_lo, int r_lo, const double* w_hi, int r_hi, int mode, double cval);
@@ -144,9 +147,10 @@ int amt_copy_rect(amt_ctx* ctx, const void* src, void* dst, int elem_size, int n
 #define AMT_THR_MINIMUM 5
 #define AMT_THR_LI 6
 /* Global threshold value per plane (thr_dev[plane], float64 -- for integer images the bin centre).
- * status_dev[plane] != 0 flags "no threshold" (threshold_minimum: fewer/more than two maxima). */
+ * status_dev[plane] != 0 flags "no threshold" (threshold_minimum: fewer/more than two maxima).
+ * minmax_dev (nullable, float64 input only) = precomputed [min, max] per plane (amt_gaussian / amt_minmax_f64). */
 int amt_threshold_value(amt_ctx* ctx, const void* in, int in_dtype, int method, int nbins, double* thr_dev,
-                        int32_t* status_dev, int nplanes, size_t n);
+                        int32_t* status_dev, int nplanes, size_t n, const double* minmax_dev);
 /* out = in > thr[plane] (uint8 0/1) */
 int amt_threshold_gt(amt_ctx* ctx, const void* in, int in_dtype, const double* thr_dev, uint8_t* out, int nplanes,
                      size_t n);
