@@ -39,23 +39,39 @@ struct comp_row {
     int x0, y0, x1, y1;  // bounding box (inclusive)
     int labmin, labmax;  // marker label range
     int cls;
-    int pad;
+    int root;            // flat index of the component's first pixel (its union-find root)
 };
 
-// out = label of the component for single-label components, markers * mask elsewhere
+// out = label of the component for single-label components, markers * mask elsewhere.
+// F[root] = that label (0 for components that need a flood), written by ws_classify_kernel.
 __global__ void __launch_bounds__(256) ws_seed_kernel(const int* __restrict__ markers, const int* __restrict__ L,
-                                                      const int* __restrict__ T, const comp_row* __restrict__ rows,
-                                                      size_t row_stride, int* __restrict__ out, size_t n) {
+                                                      const int* __restrict__ F, int* __restrict__ out, size_t n) {
     const size_t base = (size_t)blockIdx.y * n;
-    const comp_row* rr = rows + (size_t)blockIdx.y * row_stride;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const int r = L[base + i];
-        int v = 0;
-        if (r >= 0) {
-            const comp_row* c = rr + (T[base + r] - 1);
-            v = (c->cls == CLS_UNIFORM) ? c->labmin : markers[base + i];
+    for (size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i0 < n; i0 += (size_t)gridDim.x * 1024) {
+        if (i0 + 3 < n && ((base + i0) & 3) == 0) {
+            const int4 r = *reinterpret_cast<const int4*>(L + base + i0);
+            int4 v = make_int4(0, 0, 0, 0);
+            if (r.x >= 0 || r.y >= 0 || r.z >= 0 || r.w >= 0) {
+                const int4 m = *reinterpret_cast<const int4*>(markers + base + i0);
+                const int fx = r.x >= 0 ? F[base + r.x] : 0, fy = r.y >= 0 ? F[base + r.y] : 0;
+                const int fz = r.z >= 0 ? F[base + r.z] : 0, fw = r.w >= 0 ? F[base + r.w] : 0;
+                v.x = r.x >= 0 ? (fx ? fx : m.x) : 0;
+                v.y = r.y >= 0 ? (fy ? fy : m.y) : 0;
+                v.z = r.z >= 0 ? (fz ? fz : m.z) : 0;
+                v.w = r.w >= 0 ? (fw ? fw : m.w) : 0;
+            }
+            *reinterpret_cast<int4*>(out + base + i0) = v;
+        } else {
+            for (size_t i = i0; i < n && i < i0 + 4; ++i) {
+                const int r = L[base + i];
+                int v = 0;
+                if (r >= 0) {
+                    const int f = F[base + r];
+                    v = f ? f : markers[base + i];
+                }
+                out[base + i] = v;
+            }
         }
-        out[base + i] = v;
     }
 }
 
@@ -72,7 +88,7 @@ __global__ void __launch_bounds__(256) ws_rows_init_kernel(comp_row* __restrict_
         c.labmin = 0x7fffffff;
         c.labmax = 0;
         c.cls = CLS_NONE;
-        c.pad = 0;
+        c.root = -1;
         r[i] = c;
     }
 }
@@ -133,6 +149,7 @@ __global__ void __launch_bounds__(256) ws_stats_kernel(const int* __restrict__ d
         }
         if (r >= 0 && head) {
             comp_row* c = rows + (size_t)blockIdx.z * row_stride + (T[base + r] - 1);
+            if ((size_t)r == (size_t)(yb + k) * W + x) c->root = r;  // the run that starts at the root itself
             const int len = end_lane - lane + 1;
             if (use_d2) {
                 if (v > 0) atomicMax(&c->cmax, v);
@@ -158,8 +175,8 @@ __global__ void __launch_bounds__(256) ws_stats_kernel(const int* __restrict__ d
 __global__ void __launch_bounds__(256) ws_classify_kernel(comp_row* __restrict__ rows, const int* __restrict__ ncomp,
                                                           int* __restrict__ moff, int* __restrict__ boff,
                                                           int* __restrict__ has_g, int* __restrict__ wl,
-                                                          int* __restrict__ wl_count, int nplanes, size_t row_stride,
-                                                          int use_d2) {
+                                                          int* __restrict__ wl_count, int* __restrict__ Fall, size_t n,
+                                                          int nplanes, size_t row_stride, int use_d2) {
     comp_row* r = rows + (size_t)blockIdx.y * row_stride;
     int* mo = moff + (size_t)blockIdx.y * row_stride;
     int* bo = boff + (size_t)blockIdx.y * row_stride;
@@ -182,6 +199,7 @@ __global__ void __launch_bounds__(256) ws_classify_kernel(comp_row* __restrict__
             else cls = CLS_G;
         }
         r[i].cls = cls;
+        Fall[(size_t)blockIdx.y * n + c.root] = cls == CLS_UNIFORM ? c.labmin : 0;
         if (cls == CLS_G) has_g[blockIdx.y] = 1;
         if (cls == CLS_S || cls == CLS_M || cls == CLS_L) {
             // per-class worklist of this plane (order is irrelevant: components are independent)
@@ -265,7 +283,7 @@ __global__ void __launch_bounds__(64) ws_flood_lds_kernel(const int* __restrict_
     const size_t n = (size_t)H * W;
     const int* d2 = d2all + (size_t)plane * n;
     const int* L = Lall + (size_t)plane * n;
-    const int* T = Tall + (size_t)plane * n;
+    (void)Tall;
     int* out = outall + (size_t)plane * n;
     const comp_row* rr = rows + (size_t)plane * row_stride;
     const int* mylist = wl + (size_t)plane * row_stride;
@@ -282,34 +300,30 @@ __global__ void __launch_bounds__(64) ws_flood_lds_kernel(const int* __restrict_
         const int npx = tw * th;
         const int nb = cr.cmax + 1;
         const unsigned inv_tw = 0xFFFFFFFFu / (unsigned)tw + 1u;  // i / tw == (i * inv_tw) >> 32 for i < 65536
-        // ---- stage the bounding box + ring: 4 independent elements per lane in flight ----
+        // ---- stage the bounding box + ring: membership is "root of the pixel == root of the component", so
+        // the three loads of a pixel are independent; 4 pixels per lane = 12 loads in flight ----
         for (int i0 = 0; i0 < npx; i0 += 256) {
-            int rr4[4];
-            size_t g4[4];
+            int rr4[4], o4[4], d4[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int i = i0 + u * 64 + lane;
                 const int ty = (int)(((unsigned long long)(unsigned)i * inv_tw) >> 32), tx = i - ty * tw;
                 rr4[u] = -1;
-                g4[u] = 0;
+                o4[u] = 0;
+                d4[u] = 0;
                 if (i < npx && ty >= 1 && ty < th - 1 && tx >= 1 && tx < tw - 1) {
-                    g4[u] = (size_t)(cr.y0 + ty - 1) * W + (cr.x0 + tx - 1);
-                    rr4[u] = L[g4[u]];
+                    const size_t g = (size_t)(cr.y0 + ty - 1) * W + (cr.x0 + tx - 1);
+                    rr4[u] = L[g];
+                    o4[u] = out[g];
+                    d4[u] = d2[g];
                 }
-            }
-            int t4[4], o4[4], d4[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                t4[u] = rr4[u] >= 0 ? T[rr4[u]] : 0;
-                o4[u] = rr4[u] >= 0 ? out[g4[u]] : 0;
-                d4[u] = rr4[u] >= 0 ? d2[g4[u]] : 0;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int i = i0 + u * 64 + lane;
                 if (i < npx) {
                     unsigned cv = 0xFFFFu;
-                    if (rr4[u] >= 0 && t4[u] - 1 == c) {
+                    if (rr4[u] == cr.root) {
                         const int d = d4[u] < 0 ? 0 : d4[u];
                         cv = ((unsigned)o4[u] & 0xFFFFu) | ((unsigned)d << 16) | (o4[u] != 0 ? 0x80000000u : 0u);
                     }
@@ -614,7 +628,7 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     // HBM queues: bucket mode needs <= n + ncomp <= 2n ints for head and tail each (only the used prefix
     // is initialised); the heap needs <= n elements per plane.
     const size_t bstride = use_d2 ? 2 * n : n;
-    size_t need = 10 * amt_align(np * 4) + amt_align((size_t)nplanes * row_stride * sizeof(comp_row)) +
+    size_t need = 11 * amt_align(np * 4) + amt_align((size_t)nplanes * row_stride * sizeof(comp_row)) +
                   9 * amt_align(nplanes * 4 * 9);
     need += use_d2 ? 2 * amt_align((size_t)nplanes * bstride * 4) : amt_align((size_t)nplanes * bstride * sizeof(hp_elem));
     AMT_TRY(amt_arena_begin(ctx, need));
@@ -625,6 +639,7 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     int* cursor = arena_take_t<int>(ctx, np);
     int* mlist = arena_take_t<int>(ctx, np);
     int* next = arena_take_t<int>(ctx, np);
+    int* F = arena_take_t<int>(ctx, np);  // per-root fill value (only root positions are used)
     comp_row* rows = arena_take_t<comp_row>(ctx, (size_t)nplanes * row_stride);
     int* btot = arena_take_t<int>(ctx, nplanes);
     int* mtot = arena_take_t<int>(ctx, nplanes);
@@ -655,10 +670,11 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
                        use_d2 ? 1 : 0);
     AMT_LAUNCH_CHECK();
     hipLaunchKernelGGL(ws_classify_kernel, dim3(64, nplanes), dim3(256), 0, ctx->stream, rows, ncomp, moff, boff, has_g,
-                       wl, wl_count, nplanes, row_stride, use_d2 ? 1 : 0);
+                       wl, wl_count, F, n, nplanes, row_stride, use_d2 ? 1 : 0);
     AMT_LAUNCH_CHECK();
     dim3 g1(amt_grid_for(n, 256, 4096), nplanes);
-    hipLaunchKernelGGL(ws_seed_kernel, g1, dim3(256), 0, ctx->stream, markers, L, T, rows, row_stride, out, n);
+    hipLaunchKernelGGL(ws_seed_kernel, dim3(amt_grid_for(n, 1024, 4096), nplanes), dim3(256), 0, ctx->stream, markers, L, F,
+                       out, n);
     AMT_LAUNCH_CHECK();
     // ---- HBM-path bookkeeping (usually empty: only components too large for an LDS tile) ----
     AMT_TRY(amt_scan_excl_dev(ctx, moff, ncomp, row_stride, mtot, nplanes));
