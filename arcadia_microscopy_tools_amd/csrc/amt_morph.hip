@@ -242,6 +242,140 @@ extern "C" int amt_binary_close(amt_ctx* ctx, const uint8_t* in, uint8_t* out, i
     return morph_common(ctx, in, out, nplanes, H, W, footprint, fh, fw, 3, 0);
 }
 
+// ---- fused threshold -> opening -> closing ---------------------------------------------------------
+// `binary_closing(binary_opening(in > thr))` (the Gaussian -> Otsu -> '>' -> open -> close mask chain of
+// BASELINE configs[1]/[2]) in two kernels:
+//   pack_gt_kernel      streams the image once and leaves one BIT per pixel (high occupancy, HBM-bound);
+//   toc_fused_kernel    a block owns a band of TOC_BR rows x up to TOC_TWW words (64 px each): it copies the band
+//                       plus a halo of 4 * ry rows (and one halo word left / right) of the packed plane (L2-resident,
+//                       1/64 of the image) into LDS, runs erosion, dilation, dilation, erosion LDS -> LDS, and
+//                       unpacks the band to bytes -- the only other HBM traffic of the chain.
+// Positions outside the IMAGE read as each primitive's own border value (scipy's border_value: 1 for erosion,
+// 0 for dilation); positions outside the TILE also read as border, which only corrupts halo words that the band
+// never uses.
+constexpr int TOC_BR = 32, TOC_TWW = 32, TOC_MAX_OFFS = 256;
+
+// The LDS tile is physically padded by PADR rows above / below and one word left / right that are never
+// written, so the primitives need no tile-bound checks; the border substitution for positions outside the
+// image (and for the bits of the last word beyond W) is done when a word is WRITTEN, with the border value
+// of the primitive that will read it next.
+struct toc_tile {
+    int TR, TW;          // tile rows / words per tile row (logical)
+    int PW;              // physical words per row = TW + 2
+    int y_top, wx_left;  // image row of tile row 0, image word of tile column 0
+    int H, W, WW;
+};
+constexpr int TOC_PADR = 4;  // >= ry of the fused path (4 * ry <= 16)
+
+__device__ __forceinline__ u64 toc_fix(const toc_tile& t, int r, int wc, u64 v, u64 next_border) {
+    const int y = t.y_top + r, wx = t.wx_left + wc;
+    if (y < 0 || y >= t.H || wx < 0 || wx >= t.WW) return next_border;
+    if (wx == t.WW - 1 && (t.W & 63)) {
+        const u64 valid = (1ull << (t.W & 63)) - 1ull;
+        v = (v & valid) | (next_border & ~valid);
+    }
+    return v;
+}
+
+// buf points at logical (row 0, word 0); rows are PW words apart
+template <bool ERODE>
+__device__ __forceinline__ void toc_prim(const u64* src, u64* dst, const toc_tile& t, const int2* offs, int noffs,
+                                         u64 next_border) {
+    for (int idx = threadIdx.x; idx < t.TR * t.TW; idx += 256) {
+        const int r = idx / t.TW, wc = idx - r * t.TW;
+        u64 acc = ERODE ? ~0ull : 0ull;
+        int cur_dy = 0x7fffffff;
+        u64 p = 0, c = 0, nx = 0;
+        for (int k = 0; k < noffs; ++k) {
+            const int dy = ERODE ? offs[k].y : -offs[k].y;
+            const int dx = ERODE ? offs[k].x : -offs[k].x;
+            if (dy != cur_dy) {
+                cur_dy = dy;
+                const u64* row = src + (r + dy) * t.PW + wc;
+                p = row[-1];
+                c = row[0];
+                nx = row[1];
+            }
+            u64 v;
+            if (dx == 0)
+                v = c;
+            else if (dx > 0)
+                v = (c >> dx) | (nx << (64 - dx));
+            else
+                v = (c << (-dx)) | (p >> (64 + dx));
+            acc = ERODE ? (acc & v) : (acc | v);
+        }
+        dst[r * t.PW + wc] = toc_fix(t, r, wc, acc, next_border);
+    }
+}
+
+__global__ void __launch_bounds__(256) toc_fused_kernel(const u64* __restrict__ packed, uint8_t* __restrict__ out,
+                                                        int H, int W, int WW, const int2* __restrict__ offs_g,
+                                                        int noffs, int HY) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    __shared__ int2 offs[TOC_MAX_OFFS];
+    const int tww = (WW - (int)blockIdx.x * TOC_TWW) < TOC_TWW ? (WW - (int)blockIdx.x * TOC_TWW) : TOC_TWW;
+    toc_tile t;
+    t.TR = TOC_BR + 2 * HY;
+    t.TW = tww + 2;
+    t.PW = t.TW + 2;
+    t.y_top = (int)blockIdx.y * TOC_BR - HY;
+    t.wx_left = (int)blockIdx.x * TOC_TWW - 1;
+    t.H = H;
+    t.W = W;
+    t.WW = WW;
+    const int phys = (t.TR + 2 * TOC_PADR) * t.PW;
+    u64* physA = reinterpret_cast<u64*>(smem_raw);
+    u64* physB = physA + phys;
+    u64* bufA = physA + TOC_PADR * t.PW + 1;
+    u64* bufB = physB + TOC_PADR * t.PW + 1;
+    for (int i = threadIdx.x; i < noffs; i += 256) offs[i] = offs_g[i];
+    for (int i = threadIdx.x; i < 2 * phys; i += 256) physA[i] = 0ull;  // padding is never written again
+    __syncthreads();
+    const size_t plane = blockIdx.z;
+    const u64* src = packed + plane * (size_t)H * WW;
+    // ---- 1. copy the packed band + halo (outside the image: erosion's border, all ones) ----
+    for (int idx = threadIdx.x; idx < t.TR * t.TW; idx += 256) {
+        const int r = idx / t.TW, wc = idx - r * t.TW;
+        const int y = t.y_top + r, wx = t.wx_left + wc;
+        const u64 v = (y >= 0 && y < H && wx >= 0 && wx < WW) ? src[(size_t)y * WW + wx] : 0ull;
+        bufA[r * t.PW + wc] = toc_fix(t, r, wc, v, ~0ull);
+    }
+    __syncthreads();
+    // ---- 2. opening = erosion, dilation; closing = dilation, erosion (skimage: erosion sees outside = 1,
+    //         dilation sees outside = 0) ----
+    toc_prim<true>(bufA, bufB, t, offs, noffs, 0ull);
+    __syncthreads();
+    toc_prim<false>(bufB, bufA, t, offs, noffs, 0ull);
+    __syncthreads();
+    toc_prim<false>(bufA, bufB, t, offs, noffs, ~0ull);
+    __syncthreads();
+    toc_prim<true>(bufB, bufA, t, offs, noffs, 0ull);
+    __syncthreads();
+    // ---- 3. unpack the band: 16 pixels per thread and step ----
+    const int per_row = tww * 4;
+    for (int q = threadIdx.x; q < TOC_BR * per_row; q += 256) {
+        const int r = q / per_row, rem = q - r * per_row;
+        const int wc = rem >> 2, part = rem & 3;
+        const int y = (int)blockIdx.y * TOC_BR + r;
+        const int x = ((int)blockIdx.x * TOC_TWW + wc) * 64 + part * 16;
+        if (y >= H || x >= W) continue;
+        const u64 w = bufA[(HY + r) * t.PW + 1 + wc];
+        const unsigned bits = (unsigned)(w >> (part * 16)) & 0xFFFFu;
+        uint8_t* o = out + (plane * H + y) * W + x;
+        if (x + 15 < W && ((reinterpret_cast<uintptr_t>(o) & 15) == 0)) {
+            uint4 rr;
+            rr.x = spread4(bits & 0xFu);
+            rr.y = spread4((bits >> 4) & 0xFu);
+            rr.z = spread4((bits >> 8) & 0xFu);
+            rr.w = spread4((bits >> 12) & 0xFu);
+            *reinterpret_cast<uint4*>(o) = rr;
+        } else {
+            for (int k = 0; k < 16 && x + k < W; ++k) o[k] = (bits >> k) & 1u;
+        }
+    }
+}
+
 // `binary_closing(binary_opening(in > thr))` in one packed chain: compare -> 4 word-level primitives ->
 // unpack (the Gaussian -> Otsu -> '>' -> open -> close mask chain of BASELINE configs[1]/[2]).
 extern "C" int amt_threshold_open_close(amt_ctx* ctx, const void* in, int in_dtype, const double* thr_dev,
@@ -256,6 +390,30 @@ extern "C" int amt_threshold_open_close(amt_ctx* ctx, const void* in, int in_dty
     if (nplanes == 0) return AMT_OK;
     const int WW = (W + 63) / 64;
     const size_t words = (size_t)nplanes * H * WW;
+    const int ry = fh / 2, rx = fw / 2;
+    if (noffs <= TOC_MAX_OFFS && 4 * ry <= 16 && 4 * rx <= 64) {
+        // single fused kernel: halo of 4 * ry rows and one 64-pixel word per side covers the four primitives
+        AMT_TRY(amt_arena_begin(ctx, amt_align(sizeof(int2) * noffs) + amt_align(words * 8)));
+        int2* offs = arena_take_t<int2>(ctx, noffs);
+        u64* pa = arena_take_t<u64>(ctx, words);
+        AMT_TRY(amt_param_upload(ctx, offs, host, sizeof(int2) * noffs));
+        const size_t nwords = (size_t)H * WW;
+        const unsigned gpack = (unsigned)((nwords + 4 * PACK_WORDS_PER_WAVE - 1) / (4 * PACK_WORDS_PER_WAVE));
+        if (in_dtype == AMT_F64)
+            hipLaunchKernelGGL((pack_gt_kernel<double>), dim3(gpack, nplanes), dim3(256), 0, ctx->stream,
+                               (const double*)in, thr_dev, pa, H, W, WW);
+        else
+            hipLaunchKernelGGL((pack_gt_kernel<uint16_t>), dim3(gpack, nplanes), dim3(256), 0, ctx->stream,
+                               (const uint16_t*)in, thr_dev, pa, H, W, WW);
+        AMT_LAUNCH_CHECK();
+        const int HY = 4 * ry;
+        const int tww = WW < TOC_TWW ? WW : TOC_TWW;
+        const size_t smem = (size_t)2 * (TOC_BR + 2 * HY + 2 * TOC_PADR) * (tww + 4) * sizeof(u64);
+        dim3 grid((WW + TOC_TWW - 1) / TOC_TWW, (H + TOC_BR - 1) / TOC_BR, nplanes);
+        hipLaunchKernelGGL(toc_fused_kernel, grid, dim3(256), smem, ctx->stream, pa, out, H, W, WW, offs, noffs, HY);
+        AMT_LAUNCH_CHECK();
+        return AMT_OK;
+    }
     AMT_TRY(amt_arena_begin(ctx, amt_align(sizeof(int2) * noffs) + 2 * amt_align(words * 8)));
     int2* offs = arena_take_t<int2>(ctx, noffs);
     u64* pa = arena_take_t<u64>(ctx, words);

@@ -301,3 +301,28 @@ def test_label_sparse(ctx, ops, golden):
     dense = np.ones((64, 64), bool)
     _, cnt = ops.label_sparse(ctx.asarray(dense), capacity=100)
     assert cnt.numpy()[0] == -1
+
+
+def test_threshold_open_close_fused(ctx, ops):
+    """The one-kernel '>' + opening + closing chain against the three separate operators of the oracle:
+    odd sizes, widths beyond one 32-word column chunk, a footprint too large for the fused kernel, and the
+    Gaussian's folded min / max against numpy."""
+    from oracle import skops
+
+    rng = np.random.default_rng(5)
+    for shape, rad in (((70, 130), 1), ((200, 333), 2), ((96, 2200), 2), ((150, 190), 3), ((90, 100), 6)):
+        img = rng.random(shape)
+        img = skops.gaussian((img * 60000).astype(np.uint16), 1.5)
+        thr = float(np.quantile(img, 0.55))
+        fp = skops.disk(rad)
+        ref = skops.binary_closing(skops.binary_opening(img > thr, fp), fp)
+        d = ctx.asarray(img[None])
+        got = ops.threshold_open_close(d, ctx.asarray(np.array([thr])), fp).numpy()[0]
+        assert np.array_equal(got.astype(bool), ref), (shape, rad)
+    u = rng.integers(0, 65535, (3, 97, 140)).astype(np.uint16)
+    mm = ctx.empty((3, 2), np.float64)
+    g = ops.gaussian(ctx.asarray(u), 2.0, minmax_out=mm).numpy()
+    assert np.array_equal(mm.numpy(), np.stack([g.min(axis=(1, 2)), g.max(axis=(1, 2))], axis=1))
+    thr_a = ops.threshold_otsu(ctx.asarray(g)).numpy()
+    thr_b = ops.threshold_otsu(ctx.asarray(g), minmax=mm).numpy()
+    assert np.array_equal(thr_a, thr_b)
