@@ -623,28 +623,30 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     if (nplanes == 0) return AMT_OK;
     const size_t n = (size_t)H * W;
     const size_t np = (size_t)nplanes * n;
-    // per-component rows: at most n components per plane; only the first ncomp[plane] rows are touched
-    const size_t row_stride = n;
-    // HBM queues: bucket mode needs <= n + ncomp <= 2n ints for head and tail each (only the used prefix
-    // is initialised); the heap needs <= n elements per plane.
-    const size_t bstride = use_d2 ? 2 * n : n;
-    size_t need = 11 * amt_align(np * 4) + amt_align((size_t)nplanes * row_stride * sizeof(comp_row)) +
+    // per-component rows: a 4-connected component needs a background pixel between itself and the next one in
+    // its row, so a plane has at most ceil(n / 2) components; only the first ncomp[plane] rows are touched
+    const size_t row_stride = n / 2 + 1;
+    const size_t nr = (size_t)nplanes * row_stride;
+    // HBM queues: bucket mode needs <= n + ncomp ints for head and tail each (only the used prefix is
+    // initialised); the heap needs <= n elements per plane.
+    const size_t bstride = use_d2 ? n + row_stride : n;
+    size_t need = 5 * amt_align(np * 4) + 6 * amt_align(nr * 4) + amt_align(nr * sizeof(comp_row)) +
                   9 * amt_align(nplanes * 4 * 9);
     need += use_d2 ? 2 * amt_align((size_t)nplanes * bstride * 4) : amt_align((size_t)nplanes * bstride * sizeof(hp_elem));
     AMT_TRY(amt_arena_begin(ctx, need));
     int* L = arena_take_t<int>(ctx, np);
     int* T = arena_take_t<int>(ctx, np);
-    int* moff = arena_take_t<int>(ctx, np);
-    int* boff = arena_take_t<int>(ctx, np);
-    int* cursor = arena_take_t<int>(ctx, np);
+    int* moff = arena_take_t<int>(ctx, nr);
+    int* boff = arena_take_t<int>(ctx, nr);
+    int* cursor = arena_take_t<int>(ctx, nr);
     int* mlist = arena_take_t<int>(ctx, np);
     int* next = arena_take_t<int>(ctx, np);
     int* F = arena_take_t<int>(ctx, np);  // per-root fill value (only root positions are used)
-    comp_row* rows = arena_take_t<comp_row>(ctx, (size_t)nplanes * row_stride);
+    comp_row* rows = arena_take_t<comp_row>(ctx, nr);
     int* btot = arena_take_t<int>(ctx, nplanes);
     int* mtot = arena_take_t<int>(ctx, nplanes);
     int* counters = arena_take_t<int>(ctx, (size_t)nplanes * 9);
-    int* wl = arena_take_t<int>(ctx, 3 * (size_t)nplanes * row_stride);  // worklists of the three LDS classes
+    int* wl = arena_take_t<int>(ctx, 3 * nr);  // worklists of the three LDS classes
     int *head = nullptr, *tail = nullptr;
     hp_elem* heap = nullptr;
     if (use_d2) {
