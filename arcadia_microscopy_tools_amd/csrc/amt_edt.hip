@@ -127,62 +127,79 @@ extern "C" int amt_edt(amt_ctx* ctx, const uint8_t* mask, int32_t* d2_out, doubl
 // ---- peak mask ---------------------------------------------------------------------------------
 // peaks = (d2 == maximum_filter(d2, size=2m+1, mode='constant' (0))) & mask & (d2 > 0), border m cleared
 // (comparing the integer d2 is equivalent to comparing sqrt(d2)).
-// One 256-thread block per 32 x 64 tile: d2 tile + halo m staged in LDS, separable maximum (rows, then
-// columns) in LDS, compare.  Tiles without any masked pixel with d2 > 0 exit after the staging pass.
+// "d2 equals the window maximum" == "nothing in the window exceeds d2", so no maximum image is built:
+// one 256-thread block stages a 32 x 64 tile of d2 plus a halo of m in LDS; a pixel is first compared with
+// its 8 neighbours (which rejects all but a few percent of the foreground), and only the survivors scan the
+// full (2m+1)^2 window with early exit.  Tiles without any d2 > 0 exit after the staging pass.
 constexpr int PK_H = 32, PK_W = 64, PK_MAXM = 16;
 __global__ void __launch_bounds__(256) peaks_tile_kernel(const int* __restrict__ d2, const uint8_t* __restrict__ mask,
                                                          uint8_t* __restrict__ peaks, int H, int W, int m) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int TW = PK_W + 2 * m, TH = PK_H + 2 * m;
     int* tile = reinterpret_cast<int*>(smem_raw);  // TH x TW
-    int* rmax = tile + TH * TW;                    // TH x PK_W
-    __shared__ int any_fg;
     const int x0 = blockIdx.x * PK_W, y0 = blockIdx.y * PK_H;
     const size_t base = (size_t)blockIdx.z * H * W;
-    if (threadIdx.x == 0) any_fg = 0;
-    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int local_any = 0;
-    for (int i = threadIdx.x; i < TH * TW; i += 256) {
-        const int ky = i / TW, kx = i - ky * TW;
-        const int y = y0 - m + ky, x = x0 - m + kx;
-        int v = 0;  // constant 0 outside the image
-        if (y >= 0 && y < H && x >= 0 && x < W) v = d2[base + (size_t)y * W + x];
-        tile[i] = v;
-        if (v > 0 && ky >= m && ky < TH - m && kx >= m && kx < TW - m) local_any = 1;
+    // staging: wave w owns tile rows w, w + 4, ...: the 64 centre columns (aligned, coalesced) and the 2m halo
+    // columns; ALL loads of a wave are issued before the first LDS store (TH <= 64, i.e. <= 16 rows per wave)
+    constexpr int RPW = (PK_H + 2 * PK_MAXM + 3) / 4;
+    int vc[RPW], vh[RPW];
+    const int kxh = lane < m ? lane : PK_W + lane;  // halo column of lanes < 2m
+    const int xh = x0 - m + kxh;
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+        const int ky = wave + 4 * j;
+        const int y = y0 - m + ky;
+        const bool yok = ky < TH && y >= 0 && y < H;
+        const int x = x0 + lane;
+        vc[j] = (yok && x < W) ? d2[base + (size_t)y * W + x] : 0;  // constant 0 outside the image
+        vh[j] = (yok && lane < 2 * m && xh >= 0 && xh < W) ? d2[base + (size_t)y * W + xh] : 0;
     }
-    if (local_any) any_fg = 1;
-    __syncthreads();
-    if (!any_fg) {  // nothing can be a peak here
-        for (int i = threadIdx.x; i < PK_H * PK_W; i += 256) {
-            const int ky = i / PK_W, kx = i - ky * PK_W;
-            const int y = y0 + ky, x = x0 + kx;
-            if (y < H && x < W) peaks[base + (size_t)y * W + x] = 0;
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+        const int ky = wave + 4 * j;
+        if (ky < TH) {
+            tile[ky * TW + m + lane] = vc[j];
+            if (lane < 2 * m) tile[ky * TW + kxh] = vh[j];
+            if (vc[j] > 0 && ky >= m && ky < TH - m) local_any = 1;
         }
-        return;
     }
-    for (int i = threadIdx.x; i < TH * PK_W; i += 256) {
-        const int ky = i / PK_W, kx = i - ky * PK_W;
-        const int* c = tile + ky * TW + kx;  // window kx .. kx + 2m of the padded row
-        int best = 0;
-        for (int k = 0; k <= 2 * m; ++k) best = c[k] > best ? c[k] : best;
-        rmax[i] = best;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < PK_H * PK_W; i += 256) {
-        const int ky = i / PK_W, kx = i - ky * PK_W;
-        const int y = y0 + ky, x = x0 + kx;
-        if (y >= H || x >= W) continue;
-        const int v = tile[(ky + m) * TW + (kx + m)];
-        uint8_t r = 0;
-        if (v > 0 && y >= m && y < H - m && x >= m && x < W - m && mask[base + (size_t)y * W + x]) {
-            int best = 0;
-            for (int k = 0; k <= 2 * m; ++k) {
-                const int t = rmax[(ky + k) * PK_W + kx];
-                best = t > best ? t : best;
+    const int any_fg = __syncthreads_or(local_any);
+    // each thread owns 4 consecutive pixels of a row: 16 threads per row, 16 rows per pass
+    const int kx4 = (threadIdx.x & 15) * 4;
+    for (int ky = threadIdx.x >> 4; ky < PK_H; ky += 16) {
+        const int y = y0 + ky;
+        if (y >= H) break;
+        unsigned packed = 0;
+        if (any_fg) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int kx = kx4 + i, x = x0 + kx;
+                const int* c = tile + (ky + m) * TW + (kx + m);
+                const int v = c[0];
+                if (v > 0 && y >= m && y < H - m && x >= m && x < W - m) {
+                    bool gt = false;
+                    if (m >= 1)
+                        gt = c[-1] > v || c[1] > v || c[-TW] > v || c[TW] > v || c[-TW - 1] > v || c[-TW + 1] > v ||
+                             c[TW - 1] > v || c[TW + 1] > v;
+                    if (!gt && mask[base + (size_t)y * W + x]) {
+                        for (int dy = -m; dy <= m && !gt; ++dy) {
+                            const int* row = c + dy * TW;
+                            for (int dx = -m; dx <= m; ++dx) gt |= row[dx] > v;
+                        }
+                        if (!gt) packed |= 1u << (8 * i);
+                    }
+                }
             }
-            r = (v == best) ? 1 : 0;
         }
-        peaks[base + (size_t)y * W + x] = r;
+        const int x = x0 + kx4;
+        uint8_t* o = peaks + base + (size_t)y * W + x;
+        if (x + 3 < W && ((reinterpret_cast<uintptr_t>(o) & 3) == 0)) {
+            *reinterpret_cast<unsigned*>(o) = packed;
+        } else {
+            for (int i = 0; i < 4 && x + i < W; ++i) o[i] = (packed >> (8 * i)) & 1u;
+        }
     }
 }
 
@@ -194,7 +211,7 @@ extern "C" int amt_peak_mask(amt_ctx* ctx, const int32_t* d2, const uint8_t* mas
                 min_distance, PK_MAXM);
     if (nplanes == 0) return AMT_OK;
     const int m = min_distance;
-    const size_t smem = ((size_t)(PK_H + 2 * m) * (PK_W + 2 * m) + (size_t)(PK_H + 2 * m) * PK_W) * sizeof(int);
+    const size_t smem = (size_t)(PK_H + 2 * m) * (PK_W + 2 * m) * sizeof(int);
     dim3 grid((W + PK_W - 1) / PK_W, (H + PK_H - 1) / PK_H, nplanes);
     hipLaunchKernelGGL(peaks_tile_kernel, grid, dim3(256), smem, ctx->stream, d2, mask, peaks, H, W, m);
     AMT_LAUNCH_CHECK();
