@@ -60,10 +60,15 @@ __global__ void __launch_bounds__(256) edt_cols_kernel(const unsigned short* __r
     const size_t plane = (size_t)blockIdx.z * H * W;
     const unsigned short* gp = g + plane;
     const int xc = x < W ? x : W - 1;
-    for (int r = wave; r < EC_TROWS; r += 4) {
-        const int y = y0 - EC_HALO + r;
-        tile[r][lane] = (y >= 0 && y < H && x < W) ? gp[(size_t)y * W + xc] : (unsigned short)G_INF;
+    // all loads of a wave are issued before the first LDS store
+    unsigned short gv[EC_TROWS / 4];
+#pragma unroll
+    for (int j = 0; j < EC_TROWS / 4; ++j) {
+        const int y = y0 - EC_HALO + wave + 4 * j;
+        gv[j] = (y >= 0 && y < H && x < W) ? gp[(size_t)y * W + xc] : (unsigned short)G_INF;
     }
+#pragma unroll
+    for (int j = 0; j < EC_TROWS / 4; ++j) tile[wave + 4 * j][lane] = gv[j];
     __syncthreads();
     if (x >= W) return;
 #pragma unroll 1
