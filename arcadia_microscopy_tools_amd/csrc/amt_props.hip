@@ -140,39 +140,64 @@ __global__ void __launch_bounds__(64) rp_label_kernel(const int* __restrict__ la
         mn[c] = 0xffffffffu;
         mx[c] = 0;
     }
-    for (int y = y0; y <= y1; ++y) {
-        int rmin = 0x7fffffff, rmax = -1;
+    // four rows per step: their label loads are issued together, then the intensity loads of the hits
+    for (int yb = y0; yb <= y1; yb += 4) {
+        int rmin[4], rmax[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            rmin[j] = 0x7fffffff;
+            rmax[j] = -1;
+        }
         for (int xb = x0; xb <= x1; xb += 64) {
             const int x = xb + lane;
-            const bool m = x <= x1 && L[(size_t)y * W + x] == want;
-            if (m) {
-                cnt += 1;
-                sy += (u64)y;
-                sx += (u64)x;
-                syy += (u64)y * (u64)y;
-                sxx += (u64)x * (u64)x;
-                sxy += (u64)y * (u64)x;
-                if (I) {
+            int lv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) lv[j] = (x <= x1 && yb + j <= y1) ? L[(size_t)(yb + j) * W + x] : 0;
+            unsigned iv[4][RP_MAXC];
+            if (I) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int c = 0; c < RP_MAXC; ++c)
-                        if (c < nc) {
-                            const unsigned v = I[(size_t)c * n + (size_t)y * W + x];
-                            s[c] += v;
-                            q[c] += (u64)v * v;
-                            mn[c] = v < mn[c] ? v : mn[c];
-                            mx[c] = v > mx[c] ? v : mx[c];
-                        }
+                        iv[j][c] = (c < nc && lv[j] == want) ? I[(size_t)c * n + (size_t)(yb + j) * W + x] : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int y = yb + j;
+                const bool m = lv[j] == want;
+                if (m) {
+                    cnt += 1;
+                    sy += (u64)y;
+                    sx += (u64)x;
+                    syy += (u64)y * (u64)y;
+                    sxx += (u64)x * (u64)x;
+                    sxy += (u64)y * (u64)x;
+                    if (I) {
+#pragma unroll
+                        for (int c = 0; c < RP_MAXC; ++c)
+                            if (c < nc) {
+                                const unsigned v = iv[j][c];
+                                s[c] += v;
+                                q[c] += (u64)v * v;
+                                mn[c] = v < mn[c] ? v : mn[c];
+                                mx[c] = v > mx[c] ? v : mx[c];
+                            }
+                    }
+                }
+                const u64 bal = __ballot(m);
+                if (bal) {
+                    const int first = xb + __ffsll((long long)bal) - 1;
+                    const int last = xb + 63 - __clzll((long long)bal);
+                    rmin[j] = first < rmin[j] ? first : rmin[j];
+                    rmax[j] = last > rmax[j] ? last : rmax[j];
                 }
             }
-            const u64 bal = __ballot(m);
-            if (bal) {
-                const int first = xb + __ffsll((long long)bal) - 1;
-                const int last = xb + 63 - __clzll((long long)bal);
-                rmin = first < rmin ? first : rmin;
-                rmax = last > rmax ? last : rmax;
-            }
         }
-        if (rows_ok && lane == 0) myrows[y - y0] = make_int2(rmin, rmax);
+        if (rows_ok && lane == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (yb + j <= y1) myrows[yb + j - y0] = make_int2(rmin[j], rmax[j]);
+        }
     }
     cnt = wave_sum_u64(cnt);
     if (want_morph) {
@@ -226,15 +251,27 @@ __global__ void __launch_bounds__(256) rp_perimeter_kernel(const int* __restrict
     const int plane = blockIdx.z;
     const int* L = labels + (size_t)plane * n;
     constexpr int LP = PT_W + 4, BP = PT_W + 2;
-    for (int i = threadIdx.x; i < (PT_H + 4) * LP; i += 256) {
-        int ky = i / LP, kx = i - ky * LP;
-        int y = y0 - 2 + ky, x = x0 - 2 + kx;
-        int v = 0;
-        if (y >= 0 && y < H && x >= 0 && x < W) {
-            v = L[(size_t)y * W + x];
-            if (v < 0 || v > max_label) v = 0;
+    {
+        // staging: wave w owns tile rows w, w + 4, ...: 64 centre columns + 4 halo columns; every load of the wave
+        // is issued before the first LDS store
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        constexpr int RPW = (PT_H + 4) / 4;
+        int vc[RPW], vh[RPW];
+        const int kxh = lane < 2 ? lane : PT_W + lane;  // halo column of lanes 0..3
+        const int xh = x0 - 2 + kxh, xc = x0 + lane;
+#pragma unroll
+        for (int j = 0; j < RPW; ++j) {
+            const int y = y0 - 2 + wave + 4 * j;
+            const bool yok = y >= 0 && y < H;
+            vc[j] = (yok && xc < W) ? L[(size_t)y * W + xc] : 0;
+            vh[j] = (yok && lane < 4 && xh >= 0 && xh < W) ? L[(size_t)y * W + xh] : 0;
         }
-        lab[i] = v;
+#pragma unroll
+        for (int j = 0; j < RPW; ++j) {
+            const int ky = wave + 4 * j;
+            lab[ky * LP + 2 + lane] = (vc[j] < 0 || vc[j] > max_label) ? 0 : vc[j];
+            if (lane < 4) lab[ky * LP + kxh] = (vh[j] < 0 || vh[j] > max_label) ? 0 : vh[j];
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < (PT_H + 2) * BP; i += 256) {
