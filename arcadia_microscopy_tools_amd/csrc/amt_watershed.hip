@@ -94,8 +94,12 @@ __global__ void __launch_bounds__(256) ws_rows_init_kernel(comp_row* __restrict_
 }
 
 // per-component max d2 (bucket count) or size (heap capacity), marker count, marker label range and
-// bounding box.  A wave covers 64 consecutive pixels of 8 rows (loads issued up front); each run of equal
-// roots is reduced in registers and costs one set of atomics.
+// bounding box.  A wave covers 64 consecutive pixels of 8 rows (loads issued up front).  Few pixels touch
+// the component row at all:
+//   * run heads (first pixel of a run of equal roots) update the bounding box (and the size in heap mode);
+//   * marker pixels (sparse) update the marker count and label range;
+//   * max d2: only pixels that are >= their 4 neighbours inside the wave's 64 x 8 strip can be the component's
+//     maximum, so only those issue an atomicMax (the true maximum always passes the test).
 __global__ void __launch_bounds__(256) ws_stats_kernel(const int* __restrict__ d2, const int* __restrict__ L,
                                                        const int* __restrict__ T, const int* __restrict__ markers,
                                                        comp_row* __restrict__ rows, size_t row_stride, int H, int W,
@@ -109,64 +113,56 @@ __global__ void __launch_bounds__(256) ws_stats_kernel(const int* __restrict__ d
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int y = yb + k;
-        rs[k] = -1;
-        vs[k] = 0;
-        ms[k] = 0;
-        if (x < W && y < H) {
-            const size_t i = base + (size_t)y * W + x;
-            rs[k] = L[i];
-            if (rs[k] >= 0) {
-                ms[k] = markers[i];
-                if (use_d2) {
-                    const int d = d2[i];
-                    vs[k] = d < 0 ? 0 : d;
-                }
-            }
-        }
+        rs[k] = (x < W && y < H) ? L[base + (size_t)y * W + x] : -1;
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const int r = rs[k];
-        const unsigned long long anyfg = __ballot(r >= 0);
-        if (!anyfg) continue;
-        const int left = __shfl_up(r, 1);
-        const bool head = (lane == 0) || (left != r);
-        const unsigned long long heads = __ballot(head);
-        const unsigned long long later = heads & ~((2ull << lane) - 1ull);
-        const int end_lane = later ? (__ffsll((long long)later) - 2) : 63;
-        int v = vs[k];
-        const int lab = ms[k];
-        int lmin = lab != 0 ? lab : 0x7fffffff, lmax = lab;
-        const unsigned long long mk = __ballot(lab != 0);
+        const size_t i = base + (size_t)(yb + k) * W + x;
+        ms[k] = rs[k] >= 0 ? markers[i] : 0;
+        vs[k] = 0;
+        if (use_d2 && rs[k] >= 0) {
+            const int d = d2[i];
+            vs[k] = d < 0 ? 0 : d;
+        }
+    }
+    comp_row* prow = rows + (size_t)blockIdx.z * row_stride;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            int t = __shfl_down(v, off), t1 = __shfl_down(lmin, off), t2 = __shfl_down(lmax, off);
-            if (lane + off <= end_lane) {
-                v = t > v ? t : v;
-                lmin = t1 < lmin ? t1 : lmin;
-                lmax = t2 > lmax ? t2 : lmax;
+    for (int k = 0; k < 8; ++k) {
+        const int r = rs[k];
+        const unsigned long long fg = __ballot(r >= 0);
+        if (!fg) continue;  // uniform
+        const int left = __shfl_up(r, 1);
+        const bool head = r >= 0 && ((lane == 0) || (left != r));
+        const int v = vs[k];
+        bool cand = false;
+        if (use_d2) {
+            const int vl = __shfl_up(v, 1), vr = __shfl_down(v, 1);
+            cand = r >= 0 && v > 0 && (lane == 0 || v >= vl) && (lane == 63 || v >= vr) &&
+                   (k == 0 || v >= vs[k > 0 ? k - 1 : 0]) && (k == 7 || v >= vs[k < 7 ? k + 1 : 7]);
+        }
+        const int lab = ms[k];
+        if (head || cand || lab != 0) {
+            comp_row* c = prow + (T[base + r] - 1);
+            if (cand) atomicMax(&c->cmax, v);
+            if (lab != 0) {
+                atomicAdd(&c->mcnt, 1);
+                atomicMin(&c->labmin, lab);
+                atomicMax(&c->labmax, lab);
             }
         }
-        if (r >= 0 && head) {
-            comp_row* c = rows + (size_t)blockIdx.z * row_stride + (T[base + r] - 1);
-            if ((size_t)r == (size_t)(yb + k) * W + x) c->root = r;  // the run that starts at the root itself
+        // run geometry (needs the ballot of ALL lanes, so it sits outside the divergent branch)
+        const unsigned long long hb = __ballot(head || r < 0);  // run boundaries: heads and background
+        if (head) {
+            const unsigned long long later = hb & ~((2ull << lane) - 1ull);
+            const int end_lane = later ? (__ffsll((long long)later) - 2) : 63;
             const int len = end_lane - lane + 1;
-            if (use_d2) {
-                if (v > 0) atomicMax(&c->cmax, v);
-            } else {
-                atomicAdd(&c->cmax, len);
-            }
+            comp_row* c = prow + (T[base + r] - 1);
+            if ((size_t)r == (size_t)(yb + k) * W + x) c->root = r;  // the run that starts at the root itself
+            if (!use_d2) atomicAdd(&c->cmax, len);
             atomicMin(&c->x0, x);
             atomicMax(&c->x1, x + len - 1);
             atomicMin(&c->y0, yb + k);
             atomicMax(&c->y1, yb + k);
-            const unsigned long long run = (len == 64) ? ~0ull : (((1ull << len) - 1ull) << lane);
-            const int nmk = __popcll(mk & run);
-            if (nmk) {
-                atomicAdd(&c->mcnt, nmk);
-                atomicMin(&c->labmin, lmin);
-                atomicMax(&c->labmax, lmax);
-            }
         }
     }
 }
