@@ -632,16 +632,33 @@ extern "C" int amt_max_i32(amt_ctx* ctx, const int32_t* in, int32_t* max_dev, in
 // list (ballot ranks + block prefix), `out` doubles as the pixel -> list-index map, union-find runs on the
 // list only (root = smallest list index = first raster pixel of the component), roots are ranked by a scan
 // over the list and the labels are scattered back.  Same numbering as amt_label by construction.
+constexpr int SP_CHUNK = 4096;  // pixels per block: 256 threads x 16 bytes
+
+// bit j of the result = byte j of the thread's 16 pixels is non-zero (one 128-bit load when aligned)
+__device__ __forceinline__ unsigned sp_load16(const uint8_t* __restrict__ p, size_t i, size_t n) {
+    unsigned bits = 0;
+    if (i + 15 < n && ((reinterpret_cast<uintptr_t>(p + i) & 15) == 0)) {
+        const uint4 v = *reinterpret_cast<const uint4*>(p + i);
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            // high bit of every non-zero byte, gathered into 4 consecutive bits
+            unsigned t = (((w[k] & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | w[k]) & 0x80808080u;
+            t = (t >> 7) | (t >> 14) | (t >> 21) | (t >> 28);
+            bits |= (t & 0xFu) << (4 * k);
+        }
+    } else {
+        for (int k = 0; k < 16; ++k)
+            if (i + k < n && p[i + k] != 0) bits |= 1u << k;
+    }
+    return bits;
+}
+
 __global__ void __launch_bounds__(256) sp_count_kernel(const uint8_t* __restrict__ in, int* __restrict__ blockcnt,
                                                        size_t n, int nblk) {
-    const size_t base = (size_t)blockIdx.y * n;
-    const size_t start = (size_t)blockIdx.x * RN_CHUNK;
-    int c = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const size_t i = start + (size_t)k * 256 + threadIdx.x;
-        if (i < n) c += in[base + i] != 0 ? 1 : 0;
-    }
+    const uint8_t* src = in + (size_t)blockIdx.y * n;
+    const size_t i = (size_t)blockIdx.x * SP_CHUNK + (size_t)threadIdx.x * 16;
+    int c = i < n ? __popc(sp_load16(src, i, n)) : 0;
     for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off);
     __shared__ int s[4];
     if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = c;
@@ -653,35 +670,34 @@ __global__ void __launch_bounds__(256) sp_compact_kernel(const uint8_t* __restri
                                                          int* __restrict__ list, int* __restrict__ parent,
                                                          int* __restrict__ out, size_t n, int nblk, int cap) {
     const size_t base = (size_t)blockIdx.y * n;
-    const size_t start = (size_t)blockIdx.x * RN_CHUNK;
+    const uint8_t* src = in + base;
     int* lst = list + (size_t)blockIdx.y * cap;
     int* par = parent + (size_t)blockIdx.y * cap;
-    __shared__ int wave_tot[4];
-    __shared__ int running;
-    if (threadIdx.x == 0) running = blockoff[(size_t)blockIdx.y * nblk + blockIdx.x];
-    __syncthreads();
+    const size_t i = (size_t)blockIdx.x * SP_CHUNK + (size_t)threadIdx.x * 16;
+    unsigned bits = i < n ? sp_load16(src, i, n) : 0u;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int k = 0; k < 8; ++k) {
-        const size_t i = start + (size_t)k * 256 + threadIdx.x;
-        const bool fg = i < n && in[base + i] != 0;
-        const unsigned long long m = __ballot(fg);
-        const int before = __popcll(m & ((1ull << lane) - 1ull));
-        if (lane == 0) wave_tot[wave] = __popcll(m);
-        __syncthreads();
-        int woff = 0;
-        for (int w = 0; w < wave; ++w) woff += wave_tot[w];
-        const int run = running;
-        if (fg) {
-            const int idx = run + woff + before;
-            if (idx < cap) {
-                lst[idx] = (int)i;
-                par[idx] = idx;
-                out[base + i] = idx + 1;
-            }
+    // exclusive prefix sum of the per-thread counts across the block (raster order = thread order)
+    const int cnt = __popc(bits);
+    int incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    __shared__ int wave_tot[4];
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int idx = blockoff[(size_t)blockIdx.y * nblk + blockIdx.x] + incl - cnt;
+    for (int w = 0; w < wave; ++w) idx += wave_tot[w];
+    while (bits) {
+        const int k = __ffs((int)bits) - 1;
+        bits &= bits - 1;
+        if (idx < cap) {
+            lst[idx] = (int)(i + k);
+            par[idx] = idx;
+            out[base + i + k] = idx + 1;
         }
-        __syncthreads();
-        if (threadIdx.x == 0) running = run + wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
-        __syncthreads();
+        ++idx;
     }
 }
 
@@ -753,7 +769,7 @@ extern "C" int amt_label_sparse(amt_ctx* ctx, const uint8_t* in, int32_t* out, i
     AMT_REQUIRE((size_t)H * W < 0x7fffffffull, "label_sparse: plane too large");
     if (nplanes == 0) return AMT_OK;
     const size_t n = (size_t)H * W;
-    const int nblk = amt_i_rank_blocks(n);
+    const int nblk = (int)((n + SP_CHUNK - 1) / SP_CHUNK);
     const size_t capn = (size_t)nplanes * capacity;
     AMT_TRY(amt_arena_begin(ctx, 3 * amt_align(capn * 4) + amt_align((size_t)nplanes * nblk * 4) +
                                      3 * amt_align(nplanes * 4)));
