@@ -184,16 +184,36 @@ __global__ void __launch_bounds__(256) hist_f64_kernel(const double* __restrict_
     uint32_t* mine = lh + (threadIdx.x >> 6) * nbins;
     const double norm = (double)nbins / (hi - lo);
     const double* src = in + (size_t)plane * n;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        double v = src[i];
-        if (!(v >= lo && v <= hi)) continue;  // NaN / out of range: not counted
-        double f = (v - lo) * norm;
-        int b = (int)f;
-        if (b < 0) b = 0;
-        if (b > nbins - 1) b = nbins - 1;
-        while (b > 0 && v < edges[b]) --b;
-        while (b < nbins - 1 && v >= edges[b + 1]) ++b;
-        atomicAdd(&mine[b], 1u);
+    const int lane = threadIdx.x & 63;
+    // four independent loads per thread and step; a smoothed image is mostly background, so whole waves often
+    // fall into ONE bin: those add their population count once instead of 64 same-address LDS atomics
+    for (size_t i0 = (size_t)blockIdx.x * 1024 + threadIdx.x; i0 < n; i0 += (size_t)gridDim.x * 1024) {
+        double v4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v4[u] = (i0 + (size_t)u * 256 < n) ? src[i0 + (size_t)u * 256] : __builtin_nan("");
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double v = v4[u];
+            const bool ok = v >= lo && v <= hi;  // NaN / out of range: not counted
+            int b = 0;
+            if (ok) {
+                const double f = (v - lo) * norm;
+                b = (int)f;
+                if (b < 0) b = 0;
+                if (b > nbins - 1) b = nbins - 1;
+                while (b > 0 && v < edges[b]) --b;
+                while (b < nbins - 1 && v >= edges[b + 1]) ++b;
+            }
+            const unsigned long long act = __ballot(ok);
+            if (!act) continue;
+            const int b0 = __shfl(b, __ffsll((long long)act) - 1);
+            const unsigned long long same = __ballot(ok && b == b0);
+            if (same == act) {
+                if (lane == __ffsll((long long)act) - 1) atomicAdd(&mine[b0], (unsigned)__popcll(act));
+            } else if (ok) {
+                atomicAdd(&mine[b], 1u);
+            }
+        }
     }
     __syncthreads();
     uint32_t* gh = hist + (size_t)plane * nbins;
