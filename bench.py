@@ -37,6 +37,40 @@ STAGE_BYTES_PER_PX = {
 }
 
 
+# kernels (name prefixes in the rocprofv3 output) that make up each stage of the chain
+STAGE_KERNELS = {
+    "gaussian": ("gauss_fused_kernel", "conv_axis"),
+    "otsu": ("hist_f64_kernel", "otsu_f64_kernel", "minmax_"),
+    "threshold_open_close": ("pack_gt_kernel", "toc_fused_kernel", "packed_prim_kernel", "unpack_kernel"),
+    "edt": ("edt_rows_kernel", "edt_cols_kernel"),
+    "peaks": ("peaks_tile_kernel",),
+    "markers": ("sp_",),
+    "watershed": ("ccl_", "ws_"),
+    "clear_border": ("presence_", "frame_mark_kernel", "drop_flagged_kernel", "map_labels_kernel"),
+    "regionprops": ("rp_",),
+}
+
+
+def pmc_traffic_bytes(stage: str):
+    """HBM bytes per 32-FOV launch of one stage from the committed PMC summary (profiles/r01_hbm_pmc.csv:
+    FETCH_SIZE with the gfx950 x2 correction for wide reads + WRITE_SIZE), or None."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_hbm_pmc.csv")
+    if not os.path.exists(path) or stage not in STAGE_KERNELS:
+        return None
+    total = 0.0
+    with open(path) as f:
+        for line in f:
+            if line.startswith("#") or line.startswith("kernel,") or line.startswith("TOTAL"):
+                continue
+            parts = line.rstrip("\n").rsplit(",", 4)
+            if len(parts) != 5:
+                continue
+            name = parts[0].strip('"').replace("void ", "")
+            if any(name.startswith(pfx) for pfx in STAGE_KERNELS[stage]):
+                total += (float(parts[3]) + float(parts[4])) * 1e6
+    return total or None
+
+
 def log(msg):
     print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
@@ -231,7 +265,9 @@ def main():
         fm_ms = sum(stage_avg[k] for k in fm)
         roofline = {
             "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "frac": achieved / HBM_PEAK_GBS,
+            # PMC bytes of this stage's kernels for a 32-FOV launch, scaled to this run's launch size
+            "traffic": (lambda t: None if t is None else t * PB / 32.0)(pmc_traffic_bytes(dom)),
             "algorithmic_bytes_per_launch": dom_bytes, "launch_ms": stage_avg[dom],
             "chain": {"achieved": chain_bytes / (chain_ms * 1e-3) / 1e9, "frac": chain_bytes / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                       "ms": chain_ms},
