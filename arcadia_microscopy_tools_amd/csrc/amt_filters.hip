@@ -91,6 +91,197 @@ __global__ void __launch_bounds__(256) conv_axis1_kernel(const double* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// Register-blocked two-pass path for large radii (13 <= r <= 128, e.g. sigma = 16 of subtract_background_dog).
+// A thread produces EIGHT consecutive outputs along the filter axis.  scipy's order adds the pairs from the
+// outside in: at distance j the eight outputs need x[o+k-j] and x[o+k+j], k = 0..7 -- two windows of eight
+// samples that each slide by ONE sample when j decreases.  So a step costs 2 new LDS reads (instead of 16) and
+// 24 float64 operations; the windows rotate by renaming (the loop is unrolled over 8 steps), the weights are
+// wave-uniform scalar loads.  LDS traffic drops 8x and the passes become fp64-issue bound.
+//   vertical   : lanes = 64 columns, the tile keeps the RAW input type (uint16 tiles are 4x smaller);
+//   horizontal : lanes = 64 rows (row pitch odd in doubles: conflict-free), results go back through LDS so
+//                that the stores are coalesced along x.
+// ------------------------------------------------------------------------------------------------
+template <typename TIn>
+__device__ __forceinline__ double cvt_f64(TIn v, double scale);
+template <>
+__device__ __forceinline__ double cvt_f64<uint16_t>(uint16_t v, double scale) {
+    return (double)v * scale;
+}
+template <>
+__device__ __forceinline__ double cvt_f64<double>(double v, double scale) {
+    return v;
+}
+
+// eight outputs at positions o .. o+7 of a line; `at(i)` returns sample i (already converted); `w` = the
+// 2r+1 weights IN LDS (scalar loads share their counter with LDS reads and return out of order, so a scalar
+// weight load inside the steps forces a full wait on the in-flight LDS reads; LDS weight reads stay in order).
+// The two samples that enter the windows are requested TWO steps ahead (software pipeline), so the LDS latency
+// hides behind 48 float64 operations even with a single wave per SIMD.
+template <typename F>
+__device__ __forceinline__ void blocked8(F at, int o, const double* w, int r, double acc[8]) {
+    double L[8], Rw[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        acc[k] = at(o + k) * w[r];
+        L[k] = at(o + k - r);
+        Rw[k] = at(o + k + r);
+    }
+    double pl = at(o + 8 - r), pr = at(o + r - 1);  // enter after the first step
+    // one step at distance j = r - st; s = st & 7 selects the register renaming of the rotating windows
+#define AMT_BLOCKED8_STEP(s, st)                                                                   \
+    {                                                                                              \
+        const int j = r - (st);                                                                    \
+        const double nl = at(o + 9 - j), nr = at(o + j - 2); /* enter after the NEXT step */        \
+        const double wj = w[st];                                                                   \
+        _Pragma("unroll") for (int k = 0; k < 8; ++k) acc[k] += (L[(k + (s)) & 7] + Rw[(k - (s)) & 7]) * wj; \
+        L[(s) & 7] = pl;          /* the left window drops its first sample and gains x[o+8-j] */   \
+        Rw[(7 - (s)) & 7] = pr;   /* the right window drops its last sample and gains x[o+j-1] */   \
+        pl = nl;                                                                                   \
+        pr = nr;                                                                                   \
+    }
+    int st = 0;
+    for (; st + 8 <= r; st += 8) {  // full blocks of eight steps: no guards, free scheduling
+        AMT_BLOCKED8_STEP(0, st + 0)
+        AMT_BLOCKED8_STEP(1, st + 1)
+        AMT_BLOCKED8_STEP(2, st + 2)
+        AMT_BLOCKED8_STEP(3, st + 3)
+        AMT_BLOCKED8_STEP(4, st + 4)
+        AMT_BLOCKED8_STEP(5, st + 5)
+        AMT_BLOCKED8_STEP(6, st + 6)
+        AMT_BLOCKED8_STEP(7, st + 7)
+    }
+    if (st + 0 < r) AMT_BLOCKED8_STEP(0, st + 0)
+    if (st + 1 < r) AMT_BLOCKED8_STEP(1, st + 1)
+    if (st + 2 < r) AMT_BLOCKED8_STEP(2, st + 2)
+    if (st + 3 < r) AMT_BLOCKED8_STEP(3, st + 3)
+    if (st + 4 < r) AMT_BLOCKED8_STEP(4, st + 4)
+    if (st + 5 < r) AMT_BLOCKED8_STEP(5, st + 5)
+    if (st + 6 < r) AMT_BLOCKED8_STEP(6, st + 6)
+#undef AMT_BLOCKED8_STEP
+}
+
+template <typename TIn>
+__global__ void __launch_bounds__(256) conv_v8_kernel(const TIn* __restrict__ in, double scale,
+                                                      double* __restrict__ out, int H, int W,
+                                                      const double* __restrict__ wts, int r, int mode, double cval,
+                                                      int TH, size_t in_stride) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int rows = TH + 2 * r;
+    TIn* tile = reinterpret_cast<TIn*>(smem_raw);                            // rows x 64
+    double* wl = reinterpret_cast<double*>(smem_raw + (((size_t)rows * 64 * sizeof(TIn) + 7) & ~(size_t)7));  // 2r + 1
+    unsigned char* inside = reinterpret_cast<unsigned char*>(wl + 2 * r + 1);  // rows: 0 = cval row
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = blockIdx.x * 64 + lane;
+    const int y0 = blockIdx.y * TH;
+    const size_t plane = (size_t)blockIdx.z * H * W;
+    const TIn* src = in + (size_t)blockIdx.z * in_stride;
+    const int xc = x < W ? x : W - 1;
+    int any_out = 0;
+    for (int i = threadIdx.x; i < 2 * r + 1; i += 256) wl[i] = wts[i];
+    for (int k0 = wave * 8; k0 < rows; k0 += 32) {
+        TIn v[8];
+        int yy[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            yy[u] = k0 + u < rows ? amt_map_index(y0 - r + k0 + u, H, mode) : -1;
+            v[u] = yy[u] >= 0 ? src[(size_t)yy[u] * W + xc] : (TIn)0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (k0 + u < rows) {
+                tile[(k0 + u) * 64 + lane] = v[u];
+                if (lane == 0) inside[k0 + u] = yy[u] >= 0 ? 1 : 0;
+                any_out |= yy[u] < 0 ? 1 : 0;
+            }
+    }
+    const int has_out = __syncthreads_or(any_out);  // only 'constant' mode tiles at the image border
+    auto at = [&](int i) -> double {  // i = tile row
+        return inside[i] ? cvt_f64<TIn>(tile[i * 64 + lane], scale) : cval;
+    };
+    auto at_in = [&](int i) -> double { return cvt_f64<TIn>(tile[i * 64 + lane], scale); };
+    for (int c = wave; c * 8 < TH; c += 4) {
+        const int q0 = c * 8;  // first output row of the chunk (relative to y0)
+        if (y0 + q0 >= H) break;
+        double acc[8];
+        if (has_out)
+            blocked8(at, q0 + r, wl, r, acc);
+        else
+            blocked8(at_in, q0 + r, wl, r, acc);
+        if (x < W) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (y0 + q0 + k < H) out[plane + (size_t)(y0 + q0 + k) * W + x] = acc[k];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) conv_h8_kernel(const double* __restrict__ in, double* __restrict__ out, int H,
+                                                      int W, const double* __restrict__ wts, int r, int mode,
+                                                      double cval, int TW) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int cols = TW + 2 * r;
+    const int pitch = cols | 1;  // odd number of doubles per row
+    double* tile = reinterpret_cast<double*>(smem_raw);  // 64 x pitch
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x0 = blockIdx.x * TW;
+    const int y0 = blockIdx.y * 64;
+    const size_t plane = (size_t)blockIdx.z * H * W;
+    // boundary-mapped source column of every tile column, computed once (one call site of the general mapping)
+    double* wl = tile + (size_t)64 * pitch;  // 2r + 1
+    int* xmap = reinterpret_cast<int*>(wl + 2 * r + 1);
+    for (int i = threadIdx.x; i < 2 * r + 1; i += 256) wl[i] = wts[i];
+    for (int k = threadIdx.x; k < cols; k += 256) xmap[k] = amt_map_index(x0 - r + k, W, mode);
+    __syncthreads();
+    // staging: wave w owns rows w, w + 4, ...; 64 consecutive columns of 8 rows in flight per step
+    for (int k0 = 0; k0 < cols; k0 += 64) {
+        const int k = k0 + lane;
+        const int xx = k < cols ? xmap[k] : -1;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int row = wave + 4 * (half * 8 + u);
+                v[u] = (xx >= 0 && y0 + row < H) ? in[plane + (size_t)(y0 + row) * W + xx] : cval;
+            }
+            if (k < cols) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) tile[(wave + 4 * (half * 8 + u)) * pitch + k] = v[u];
+            }
+        }
+    }
+    __syncthreads();
+    const double* myrow = tile + lane * pitch;
+    auto at = [&](int i) -> double { return myrow[i]; };
+    // results are parked in registers until every wave has finished reading the tile (TW <= 64: at most two
+    // 8-output chunks per wave)
+    double res0[8], res1[8];
+    const int c0 = wave, c1 = wave + 4;
+    if (c0 * 8 < TW) blocked8(at, c0 * 8 + r, wl, r, res0);
+    if (c1 * 8 < TW) blocked8(at, c1 * 8 + r, wl, r, res1);
+    __syncthreads();
+    // park the outputs in the (now free) tile as a 64 x TW block, then store rows coalesced along x
+    const int opitch = TW | 1;
+    if (c0 * 8 < TW) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tile[lane * opitch + c0 * 8 + k] = res0[k];
+    }
+    if (c1 * 8 < TW) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tile[lane * opitch + c1 * 8 + k] = res1[k];
+    }
+    __syncthreads();
+    for (int row = wave; row < 64; row += 4) {
+        const int y = y0 + row;
+        if (y >= H) break;
+        for (int k = lane; k < TW; k += 64) {
+            const int x = x0 + k;
+            if (x < W) out[plane + (size_t)y * W + x] = tile[row * opitch + k];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Fused single-kernel path for small radii (r <= 12): one HBM read of the input, one write of the
 // result, no intermediate in HBM.
 //   * a 256-thread block owns 256 - 2R output columns (+ R halo columns each side) and a chunk of rows;
@@ -262,17 +453,25 @@ static int gaussian_typed(amt_ctx* ctx, const TIn* in, double scale, double* out
         default:
             break;
     }
-    // generic two-pass path
-    int TH = (r <= 32) ? 64 : 32;
-    size_t smem0 = ((size_t)(TH + 2 * r) * 64 + (2 * r + 1)) * sizeof(double);
-    dim3 g0((W + 63) / 64, (H + TH - 1) / TH, nplanes);
-    hipLaunchKernelGGL((conv_axis0_kernel<TIn>), g0, dim3(64, 4), smem0, ctx->stream, in, scale, tmp, H, W, wdev, r,
-                       mode, cval, TH, in_stride);
-    AMT_LAUNCH_CHECK();
-    size_t smem1 = ((size_t)4 * (256 + 2 * r) + (2 * r + 1)) * sizeof(double);
-    dim3 g1((W + 255) / 256, (H + 3) / 4, nplanes);
-    hipLaunchKernelGGL(conv_axis1_kernel, g1, dim3(256), smem1, ctx->stream, tmp, out, H, W, wdev, r, mode, cval);
-    AMT_LAUNCH_CHECK();
+    // register-blocked two-pass path
+    {
+        // vertical: rows per block chosen so that the raw-type tile stays within ~96 KB
+        int TH = 128;
+        while (TH > 32 && ((size_t)(TH + 2 * r) * 64 * sizeof(TIn) + (size_t)(TH + 2 * r)) > 96 * 1024) TH >>= 1;
+        const size_t smem0 = (size_t)(TH + 2 * r) * 64 * sizeof(TIn) + 8 + (size_t)(2 * r + 1) * 8 + (size_t)(TH + 2 * r);
+        dim3 g0((W + 63) / 64, (H + TH - 1) / TH, nplanes);
+        hipLaunchKernelGGL((conv_v8_kernel<TIn>), g0, dim3(256), smem0, ctx->stream, in, scale, tmp, H, W, wdev, r, mode,
+                           cval, TH, in_stride);
+        AMT_LAUNCH_CHECK();
+        // horizontal: 64 rows x TW columns per block, at most two 8-output chunks per wave (TW <= 64)
+        int TW = 64;
+        while (TW > 32 && (size_t)64 * ((TW + 2 * r) | 1) * sizeof(double) > 100 * 1024) TW >>= 1;
+        const size_t smem1 = (size_t)64 * ((TW + 2 * r) | 1) * sizeof(double) + (size_t)(2 * r + 1) * 8 +
+                             (size_t)(TW + 2 * r) * sizeof(int);
+        dim3 g1((W + TW - 1) / TW, (H + 63) / 64, nplanes);
+        hipLaunchKernelGGL(conv_h8_kernel, g1, dim3(256), smem1, ctx->stream, tmp, out, H, W, wdev, r, mode, cval, TW);
+        AMT_LAUNCH_CHECK();
+    }
     return AMT_OK;
 }
 
