@@ -253,33 +253,27 @@ __global__ void __launch_bounds__(256) conv_h8_kernel(const double* __restrict__
     __syncthreads();
     const double* myrow = tile + lane * pitch;
     auto at = [&](int i) -> double { return myrow[i]; };
-    // results are parked in registers until every wave has finished reading the tile (TW <= 64: at most two
-    // 8-output chunks per wave)
-    double res0[8], res1[8];
-    const int c0 = wave, c1 = wave + 4;
-    if (c0 * 8 < TW) blocked8(at, c0 * 8 + r, wl, r, res0);
-    if (c1 * 8 < TW) blocked8(at, c1 * 8 + r, wl, r, res1);
-    __syncthreads();
-    // park the outputs in the (now free) tile as a 64 x TW block, then store rows coalesced along x
-    const int opitch = TW | 1;
-    if (c0 * 8 < TW) {
+    // every wave walks over its chunks of eight outputs; a lane stores its eight consecutive doubles (64 bytes,
+    // whole sectors) straight from registers
+    const int y = y0 + lane;
+    for (int c = wave; c * 8 < TW; c += 4) {
+        double res[8];
+        blocked8(at, c * 8 + r, wl, r, res);
+        const int x = x0 + c * 8;
+        if (y < H && x < W) {
+            double* dst = out + plane + (size_t)y * W + x;
+            if (x + 7 < W && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) tile[lane * opitch + c0 * 8 + k] = res0[k];
-    }
-    if (c1 * 8 < TW) {
+                for (int k = 0; k < 8; k += 2) *reinterpret_cast<double2*>(dst + k) = make_double2(res[k], res[k + 1]);
+            } else {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) tile[lane * opitch + c1 * 8 + k] = res1[k];
-    }
-    __syncthreads();
-    for (int row = wave; row < 64; row += 4) {
-        const int y = y0 + row;
-        if (y >= H) break;
-        for (int k = lane; k < TW; k += 64) {
-            const int x = x0 + k;
-            if (x < W) out[plane + (size_t)y * W + x] = tile[row * opitch + k];
+                for (int k = 0; k < 8; ++k)
+                    if (x + k < W) dst[k] = res[k];
+            }
         }
     }
 }
+
 
 // ------------------------------------------------------------------------------------------------
 // Fused single-kernel path for small radii (r <= 12): one HBM read of the input, one write of the
@@ -463,9 +457,9 @@ static int gaussian_typed(amt_ctx* ctx, const TIn* in, double scale, double* out
         hipLaunchKernelGGL((conv_v8_kernel<TIn>), g0, dim3(256), smem0, ctx->stream, in, scale, tmp, H, W, wdev, r, mode,
                            cval, TH, in_stride);
         AMT_LAUNCH_CHECK();
-        // horizontal: 64 rows x TW columns per block, at most two 8-output chunks per wave (TW <= 64)
-        int TW = 64;
-        while (TW > 32 && (size_t)64 * ((TW + 2 * r) | 1) * sizeof(double) > 100 * 1024) TW >>= 1;
+        // horizontal: 64 rows x TW columns per block; wide tiles amortise the 2r halo columns
+        int TW = 128;
+        while (TW > 32 && (size_t)64 * ((TW + 2 * r) | 1) * sizeof(double) > 136 * 1024) TW >>= 1;
         const size_t smem1 = (size_t)64 * ((TW + 2 * r) | 1) * sizeof(double) + (size_t)(2 * r + 1) * 8 +
                              (size_t)(TW + 2 * r) * sizeof(int);
         dim3 g1((W + TW - 1) / TW, (H + 63) / 64, nplanes);
