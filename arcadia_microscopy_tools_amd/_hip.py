@@ -101,6 +101,9 @@ _SIGS = {
     "amt_regionprops_intensity_u16": (c_int, [_P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int]),
     "amt_regionprops_full_u16": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int]),
     "amt_max_i32": (c_int, [_P, _P, _P, c_int, c_size_t]),
+    "amt_label_bboxes": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int]),
+    "amt_contours_find": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, c_size_t, _P]),
+    "amt_contours_emit": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),
 }
 
 _lib = None

@@ -572,3 +572,27 @@ extern "C" int amt_regionprops_full_u16(amt_ctx* ctx, const int32_t* labels, con
                 "regionprops_full: bad arguments");
     return regionprops_common(ctx, labels, intensity, C, table_dev, itable_dev, nplanes, H, W, max_label);
 }
+
+// ---- bounding boxes only (what the outline extractor needs, R/masks.py:99) ---------------------------
+__global__ void __launch_bounds__(256) bbox_init_kernel(int* __restrict__ bbox, size_t nlab) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nlab; i += (size_t)gridDim.x * 256) {
+        bbox[i * 4 + 0] = 0x7fffffff;
+        bbox[i * 4 + 1] = 0x7fffffff;
+        bbox[i * 4 + 2] = -1;
+        bbox[i * 4 + 3] = -1;
+    }
+}
+
+extern "C" int amt_label_bboxes(amt_ctx* ctx, const int32_t* labels, int32_t* bbox_dev, int nplanes, int H, int W,
+                                int max_label) {
+    AMT_TRY(amt_set_device(ctx));
+    AMT_REQUIRE(labels && bbox_dev && nplanes >= 0 && H > 0 && W > 0 && max_label >= 1, "label_bboxes: bad arguments");
+    if (nplanes == 0) return AMT_OK;
+    const size_t nlab = (size_t)nplanes * max_label;
+    hipLaunchKernelGGL(bbox_init_kernel, dim3(amt_grid_for(nlab, 256, 1024)), dim3(256), 0, ctx->stream, bbox_dev, nlab);
+    AMT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(rp_bbox_kernel, dim3((W + 63) / 64, (H + 31) / 32, nplanes), dim3(256), 0, ctx->stream, labels,
+                       bbox_dev, H, W, max_label);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}

@@ -609,3 +609,57 @@ def regionprops_intensity(labels: DeviceArray, intensity: DeviceArray, max_label
     _hip.check(_lib().amt_regionprops_intensity_u16(ctx.handle, labels.ptr, intensity.ptr, C, o.ptr, n, H, W,
                                                     int(max_label)), "amt_regionprops_intensity_u16")
     return o
+
+
+def label_bboxes(labels: DeviceArray, max_label: int) -> np.ndarray:
+    """(nplanes, max_label, 4) int32 {min row, min col, max row, max col}, inclusive; absent labels have max < min."""
+    ctx = labels.ctx
+    n, H, W = _planes(labels)
+    if labels.dtype != np.int32:
+        raise TypeError("label_bboxes expects int32 labels")
+    o = ctx.empty((n, int(max_label), 4), np.int32)
+    _hip.check(_lib().amt_label_bboxes(ctx.handle, labels.ptr, o.ptr, n, H, W, int(max_label)), "amt_label_bboxes")
+    return o.numpy()
+
+
+def cell_outlines(labels: DeviceArray, max_label: int) -> list[np.ndarray]:
+    """Outline of every label present in ONE int32 label plane, as ``_extract_outlines_skimage`` returns them
+    (R/masks.py:82-115): marching squares at level 0.5 on the bounding box padded by one pixel, longest contour,
+    (row, col) float64 vertices in image coordinates, ascending label order, empty (0, 2) arrays where no
+    contour exists.  The walks run on the device; the host only sizes the scratch and output buffers."""
+    ctx = labels.ctx
+    if labels.ndim != 2 or labels.dtype != np.int32:
+        raise TypeError("cell_outlines expects one (Y, X) int32 label plane")
+    H, W = labels.shape
+    bb = label_bboxes(labels, max(int(max_label), 1))[0]
+    present = np.nonzero(bb[:, 2] >= bb[:, 0])[0]
+    nlab = len(present)
+    if nlab == 0:
+        return []
+    boxes = np.empty((nlab, 5), dtype=np.int32)
+    boxes[:, 0] = present + 1
+    boxes[:, 1] = np.maximum(bb[present, 0] - 1, 0)
+    boxes[:, 2] = np.maximum(bb[present, 1] - 1, 0)
+    boxes[:, 3] = np.minimum(bb[present, 2] + 2, H)
+    boxes[:, 4] = np.minimum(bb[present, 3] + 2, W)
+    squares = np.maximum(boxes[:, 3] - boxes[:, 1] - 1, 0).astype(np.int64) * np.maximum(
+        boxes[:, 4] - boxes[:, 2] - 1, 0)
+    voff = np.concatenate([[0], np.cumsum(squares)]).astype(np.int64)
+    d_boxes, d_voff = ctx.asarray(boxes), ctx.asarray(voff)
+    nvis = int(voff[-1])
+    d_vis = ctx.empty((max(nvis, 1),), np.uint8)
+    d_info = ctx.empty((nlab, 4), np.int32)
+    _hip.check(_lib().amt_contours_find(ctx.handle, labels.ptr, H, W, nlab, d_boxes.ptr, d_voff.ptr, d_vis.ptr, nvis,
+                                        d_info.ptr), "amt_contours_find")
+    info = d_info.numpy()
+    poff = np.concatenate([[0], np.cumsum(info[:, 0].astype(np.int64))]).astype(np.int64)
+    total = int(poff[-1])
+    if total == 0:
+        return [np.array([]).reshape(0, 2) for _ in range(nlab)]
+    d_poff = ctx.asarray(poff)
+    d_pts = ctx.empty((total, 2), np.float64)
+    _hip.check(_lib().amt_contours_emit(ctx.handle, labels.ptr, H, W, nlab, d_boxes.ptr, d_info.ptr, d_poff.ptr,
+                                        d_pts.ptr), "amt_contours_emit")
+    pts = d_pts.numpy()
+    return [pts[poff[i]:poff[i + 1]].copy() if poff[i + 1] > poff[i] else np.array([]).reshape(0, 2)
+            for i in range(nlab)]

@@ -156,11 +156,22 @@ class SegmentationMask:
 
     @cached_property
     def cell_outlines(self) -> list[Float64Array]:
-        """Per-cell outline extraction (R/masks.py:68-115,229-245) is a 'next' row of the hot-path scope
-         and is not implemented on the device yet."""
-        raise NotImplementedError(
-            "cell_outlines is not implemented on the MI355X path yet (SURVEY.md section 8f, rank 2)"
-        )
+        """Per-cell outlines, one (n, 2) array of (y, x) vertices per cell (R/masks.py:229-245).
+
+        ``outline_extractor="skimage"`` runs on the device: marching squares at level 0.5 on each cell's padded
+        bounding box, longest contour, in scikit-image's vertex order (R/masks.py:82-115).
+        ``outline_extractor="cellpose"`` (``cellpose.utils.outlines_list`` -> OpenCV ``findContours``,
+        R/masks.py:68-79) has no pinned oracle in this environment (neither package is installed) and is refused
+        loudly rather than approximated."""
+        if self.outline_extractor == "cellpose":
+            raise NotImplementedError(
+                "outline_extractor='cellpose' (OpenCV findContours via cellpose.utils.outlines_list) is not "
+                "implemented on the MI355X path; use outline_extractor='skimage'"
+            )
+        from . import hipops
+
+        lab, k = self._labels_device
+        return hipops.cell_outlines(lab[0] if lab.ndim == 3 else lab, int(k))
 
     @cached_property
     def cell_properties(self) -> dict[str, ScalarArray]:

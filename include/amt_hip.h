@@ -264,6 +264,23 @@ int amt_regionprops_full_u16(amt_ctx* ctx, const int32_t* labels, const uint16_t
                              double* itable_dev, int nplanes, int H, int W, int max_label);
 int amt_max_i32(amt_ctx* ctx, const int32_t* in, int32_t* max_dev, int nplanes, size_t n);
 
+/* ---- cell outlines: R/masks.py:82-115 (_extract_outlines_skimage), SK/measure/_find_contours.py ------
+ * bbox_dev = nplanes x max_label x 4 ints {min row, min col, max row, max col} INCLUSIVE; labels absent from a
+ * plane give max < min. */
+int amt_label_bboxes(amt_ctx* ctx, const int32_t* labels, int32_t* bbox_dev, int nplanes, int H, int W, int max_label);
+/* Marching squares at level 0.5 on the crop of every listed label of ONE label plane (H x W int32), longest
+ * contour kept (first among equals), in scikit-image's vertex order.  Two calls with a host step in between
+ * (the outline lengths size the output):
+ *   boxes_dev   nlab x 5 ints {label, r_lo, c_lo, r_hi, c_hi}: the bounding box padded by one pixel and clamped
+ *               to the image, half-open (R/masks.py:99-104)
+ *   voff_dev    nlab + 1 offsets into visited_dev, one scratch byte per square ((h-1) x (w-1)) of each crop
+ *   info_dev    nlab x 4 ints {points, closed, start square, start segment}; points = 0 for an empty outline
+ *   poff_dev    nlab + 1 offsets (in points) into points_dev = (row, col) float64 pairs, image coordinates */
+int amt_contours_find(amt_ctx* ctx, const int32_t* labels, int H, int W, int nlab, const int32_t* boxes_dev,
+                      const int64_t* voff_dev, uint8_t* visited_dev, size_t visited_bytes, int32_t* info_dev);
+int amt_contours_emit(amt_ctx* ctx, const int32_t* labels, int H, int W, int nlab, const int32_t* boxes_dev,
+                      const int32_t* info_dev, const int64_t* poff_dev, double* points_dev);
+
 #ifdef __cplusplus
 }
 #endif

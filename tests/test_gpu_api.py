@@ -174,8 +174,16 @@ def test_segmentation_mask_disks(golden):
         assert SegmentationMask(labels, property_names=["label", "area"]).centroids_yx.shape == (0, 2)
     sub = SegmentationMask(labels, property_names=["label", "circularity"]).cell_properties
     assert list(sub.keys()) == ["label", "circularity"]
-    with pytest.raises(NotImplementedError):
-        sm.cell_outlines
+    with pytest.raises(NotImplementedError, match="cellpose"):
+        sm.cell_outlines  # default extractor = cellpose / OpenCV: refused loudly, never approximated
+    from oracle import contours
+
+    sk = SegmentationMask(labels, outline_extractor="skimage")
+    outs = sk.cell_outlines
+    ref = contours.extract_outlines_skimage(sk.label_image)
+    assert len(outs) == sk.num_cells == len(ref)
+    for a, b in zip(outs, ref):
+        assert a.dtype == np.float64 and a.shape == b.shape and np.array_equal(a, b)
 
 
 def test_segmentation_mask_edges_and_bool(golden):
@@ -249,3 +257,32 @@ def test_microscopy_image_to_device(golden):
         dev.get_channel_intensities("CY5")
     out = im.apply_pipeline(Pipeline([ImageOperation(apply_threshold)]), DAPI)
     assert out.dtype == bool and int(out.sum()) == 1297
+
+
+def test_cell_outlines_golden_and_random(golden):
+    """Device outline walks against the REAL scikit-image output (tests/golden/outlines_96.npz: rings, holes
+    longer than the outer boundary, diagonal contact, clipped cells, single pixels, split labels, lines) and
+    against the oracle on random multi-label images."""
+    from arcadia_microscopy_tools_amd import hipops
+    from arcadia_microscopy_tools_amd.device import get_context
+    from oracle import contours
+
+    ctx = get_context()
+    g = golden("outlines_96")
+    for name in ("shapes", "nuclei"):
+        lab, pts, offs = g[f"{name}_labels"], g[f"{name}_points"], g[f"{name}_offsets"]
+        outs = hipops.cell_outlines(ctx.asarray(lab.astype(np.int32)), int(lab.max()))
+        assert len(outs) == len(offs) - 1
+        for i, o in enumerate(outs):
+            ref = pts[offs[i]:offs[i + 1]]
+            assert o.shape == ref.shape and np.array_equal(o, ref), (name, i)
+    rng = np.random.default_rng(12)
+    for t in range(25):
+        h, w = rng.integers(2, 40, 2)
+        lab = ((rng.random((h, w)) < rng.uniform(0.2, 0.8)) * rng.integers(1, 5, (h, w))).astype(np.int32)
+        outs = hipops.cell_outlines(ctx.asarray(lab), max(int(lab.max()), 1))
+        ref = contours.extract_outlines_skimage(lab)
+        assert len(outs) == len(ref), t
+        for a, b in zip(outs, ref):
+            assert a.shape == b.shape and np.array_equal(a, b), t
+    assert hipops.cell_outlines(ctx.asarray(np.zeros((8, 8), np.int32)), 1) == []

@@ -185,3 +185,24 @@ def test_reference_ops_on_fixture(golden):
     np.testing.assert_allclose(bg, g["bgsub_fitc_p90"], rtol=0, atol=5e-16)
     p1, p2 = np.percentile(fitc, (1, 99))
     assert np.array_equal(skops.rescale_intensity(fitc, (p1, p2), (0, 1)), g["rescale_fitc_1_99"])
+
+
+def test_contours_oracle_vs_skimage(golden):
+    """oracle/contours.py against scikit-image 0.18.3: the 16-case marching-squares table and the full
+    `_extract_outlines_skimage` recipe (R/masks.py:82-115) on two label images."""
+    from oracle import contours
+
+    g = golden("outlines_96")
+    table = g["case_table"]
+    for case in range(16):
+        segs = contours.CASES[case]
+        for k, (f, t) in enumerate(segs):
+            assert np.array_equal(table[case, k, 0], f) and np.array_equal(table[case, k, 1], t), case
+        assert np.isnan(table[case, len(segs):]).all(), case
+    for name in ("shapes", "nuclei"):
+        lab, pts, offs = g[f"{name}_labels"], g[f"{name}_points"], g[f"{name}_offsets"]
+        outs = contours.extract_outlines_skimage(lab)
+        assert len(outs) == len(offs) - 1
+        for i, o in enumerate(outs):
+            ref = pts[offs[i]:offs[i + 1]]
+            assert o.shape == ref.shape and np.array_equal(o, ref), (name, i)

@@ -260,8 +260,77 @@ def gold_disks():
     print("disks: area", out["rp_area"], "perimeter", out["rp_perimeter"], "convex", out["rp_area_convex"])
 
 
+def outline_label_image():
+    """96 x 96 label image with the shapes the outline extractor has to survive: blobs, a ring (hole), a hole
+    longer than its outer boundary, diagonal-only contact, cells clipped by every image edge, a single pixel,
+    a label made of two separate pieces, a thin line, and a label number gap."""
+    lab = np.zeros((96, 96), dtype=np.int64)
+    yy, xx = np.mgrid[0:96, 0:96]
+    lab[(yy - 20) ** 2 + (xx - 20) ** 2 <= 81] = 1                          # disk
+    ring = ((yy - 20) ** 2 + (xx - 55) ** 2 <= 144) & ((yy - 20) ** 2 + (xx - 55) ** 2 > 25)
+    lab[ring] = 2                                                           # ring: outer + hole contour
+    lab[40:60, 5:40] = 3                                                    # rectangle with a comb-shaped hole
+    for k in range(8, 37, 4):
+        lab[43:57, k:k + 2] = 0
+    lab[44:46, 8:38] = 0
+    lab[70, 10] = 4                                                         # single pixel
+    lab[72:75, 20:23] = 5
+    lab[75:78, 23:26] = 5                                                   # two squares touching diagonally
+    lab[0:6, 30:42] = 6                                                     # clipped by the top edge
+    lab[85:96, 0:7] = 7                                                     # bottom-left corner
+    lab[60:75, 90:96] = 9                                                   # right edge (label 8 is unused)
+    lab[80:83, 40:43] = 10
+    lab[86:90, 50:55] = 10                                                  # one label, two pieces
+    lab[64, 45:70] = 11                                                     # horizontal line, 1 px thick
+    lab[70:92, 62] = 12                                                     # vertical line
+    rng = np.random.default_rng(3)
+    noise = rng.random((20, 24)) < 0.55
+    lab[30:50, 66:90][noise] = 13                                           # ragged random blob with many holes
+    return lab
+
+
+def gold_outlines():
+    """find_contours case table (all 16 squares) and ``_extract_outlines_skimage`` (R/masks.py:82-115)."""
+    from skimage.measure import _find_contours_cy as cy
+
+    out = {"versions": VERSIONS}
+    table = np.full((16, 2, 2, 2), np.nan)
+    for case in range(16):
+        img = np.array([[case & 1, (case >> 1) & 1], [(case >> 2) & 1, (case >> 3) & 1]], dtype=np.double)
+        for k, (f, t) in enumerate(cy._get_contour_segments(img, 0.5, False, None)):
+            table[case, k, 0] = f
+            table[case, k, 1] = t
+    out["case_table"] = table
+    images = {"shapes": outline_label_image()}
+    fov = synth.synth_fov(7, size=256)
+    g = filters.gaussian(fov[1], sigma=2.0)
+    m = g > filters.threshold_otsu(g)
+    m = morphology.binary_closing(morphology.binary_opening(m, morphology.disk(2)), morphology.disk(2))
+    images["nuclei"] = measure.label(m).astype(np.int64)
+    for name, lab in images.items():
+        h, w = lab.shape
+        pts, offs = [], [0]
+        for region in measure.regionprops(lab):
+            minr, minc, maxr, maxc = region.bbox
+            r0, c0, r1, c1 = max(minr - 1, 0), max(minc - 1, 0), min(maxr + 1, h), min(maxc + 1, w)
+            crop = (lab[r0:r1, c0:c1] == region.label).astype(np.uint8)
+            contours = measure.find_contours(crop, level=0.5)
+            if contours:
+                main = max(contours, key=len)
+                main = main + np.array([r0, c0])
+                pts.append(main)
+                offs.append(offs[-1] + len(main))
+            else:
+                offs.append(offs[-1])
+        out[f"{name}_labels"] = lab
+        out[f"{name}_points"] = np.concatenate(pts, axis=0) if pts else np.zeros((0, 2))
+        out[f"{name}_offsets"] = np.array(offs, dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "outlines_96.npz"), **out)
+    print("outlines:", {k: v.shape for k, v in out.items() if k.endswith("points")})
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["nd2", "c2c3", "watershed", "ops", "disks"]
+    which = sys.argv[1:] or ["nd2", "c2c3", "watershed", "ops", "disks", "outlines"]
     for w in which:
         globals()["gold_" + w]()
