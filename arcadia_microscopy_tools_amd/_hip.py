@@ -90,7 +90,7 @@ _SIGS = {
     "amt_label_sparse": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int]),
     "amt_clear_border": (c_int, [_P, _P, _P, c_int, c_int, c_int]),
     "amt_relabel_sequential": (c_int, [_P, _P, _P, _P, c_int, c_size_t, c_int]),
-    "amt_clear_border_relabel": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int]),
+    "amt_clear_border_relabel": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "amt_keep_labels": (c_int, [_P, _P, _P, _P, c_int, c_size_t, c_int]),
     "amt_cast_i32_i64": (c_int, [_P, _P, _P, c_size_t]),
     "amt_edt": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int]),

@@ -530,8 +530,16 @@ __global__ void __launch_bounds__(256) drop_flagged_kernel(int* __restrict__ pre
     for (int l = blockIdx.x * 256 + threadIdx.x; l <= max_label; l += gridDim.x * 256) P[l] = (P[l] == 1) ? 1 : 0;
 }
 
+// present[l] = 1 for l = 1 .. nlabels[plane] (the caller vouches that exactly these labels occur)
+__global__ void __launch_bounds__(256) presence_fill_kernel(int* __restrict__ present, const int* __restrict__ nlabels,
+                                                            int max_label) {
+    int* P = present + (size_t)blockIdx.y * (max_label + 1);
+    const int k = nlabels[blockIdx.y] < max_label ? nlabels[blockIdx.y] : max_label;
+    for (int l = blockIdx.x * 256 + threadIdx.x; l <= max_label; l += gridDim.x * 256) P[l] = (l >= 1 && l <= k) ? 1 : 0;
+}
+
 extern "C" int amt_clear_border_relabel(amt_ctx* ctx, const int32_t* in, int32_t* out, int32_t* count_dev, int nplanes,
-                                        int H, int W, int max_label) {
+                                        int H, int W, int max_label, const int32_t* nlabels_dev) {
     AMT_TRY(amt_set_device(ctx));
     AMT_REQUIRE(in && out && nplanes >= 0 && H > 0 && W > 0 && max_label >= 0, "clear_border_relabel: bad arguments");
     if (nplanes == 0) return AMT_OK;
@@ -539,9 +547,14 @@ extern "C" int amt_clear_border_relabel(amt_ctx* ctx, const int32_t* in, int32_t
     size_t msz = (size_t)nplanes * ((size_t)max_label + 1);
     AMT_TRY(amt_arena_begin(ctx, amt_align(msz * 4)));
     int* P = arena_take_t<int>(ctx, msz);
-    AMT_HIP_CHECK(hipMemsetAsync(P, 0, msz * 4, ctx->stream));
     dim3 g1(amt_grid_for(n, 256, 4096), nplanes);
-    hipLaunchKernelGGL(presence_kernel, g1, dim3(256), 0, ctx->stream, in, P, n, max_label);
+    if (nlabels_dev) {  // labels 1 .. nlabels[plane] are known to be present: no pass over the image
+        hipLaunchKernelGGL(presence_fill_kernel, dim3(amt_grid_for((size_t)max_label + 1, 256, 64), nplanes), dim3(256),
+                           0, ctx->stream, P, nlabels_dev, max_label);
+    } else {
+        AMT_HIP_CHECK(hipMemsetAsync(P, 0, msz * 4, ctx->stream));
+        hipLaunchKernelGGL(presence_kernel, g1, dim3(256), 0, ctx->stream, in, P, n, max_label);
+    }
     AMT_LAUNCH_CHECK();
     hipLaunchKernelGGL(frame_mark_kernel, dim3(amt_grid_for((size_t)2 * W + 2 * H, 256, 64), nplanes), dim3(256), 0,
                        ctx->stream, in, P, H, W, max_label);

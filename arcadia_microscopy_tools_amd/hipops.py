@@ -483,14 +483,19 @@ def relabel_sequential(labels: DeviceArray, max_label: int, out=None, count=None
     return o, c
 
 
-def clear_border_relabel(labels: DeviceArray, max_label: int, out=None, count=None):
+def clear_border_relabel(labels: DeviceArray, max_label: int, out=None, count=None, nlabels: DeviceArray | None = None):
     """``relabel_sequential(clear_border(labels))`` in one pass (R/masks.py:56,65) for label images whose
-    labels are each one connected component (outputs of ``label`` / ``watershed``)."""
+    labels are each one connected component (outputs of ``label`` / ``watershed``).  ``nlabels`` (int32 per
+    plane, on the device): the caller vouches that each plane holds exactly the labels 1..nlabels[plane], which
+    spares the pass that looks for the labels present."""
     ctx = labels.ctx
     n, H, W = _planes(labels)
     o = _out(ctx, out, labels.shape, np.int32)
     c = _out(ctx, count, (n,), np.int32)
-    _hip.check(_lib().amt_clear_border_relabel(ctx.handle, labels.ptr, o.ptr, c.ptr, n, H, W, int(max_label)),
+    if nlabels is not None and (nlabels.dtype != np.int32 or nlabels.size != n):
+        raise ValueError("nlabels must hold one int32 per plane")
+    _hip.check(_lib().amt_clear_border_relabel(ctx.handle, labels.ptr, o.ptr, c.ptr, n, H, W, int(max_label),
+                                               nlabels.ptr if nlabels is not None else None),
                "amt_clear_border_relabel")
     return o, c
 

@@ -126,9 +126,11 @@ class FovSegmenter:
         self._stage("watershed")
         hipops.watershed_edt(self.d2, self.markers, mask, seeds_first=True, out=self.ws)
         # every watershed label is one 4-connected region grown from one marker component, so
-        # clear_border + relabel_sequential (R/masks.py:56,65) collapse into one flag-and-renumber pass
+        # clear_border + relabel_sequential (R/masks.py:56,65) collapse into one flag-and-renumber pass; the
+        # markers lie inside the mask, so exactly the labels 1..nmarkers occur in the result
         self._stage("clear_border")
-        hipops.clear_border_relabel(self.ws, self.max_cells, out=self.labels, count=self.ncells)
+        hipops.clear_border_relabel(self.ws, self.max_cells, out=self.labels, count=self.ncells,
+                                    nlabels=self.nmarkers)
         if self.props:
             self._stage("regionprops")
             hipops.regionprops_full(self.labels, fovs, self.max_cells, out=self.table, iout=self.itable)

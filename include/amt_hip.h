@@ -206,9 +206,11 @@ int amt_relabel_sequential(amt_ctx* ctx, const int32_t* in, int32_t* out, int32_
                            int max_label);
 /* clear_border followed by relabel_sequential (R/masks.py:56,65) in one pass, valid when every label of
  * `in` is a single connected component (outputs of amt_label and amt_watershed_*): a label is removed
- * iff one of its pixels lies on the 1-px frame; survivors -> 1..K in ascending old-label order. */
+ * iff one of its pixels lies on the 1-px frame; survivors -> 1..K in ascending old-label order.
+ * nlabels_dev (nullable): the caller vouches that plane p holds exactly the labels 1..nlabels_dev[p] (true for a
+ * watershed of a mask from markers numbered 1..K that lie inside the mask); the presence pass is then skipped. */
 int amt_clear_border_relabel(amt_ctx* ctx, const int32_t* in, int32_t* out, int32_t* count_dev, int nplanes, int H,
-                             int W, int max_label);
+                             int W, int max_label, const int32_t* nlabels_dev);
 /* np.where(np.isin(labels, keep), labels, 0): keep_dev = nplanes x (max_label+1) uint8 flags */
 int amt_keep_labels(amt_ctx* ctx, const int32_t* in, const uint8_t* keep_dev, int32_t* out, int nplanes, size_t n,
                     int max_label);
