@@ -242,8 +242,10 @@ __global__ void __launch_bounds__(64) rp_label_kernel(const int* __restrict__ la
 
 // perimeter: border pixels (4-neighbourhood, outside = background) and their 3x3 weighted codes.
 constexpr int PT_H = 16, PT_W = 64;
+// With `bbox` the kernel also folds the bounding boxes (same per-run atomics as rp_bbox_kernel) from the tile it
+// has staged anyway, which spares the morphology path a separate pass over the label image.
 __global__ void __launch_bounds__(256) rp_perimeter_kernel(const int* __restrict__ labels, u64* __restrict__ acc, int H,
-                                                           int W, int max_label) {
+                                                           int W, int max_label, int* __restrict__ bbox) {
     __shared__ int lab[(PT_H + 4) * (PT_W + 4)];
     __shared__ uint8_t bor[(PT_H + 2) * (PT_W + 2)];
     const int x0 = blockIdx.x * PT_W, y0 = blockIdx.y * PT_H;
@@ -274,6 +276,27 @@ __global__ void __launch_bounds__(256) rp_perimeter_kernel(const int* __restrict
         }
     }
     __syncthreads();
+    if (bbox) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int j = 0; j < PT_H / 4; ++j) {
+            const int ky = wave + 4 * j;
+            const int y = y0 + ky, x = x0 + lane;
+            const int lv = (y < H && x < W) ? lab[(ky + 2) * LP + 2 + lane] : 0;
+            const int left = __shfl_up(lv, 1);
+            const bool head = (lane == 0) || (left != lv);
+            const u64 heads = __ballot(head);
+            if (lv != 0 && head) {
+                const u64 later = heads & ~((2ull << lane) - 1ull);
+                const int end_lane = later ? (__ffsll((long long)later) - 2) : 63;
+                int* B = bbox + ((size_t)plane * max_label + (lv - 1)) * 4;
+                atomicMin(&B[0], y);
+                atomicMin(&B[1], x);
+                atomicMax(&B[2], y);
+                atomicMax(&B[3], x + (end_lane - lane));
+            }
+        }
+    }
     for (int i = threadIdx.x; i < (PT_H + 2) * BP; i += 256) {
         int ky = i / BP, kx = i - ky * BP;  // position (y0-1+ky, x0-1+kx) == lab index (ky+1, kx+1)
         const int* c = lab + (ky + 1) * LP + (kx + 1);
@@ -515,18 +538,18 @@ static int regionprops_common(amt_ctx* ctx, const int32_t* labels, const uint16_
     int2* chainR = arena_take_t<int2>(ctx, (size_t)nplanes * 3 * cap);
     hipLaunchKernelGGL(rp_init_kernel, dim3(amt_grid_for(nlab, 256, 1024)), dim3(256), 0, ctx->stream, acc, bbox, nlab);
     AMT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(rp_bbox_kernel, dim3((W + 63) / 64, (H + 31) / 32, nplanes), dim3(256), 0, ctx->stream, labels,
-                       bbox, H, W, max_label);
+    if (want_morph) {  // the perimeter pass stages every label tile anyway: it folds the bounding boxes too
+        dim3 gper((W + PT_W - 1) / PT_W, (H + PT_H - 1) / PT_H, nplanes);
+        hipLaunchKernelGGL(rp_perimeter_kernel, gper, dim3(256), 0, ctx->stream, labels, acc, H, W, max_label, bbox);
+    } else {
+        hipLaunchKernelGGL(rp_bbox_kernel, dim3((W + 63) / 64, (H + 31) / 32, nplanes), dim3(256), 0, ctx->stream,
+                           labels, bbox, H, W, max_label);
+    }
     AMT_LAUNCH_CHECK();
     hipLaunchKernelGGL(rp_heights_kernel, dim3(amt_grid_for(max_label, 256, 256), nplanes), dim3(256), 0, ctx->stream,
                        bbox, hoff, max_label);
     AMT_LAUNCH_CHECK();
     AMT_TRY(amt_scan_excl(ctx, hoff, max_label, (size_t)max_label, htot, nplanes));
-    if (want_morph) {
-        dim3 gper((W + PT_W - 1) / PT_W, (H + PT_H - 1) / PT_H, nplanes);
-        hipLaunchKernelGGL(rp_perimeter_kernel, gper, dim3(256), 0, ctx->stream, labels, acc, H, W, max_label);
-        AMT_LAUNCH_CHECK();
-    }
     // per-label scan: moments + row extents on the first call, intensity channels in groups of RP_MAXC
     const int groups = intensity ? (C + RP_MAXC - 1) / RP_MAXC : 1;
     for (int g = 0; g < groups; ++g) {
