@@ -88,6 +88,9 @@ def parse_args():
                     help="HIP streams per GPU; the batch is split over them so that the latency-bound flood of one "
                          "part overlaps the bandwidth-bound stages of the other")
     ap.add_argument("--size", type=int, default=2048)
+    ap.add_argument("--max-cells", type=int, default=2048,
+                    help="row capacity of the per-FOV feature tables (the synthetic FOVs hold ~1,360 nuclei); it sizes "
+                         "the per-plate block that the ranks all-gather, and a FOV that exceeds it raises")
     ap.add_argument("--unique", type=int, default=8,
                     help="distinct synthetic FOVs generated per GPU (host-side generation costs ~0.5 s each); the "
                          "batch cycles through them")
@@ -182,7 +185,8 @@ def main():
     bounds = [round(i * B / nstreams) for i in range(nstreams + 1)]
     ctxs = [ctx] + [Context(local_rank) for _ in range(nstreams - 1)]
     parts = [d_fovs[bounds[i]:bounds[i + 1]] for i in range(nstreams)]
-    segs = [FovSegmenter(bounds[i + 1] - bounds[i], 4, S, S, ctx=ctxs[i]) for i in range(nstreams)]
+    segs = [FovSegmenter(bounds[i + 1] - bounds[i], 4, S, S, ctx=ctxs[i], max_cells=args.max_cells)
+            for i in range(nstreams)]
     seg = segs[0]
     packed = None
     if distributed:
@@ -235,7 +239,7 @@ def main():
     # ---- per-stage device times (HIP events on the kernels' own stream), outside the timed region ----
     # one launch of the timed region covers the FOVs of ONE stream: profile that launch size
     PB = bounds[1] - bounds[0]
-    prof = FovSegmenter(PB, 4, S, S, ctx=ctx, profile=True)
+    prof = FovSegmenter(PB, 4, S, S, ctx=ctx, profile=True, max_cells=args.max_cells)
     d_prof = d_fovs[:PB]
     stage_ms: dict[str, list[float]] = {}
     reps = 3
@@ -248,6 +252,11 @@ def main():
             stage_ms.setdefault(k, []).append(v)
     stage_avg = {k: float(np.mean(v)) for k, v in stage_ms.items()}
     ncells = prof.ncells.numpy() if args.workload == "c3" else prof.count8.numpy()
+    if args.workload == "c3":  # a run whose tables overflowed would have skipped work: refuse to report it
+        for sg in segs + [prof]:
+            nm = sg.nmarkers.numpy()
+            if (nm < 0).any() or (nm > args.max_cells).any():
+                raise RuntimeError(f"a field of view produced {int(nm.max())} markers, above --max-cells {args.max_cells}")
     log("stage ms: " + ", ".join(f"{k}={v:.3f}" for k, v in stage_avg.items()))
 
     if rank == 0:
@@ -294,7 +303,8 @@ def main():
                              "watershed nuclei + morphology and 4-channel intensity regionprops"
                              if args.workload == "c3" else
                              "configs[1]: synthetic 2048x2048 uint16 DAPI plane, Gaussian(2)+Otsu+open/close+CCL"),
-                "fovs_per_gpu_per_step": B, "streams_per_gpu": nstreams, "fovs_per_launch": PB, "fov_shape": [4, S, S],
+                "fovs_per_gpu_per_step": B, "streams_per_gpu": nstreams, "fovs_per_launch": PB,
+                "max_cells_per_fov": args.max_cells, "fov_shape": [4, S, S],
                 "resident_in_hbm": True,
                 "cells_per_fov_mean": float(np.mean(ncells)),
                 "feature_table_all_gather": bool(distributed and args.workload == "c3"),
