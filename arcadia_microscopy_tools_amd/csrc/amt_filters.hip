@@ -7,10 +7,6 @@
 // (numpy), so np.exp rounding is shared with the CPU path.
 #include "amt_internal.h"
 
-// ------------------------------------------------------------------------------------------------
-// Generic two-pass path (any radius up to 128): each pass stages a tile plus halo in LDS.
-// Vertical pass: block (64, 4) covers 64 columns x TH rows; LDS tile (TH + 2r) x 64 doubles.
-// ------------------------------------------------------------------------------------------------
 template <typename TIn>
 __device__ __forceinline__ double load_as_f64(const TIn* p, size_t i, double scale);
 template <>
@@ -20,74 +16,6 @@ __device__ __forceinline__ double load_as_f64<uint16_t>(const uint16_t* p, size_
 template <>
 __device__ __forceinline__ double load_as_f64<double>(const double* p, size_t i, double scale) {
     return p[i];
-}
-
-template <typename TIn>
-__global__ void __launch_bounds__(256) conv_axis0_kernel(const TIn* __restrict__ in, double scale,
-                                                         double* __restrict__ out, int H, int W,
-                                                         const double* __restrict__ wts, int r, int mode, double cval,
-                                                         int TH, size_t in_stride) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    double* tile = reinterpret_cast<double*>(smem_raw);  // (TH + 2r) x 64
-    double* w = tile + (size_t)(TH + 2 * r) * 64;        // 2r + 1
-    const int tx = threadIdx.x, ty = threadIdx.y;
-    const int x = blockIdx.x * 64 + tx;
-    const int y0 = blockIdx.y * TH;
-    const size_t plane = (size_t)blockIdx.z * H * W;
-    const size_t iplane = (size_t)blockIdx.z * in_stride;
-    const int tid = ty * 64 + tx;
-    for (int i = tid; i < 2 * r + 1; i += 256) w[i] = wts[i];
-    const int rows = TH + 2 * r;
-    for (int k = ty; k < rows; k += 4) {
-        int yy = amt_map_index(y0 - r + k, H, mode);
-        double v = cval;
-        if (x < W && yy >= 0) v = load_as_f64<TIn>(in, iplane + (size_t)yy * W + x, scale);
-        tile[k * 64 + tx] = v;
-    }
-    __syncthreads();
-    if (x >= W) return;
-    for (int k = ty; k < TH; k += 4) {
-        int y = y0 + k;
-        if (y >= H) break;
-        const double* c = tile + (size_t)(k + r) * 64 + tx;
-        double acc = c[0] * w[r];
-        for (int j = r; j >= 1; --j) acc += (c[-j * 64] + c[j * 64]) * w[r - j];
-        out[plane + (size_t)y * W + x] = acc;
-    }
-}
-
-// Horizontal pass: block 256 threads covers TW = 256 columns x 4 rows; LDS tile 4 x (256 + 2r).
-__global__ void __launch_bounds__(256) conv_axis1_kernel(const double* __restrict__ in, double* __restrict__ out,
-                                                         int H, int W, const double* __restrict__ wts, int r, int mode,
-                                                         double cval) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int TWP = 256 + 2 * r;
-    double* tile = reinterpret_cast<double*>(smem_raw);  // 4 x TWP
-    double* w = tile + (size_t)4 * TWP;
-    const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * 256;
-    const int y0 = blockIdx.y * 4;
-    const size_t plane = (size_t)blockIdx.z * H * W;
-    for (int i = tid; i < 2 * r + 1; i += 256) w[i] = wts[i];
-    for (int row = 0; row < 4; ++row) {
-        int y = y0 + row;
-        if (y >= H) break;
-        for (int k = tid; k < TWP; k += 256) {
-            int xx = amt_map_index(x0 - r + k, W, mode);
-            tile[row * TWP + k] = (xx >= 0) ? in[plane + (size_t)y * W + xx] : cval;
-        }
-    }
-    __syncthreads();
-    const int x = x0 + tid;
-    if (x >= W) return;
-    for (int row = 0; row < 4; ++row) {
-        int y = y0 + row;
-        if (y >= H) break;
-        const double* c = tile + row * TWP + tid + r;
-        double acc = c[0] * w[r];
-        for (int j = r; j >= 1; --j) acc += (c[-j] + c[j]) * w[r - j];
-        out[plane + (size_t)y * W + x] = acc;
-    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -39,7 +39,7 @@ STAGE_BYTES_PER_PX = {
 
 # kernels (name prefixes in the rocprofv3 output) that make up each stage of the chain
 STAGE_KERNELS = {
-    "gaussian": ("gauss_fused_kernel", "conv_axis"),
+    "gaussian": ("gauss_fused_kernel", "conv_v8_kernel", "conv_h8_kernel"),
     "otsu": ("hist_f64_kernel", "otsu_f64_kernel", "minmax_"),
     "threshold_open_close": ("pack_gt_kernel", "toc_fused_kernel", "packed_prim_kernel", "unpack_kernel"),
     "edt": ("edt_rows_kernel", "edt_cols_kernel"),

@@ -24,7 +24,6 @@ uniq = np.stack([synth.synth_fov(i, size=a.size) for i in range(4)])
 fovs = ctx.asarray(np.concatenate([uniq] * (a.batch // 4)))
 seg = FovSegmenter(a.batch, 4, a.size, a.size, ctx=ctx)
 seg.run_c3(fovs)
-dapi = hipops.crop(fovs.reshape(a.batch * 4, a.size, a.size), 0, 0, a.size, a.size) if False else None
 from arcadia_microscopy_tools_amd import _hip
 import numpy as _np
 dapi = ctx.empty((a.batch, a.size, a.size), _np.uint16)
