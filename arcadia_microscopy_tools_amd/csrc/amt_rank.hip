@@ -97,6 +97,118 @@ __global__ void __launch_bounds__(256) rank_kernel(const T* __restrict__ in, T* 
     }
 }
 
+// ---- median over small footprints (|S| <= 49): selection in registers ---------------------------------
+// The |S| samples are fetched once from the LDS tile (offsets are wave-uniform scalars) and the median is found
+// by "forgetful selection": keep a working set of |S|/2 + 2 values, repeatedly discard its minimum and maximum
+// (neither can be the median) and admit the next sample, until three values remain.  About 1.5 compare-exchanges
+// per step and element, all min / max instructions on registers -- versus 16 (64) passes over the footprint in
+// the generic bitwise rank select.
+template <typename K>
+__device__ __forceinline__ void cmpxchg(K& a, K& b) {
+    const K lo = a < b ? a : b, hi = a < b ? b : a;
+    a = lo;
+    b = hi;
+}
+
+template <typename K, int N>
+__device__ __forceinline__ K median_select(const K (&v)[N]) {
+    constexpr int W0 = N / 2 + 2;
+    K w[W0];
+#pragma unroll
+    for (int i = 0; i < W0; ++i) w[i] = v[i < N ? i : N - 1];
+#pragma unroll
+    for (int m = (W0 < N ? W0 : N); m >= 3; --m) {
+#pragma unroll
+        for (int i = 0; i < m / 2; ++i) cmpxchg(w[i], w[m - 1 - i]);   // lower half <= upper half pairwise
+#pragma unroll
+        for (int i = 1; i < (m + 1) / 2; ++i) cmpxchg(w[0], w[i]);     // minimum -> w[0]
+#pragma unroll
+        for (int i = m / 2; i < m - 1; ++i) cmpxchg(w[i], w[m - 1]);   // maximum -> w[m - 1]
+        if (m > 3) w[0] = v[W0 + (W0 - m) < N ? W0 + (W0 - m) : N - 1];  // drop both, admit the next sample
+    }
+    return w[1];
+}
+
+template <typename T, int N>
+__global__ void __launch_bounds__(256) median_small_kernel(const T* __restrict__ in, T* __restrict__ out, int H, int W,
+                                                           const int2* __restrict__ offs_g, int ry, int rx, int mode,
+                                                           T cval) {
+    typedef typename key_traits<T>::key_t key_t;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int pitch = RT_W + 2 * rx;
+    const int rows = RT_H + 2 * ry;
+    key_t* tile = reinterpret_cast<key_t*>(smem_raw);
+    int* xmap = reinterpret_cast<int*>(smem_raw + amt_align((size_t)rows * pitch * sizeof(key_t), 16));
+    int* ymap = xmap + pitch;
+    const int x0 = blockIdx.x * RT_W, y0 = blockIdx.y * RT_H;
+    const size_t plane = (size_t)blockIdx.z * H * W;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < pitch; i += 256) xmap[i] = amt_map_index(x0 - rx + i, W, mode);
+    for (int i = threadIdx.x; i < rows; i += 256) ymap[i] = amt_map_index(y0 - ry + i, H, mode);
+    __syncthreads();
+    // staging: wave w owns tile rows w, w + 4, ...; 64 columns of up to 8 rows in flight
+    for (int k0 = 0; k0 < pitch; k0 += 64) {
+        const int kx = k0 + lane;
+        const int xx = kx < pitch ? xmap[kx] : -1;
+        for (int r0 = wave; r0 < rows; r0 += 32) {
+            T v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int ky = r0 + 4 * u;
+                const int yy = ky < rows ? ymap[ky] : -1;
+                v[u] = (xx >= 0 && yy >= 0) ? in[plane + (size_t)yy * W + xx] : cval;
+            }
+            if (kx < pitch) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (r0 + 4 * u < rows) tile[(r0 + 4 * u) * pitch + kx] = key_traits<T>::to_key(v[u]);
+            }
+        }
+    }
+    __syncthreads();
+    int off[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) off[k] = offs_g[k].y * pitch + offs_g[k].x;  // uniform: scalar loads
+    for (int i = threadIdx.x; i < RT_H * RT_W; i += 256) {
+        const int ky = i / RT_W, kx = i - ky * RT_W;
+        const int y = y0 + ky, x = x0 + kx;
+        if (y >= H || x >= W) continue;
+        const key_t* c = tile + (ky + ry) * pitch + (kx + rx);
+        key_t v[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] = c[off[k]];
+        out[plane + (size_t)y * W + x] = key_traits<T>::from_key(median_select<key_t, N>(v));
+    }
+}
+
+template <typename T>
+static bool launch_median_small(amt_ctx* ctx, const T* in, T* out, int nplanes, int H, int W, const int2* offs, int noffs,
+                                int ry, int rx, int mode, T cval) {
+    dim3 grid((W + RT_W - 1) / RT_W, (H + RT_H - 1) / RT_H, nplanes);
+    const size_t ksz = sizeof(typename key_traits<T>::key_t);
+    const size_t smem = amt_align((size_t)(RT_H + 2 * ry) * (RT_W + 2 * rx) * ksz, 16) +
+                        (size_t)(RT_W + 2 * rx + RT_H + 2 * ry) * sizeof(int);
+    switch (noffs) {
+#define AMT_MEDIAN_CASE(NN)                                                                                          \
+    case NN:                                                                                                         \
+        hipLaunchKernelGGL((median_small_kernel<T, NN>), grid, dim3(256), smem, ctx->stream, in, out, H, W, offs, ry, \
+                           rx, mode, cval);                                                                          \
+        return true;
+        AMT_MEDIAN_CASE(5)
+        AMT_MEDIAN_CASE(9)
+        AMT_MEDIAN_CASE(13)
+        AMT_MEDIAN_CASE(21)
+        AMT_MEDIAN_CASE(25)
+        AMT_MEDIAN_CASE(29)
+        AMT_MEDIAN_CASE(37)
+        AMT_MEDIAN_CASE(45)
+        AMT_MEDIAN_CASE(49)
+#undef AMT_MEDIAN_CASE
+        default:
+            return false;
+    }
+}
+
 extern "C" int amt_rank_filter(amt_ctx* ctx, const void* in, void* out, int dtype, int nplanes, int H, int W,
                                const uint8_t* footprint, int fh, int fw, int op, int mode, double cval) {
     AMT_TRY(amt_set_device(ctx));
@@ -122,6 +234,17 @@ extern "C" int amt_rank_filter(amt_ctx* ctx, const void* in, void* out, int dtyp
     AMT_TRY(amt_arena_begin(ctx, amt_align(sizeof(int2) * noffs)));
     int2* offs = (int2*)amt_arena_take(ctx, sizeof(int2) * noffs);
     AMT_TRY(amt_param_upload(ctx, offs, host, sizeof(int2) * noffs));
+    if (op == 2) {  // median over a small footprint: register selection
+        const bool done = dtype == AMT_U16
+                              ? launch_median_small<uint16_t>(ctx, (const uint16_t*)in, (uint16_t*)out, nplanes, H, W, offs,
+                                                              noffs, ry, rx, mode, (uint16_t)cval)
+                              : launch_median_small<double>(ctx, (const double*)in, (double*)out, nplanes, H, W, offs,
+                                                            noffs, ry, rx, mode, cval);
+        if (done) {
+            AMT_LAUNCH_CHECK();
+            return AMT_OK;
+        }
+    }
     dim3 grid((W + RT_W - 1) / RT_W, (H + RT_H - 1) / RT_H, nplanes);
     const size_t ksz = dtype == AMT_U16 ? sizeof(unsigned) : sizeof(unsigned long long);
     size_t smem = amt_align((size_t)(RT_H + 2 * ry) * (RT_W + 2 * rx) * ksz, 16) + sizeof(int2) * noffs;
