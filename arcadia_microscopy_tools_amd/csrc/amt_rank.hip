@@ -209,6 +209,84 @@ static bool launch_median_small(amt_ctx* ctx, const T* in, T* out, int nplanes, 
     }
 }
 
+// ---- erosion / dilation over footprints whose rows are contiguous runs (disks, squares, diamonds, ...) ------
+// min / max over a run of length L = op of two overlapping power-of-two windows (sparse table): level k of the
+// LDS tile holds M_k[r][x] = op over [x, x + 2^k).  A footprint row then costs two LDS reads instead of L; the
+// levels are built once per tile (one pass per level).
+struct run3 {
+    int dy, lo, hi;  // offsets dx in [lo, hi] at row offset dy (already mirrored for dilation)
+};
+constexpr int RUN_MAX_ROWS = 63;
+
+template <typename T, bool ISMAX>
+__global__ void __launch_bounds__(256) minmax_runs_kernel(const T* __restrict__ in, T* __restrict__ out, int H, int W,
+                                                          const run3* __restrict__ runs_g, int nruns, int ry, int rx,
+                                                          int kmax, int mode, T cval) {
+    typedef typename key_traits<T>::key_t key_t;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int pitch = RT_W + 2 * rx;
+    const int rows = RT_H + 2 * ry;
+    const int tsz = rows * pitch;
+    key_t* lev = reinterpret_cast<key_t*>(smem_raw);  // (kmax + 1) levels of tsz keys
+    int* xmap = reinterpret_cast<int*>(smem_raw + amt_align((size_t)(kmax + 1) * tsz * sizeof(key_t), 16));
+    int* ymap = xmap + pitch;
+    __shared__ run3 runs[RUN_MAX_ROWS];
+    const int x0 = blockIdx.x * RT_W, y0 = blockIdx.y * RT_H;
+    const size_t plane = (size_t)blockIdx.z * H * W;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < nruns; i += 256) runs[i] = runs_g[i];
+    for (int i = threadIdx.x; i < pitch; i += 256) xmap[i] = amt_map_index(x0 - rx + i, W, mode);
+    for (int i = threadIdx.x; i < rows; i += 256) ymap[i] = amt_map_index(y0 - ry + i, H, mode);
+    __syncthreads();
+    for (int k0 = 0; k0 < pitch; k0 += 64) {
+        const int kx = k0 + lane;
+        const int xx = kx < pitch ? xmap[kx] : -1;
+        for (int r0 = wave; r0 < rows; r0 += 32) {
+            T v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int ky = r0 + 4 * u;
+                const int yy = ky < rows ? ymap[ky] : -1;
+                v[u] = (xx >= 0 && yy >= 0) ? in[plane + (size_t)yy * W + xx] : cval;
+            }
+            if (kx < pitch) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (r0 + 4 * u < rows) lev[(r0 + 4 * u) * pitch + kx] = key_traits<T>::to_key(v[u]);
+            }
+        }
+    }
+    __syncthreads();
+    for (int k = 1; k <= kmax; ++k) {  // M_k[x] = op(M_{k-1}[x], M_{k-1}[x + 2^(k-1)]) (clamped at the row end)
+        const key_t* src = lev + (size_t)(k - 1) * tsz;
+        key_t* dst = lev + (size_t)k * tsz;
+        const int h = 1 << (k - 1);
+        for (int i = threadIdx.x; i < tsz; i += 256) {
+            const int r = i / pitch, x = i - r * pitch;
+            const key_t a = src[i];
+            const key_t b = x + h < pitch ? src[i + h] : a;
+            dst[i] = ISMAX ? (a > b ? a : b) : (a < b ? a : b);
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < RT_H * RT_W; i += 256) {
+        const int ky = i / RT_W, kx = i - ky * RT_W;
+        const int y = y0 + ky, x = x0 + kx;
+        if (y >= H || x >= W) continue;
+        key_t r = ISMAX ? (key_t)0 : ~(key_t)0;
+        for (int q = 0; q < nruns; ++q) {
+            const run3 rn = runs[q];
+            const int len = rn.hi - rn.lo + 1;
+            const int k = 31 - __clz(len);
+            const key_t* row = lev + (size_t)k * tsz + (ky + ry + rn.dy) * pitch + (kx + rx);
+            const key_t a = row[rn.lo], b = row[rn.hi - (1 << k) + 1];
+            const key_t m = ISMAX ? (a > b ? a : b) : (a < b ? a : b);
+            r = ISMAX ? (m > r ? m : r) : (m < r ? m : r);
+        }
+        out[plane + (size_t)y * W + x] = key_traits<T>::from_key(r);
+    }
+}
+
 extern "C" int amt_rank_filter(amt_ctx* ctx, const void* in, void* out, int dtype, int nplanes, int H, int W,
                                const uint8_t* footprint, int fh, int fw, int op, int mode, double cval) {
     AMT_TRY(amt_set_device(ctx));
@@ -234,6 +312,60 @@ extern "C" int amt_rank_filter(amt_ctx* ctx, const void* in, void* out, int dtyp
     AMT_TRY(amt_arena_begin(ctx, amt_align(sizeof(int2) * noffs)));
     int2* offs = (int2*)amt_arena_take(ctx, sizeof(int2) * noffs);
     AMT_TRY(amt_param_upload(ctx, offs, host, sizeof(int2) * noffs));
+    if (op <= 1 && noffs >= 21) {  // erosion / dilation: rows of the footprint that are contiguous runs
+        static thread_local run3 hruns[RUN_MAX_ROWS];
+        int nruns = 0, maxlen = 1;
+        bool ok = true;
+        for (int y = 0; y < fh && ok; ++y) {
+            int lo = -1, hi = -1, cnt = 0;
+            for (int x = 0; x < fw; ++x)
+                if (footprint[y * fw + x]) {
+                    if (lo < 0) lo = x;
+                    hi = x;
+                    ++cnt;
+                }
+            if (cnt == 0) continue;
+            if (hi - lo + 1 != cnt) ok = false;  // holes in this row: generic kernel
+            const int dy = y - fh / 2, a = lo - fw / 2, b = hi - fw / 2;
+            // erosion reads in[p + s]; dilation reads in[p - s]
+            hruns[nruns].dy = op == 0 ? dy : -dy;
+            hruns[nruns].lo = op == 0 ? a : -b;
+            hruns[nruns].hi = op == 0 ? b : -a;
+            ++nruns;
+            maxlen = cnt > maxlen ? cnt : maxlen;
+        }
+        int kmax = 0;
+        while ((2 << kmax) <= maxlen) ++kmax;
+        const size_t ksz2 = dtype == AMT_U16 ? sizeof(unsigned) : sizeof(unsigned long long);
+        const size_t tsz = (size_t)(RT_H + 2 * ry) * (RT_W + 2 * rx);
+        const size_t smem2 = amt_align((size_t)(kmax + 1) * tsz * ksz2, 16) +
+                             (size_t)(RT_W + 2 * rx + RT_H + 2 * ry) * sizeof(int);
+        if (ok && smem2 <= 96 * 1024) {
+            AMT_TRY(amt_arena_begin(ctx, amt_align(sizeof(run3) * nruns)));
+            run3* druns = (run3*)amt_arena_take(ctx, sizeof(run3) * nruns);
+            AMT_TRY(amt_param_upload(ctx, druns, hruns, sizeof(run3) * nruns));
+            dim3 grid2((W + RT_W - 1) / RT_W, (H + RT_H - 1) / RT_H, nplanes);
+            if (dtype == AMT_U16) {
+                if (op == 0)
+                    hipLaunchKernelGGL((minmax_runs_kernel<uint16_t, false>), grid2, dim3(256), smem2, ctx->stream,
+                                       (const uint16_t*)in, (uint16_t*)out, H, W, druns, nruns, ry, rx, kmax, mode,
+                                       (uint16_t)cval);
+                else
+                    hipLaunchKernelGGL((minmax_runs_kernel<uint16_t, true>), grid2, dim3(256), smem2, ctx->stream,
+                                       (const uint16_t*)in, (uint16_t*)out, H, W, druns, nruns, ry, rx, kmax, mode,
+                                       (uint16_t)cval);
+            } else {
+                if (op == 0)
+                    hipLaunchKernelGGL((minmax_runs_kernel<double, false>), grid2, dim3(256), smem2, ctx->stream,
+                                       (const double*)in, (double*)out, H, W, druns, nruns, ry, rx, kmax, mode, cval);
+                else
+                    hipLaunchKernelGGL((minmax_runs_kernel<double, true>), grid2, dim3(256), smem2, ctx->stream,
+                                       (const double*)in, (double*)out, H, W, druns, nruns, ry, rx, kmax, mode, cval);
+            }
+            AMT_LAUNCH_CHECK();
+            return AMT_OK;
+        }
+    }
     if (op == 2) {  // median over a small footprint: register selection
         const bool done = dtype == AMT_U16
                               ? launch_median_small<uint16_t>(ctx, (const uint16_t*)in, (uint16_t*)out, nplanes, H, W, offs,
