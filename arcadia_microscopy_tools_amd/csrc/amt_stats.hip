@@ -646,9 +646,14 @@ __global__ void sel_init_kernel(sel_state* st, const rank_req* reqs, int nq, int
 }
 
 // counts[plane][slot][256]: histogram of the next 8-bit digit among keys matching each slot's prefix
+// With `cand` (pass SEL_LIST_PASS) every key that matches a slot's prefix is also appended to that slot's candidate
+// list (order is irrelevant for a selection); the remaining passes then read the lists instead of the image.
+constexpr int SEL_LIST_PASS = 3;  // after it 32 bits are resolved; the lists hold the keys matching the first 24
 __global__ void __launch_bounds__(256) sel_count_kernel(const double* __restrict__ in,
                                                         const sel_state* __restrict__ st,
-                                                        uint32_t* __restrict__ counts, int nslots, int pass, size_t n) {
+                                                        uint32_t* __restrict__ counts, int nslots, int pass, size_t n,
+                                                        unsigned long long* __restrict__ cand,
+                                                        unsigned* __restrict__ ncand, size_t cap) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     uint32_t* lh = reinterpret_cast<uint32_t*>(smem_raw);  // nslots x 256
     unsigned long long* pre = reinterpret_cast<unsigned long long*>(lh + nslots * 256);
@@ -659,16 +664,46 @@ __global__ void __launch_bounds__(256) sel_count_kernel(const double* __restrict
     const int shift = 56 - 8 * pass;
     const unsigned long long himask = pass == 0 ? 0ull : (~0ull << (shift + 8));
     const double* src = in + (size_t)plane * n;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        unsigned long long k = amt_f64_key(src[i]);
-        unsigned digit = (unsigned)(k >> shift) & 255u;
-        unsigned long long hk = k & himask;
-        for (int s = 0; s < nslots; ++s) {
-            // identical prefixes (e.g. lo and hi of one percentile) share the first matching slot
-            if (hk == pre[s]) {
-                bool dup = false;
-                for (int s2 = 0; s2 < s; ++s2) dup |= (pre[s2] == pre[s]);
-                if (!dup) atomicAdd(&lh[s * 256 + digit], 1u);
+    // identical prefixes (e.g. lo and hi of one percentile) share the first matching slot: bit s of `uniq` is set
+    // when slot s is the first of its group
+    unsigned uniq = 0;
+    for (int s = 0; s < nslots; ++s) {
+        bool dup = false;
+        for (int s2 = 0; s2 < s; ++s2) dup |= (pre[s2] == pre[s]);
+        if (!dup) uniq |= 1u << s;
+    }
+    const int lane = threadIdx.x & 63;
+    // four independent loads per thread and step; in the first passes whole waves fall into one (slot, digit):
+    // those add their population count once instead of 64 same-address LDS atomics
+    for (size_t i0 = (size_t)blockIdx.x * 1024 + threadIdx.x; i0 < n; i0 += (size_t)gridDim.x * 1024) {
+        unsigned long long k4[4];
+        bool ok4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            ok4[u] = i0 + (size_t)u * 256 < n;
+            k4[u] = ok4[u] ? amt_f64_key(src[i0 + (size_t)u * 256]) : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned long long k = k4[u];
+            const unsigned digit = (unsigned)(k >> shift) & 255u;
+            const unsigned long long hk = k & himask;
+            int slot = -1;
+            for (int s = 0; s < nslots; ++s)
+                if (ok4[u] && ((uniq >> s) & 1u) && hk == pre[s]) slot = s;
+            const int bin = slot >= 0 ? slot * 256 + (int)digit : -1;
+            const unsigned long long act = __ballot(bin >= 0);
+            if (!act) continue;
+            const int first = __ffsll((long long)act) - 1;
+            const int bin0 = __shfl(bin, first);
+            if (__ballot(bin >= 0 && bin == bin0) == act) {
+                if (lane == first) atomicAdd(&lh[bin0], (unsigned)__popcll(act));
+            } else if (bin >= 0) {
+                atomicAdd(&lh[bin], 1u);
+            }
+            if (cand && slot >= 0) {
+                const unsigned pos = atomicAdd(&ncand[plane * nslots + slot], 1u);
+                if (pos < cap) cand[((size_t)plane * nslots + slot) * cap + pos] = k;
             }
         }
     }
@@ -678,20 +713,87 @@ __global__ void __launch_bounds__(256) sel_count_kernel(const double* __restrict
         if (lh[i]) atomicAdd(&g[i], lh[i]);
 }
 
-__global__ void sel_pick_kernel(sel_state* st, uint32_t* counts, int nslots, int pass, int nplanes) {
-    // one thread per (plane, slot)
+// passes after SEL_LIST_PASS, ALL in one launch: one block per (plane, slot) walks that slot's candidate list
+// (or, if the list overflowed -- massive ties, e.g. a constant image -- the whole plane) once per remaining digit,
+// picks the digit and narrows its own state.  Slots never depend on each other here: a slot whose group shared a
+// list in pass SEL_LIST_PASS just reads the list that hangs on the group's first slot.
+__global__ void __launch_bounds__(256) sel_list_passes_kernel(const double* __restrict__ in, sel_state* __restrict__ st,
+                                                              int nslots, size_t n,
+                                                              const unsigned long long* __restrict__ cand,
+                                                              const unsigned* __restrict__ ncand, size_t cap) {
+    __shared__ uint32_t lh[256];
+    __shared__ unsigned long long s_prefix, s_rank;
+    const int s = blockIdx.x, plane = blockIdx.y;
+    sel_state* sp = st + (size_t)plane * nslots;
+    if (threadIdx.x == 0) {
+        s_prefix = sp[s].prefix;
+        s_rank = sp[s].rank;
+    }
+    __syncthreads();
+    // the list of a group of equal 24-bit prefixes hangs on its first slot (the top 24 bits never change again)
+    int src = s;
+    for (int s2 = 0; s2 < s; ++s2)
+        if (sp[s2].prefix >> 40 == s_prefix >> 40) {
+            src = s2;
+            break;
+        }
+    const unsigned cnt = ncand[plane * nslots + src];
+    const unsigned long long* lst = cand + ((size_t)plane * nslots + src) * cap;
+    const double* srcp = in + (size_t)plane * n;
+    for (int pass = SEL_LIST_PASS + 1; pass < 8; ++pass) {
+        lh[threadIdx.x] = 0;
+        __syncthreads();
+        const int shift = 56 - 8 * pass;
+        const unsigned long long himask = ~0ull << (shift + 8);
+        const unsigned long long mine = s_prefix;
+        if (cnt <= cap) {
+            for (unsigned i = threadIdx.x; i < cnt; i += 256) {
+                const unsigned long long k = lst[i];
+                if ((k & himask) == mine) atomicAdd(&lh[(unsigned)(k >> shift) & 255u], 1u);
+            }
+        } else {
+            for (size_t i = threadIdx.x; i < n; i += 256) {
+                const unsigned long long k = amt_f64_key(srcp[i]);
+                if ((k & himask) == mine) atomicAdd(&lh[(unsigned)(k >> shift) & 255u], 1u);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long run = 0;
+            int d = 0;
+            for (; d < 256; ++d) {
+                const unsigned long long nxt = run + lh[d];
+                if (s_rank < nxt) break;
+                run = nxt;
+            }
+            if (d == 256) d = 255;
+            s_prefix = mine | ((unsigned long long)d << shift);
+            s_rank -= run;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        sp[s].prefix = s_prefix;
+        sp[s].rank = s_rank;
+    }
+}
+
+// one thread per (plane, slot): pick the digit from the counts of this pass.  State is double-buffered (read
+// st_in, write st_out) because slots of one plane read each other's prefixes to find their shared counts.
+__global__ void sel_pick_kernel(const sel_state* __restrict__ st_in, sel_state* __restrict__ st_out,
+                                const uint32_t* __restrict__ counts, int nslots, int pass, int nplanes) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nplanes * nslots) return;
     int plane = i / nslots, s = i - plane * nslots;
     // find the first slot with the same prefix (that is where the counts were accumulated)
     int src = s;
     for (int s2 = 0; s2 < s; ++s2)
-        if (st[plane * nslots + s2].prefix == st[i].prefix) {
+        if (st_in[plane * nslots + s2].prefix == st_in[i].prefix) {
             src = s2;
             break;
         }
     const uint32_t* c = counts + ((size_t)plane * nslots + src) * 256;
-    unsigned long long rank = st[i].rank, run = 0;
+    unsigned long long rank = st_in[i].rank, run = 0;
     int d = 0;
     for (; d < 256; ++d) {
         unsigned long long nxt = run + c[d];
@@ -700,14 +802,8 @@ __global__ void sel_pick_kernel(sel_state* st, uint32_t* counts, int nslots, int
     }
     if (d == 256) d = 255;
     const int shift = 56 - 8 * pass;
-    // all threads must finish reading prefixes before anyone writes: done by a separate commit kernel
-    st[i + (size_t)nplanes * nslots].prefix = st[i].prefix | ((unsigned long long)d << shift);
-    st[i + (size_t)nplanes * nslots].rank = rank - run;
-}
-
-__global__ void sel_commit_kernel(sel_state* st, int total) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < total) st[i] = st[i + total];
+    st_out[i].prefix = st_in[i].prefix | ((unsigned long long)d << shift);
+    st_out[i].rank = rank - run;
 }
 
 __global__ void sel_finish_kernel(const sel_state* st, const rank_req* reqs, int nq, int nplanes, double* out) {
@@ -732,27 +828,44 @@ extern "C" int amt_percentile_f64(amt_ctx* ctx, const double* in, const double* 
     make_rank_reqs(q_host, nq, n, reqs);
     const int nslots = 2 * nq;
     const int total = nplanes * nslots;
+    // candidate lists: keys matching the first 24 resolved bits (a 1/4096 slice of the exponent / mantissa space);
+    // n / 16 entries per slot cover everything but massive ties, which fall back to full scans
+    const size_t cap = n / 16 + 1024;
     size_t need = amt_align(sizeof(rank_req) * 8) + amt_align(sizeof(sel_state) * 2 * total) +
-                  amt_align((size_t)total * 256 * 4);
+                  amt_align((size_t)(SEL_LIST_PASS + 1) * total * 256 * 4) + amt_align((size_t)total * cap * 8) +
+                  amt_align((size_t)total * 4);
     AMT_TRY(amt_arena_begin(ctx, need));
     rank_req* rd = arena_take_t<rank_req>(ctx, 8);
     sel_state* st = arena_take_t<sel_state>(ctx, 2 * (size_t)total);
-    uint32_t* counts = arena_take_t<uint32_t>(ctx, (size_t)total * 256);
+    uint32_t* counts = arena_take_t<uint32_t>(ctx, (size_t)(SEL_LIST_PASS + 1) * total * 256);
+    unsigned long long* cand = arena_take_t<unsigned long long>(ctx, (size_t)total * cap);
+    unsigned* ncand = arena_take_t<unsigned>(ctx, (size_t)total);
     AMT_TRY(amt_param_upload(ctx, rd, reqs, sizeof(rank_req) * nq));
     hipLaunchKernelGGL(sel_init_kernel, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, st, rd, nq, nplanes);
     AMT_LAUNCH_CHECK();
     size_t smem = (size_t)nslots * 256 * 4 + (size_t)nslots * 8;
-    for (int pass = 0; pass < 8; ++pass) {
-        AMT_HIP_CHECK(hipMemsetAsync(counts, 0, (size_t)total * 256 * 4, ctx->stream));
+    // counts of the four full passes live side by side (one memset); the state ping-pongs between two buffers
+    AMT_HIP_CHECK(hipMemsetAsync(counts, 0, (size_t)(SEL_LIST_PASS + 1) * total * 256 * 4, ctx->stream));
+    AMT_HIP_CHECK(hipMemsetAsync(ncand, 0, (size_t)total * 4, ctx->stream));
+    sel_state* cur = st;
+    sel_state* nxt = st + total;
+    for (int pass = 0; pass <= SEL_LIST_PASS; ++pass) {
+        uint32_t* cnt = counts + (size_t)pass * total * 256;
         dim3 grid(amt_grid_for(n, 256 * 16, 512), nplanes);
-        hipLaunchKernelGGL(sel_count_kernel, grid, dim3(256), smem, ctx->stream, in, st, counts, nslots, pass, n);
+        hipLaunchKernelGGL(sel_count_kernel, grid, dim3(256), smem, ctx->stream, in, cur, cnt, nslots, pass, n,
+                           pass == SEL_LIST_PASS ? cand : (unsigned long long*)nullptr, ncand, cap);
         AMT_LAUNCH_CHECK();
-        hipLaunchKernelGGL(sel_pick_kernel, dim3((total + 63) / 64), dim3(64), 0, ctx->stream, st, counts, nslots, pass,
+        hipLaunchKernelGGL(sel_pick_kernel, dim3((total + 63) / 64), dim3(64), 0, ctx->stream, cur, nxt, cnt, nslots, pass,
                            nplanes);
         AMT_LAUNCH_CHECK();
-        hipLaunchKernelGGL(sel_commit_kernel, dim3((total + 63) / 64), dim3(64), 0, ctx->stream, st, total);
-        AMT_LAUNCH_CHECK();
+        sel_state* t = cur;
+        cur = nxt;
+        nxt = t;
     }
+    hipLaunchKernelGGL(sel_list_passes_kernel, dim3(nslots, nplanes), dim3(256), 0, ctx->stream, in, cur, nslots, n, cand,
+                       ncand, cap);
+    AMT_LAUNCH_CHECK();
+    st = cur;
     hipLaunchKernelGGL(sel_finish_kernel, dim3((nplanes * nq + 63) / 64), dim3(64), 0, ctx->stream, st, rd, nq, nplanes,
                        out_dev);
     AMT_LAUNCH_CHECK();

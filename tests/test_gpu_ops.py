@@ -116,6 +116,19 @@ def test_percentile_rescale(ctx, ops, golden):
             assert np.array_equal(r, skops.rescale_intensity(img, (ref[0], ref[1]), (0, 1)))
         single = ops.percentile(d, 90).numpy()
         assert single.shape == (1, 1) and single[0, 0] == np.percentile(img, 90)
+    # float images with massive ties (candidate lists overflow -> full-scan fallback), negative values, several
+    # planes with different distributions in one call
+    rng = np.random.default_rng(8)
+    planes = np.stack([
+        np.full((128, 160), 0.25),
+        rng.integers(0, 3, (128, 160)).astype(np.float64),
+        rng.normal(0.0, 1e-3, (128, 160)),
+        np.exp(rng.normal(0.0, 4.0, (128, 160))) * np.sign(rng.normal(size=(128, 160))),
+    ])
+    for q in ((0, 100), (1, 99), (50,), (12.5, 87.5, 99.99)):
+        got = ops.percentile(ctx.asarray(planes), q).numpy()
+        for b in range(planes.shape[0]):
+            assert np.array_equal(got[b], np.atleast_1d(np.percentile(planes[b], q))), (b, q)
 
 
 def test_binary_morphology(ctx, ops, golden):
