@@ -241,7 +241,7 @@ __global__ void __launch_bounds__(64) rp_label_kernel(const int* __restrict__ la
 }
 
 // perimeter: border pixels (4-neighbourhood, outside = background) and their 3x3 weighted codes.
-constexpr int PT_H = 16, PT_W = 64;
+constexpr int PT_H = 32, PT_W = 64;
 // With `bbox` the kernel also folds the bounding boxes (same per-run atomics as rp_bbox_kernel) from the tile it
 // has staged anyway, which spares the morphology path a separate pass over the label image.
 __global__ void __launch_bounds__(256) rp_perimeter_kernel(const int* __restrict__ labels, u64* __restrict__ acc, int H,
