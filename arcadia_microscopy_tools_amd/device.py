@@ -92,6 +92,14 @@ class Context:
     def synchronize(self):
         _hip.check(self._lib.amt_sync(self.handle), "amt_sync")
 
+    def copy_from_host_async(self, dst: "DeviceArray", src: np.ndarray):
+        """Enqueue a host -> device copy on this context's stream WITHOUT waiting for it.  ``src`` must stay
+        alive and unchanged until the stream has passed the copy; it only overlaps with other streams when it
+        is page-locked (``pinned_empty``)."""
+        if not src.flags["C_CONTIGUOUS"] or src.nbytes != dst.nbytes:
+            raise ValueError("copy_from_host_async needs a C-contiguous source of the destination's size")
+        _hip.check(self._lib.amt_memcpy_h2d(self.handle, dst.ptr, src.ctypes.data, src.nbytes), "amt_memcpy_h2d")
+
     @property
     def stream_ptr(self) -> int:
         """The context's hipStream_t as an integer (0 = the null stream)."""
@@ -238,6 +246,38 @@ class DeviceArray:
 
     def __repr__(self):
         return f"<DeviceArray shape={self.shape} dtype={self.dtype} device={self.ctx.device}>"
+
+
+class PinnedBuffer:
+    """Page-locked host memory (hipHostMalloc) exposed as a numpy array: the source of asynchronous H2D copies."""
+
+    def __init__(self, shape, dtype):
+        self._lib = _hip.load_library()
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        p = ctypes.c_void_p()
+        _hip.check(self._lib.amt_host_alloc(nbytes, ctypes.byref(p)), "amt_host_alloc")
+        self._ptr = p
+        buf = (ctypes.c_char * max(nbytes, 1)).from_address(p.value)
+        self.array = np.frombuffer(buf, dtype=self.dtype, count=int(np.prod(self.shape, dtype=np.int64))).reshape(
+            self.shape)
+
+    def close(self):
+        if getattr(self, "_ptr", None):
+            self.array = None
+            self._lib.amt_host_free(self._ptr)
+            self._ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype) -> PinnedBuffer:
+    return PinnedBuffer(shape, dtype)
 
 
 _tls = threading.local()
