@@ -253,39 +253,59 @@ __global__ void __launch_bounds__(256) ccl_compress_count_kernel(int* __restrict
     if (threadIdx.x == 0) blockcnt[(size_t)blockIdx.y * nblk + blockIdx.x] = s[0] + s[1] + s[2] + s[3];
 }
 
-// rank of every root (1-based) written at the root's own position of T
+// rank of every root (1-based) written at the root's own position of T.  A block owns RN_CHUNK pixels in the
+// order (k, thread): all eight loads are issued first, each wave ballots its root flags per k, and ONE barrier
+// later every root knows how many roots precede it in the block.
 __global__ void __launch_bounds__(256) root_rank_kernel(const int* __restrict__ L, const int* __restrict__ blockoff,
                                                         int* __restrict__ T, size_t n, int nblk) {
     const size_t base = (size_t)blockIdx.y * n;
     const size_t start = (size_t)blockIdx.x * RN_CHUNK;
-    __shared__ int wave_tot[4];
-    __shared__ int running;
-    if (threadIdx.x == 0) running = blockoff[(size_t)blockIdx.y * nblk + blockIdx.x];
-    __syncthreads();
+    __shared__ int wtot[8][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int l[8];
+#pragma unroll
     for (int k = 0; k < 8; ++k) {
-        size_t i = start + (size_t)k * 256 + threadIdx.x;
-        bool is_root = i < n && L[base + i] == (int)i;
-        unsigned long long m = __ballot(is_root);
-        int before = __popcll(m & ((1ull << lane) - 1ull));
-        if (lane == 0) wave_tot[wave] = __popcll(m);
-        __syncthreads();
-        int woff = 0;
-        for (int w = 0; w < wave; ++w) woff += wave_tot[w];
-        int run = running;
-        if (is_root) T[base + i] = run + woff + before + 1;
-        __syncthreads();
-        if (threadIdx.x == 0) running = run + wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
-        __syncthreads();
+        const size_t i = start + (size_t)k * 256 + threadIdx.x;
+        l[k] = i < n ? L[base + i] : -1;
+    }
+    unsigned long long m[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const size_t i = start + (size_t)k * 256 + threadIdx.x;
+        m[k] = __ballot(l[k] == (int)i && i < n);
+        if (lane == 0) wtot[k][wave] = __popcll(m[k]);
+    }
+    __syncthreads();
+    int run = blockoff[(size_t)blockIdx.y * nblk + blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const size_t i = start + (size_t)k * 256 + threadIdx.x;
+        int before = run;
+        for (int w = 0; w < wave; ++w) before += wtot[k][w];
+        if ((m[k] >> lane) & 1ull) T[base + i] = before + __popcll(m[k] & ((1ull << lane) - 1ull)) + 1;
+        run += wtot[k][0] + wtot[k][1] + wtot[k][2] + wtot[k][3];
     }
 }
 
 __global__ void __launch_bounds__(256) apply_rank_kernel(const int* __restrict__ L, const int* __restrict__ T,
                                                          int* __restrict__ out, size_t n) {
     const size_t base = (size_t)blockIdx.y * n;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        int l = L[base + i];
-        out[base + i] = l >= 0 ? T[base + l] : 0;
+    // four pixels per thread and step: one 16-byte load, up to four independent rank lookups, one 16-byte store
+    for (size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i0 < n; i0 += (size_t)gridDim.x * 1024) {
+        if (i0 + 3 < n && ((base + i0) & 3) == 0) {
+            const int4 l = *reinterpret_cast<const int4*>(L + base + i0);
+            int4 o;
+            o.x = l.x >= 0 ? T[base + l.x] : 0;
+            o.y = l.y >= 0 ? T[base + l.y] : 0;
+            o.z = l.z >= 0 ? T[base + l.z] : 0;
+            o.w = l.w >= 0 ? T[base + l.w] : 0;
+            *reinterpret_cast<int4*>(out + base + i0) = o;
+        } else {
+            for (size_t i = i0; i < n && i < i0 + 4; ++i) {
+                const int l = L[base + i];
+                out[base + i] = l >= 0 ? T[base + l] : 0;
+            }
+        }
     }
 }
 
@@ -358,7 +378,7 @@ extern "C" int amt_label(amt_ctx* ctx, const void* in, int in_dtype, int32_t* ou
     int* L = out;
     AMT_TRY(amt_i_ccl_roots(ctx, in, in_dtype, L, blk, nplanes, H, W, connectivity == 2));
     AMT_TRY(amt_i_rank_roots(ctx, L, T, blk, count_dev, nplanes, n));
-    dim3 g1(amt_grid_for(n, 256, 4096), nplanes);
+    dim3 g1(amt_grid_for(n, 1024, 4096), nplanes);
     hipLaunchKernelGGL(apply_rank_kernel, g1, dim3(256), 0, ctx->stream, L, T, out, n);
     AMT_LAUNCH_CHECK();
     return AMT_OK;
