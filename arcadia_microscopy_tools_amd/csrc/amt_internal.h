@@ -77,11 +77,11 @@ int amt_i_minmax_f64(amt_ctx* ctx, const double* in, unsigned long long* keys, d
 // blk (nullable) = nplanes * amt_i_rank_blocks(n) ints receiving the per-block root counts for amt_i_rank_roots.
 int amt_i_ccl_roots(amt_ctx* ctx, const void* in, int in_dtype, int* L, int* blk, int nplanes, int H, int W,
                     int conn8);
-// Same for a uint8 mask, plus dense 1-based component ids in ARBITRARY order written at the roots of `ids`
-// (one wave-aggregated atomic per 64 pixels instead of the raster-rank scan); nids[plane] must be zero on entry
-// and receives the component count.
-int amt_i_ccl_ids_u8(amt_ctx* ctx, const uint8_t* in, int* L, int* ids, int* nids, int nplanes, int H, int W,
-                     int conn8);
+// 4-connected components of a uint8 mask without the per-pixel compression pass: pixels point at their tile-local
+// root, tile-local roots are appended to rootlist[plane * cap ...] (nroots[plane] zero on entry); callers compress
+// the listed roots themselves and resolve a pixel as L[L[p]].
+int amt_i_ccl_tileroots_u8(amt_ctx* ctx, const uint8_t* in, int* L, int* rootlist, int* nroots, size_t cap,
+                           int nplanes, int H, int W);
 // T[plane][root] = 1-based rank of the root in raster order; count_dev[plane] = number of roots.
 // blk = scratch of nplanes * amt_i_rank_blocks(n) ints.
 int amt_i_rank_blocks(size_t n);

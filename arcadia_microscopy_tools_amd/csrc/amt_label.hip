@@ -116,8 +116,13 @@ __device__ __forceinline__ void ccl_stitch_rows(int* L, int p, int pitch, int la
     }
 }
 
+// rootlist / nroots (nullable): every tile-local root (global flat index) is appended to rootlist[plane][...]
+// (capacity `cap` entries per plane, order arbitrary) -- callers that only need roots compressed walk this list
+// instead of the whole plane.
 template <typename T, bool CONN8>
-__global__ void __launch_bounds__(256) ccl_tile_kernel(const T* __restrict__ in, int* __restrict__ Lall, int H, int W) {
+__global__ void __launch_bounds__(256) ccl_tile_kernel(const T* __restrict__ in, int* __restrict__ Lall, int H, int W,
+                                                       int* __restrict__ rootlist, int* __restrict__ nroots,
+                                                       size_t cap) {
     __shared__ int S[TILE_R * 64];
     __shared__ long long vlast[4][64];
     const size_t n = (size_t)H * W;
@@ -149,16 +154,34 @@ __global__ void __launch_bounds__(256) ccl_tile_kernel(const T* __restrict__ in,
     for (int k = 1; k < STRIP_R; ++k) ccl_stitch_rows<CONN8, true>(S, (r0 + k) * 64 + lane, 64, lane, v[k], v[k - 1]);
     if (wave > 0) ccl_stitch_rows<CONN8, true>(S, r0 * 64 + lane, 64, lane, v[0], vlast[wave - 1][lane]);
     __syncthreads();
+    // tile-local roots are counted in LDS first, so that the block reserves its slice of the list with ONE atomic
+    __shared__ int s_nroots, s_base;
+    if (threadIdx.x == 0) s_nroots = 0;
+    __syncthreads();
+    int outv[STRIP_R], lidx[STRIP_R];
+#pragma unroll
+    for (int k = 0; k < STRIP_R; ++k) {
+        const int y = ty0 + r0 + k;
+        outv[k] = -1;
+        lidx[k] = -1;
+        if (x < W && y < H && v[k] != 0) {
+            const int r = lds_find(S, (r0 + k) * 64 + lane);
+            outv[k] = (ty0 + (r >> 6)) * W + x0 + (r & 63);
+            if (rootlist && r == (r0 + k) * 64 + lane) lidx[k] = atomicAdd(&s_nroots, 1);
+        }
+    }
+    if (rootlist) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_base = s_nroots ? atomicAdd(&nroots[blockIdx.z], s_nroots) : 0;
+        __syncthreads();
+    }
 #pragma unroll
     for (int k = 0; k < STRIP_R; ++k) {
         const int y = ty0 + r0 + k;
         if (x < W && y < H) {
-            int out = -1;
-            if (v[k] != 0) {
-                const int r = lds_find(S, (r0 + k) * 64 + lane);
-                out = (ty0 + (r >> 6)) * W + x0 + (r & 63);
-            }
-            L[(size_t)y * W + x] = out;
+            L[(size_t)y * W + x] = outv[k];
+            if (lidx[k] >= 0 && (size_t)(s_base + lidx[k]) < cap)
+                rootlist[(size_t)blockIdx.z * cap + s_base + lidx[k]] = outv[k];
         }
     }
 }
@@ -202,11 +225,8 @@ constexpr int RN_CHUNK = 2048;  // pixels per block in the compress / rank passe
 // Path compression (every pixel points at its root afterwards) fused with the per-block root count that
 // the raster renumbering needs: a pixel is a root iff L[p] == p, which compression never changes.
 // The first two hops of all eight pixels of a thread are issued as independent loads; only deeper chains loop.
-// With `ids` the roots additionally receive dense 1-based component ids in arbitrary order (one atomic per
-// wave), for callers that need a component index but not the raster numbering.
 __global__ void __launch_bounds__(256) ccl_compress_count_kernel(int* __restrict__ L, int* __restrict__ blockcnt,
-                                                                 size_t n, int nblk, int* __restrict__ ids,
-                                                                 int* __restrict__ nids) {
+                                                                 size_t n, int nblk) {
     const size_t base = (size_t)blockIdx.y * n;
     const size_t start = (size_t)blockIdx.x * RN_CHUNK;
     int l[8], r[8], r2[8];
@@ -220,7 +240,6 @@ __global__ void __launch_bounds__(256) ccl_compress_count_kernel(int* __restrict
 #pragma unroll
     for (int k = 0; k < 8; ++k) r2[k] = (r[k] >= 0 && r[k] != l[k]) ? L[base + r[k]] : r[k];
     int c = 0;
-    const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const size_t i = start + (size_t)k * 256 + threadIdx.x;
@@ -234,15 +253,6 @@ __global__ void __launch_bounds__(256) ccl_compress_count_kernel(int* __restrict
             if (root != l[k]) L[base + i] = root;
             is_root = root == (int)i;
             c += is_root ? 1 : 0;
-        }
-        if (ids) {
-            const unsigned long long m = __ballot(is_root);
-            if (m) {
-                int first = 0;
-                if (lane == 0) first = atomicAdd(&nids[blockIdx.y], __popcll(m));
-                first = __shfl(first, 0);
-                if (is_root) ids[base + i] = first + __popcll(m & ((1ull << lane) - 1ull)) + 1;
-            }
         }
     }
     if (!blockcnt) return;
@@ -310,8 +320,7 @@ __global__ void __launch_bounds__(256) apply_rank_kernel(const int* __restrict__
 }
 
 template <typename T>
-static int ccl_roots(amt_ctx* ctx, const T* in, int* L, int* blk, int nplanes, int H, int W, int conn8, int* ids,
-                     int* nids) {
+static int ccl_roots(amt_ctx* ctx, const T* in, int* L, int* blk, int nplanes, int H, int W, int conn8) {
     const size_t n = (size_t)H * W;
     const int nblk = amt_i_rank_blocks(n);
     const int segs = (W + 63) / 64;
@@ -322,17 +331,18 @@ static int ccl_roots(amt_ctx* ctx, const T* in, int* L, int* blk, int nplanes, i
     const int ncol_blocks = (ncol_jobs + 256 * segs - 1) / (256 * segs);
     dim3 gb(segs, nrow_blocks + ncol_blocks, nplanes);
     if (conn8) {
-        hipLaunchKernelGGL((ccl_tile_kernel<T, true>), gs, dim3(256), 0, ctx->stream, in, L, H, W);
+        hipLaunchKernelGGL((ccl_tile_kernel<T, true>), gs, dim3(256), 0, ctx->stream, in, L, H, W, (int*)nullptr,
+                           (int*)nullptr, (size_t)0);
         AMT_LAUNCH_CHECK();
         if (gb.y > 0) hipLaunchKernelGGL((ccl_border_kernel<T, true>), gb, dim3(256), 0, ctx->stream, in, L, H, W, nrow_blocks);
     } else {
-        hipLaunchKernelGGL((ccl_tile_kernel<T, false>), gs, dim3(256), 0, ctx->stream, in, L, H, W);
+        hipLaunchKernelGGL((ccl_tile_kernel<T, false>), gs, dim3(256), 0, ctx->stream, in, L, H, W, (int*)nullptr,
+                           (int*)nullptr, (size_t)0);
         AMT_LAUNCH_CHECK();
         if (gb.y > 0) hipLaunchKernelGGL((ccl_border_kernel<T, false>), gb, dim3(256), 0, ctx->stream, in, L, H, W, nrow_blocks);
     }
     AMT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ccl_compress_count_kernel, dim3(nblk, nplanes), dim3(256), 0, ctx->stream, L, blk, n, nblk, ids,
-                       nids);
+    hipLaunchKernelGGL(ccl_compress_count_kernel, dim3(nblk, nplanes), dim3(256), 0, ctx->stream, L, blk, n, nblk);
     AMT_LAUNCH_CHECK();
     return AMT_OK;
 }
@@ -340,15 +350,31 @@ static int ccl_roots(amt_ctx* ctx, const T* in, int* L, int* blk, int nplanes, i
 int amt_i_ccl_roots(amt_ctx* ctx, const void* in, int in_dtype, int* L, int* blk, int nplanes, int H, int W,
                     int conn8) {
     if (in_dtype == AMT_U8)
-        return ccl_roots<uint8_t>(ctx, (const uint8_t*)in, L, blk, nplanes, H, W, conn8, nullptr, nullptr);
-    return ccl_roots<int32_t>(ctx, (const int32_t*)in, L, blk, nplanes, H, W, conn8, nullptr, nullptr);
+        return ccl_roots<uint8_t>(ctx, (const uint8_t*)in, L, blk, nplanes, H, W, conn8);
+    return ccl_roots<int32_t>(ctx, (const int32_t*)in, L, blk, nplanes, H, W, conn8);
 }
 
-// Components of a uint8 mask with dense (unordered) 1-based ids written at the roots of `ids`; `nids[plane]`
-// must be zero on entry and holds the component count afterwards.
-int amt_i_ccl_ids_u8(amt_ctx* ctx, const uint8_t* in, int* L, int* ids, int* nids, int nplanes, int H, int W,
-                     int conn8) {
-    return ccl_roots<uint8_t>(ctx, in, L, nullptr, nplanes, H, W, conn8, ids, nids);
+// 4-connected components of a uint8 mask WITHOUT the per-pixel compression pass: afterwards every foreground pixel
+// points at its tile-local root and every tile-local root is listed in rootlist (nroots[plane] entries, zero on
+// entry); the caller compresses the listed roots (find + path compression) and resolves pixels with two hops,
+// L[L[p]].
+int amt_i_ccl_tileroots_u8(amt_ctx* ctx, const uint8_t* in, int* L, int* rootlist, int* nroots, size_t cap,
+                           int nplanes, int H, int W) {
+    const int segs = (W + 63) / 64;
+    dim3 gs(segs, (H + TILE_R - 1) / TILE_R, nplanes);
+    const int nrow_jobs = (H - 1) / TILE_R;
+    const int nrow_blocks = (nrow_jobs + 3) / 4;
+    const int ncol_jobs = H * ((W - 1) / 64);
+    const int ncol_blocks = (ncol_jobs + 256 * segs - 1) / (256 * segs);
+    dim3 gb(segs, nrow_blocks + ncol_blocks, nplanes);
+    hipLaunchKernelGGL((ccl_tile_kernel<uint8_t, false>), gs, dim3(256), 0, ctx->stream, in, L, H, W, rootlist, nroots,
+                       cap);
+    AMT_LAUNCH_CHECK();
+    if (gb.y > 0) {
+        hipLaunchKernelGGL((ccl_border_kernel<uint8_t, false>), gb, dim3(256), 0, ctx->stream, in, L, H, W, nrow_blocks);
+        AMT_LAUNCH_CHECK();
+    }
+    return AMT_OK;
 }
 
 int amt_i_rank_blocks(size_t n) { return (int)((n + RN_CHUNK - 1) / RN_CHUNK); }
@@ -430,7 +456,7 @@ extern "C" int amt_clear_border(amt_ctx* ctx, const int32_t* in, int32_t* out, i
     int* L = arena_take_t<int>(ctx, (size_t)nplanes * n);
     int* T = arena_take_t<int>(ctx, (size_t)nplanes * n);
     AMT_HIP_CHECK(hipMemsetAsync(T, 0, (size_t)nplanes * n * 4, ctx->stream));
-    AMT_TRY(ccl_roots<int32_t>(ctx, in, L, nullptr, nplanes, H, W, 1, nullptr, nullptr));
+    AMT_TRY(ccl_roots<int32_t>(ctx, in, L, nullptr, nplanes, H, W, 1));
     dim3 gf(amt_grid_for((size_t)2 * W + 2 * H, 256, 64), nplanes);
     hipLaunchKernelGGL(frame_flag_kernel, gf, dim3(256), 0, ctx->stream, L, T, H, W);
     AMT_LAUNCH_CHECK();

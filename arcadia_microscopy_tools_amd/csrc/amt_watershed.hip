@@ -53,8 +53,11 @@ __global__ void __launch_bounds__(256) ws_seed_kernel(const int* __restrict__ ma
             int4 v = make_int4(0, 0, 0, 0);
             if (r.x >= 0 || r.y >= 0 || r.z >= 0 || r.w >= 0) {
                 const int4 m = *reinterpret_cast<const int4*>(markers + base + i0);
-                const int fx = r.x >= 0 ? F[base + r.x] : 0, fy = r.y >= 0 ? F[base + r.y] : 0;
-                const int fz = r.z >= 0 ? F[base + r.z] : 0, fw = r.w >= 0 ? F[base + r.w] : 0;
+                // pixel -> tile root -> component root (compressed by ws_roots_kernel) -> fill value
+                const int gx = r.x >= 0 ? L[base + r.x] : -1, gy = r.y >= 0 ? L[base + r.y] : -1;
+                const int gz = r.z >= 0 ? L[base + r.z] : -1, gw = r.w >= 0 ? L[base + r.w] : -1;
+                const int fx = gx >= 0 ? F[base + gx] : 0, fy = gy >= 0 ? F[base + gy] : 0;
+                const int fz = gz >= 0 ? F[base + gz] : 0, fw = gw >= 0 ? F[base + gw] : 0;
                 v.x = r.x >= 0 ? (fx ? fx : m.x) : 0;
                 v.y = r.y >= 0 ? (fy ? fy : m.y) : 0;
                 v.z = r.z >= 0 ? (fz ? fz : m.z) : 0;
@@ -66,12 +69,34 @@ __global__ void __launch_bounds__(256) ws_seed_kernel(const int* __restrict__ ma
                 const int r = L[base + i];
                 int v = 0;
                 if (r >= 0) {
-                    const int f = F[base + r];
+                    const int f = F[base + L[base + r]];
                     v = f ? f : markers[base + i];
                 }
                 out[base + i] = v;
             }
         }
+    }
+}
+
+// compress the listed tile roots (every one then points straight at its component's root) and give every component
+// root a dense 1-based id in T (arbitrary order; nothing in the output depends on the numbering)
+__global__ void __launch_bounds__(256) ws_roots_kernel(int* __restrict__ Lall, int* __restrict__ Tall,
+                                                       const int* __restrict__ rootlist, const int* __restrict__ nroots,
+                                                       int* __restrict__ ncomp, size_t cap, size_t n) {
+    int* L = Lall + (size_t)blockIdx.y * n;
+    int* T = Tall + (size_t)blockIdx.y * n;
+    const int cnt = nroots[blockIdx.y] < (int)cap ? nroots[blockIdx.y] : (int)cap;
+    const int* lst = rootlist + (size_t)blockIdx.y * cap;
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < cnt; k += gridDim.x * 256) {
+        const int t = lst[k];
+        int r = L[t];
+        int p = L[r];
+        while (p != r) {  // roots only ever point at smaller indices: the chain ends at the component root
+            r = p;
+            p = L[r];
+        }
+        if (r != t) L[t] = r;
+        else T[t] = atomicAdd(&ncomp[blockIdx.y], 1) + 1;
     }
 }
 
@@ -141,8 +166,11 @@ __global__ void __launch_bounds__(256) ws_stats_kernel(const int* __restrict__ d
                    (k == 0 || v >= vs[k > 0 ? k - 1 : 0]) && (k == 7 || v >= vs[k < 7 ? k + 1 : 7]);
         }
         const int lab = ms[k];
+        // r is the TILE root of the pixel (equal inside a run, since a run never leaves its tile); the component's
+        // root is one more hop away
+        const int gr = (head || cand || lab != 0) ? L[base + r] : -1;
         if (head || cand || lab != 0) {
-            comp_row* c = prow + (T[base + r] - 1);
+            comp_row* c = prow + (T[base + gr] - 1);
             if (cand) atomicMax(&c->cmax, v);
             if (lab != 0) {
                 atomicAdd(&c->mcnt, 1);
@@ -156,8 +184,8 @@ __global__ void __launch_bounds__(256) ws_stats_kernel(const int* __restrict__ d
             const unsigned long long later = hb & ~((2ull << lane) - 1ull);
             const int end_lane = later ? (__ffsll((long long)later) - 2) : 63;
             const int len = end_lane - lane + 1;
-            comp_row* c = prow + (T[base + r] - 1);
-            if ((size_t)r == (size_t)(yb + k) * W + x) c->root = r;  // the run that starts at the root itself
+            comp_row* c = prow + (T[base + gr] - 1);
+            if ((size_t)gr == (size_t)(yb + k) * W + x) c->root = gr;  // the run that starts at the root itself
             if (!use_d2) atomicAdd(&c->cmax, len);
             atomicMin(&c->x0, x);
             atomicMax(&c->x1, x + len - 1);
@@ -221,7 +249,7 @@ __global__ void __launch_bounds__(256) ws_fill_markers_kernel(const int* __restr
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const int r = L[base + i];
         if (r < 0 || out[base + i] == 0) continue;
-        const int cid = T[base + r] - 1;
+        const int cid = T[base + L[base + r]] - 1;
         if (rows[cb + cid].cls != CLS_G) continue;
         const int pos = atomicAdd(&cursor[cb + cid], 1);
         mlist[base + moff[cb + cid] + pos] = (int)i;
@@ -314,6 +342,8 @@ __global__ void __launch_bounds__(64) ws_flood_lds_kernel(const int* __restrict_
                     d4[u] = d2[g];
                 }
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) rr4[u] = rr4[u] >= 0 ? L[rr4[u]] : -1;  // tile root -> component root
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int i = i0 + u * 64 + lane;
@@ -627,7 +657,7 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     // initialised); the heap needs <= n elements per plane.
     const size_t bstride = use_d2 ? n + row_stride : n;
     size_t need = 5 * amt_align(np * 4) + 6 * amt_align(nr * 4) + amt_align(nr * sizeof(comp_row)) +
-                  9 * amt_align(nplanes * 4 * 9);
+                  9 * amt_align(nplanes * 4 * 10);
     need += use_d2 ? 2 * amt_align((size_t)nplanes * bstride * 4) : amt_align((size_t)nplanes * bstride * sizeof(hp_elem));
     AMT_TRY(amt_arena_begin(ctx, need));
     int* L = arena_take_t<int>(ctx, np);
@@ -641,7 +671,7 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     comp_row* rows = arena_take_t<comp_row>(ctx, nr);
     int* btot = arena_take_t<int>(ctx, nplanes);
     int* mtot = arena_take_t<int>(ctx, nplanes);
-    int* counters = arena_take_t<int>(ctx, (size_t)nplanes * 9);
+    int* counters = arena_take_t<int>(ctx, (size_t)nplanes * 10);
     int* wl = arena_take_t<int>(ctx, 3 * nr);  // worklists of the three LDS classes
     int *head = nullptr, *tail = nullptr;
     hp_elem* heap = nullptr;
@@ -653,12 +683,17 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     }
 
     int* ncomp = counters + 8 * (size_t)nplanes;
-    hipLaunchKernelGGL(ws_zero_counters_kernel, dim3((nplanes * 9 + 63) / 64), dim3(64), 0, ctx->stream, counters,
-                       nplanes * 9);
+    hipLaunchKernelGGL(ws_zero_counters_kernel, dim3((nplanes * 10 + 63) / 64), dim3(64), 0, ctx->stream, counters,
+                       nplanes * 10);
     AMT_LAUNCH_CHECK();
     // components of the mask with dense ids in T (the order of the ids is irrelevant: components are
     // independent work items and nothing in the output depends on their numbering)
-    AMT_TRY(amt_i_ccl_ids_u8(ctx, mask, L, T, ncomp, nplanes, H, W, /*conn8=*/0));
+    int* nroots = counters + 9 * (size_t)nplanes;
+    int* rootlist = mlist;  // the marker lists of the HBM path are built later: the space is free until then
+    AMT_TRY(amt_i_ccl_tileroots_u8(ctx, mask, L, rootlist, nroots, n, nplanes, H, W));
+    hipLaunchKernelGGL(ws_roots_kernel, dim3(32, nplanes), dim3(256), 0, ctx->stream, L, T, rootlist, nroots, ncomp, n,
+                       n);
+    AMT_LAUNCH_CHECK();
     hipLaunchKernelGGL(ws_rows_init_kernel, dim3(64, nplanes), dim3(256), 0, ctx->stream, rows, ncomp, row_stride);
     AMT_LAUNCH_CHECK();
     int* has_g = counters + 4 * nplanes;
