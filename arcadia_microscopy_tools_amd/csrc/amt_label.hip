@@ -297,28 +297,6 @@ __global__ void __launch_bounds__(256) root_rank_kernel(const int* __restrict__ 
     }
 }
 
-__global__ void __launch_bounds__(256) apply_rank_kernel(const int* __restrict__ L, const int* __restrict__ T,
-                                                         int* __restrict__ out, size_t n) {
-    const size_t base = (size_t)blockIdx.y * n;
-    // four pixels per thread and step: one 16-byte load, up to four independent rank lookups, one 16-byte store
-    for (size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i0 < n; i0 += (size_t)gridDim.x * 1024) {
-        if (i0 + 3 < n && ((base + i0) & 3) == 0) {
-            const int4 l = *reinterpret_cast<const int4*>(L + base + i0);
-            int4 o;
-            o.x = l.x >= 0 ? T[base + l.x] : 0;
-            o.y = l.y >= 0 ? T[base + l.y] : 0;
-            o.z = l.z >= 0 ? T[base + l.z] : 0;
-            o.w = l.w >= 0 ? T[base + l.w] : 0;
-            *reinterpret_cast<int4*>(out + base + i0) = o;
-        } else {
-            for (size_t i = i0; i < n && i < i0 + 4; ++i) {
-                const int l = L[base + i];
-                out[base + i] = l >= 0 ? T[base + l] : 0;
-            }
-        }
-    }
-}
-
 template <typename T>
 static int ccl_roots(amt_ctx* ctx, const T* in, int* L, int* blk, int nplanes, int H, int W, int conn8) {
     const size_t n = (size_t)H * W;
@@ -358,8 +336,9 @@ int amt_i_ccl_roots(amt_ctx* ctx, const void* in, int in_dtype, int* L, int* blk
 // points at its tile-local root and every tile-local root is listed in rootlist (nroots[plane] entries, zero on
 // entry); the caller compresses the listed roots (find + path compression) and resolves pixels with two hops,
 // L[L[p]].
-int amt_i_ccl_tileroots_u8(amt_ctx* ctx, const uint8_t* in, int* L, int* rootlist, int* nroots, size_t cap,
-                           int nplanes, int H, int W) {
+template <typename T, bool CONN8>
+static int ccl_tileroots(amt_ctx* ctx, const T* in, int* L, int* rootlist, int* nroots, size_t cap, int nplanes, int H,
+                         int W) {
     const int segs = (W + 63) / 64;
     dim3 gs(segs, (H + TILE_R - 1) / TILE_R, nplanes);
     const int nrow_jobs = (H - 1) / TILE_R;
@@ -367,14 +346,66 @@ int amt_i_ccl_tileroots_u8(amt_ctx* ctx, const uint8_t* in, int* L, int* rootlis
     const int ncol_jobs = H * ((W - 1) / 64);
     const int ncol_blocks = (ncol_jobs + 256 * segs - 1) / (256 * segs);
     dim3 gb(segs, nrow_blocks + ncol_blocks, nplanes);
-    hipLaunchKernelGGL((ccl_tile_kernel<uint8_t, false>), gs, dim3(256), 0, ctx->stream, in, L, H, W, rootlist, nroots,
-                       cap);
+    hipLaunchKernelGGL((ccl_tile_kernel<T, CONN8>), gs, dim3(256), 0, ctx->stream, in, L, H, W, rootlist, nroots, cap);
     AMT_LAUNCH_CHECK();
     if (gb.y > 0) {
-        hipLaunchKernelGGL((ccl_border_kernel<uint8_t, false>), gb, dim3(256), 0, ctx->stream, in, L, H, W, nrow_blocks);
+        hipLaunchKernelGGL((ccl_border_kernel<T, CONN8>), gb, dim3(256), 0, ctx->stream, in, L, H, W, nrow_blocks);
         AMT_LAUNCH_CHECK();
     }
     return AMT_OK;
+}
+
+int amt_i_ccl_tileroots_u8(amt_ctx* ctx, const uint8_t* in, int* L, int* rootlist, int* nroots, size_t cap,
+                           int nplanes, int H, int W) {
+    return ccl_tileroots<uint8_t, false>(ctx, in, L, rootlist, nroots, cap, nplanes, H, W);
+}
+
+// compress the listed tile roots and count the component roots of every RN_CHUNK-pixel chunk (what the raster
+// renumbering scans); blockcnt must be zero on entry
+__global__ void __launch_bounds__(256) roots_compress_count_kernel(int* __restrict__ Lall, const int* __restrict__ rootlist,
+                                                                   const int* __restrict__ nroots,
+                                                                   int* __restrict__ blockcnt, size_t cap, size_t n,
+                                                                   int nblk) {
+    int* L = Lall + (size_t)blockIdx.y * n;
+    const int cnt = nroots[blockIdx.y] < (int)cap ? nroots[blockIdx.y] : (int)cap;
+    const int* lst = rootlist + (size_t)blockIdx.y * cap;
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < cnt; k += gridDim.x * 256) {
+        const int t = lst[k];
+        int r = L[t];
+        int p = L[r];
+        while (p != r) {
+            r = p;
+            p = L[r];
+        }
+        if (r != t) L[t] = r;
+        else atomicAdd(&blockcnt[(size_t)blockIdx.y * nblk + t / RN_CHUNK], 1);
+    }
+}
+
+// out = rank of the component root of every pixel: pixel -> tile root -> component root -> rank
+__global__ void __launch_bounds__(256) apply_rank2_kernel(const int* __restrict__ L, const int* __restrict__ T,
+                                                          int* __restrict__ out, size_t n) {
+    const size_t base = (size_t)blockIdx.y * n;
+    for (size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i0 < n; i0 += (size_t)gridDim.x * 1024) {
+        if (i0 + 3 < n && ((base + i0) & 3) == 0) {
+            const int4 l = *reinterpret_cast<const int4*>(L + base + i0);
+            int4 g, o;
+            g.x = l.x >= 0 ? L[base + l.x] : -1;
+            g.y = l.y >= 0 ? L[base + l.y] : -1;
+            g.z = l.z >= 0 ? L[base + l.z] : -1;
+            g.w = l.w >= 0 ? L[base + l.w] : -1;
+            o.x = g.x >= 0 ? T[base + g.x] : 0;
+            o.y = g.y >= 0 ? T[base + g.y] : 0;
+            o.z = g.z >= 0 ? T[base + g.z] : 0;
+            o.w = g.w >= 0 ? T[base + g.w] : 0;
+            *reinterpret_cast<int4*>(out + base + i0) = o;
+        } else {
+            for (size_t i = i0; i < n && i < i0 + 4; ++i) {
+                const int l = L[base + i];
+                out[base + i] = l >= 0 ? T[base + L[base + l]] : 0;
+            }
+        }
+    }
 }
 
 int amt_i_rank_blocks(size_t n) { return (int)((n + RN_CHUNK - 1) / RN_CHUNK); }
@@ -398,14 +429,36 @@ extern "C" int amt_label(amt_ctx* ctx, const void* in, int in_dtype, int32_t* ou
     if (nplanes == 0) return AMT_OK;
     const size_t n = (size_t)H * W;
     const int nblk = amt_i_rank_blocks(n);
-    AMT_TRY(amt_arena_begin(ctx, amt_align((size_t)nplanes * n * 4) + amt_align((size_t)nplanes * nblk * 4)));
+    // union-find parents L, ranks T, the list of tile-local roots (components are sets of EQUAL-valued pixels, so
+    // every pixel can be a root of its own), per-chunk root counts
+    const size_t cap = n;
+    AMT_TRY(amt_arena_begin(ctx, 2 * amt_align((size_t)nplanes * n * 4) + amt_align((size_t)nplanes * cap * 4) +
+                                     amt_align((size_t)nplanes * nblk * 4) + amt_align((size_t)nplanes * 4)));
+    int* L = arena_take_t<int>(ctx, (size_t)nplanes * n);
     int* T = arena_take_t<int>(ctx, (size_t)nplanes * n);
+    int* rootlist = arena_take_t<int>(ctx, (size_t)nplanes * cap);
     int* blk = arena_take_t<int>(ctx, (size_t)nplanes * nblk);
-    int* L = out;
-    AMT_TRY(amt_i_ccl_roots(ctx, in, in_dtype, L, blk, nplanes, H, W, connectivity == 2));
+    int* nroots = arena_take_t<int>(ctx, nplanes);
+    AMT_HIP_CHECK(hipMemsetAsync(blk, 0, (size_t)nplanes * nblk * 4, ctx->stream));
+    AMT_HIP_CHECK(hipMemsetAsync(nroots, 0, (size_t)nplanes * 4, ctx->stream));
+    // tile-local union-find + seams; only the listed tile roots are compressed, pixels resolve in two hops
+    if (in_dtype == AMT_U8) {
+        if (connectivity == 2)
+            AMT_TRY((ccl_tileroots<uint8_t, true>(ctx, (const uint8_t*)in, L, rootlist, nroots, cap, nplanes, H, W)));
+        else
+            AMT_TRY((ccl_tileroots<uint8_t, false>(ctx, (const uint8_t*)in, L, rootlist, nroots, cap, nplanes, H, W)));
+    } else {
+        if (connectivity == 2)
+            AMT_TRY((ccl_tileroots<int32_t, true>(ctx, (const int32_t*)in, L, rootlist, nroots, cap, nplanes, H, W)));
+        else
+            AMT_TRY((ccl_tileroots<int32_t, false>(ctx, (const int32_t*)in, L, rootlist, nroots, cap, nplanes, H, W)));
+    }
+    hipLaunchKernelGGL(roots_compress_count_kernel, dim3(32, nplanes), dim3(256), 0, ctx->stream, L, rootlist, nroots, blk,
+                       cap, n, nblk);
+    AMT_LAUNCH_CHECK();
     AMT_TRY(amt_i_rank_roots(ctx, L, T, blk, count_dev, nplanes, n));
     dim3 g1(amt_grid_for(n, 1024, 4096), nplanes);
-    hipLaunchKernelGGL(apply_rank_kernel, g1, dim3(256), 0, ctx->stream, L, T, out, n);
+    hipLaunchKernelGGL(apply_rank2_kernel, g1, dim3(256), 0, ctx->stream, L, T, out, n);
     AMT_LAUNCH_CHECK();
     return AMT_OK;
 }
