@@ -150,46 +150,3 @@ class PlateTables:
         nc = g[:, self.n_table + self.n_itable: self.n_table + self.n_itable + n * 4].contiguous().view(
             torch.int32).view(world, n)
         return t, it, nc
-
-
-class DevicePackedTables:
-    """Device-resident packed blocks for the bench / plate loop: the segmenter's raw tables
-    (B, max_cells, 14) + (B, max_cells, C, 4) + counts are gathered as they are (fixed shape, so a single
-    all_gather_into_tensor per array and no host round trip inside the timed region)."""
-
-    def __init__(self, segs, torch_device):
-        import torch
-
-        self.segs = list(segs) if isinstance(segs, (list, tuple)) else [segs]
-        self.torch = torch
-        B = sum(s.B for s in self.segs)
-        K, C = self.segs[0].max_cells, self.segs[0].C
-        self.table = torch.empty((B, K, _hip.RP_NCOLS), dtype=torch.float64, device=torch_device)
-        self.itable = torch.empty((B, K, C, 4), dtype=torch.float64, device=torch_device)
-        self.ncells = torch.empty((B,), dtype=torch.int32, device=torch_device)
-
-    def adopt(self):
-        """Point every segmenter's output tables at its slice of the torch allocations (so RCCL can send
-        the whole rank's block in one call)."""
-        from .device import DeviceArray
-
-        b0 = 0
-        for s in self.segs:
-            t, it, nc = self.table[b0:b0 + s.B], self.itable[b0:b0 + s.B], self.ncells[b0:b0 + s.B]
-            s.table = DeviceArray(s.ctx, t.data_ptr(), tuple(t.shape), np.float64)
-            s.itable = DeviceArray(s.ctx, it.data_ptr(), tuple(it.shape), np.float64)
-            s.ncells = DeviceArray(s.ctx, nc.data_ptr(), tuple(nc.shape), np.int32)
-            b0 += s.B
-
-    def all_gather(self, group=None):
-        import torch.distributed as dist
-
-        torch = self.torch
-        world = dist.get_world_size(group)
-        g_table = torch.empty((world,) + tuple(self.table.shape), dtype=self.table.dtype, device=self.table.device)
-        g_itable = torch.empty((world,) + tuple(self.itable.shape), dtype=self.itable.dtype, device=self.table.device)
-        g_n = torch.empty((world,) + tuple(self.ncells.shape), dtype=self.ncells.dtype, device=self.table.device)
-        dist.all_gather_into_tensor(g_n, self.ncells, group=group)
-        dist.all_gather_into_tensor(g_table, self.table, group=group)
-        dist.all_gather_into_tensor(g_itable, self.itable, group=group)
-        return g_table, g_itable, g_n
