@@ -136,7 +136,7 @@ extern "C" int amt_edt(amt_ctx* ctx, const uint8_t* mask, int32_t* d2_out, doubl
 // one 256-thread block stages a 32 x 64 tile of d2 plus a halo of m in LDS; a pixel is first compared with
 // its 8 neighbours (which rejects all but a few percent of the foreground), and only the survivors scan the
 // full (2m+1)^2 window with early exit.  Tiles without any d2 > 0 exit after the staging pass.
-constexpr int PK_H = 32, PK_W = 64, PK_MAXM = 16;
+constexpr int PK_H = 64, PK_W = 64, PK_MAXM = 16;
 __global__ void __launch_bounds__(256) peaks_tile_kernel(const int* __restrict__ d2, const uint8_t* __restrict__ mask,
                                                          uint8_t* __restrict__ peaks, int H, int W, int m) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
