@@ -290,10 +290,14 @@ __global__ void __launch_bounds__(256) rp_perimeter_kernel(const int* __restrict
                 const u64 later = heads & ~((2ull << lane) - 1ull);
                 const int end_lane = later ? (__ffsll((long long)later) - 2) : 63;
                 int* B = bbox + ((size_t)plane * max_label + (lv - 1)) * 4;
-                atomicMin(&B[0], y);
-                atomicMin(&B[1], x);
-                atomicMax(&B[2], y);
-                atomicMax(&B[3], x + (end_lane - lane));
+                // an end of the run is an extreme of the label only if no pixel of the label lies beyond it in the
+                // rows above / below (the tile's halo shows them): most runs of a blob touch no side of its box
+                const int* c = lab + (ky + 2) * LP + 2 + lane;       // head pixel
+                const int* e = c + (end_lane - lane);                 // last pixel of the run
+                if (c[-LP] != lv) atomicMin(&B[0], y);
+                if (c[LP] != lv) atomicMax(&B[2], y);
+                if (c[-LP - 1] != lv && c[LP - 1] != lv) atomicMin(&B[1], x);
+                if (e[-LP + 1] != lv && e[LP + 1] != lv) atomicMax(&B[3], x + (end_lane - lane));
             }
         }
     }

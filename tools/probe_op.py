@@ -42,6 +42,8 @@ for _ in range(a.reps):
         hipops.edt(seg.mask_a, want_edt=False, d2_out=seg.d2)
     elif a.op == "peaks":
         hipops.peak_mask(seg.d2, seg.mask_a, 5, out=seg.peaks)
+    elif a.op == "props":
+        hipops.regionprops_full(seg.labels, fovs, seg.max_cells, out=seg.table, iout=seg.itable)
     elif a.op == "convert":
         hipops.to_float64(dapi, out=seg.gauss)
     elif a.op == "memset":
