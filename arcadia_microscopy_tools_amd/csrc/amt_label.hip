@@ -134,6 +134,7 @@ __global__ void __launch_bounds__(256) ccl_tile_kernel(const T* __restrict__ in,
     const int xc = x < W ? x : W - 1;
     const int r0 = wave * STRIP_R;  // first tile row of this wave
     long long v[STRIP_R];
+    unsigned fgrows = 0;
 #pragma unroll
     for (int k = 0; k < STRIP_R; ++k) {
         const int y = ty0 + r0 + k;
@@ -147,12 +148,15 @@ __global__ void __launch_bounds__(256) ccl_tile_kernel(const T* __restrict__ in,
         const unsigned long long upto = heads & ((2ull << lane) - 1ull);
         const int start_lane = 63 - __clzll((long long)upto);
         S[(r0 + k) * 64 + lane] = (r0 + k) * 64 + start_lane;
+        if (__ballot(v[k] != 0 && v[k] != CCL_NOVAL)) fgrows |= 1u << k;  // uniform: rows holding foreground
     }
     vlast[wave][lane] = v[STRIP_R - 1];
     __syncthreads();
+    // a row without foreground starts no union: most rows of a sparse mask are skipped here
 #pragma unroll
-    for (int k = 1; k < STRIP_R; ++k) ccl_stitch_rows<CONN8, true>(S, (r0 + k) * 64 + lane, 64, lane, v[k], v[k - 1]);
-    if (wave > 0) ccl_stitch_rows<CONN8, true>(S, r0 * 64 + lane, 64, lane, v[0], vlast[wave - 1][lane]);
+    for (int k = 1; k < STRIP_R; ++k)
+        if ((fgrows >> k) & 1u) ccl_stitch_rows<CONN8, true>(S, (r0 + k) * 64 + lane, 64, lane, v[k], v[k - 1]);
+    if (wave > 0 && (fgrows & 1u)) ccl_stitch_rows<CONN8, true>(S, r0 * 64 + lane, 64, lane, v[0], vlast[wave - 1][lane]);
     __syncthreads();
     // tile-local roots are counted in LDS first, so that the block reserves its slice of the list with ONE atomic
     __shared__ int s_nroots, s_base;
