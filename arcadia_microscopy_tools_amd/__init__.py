@@ -1,11 +1,11 @@
 """MI355X-native drop-in for the per-image preprocessing + segmentation + region-props hot path of
-arcadia-microscopy-tools (names re-exported as in the reference, src/arcadia_microscopy_tools/__init__.py:1-20;
-the blending / overlay helpers of the reference are visualisation code outside the hot path).
+arcadia-microscopy-tools (names re-exported as in the reference, src/arcadia_microscopy_tools/__init__.py:1-20).
 
 Importing the package never touches the GPU; the HIP library (libamt_hip.so) is loaded on first use, and
 a missing library or missing MI355X raises ``HipUnavailableError`` -- there is no CPU fallback.
 """
 from ._hip import HipError, HipUnavailableError
+from .blending import BlendMode, Layer, create_overlay, overlay_channels
 from .channels import Channel
 from .exceptions import MetadataWarning, SegmentationWarning
 from .microscopy import MicroscopyImage
@@ -14,12 +14,16 @@ from .pipeline import ImageOperation, Pipeline
 __version__ = "0.4.1+amd.1"
 
 __all__ = [
+    "BlendMode",
     "Channel",
     "HipError",
     "HipUnavailableError",
     "ImageOperation",
+    "Layer",
     "MetadataWarning",
     "MicroscopyImage",
     "Pipeline",
     "SegmentationWarning",
+    "create_overlay",
+    "overlay_channels",
 ]

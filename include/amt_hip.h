@@ -283,6 +283,15 @@ int amt_contours_find(amt_ctx* ctx, const int32_t* labels, int H, int W, int nla
 int amt_contours_emit(amt_ctx* ctx, const int32_t* labels, int H, int W, int nlab, const int32_t* boxes_dev,
                       const int32_t* info_dev, const int64_t* poff_dev, double* points_dev);
 
+/* ---- channel overlay: R/blending.py:116-226 (create_overlay / overlay_channels) ------------------------
+ * out_rgb = H x W x 3 float64 (interleaved).  background and every layer are H x W float64 planes on the device
+ * (values outside [0, 1] are clipped, as the reference does).  layers_host = nlayers device pointers;
+ * luts_host = nlayers x 256 x 4 float64 RGBA tables (matplotlib's LinearSegmentedColormap table of each layer);
+ * opacity_host in [0, 1]; mode_host 0 = ALPHA ("over"), 1 = ADDITIVE.  At most 8 layers per call. */
+int amt_overlay(amt_ctx* ctx, const double* background, const double* const* layers_host, int nlayers,
+                const double* luts_host, const double* opacity_host, const int32_t* mode_host, double* out_rgb, int H,
+                int W);
+
 #ifdef __cplusplus
 }
 #endif

@@ -316,3 +316,52 @@ def test_fov_feeder_double_buffer():
     feeder.close()
     for a, b in zip(got, ref):
         assert np.array_equal(a, b)
+
+
+def test_overlay_against_matplotlib_golden(golden):
+    """create_overlay / overlay_channels against canvases produced by the REAL matplotlib 3.10.8
+    (tests/golden/overlay_64.npz), numpy and device inputs, plus the reference's validation and warnings."""
+    from arcadia_microscopy_tools_amd import BlendMode, Channel, Layer, create_overlay, overlay_channels
+    from arcadia_microscopy_tools_amd.channels import CY5, DAPI, FITC, TRITC
+    from arcadia_microscopy_tools_amd.device import get_context
+
+    g = golden("overlay_64")
+    bg, dapi, fitc, tritc = g["background"], g["dapi"], g["fitc"], g["tritc"]
+    A, D = BlendMode.ALPHA, BlendMode.ADDITIVE
+    cases = {
+        "alpha3": [Layer(DAPI, dapi, 1.0, True, A), Layer(FITC, fitc, 0.8, True, A), Layer(TRITC, tritc, 0.5, True, A)],
+        "additive3": [Layer(DAPI, dapi, 1.0, True, D), Layer(FITC, fitc, 1.0, True, D), Layer(TRITC, tritc, 0.7, True, D)],
+        "opaque_mixed": [Layer(CY5, dapi, 1.0, False, A), Layer(FITC, fitc, 0.6, True, D)],
+        "short_hex": [Layer(Channel("X", "#F0A"), tritc, 0.9, True, A)],
+    }
+    for name, layers in cases.items():
+        out = create_overlay(bg, layers)
+        assert out.shape == bg.shape + (3,) and out.dtype == np.float64
+        assert np.array_equal(out, g[name]), name
+    uniform = overlay_channels(bg, {DAPI: dapi, FITC: fitc, TRITC: tritc}, opacity=1.0, blend_mode=D)
+    assert np.array_equal(uniform, create_overlay(bg, [Layer(c, x, 1.0, True, D) for c, x in
+                                                        ((DAPI, dapi), (FITC, fitc), (TRITC, tritc))]))
+    # device planes in, device canvas out
+    ctx = get_context()
+    dev = create_overlay(ctx.asarray(bg), [Layer(DAPI, ctx.asarray(dapi), 1.0, True, A),
+                                           Layer(FITC, ctx.asarray(fitc), 0.8, True, A),
+                                           Layer(TRITC, ctx.asarray(tritc), 0.5, True, A)])
+    assert np.array_equal(dev.numpy(), g["alpha3"])
+    # values outside [0, 1]: warnings + clipping, as the reference
+    with pytest.warns(UserWarning, match="Layer 'DAPI' has intensity values outside"):
+        lay = Layer(DAPI, dapi * 1.3 - 0.1)
+    with pytest.warns(UserWarning, match="Background has values outside"):
+        assert np.array_equal(create_overlay(bg * 1.5 - 0.2, [lay]), g["range"])
+    with pytest.warns(UserWarning):
+        dlay = Layer(DAPI, ctx.asarray(dapi * 1.3 - 0.1))
+    with pytest.warns(UserWarning):
+        assert np.array_equal(create_overlay(ctx.asarray(bg * 1.5 - 0.2), [dlay]).numpy(), g["range"])
+    assert np.array_equal(create_overlay(bg, []), np.repeat(bg[:, :, None], 3, axis=2))
+    with pytest.raises(ValueError, match="Expected 2D intensities array"):
+        Layer(DAPI, np.zeros((2, 3, 4)))
+    with pytest.raises(ValueError, match="Opacity must be in"):
+        Layer(DAPI, dapi, opacity=1.5)
+    with pytest.raises(ValueError, match="Expected 2D background array"):
+        create_overlay(np.zeros((2, 3, 4)), [])
+    with pytest.raises(ValueError, match="but background has shape"):
+        create_overlay(bg, [Layer(DAPI, dapi[:10])])

@@ -206,3 +206,25 @@ def test_contours_oracle_vs_skimage(golden):
         for i, o in enumerate(outs):
             ref = pts[offs[i]:offs[i + 1]]
             assert o.shape == ref.shape and np.array_equal(o, ref), (name, i)
+
+
+def test_blending_oracle_vs_matplotlib(golden):
+    """oracle/blending.py against matplotlib 3.10.8: colour tables and composited canvases."""
+    from oracle import blending as ob
+
+    g = golden("overlay_64")
+    assert np.array_equal(ob.build_lut("#0033FF", True), g["lut_dapi_t"])
+    assert np.array_equal(ob.build_lut("#FFBF00", False), g["lut_tritc_o"])
+    bg, dapi, fitc, tritc = g["background"], g["dapi"], g["fitc"], g["tritc"]
+    cases = {
+        "alpha3": [("#0033FF", dapi, 1.0, True, "alpha"), ("#07FF00", fitc, 0.8, True, "alpha"),
+                   ("#FFBF00", tritc, 0.5, True, "alpha")],
+        "additive3": [("#0033FF", dapi, 1.0, True, "additive"), ("#07FF00", fitc, 1.0, True, "additive"),
+                      ("#FFBF00", tritc, 0.7, True, "additive")],
+        "opaque_mixed": [("#A30000", dapi, 1.0, False, "alpha"), ("#07FF00", fitc, 0.6, True, "additive")],
+        "short_hex": [("#F0A", tritc, 0.9, True, "alpha")],
+    }
+    for name, layers in cases.items():
+        assert np.array_equal(ob.create_overlay(bg, layers), g[name]), name
+    assert np.array_equal(ob.create_overlay(bg * 1.5 - 0.2, [("#0033FF", dapi * 1.3 - 0.1, 1.0, True, "alpha")]),
+                          g["range"])
