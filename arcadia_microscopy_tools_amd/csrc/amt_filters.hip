@@ -223,6 +223,19 @@ __global__ void __launch_bounds__(256) conv_h8_kernel(const double* __restrict__
 // ------------------------------------------------------------------------------------------------
 constexpr int FR_MAX = 12;
 
+// one-instruction min / max (fmin / fmax add a canonicalisation per operand; the values here are never NaN unless
+// the input is, in which case the histogram range is meaningless anyway)
+__device__ __forceinline__ double vmin_f64(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double vmax_f64(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 template <typename TIn, int R>
 __global__ void __launch_bounds__(256) gauss_fused_kernel(const TIn* __restrict__ in, double scale,
                                                           double* __restrict__ out, int H, int W,
@@ -276,8 +289,8 @@ __global__ void __launch_bounds__(256) gauss_fused_kernel(const TIn* __restrict_
                 if (keys) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        vlo = fmin(vlo, a[i]);
-                        vhi = fmax(vhi, a[i]);
+                        vlo = vmin_f64(vlo, a[i]);
+                        vhi = vmax_f64(vhi, a[i]);
                     }
                 }
             } else {
@@ -286,8 +299,8 @@ __global__ void __launch_bounds__(256) gauss_fused_kernel(const TIn* __restrict_
                     if (4 * seg + i < OUTW && xo + i < W) {
                         dst[i] = a[i];
                         if (keys) {
-                            vlo = fmin(vlo, a[i]);
-                            vhi = fmax(vhi, a[i]);
+                            vlo = vmin_f64(vlo, a[i]);
+                            vhi = vmax_f64(vhi, a[i]);
                         }
                     }
                 }
