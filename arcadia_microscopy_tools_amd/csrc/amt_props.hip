@@ -140,29 +140,30 @@ __global__ void __launch_bounds__(64) rp_label_kernel(const int* __restrict__ la
         mn[c] = 0xffffffffu;
         mx[c] = 0;
     }
-    // four rows per step: their label loads are issued together, then the intensity loads of the hits
-    for (int yb = y0; yb <= y1; yb += 4) {
-        int rmin[4], rmax[4];
+    constexpr int RPS = 8;  // rows per step
+    // eight rows per step: their label loads are issued together, then the intensity loads of the hits
+    for (int yb = y0; yb <= y1; yb += RPS) {
+        int rmin[RPS], rmax[RPS];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < RPS; ++j) {
             rmin[j] = 0x7fffffff;
             rmax[j] = -1;
         }
         for (int xb = x0; xb <= x1; xb += 64) {
             const int x = xb + lane;
-            int lv[4];
+            int lv[RPS];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) lv[j] = (x <= x1 && yb + j <= y1) ? L[(size_t)(yb + j) * W + x] : 0;
-            unsigned iv[4][RP_MAXC];
+            for (int j = 0; j < RPS; ++j) lv[j] = (x <= x1 && yb + j <= y1) ? L[(size_t)(yb + j) * W + x] : 0;
+            unsigned iv[RPS][RP_MAXC];
             if (I) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < RPS; ++j)
 #pragma unroll
                     for (int c = 0; c < RP_MAXC; ++c)
                         iv[j][c] = (c < nc && lv[j] == want) ? I[(size_t)c * n + (size_t)(yb + j) * W + x] : 0u;
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < RPS; ++j) {
                 const int y = yb + j;
                 const bool m = lv[j] == want;
                 if (m) {
@@ -195,7 +196,7 @@ __global__ void __launch_bounds__(64) rp_label_kernel(const int* __restrict__ la
         }
         if (rows_ok && lane == 0) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < RPS; ++j)
                 if (yb + j <= y1) myrows[yb + j - y0] = make_int2(rmin[j], rmax[j]);
         }
     }
