@@ -71,6 +71,24 @@ def pmc_traffic_bytes(stage: str):
     return total or None
 
 
+def rocprof_kernel_us(stage: str):
+    """Average duration (us per 32-FOV launch) of the kernels of one stage from the committed rocprofv3 summary
+    (profiles/r01_kernel_stats.csv), for comparison with the live HIP-event time of the stage."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_kernel_stats.csv")
+    if not os.path.exists(path) or stage not in STAGE_KERNELS:
+        return None
+    out = {}
+    with open(path) as f:
+        for line in f:
+            if not line.startswith('"'):
+                continue
+            name, rest = line[1:].split('",', 1)
+            short = name.replace("void ", "").split("(")[0]
+            if any(short.startswith(pfx) for pfx in STAGE_KERNELS[stage]):
+                out[short] = float(rest.split(",")[1])
+    return out or None
+
+
 def log(msg):
     print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
@@ -319,6 +337,9 @@ def main():
             # PMC bytes of this stage's kernels for a 32-FOV launch, scaled to this run's launch size
             "traffic": (lambda t: None if t is None else t * PB / 32.0)(pmc_traffic_bytes(dom)),
             "algorithmic_bytes_per_launch": dom_bytes, "launch_ms": stage_avg[dom],
+            # the stage is one C-ABI call = several kernels (the flood classes run concurrently): their rocprofv3
+            # averages from the committed summary, per 32-FOV launch
+            "stage_kernels_rocprof_us": rocprof_kernel_us(dom),
             "chain": {"achieved": chain_bytes / (chain_ms * 1e-3) / 1e9, "frac": chain_bytes / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                       "ms": chain_ms},
             "filter_morphology_chain": {"achieved": fm_bytes / (fm_ms * 1e-3) / 1e9,
