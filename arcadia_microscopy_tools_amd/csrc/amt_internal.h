@@ -78,10 +78,13 @@ int amt_i_minmax_f64(amt_ctx* ctx, const double* in, unsigned long long* keys, d
 int amt_i_ccl_roots(amt_ctx* ctx, const void* in, int in_dtype, int* L, int* blk, int nplanes, int H, int W,
                     int conn8);
 // 4-connected components of a uint8 mask without the per-pixel compression pass: pixels point at their tile-local
-// root, tile-local roots are appended to rootlist[plane * cap ...] (nroots[plane] zero on entry); callers compress
-// the listed roots themselves and resolve a pixel as L[L[p]].
-int amt_i_ccl_tileroots_u8(amt_ctx* ctx, const uint8_t* in, int* L, int* rootlist, int* nroots, size_t cap,
-                           int nplanes, int H, int W);
+// root; tile-local roots are appended to one list per TILE ROW, rootlist[(plane * amt_i_tile_rows(H) + tile_row) *
+// amt_i_rootlist_cap(W) ...], counted in nroots[plane * tile_rows + tile_row] (zero on entry).  Callers compress the
+// listed roots themselves and resolve a pixel as L[L[p]].
+int amt_i_tile_rows(int H);
+size_t amt_i_rootlist_cap(int W);
+int amt_i_ccl_tileroots_u8(amt_ctx* ctx, const uint8_t* in, int* L, int* rootlist, int* nroots, int nplanes, int H,
+                           int W);
 // T[plane][root] = 1-based rank of the root in raster order; count_dev[plane] = number of roots.
 // blk = scratch of nplanes * amt_i_rank_blocks(n) ints.
 int amt_i_rank_blocks(size_t n);

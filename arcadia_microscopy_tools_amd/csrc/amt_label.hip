@@ -116,9 +116,10 @@ __device__ __forceinline__ void ccl_stitch_rows(int* L, int p, int pitch, int la
     }
 }
 
-// rootlist / nroots (nullable): every tile-local root (global flat index) is appended to rootlist[plane][...]
-// (capacity `cap` entries per plane, order arbitrary) -- callers that only need roots compressed walk this list
-// instead of the whole plane.
+// rootlist / nroots (nullable): every tile-local root (global flat index) is appended to the list of its TILE ROW,
+// rootlist[(plane * tile_rows + tile_row) * cap ...] with cap = TILE_R * W entries (order arbitrary; one counter per
+// tile row keeps the reserving atomics of a plane off a single address) -- callers that only need roots compressed
+// walk these lists instead of the whole plane.
 template <typename T, bool CONN8>
 __global__ void __launch_bounds__(256) ccl_tile_kernel(const T* __restrict__ in, int* __restrict__ Lall, int H, int W,
                                                        int* __restrict__ rootlist, int* __restrict__ nroots,
@@ -158,34 +159,56 @@ __global__ void __launch_bounds__(256) ccl_tile_kernel(const T* __restrict__ in,
         if ((fgrows >> k) & 1u) ccl_stitch_rows<CONN8, true>(S, (r0 + k) * 64 + lane, 64, lane, v[k], v[k - 1]);
     if (wave > 0 && (fgrows & 1u)) ccl_stitch_rows<CONN8, true>(S, r0 * 64 + lane, 64, lane, v[0], vlast[wave - 1][lane]);
     __syncthreads();
-    // tile-local roots are counted in LDS first, so that the block reserves its slice of the list with ONE atomic
-    __shared__ int s_nroots, s_base;
-    if (threadIdx.x == 0) s_nroots = 0;
-    __syncthreads();
-    int outv[STRIP_R], lidx[STRIP_R];
+    // Phase A: every pixel finds its tile root and writes it back (path compression: phase B then needs one LDS
+    // read); each wave counts its roots with ballots.  The block reserves its slice of the list with ONE atomic.
+    __shared__ int s_wroots[4], s_base;
+    int wroots = 0;
 #pragma unroll
     for (int k = 0; k < STRIP_R; ++k) {
         const int y = ty0 + r0 + k;
-        outv[k] = -1;
-        lidx[k] = -1;
+        const int own = (r0 + k) * 64 + lane;
+        bool is_root = false;
         if (x < W && y < H && v[k] != 0) {
-            const int r = lds_find(S, (r0 + k) * 64 + lane);
-            outv[k] = (ty0 + (r >> 6)) * W + x0 + (r & 63);
-            if (rootlist && r == (r0 + k) * 64 + lane) lidx[k] = atomicAdd(&s_nroots, 1);
+            const int r = lds_find(S, own);
+            if (r != own) S[own] = r;
+            is_root = r == own;
         }
+        if (rootlist) wroots += __popcll(__ballot(is_root));
     }
     if (rootlist) {
+        if (lane == 0) s_wroots[wave] = wroots;
         __syncthreads();
-        if (threadIdx.x == 0) s_base = s_nroots ? atomicAdd(&nroots[blockIdx.z], s_nroots) : 0;
-        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int tot = s_wroots[0] + s_wroots[1] + s_wroots[2] + s_wroots[3];
+            s_base = tot ? atomicAdd(&nroots[blockIdx.z * gridDim.y + blockIdx.y], tot) : 0;
+        }
+    }
+    __syncthreads();
+    // Phase B: write the labels (global index of the tile root) and append the roots in (wave, row, lane) order
+    int run = 0;
+    if (rootlist) {
+        run = s_base;
+        for (int w2 = 0; w2 < wave; ++w2) run += s_wroots[w2];
     }
 #pragma unroll
     for (int k = 0; k < STRIP_R; ++k) {
         const int y = ty0 + r0 + k;
-        if (x < W && y < H) {
-            L[(size_t)y * W + x] = outv[k];
-            if (lidx[k] >= 0 && (size_t)(s_base + lidx[k]) < cap)
-                rootlist[(size_t)blockIdx.z * cap + s_base + lidx[k]] = outv[k];
+        const int own = (r0 + k) * 64 + lane;
+        const bool inside = x < W && y < H;
+        int out = -1;
+        if (inside && v[k] != 0) {
+            const int r = S[own];
+            out = (ty0 + (r >> 6)) * W + x0 + (r & 63);
+        }
+        if (inside) L[(size_t)y * W + x] = out;
+        if (rootlist) {
+            const bool is_root = out >= 0 && S[own] == own;
+            const unsigned long long m = __ballot(is_root);
+            if (is_root) {
+                const size_t pos = (size_t)run + __popcll(m & ((1ull << lane) - 1ull));
+                if (pos < cap) rootlist[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * cap + pos] = out;
+            }
+            run += __popcll(m);
         }
     }
 }
@@ -340,9 +363,12 @@ int amt_i_ccl_roots(amt_ctx* ctx, const void* in, int in_dtype, int* L, int* blk
 // points at its tile-local root and every tile-local root is listed in rootlist (nroots[plane] entries, zero on
 // entry); the caller compresses the listed roots (find + path compression) and resolves pixels with two hops,
 // L[L[p]].
+int amt_i_tile_rows(int H) { return (H + TILE_R - 1) / TILE_R; }
+size_t amt_i_rootlist_cap(int W) { return (size_t)TILE_R * W; }
+
 template <typename T, bool CONN8>
-static int ccl_tileroots(amt_ctx* ctx, const T* in, int* L, int* rootlist, int* nroots, size_t cap, int nplanes, int H,
-                         int W) {
+static int ccl_tileroots(amt_ctx* ctx, const T* in, int* L, int* rootlist, int* nroots, int nplanes, int H, int W) {
+    const size_t cap = amt_i_rootlist_cap(W);
     const int segs = (W + 63) / 64;
     dim3 gs(segs, (H + TILE_R - 1) / TILE_R, nplanes);
     const int nrow_jobs = (H - 1) / TILE_R;
@@ -359,9 +385,9 @@ static int ccl_tileroots(amt_ctx* ctx, const T* in, int* L, int* rootlist, int* 
     return AMT_OK;
 }
 
-int amt_i_ccl_tileroots_u8(amt_ctx* ctx, const uint8_t* in, int* L, int* rootlist, int* nroots, size_t cap,
-                           int nplanes, int H, int W) {
-    return ccl_tileroots<uint8_t, false>(ctx, in, L, rootlist, nroots, cap, nplanes, H, W);
+int amt_i_ccl_tileroots_u8(amt_ctx* ctx, const uint8_t* in, int* L, int* rootlist, int* nroots, int nplanes, int H,
+                           int W) {
+    return ccl_tileroots<uint8_t, false>(ctx, in, L, rootlist, nroots, nplanes, H, W);
 }
 
 // compress the listed tile roots and count the component roots of every RN_CHUNK-pixel chunk (what the raster
@@ -370,9 +396,10 @@ __global__ void __launch_bounds__(256) roots_compress_count_kernel(int* __restri
                                                                    const int* __restrict__ nroots,
                                                                    int* __restrict__ blockcnt, size_t cap, size_t n,
                                                                    int nblk) {
-    int* L = Lall + (size_t)blockIdx.y * n;
-    const int cnt = nroots[blockIdx.y] < (int)cap ? nroots[blockIdx.y] : (int)cap;
-    const int* lst = rootlist + (size_t)blockIdx.y * cap;
+    const int plane = blockIdx.z, shard = plane * gridDim.y + blockIdx.y;
+    int* L = Lall + (size_t)plane * n;
+    const int cnt = nroots[shard] < (int)cap ? nroots[shard] : (int)cap;
+    const int* lst = rootlist + (size_t)shard * cap;
     for (int k = blockIdx.x * 256 + threadIdx.x; k < cnt; k += gridDim.x * 256) {
         const int t = lst[k];
         int r = L[t];
@@ -382,7 +409,7 @@ __global__ void __launch_bounds__(256) roots_compress_count_kernel(int* __restri
             p = L[r];
         }
         if (r != t) L[t] = r;
-        else atomicAdd(&blockcnt[(size_t)blockIdx.y * nblk + t / RN_CHUNK], 1);
+        else atomicAdd(&blockcnt[(size_t)plane * nblk + t / RN_CHUNK], 1);
     }
 }
 
@@ -433,32 +460,34 @@ extern "C" int amt_label(amt_ctx* ctx, const void* in, int in_dtype, int32_t* ou
     if (nplanes == 0) return AMT_OK;
     const size_t n = (size_t)H * W;
     const int nblk = amt_i_rank_blocks(n);
-    // union-find parents L, ranks T, the list of tile-local roots (components are sets of EQUAL-valued pixels, so
-    // every pixel can be a root of its own), per-chunk root counts
-    const size_t cap = n;
-    AMT_TRY(amt_arena_begin(ctx, 2 * amt_align((size_t)nplanes * n * 4) + amt_align((size_t)nplanes * cap * 4) +
-                                     amt_align((size_t)nplanes * nblk * 4) + amt_align((size_t)nplanes * 4)));
+    // union-find parents L, ranks T, the lists of tile-local roots (one list per tile row; components are sets of
+    // EQUAL-valued pixels, so every pixel can be a root of its own), per-chunk root counts
+    const int trows = amt_i_tile_rows(H);
+    const size_t cap = amt_i_rootlist_cap(W);
+    const size_t nlist = (size_t)nplanes * trows;
+    AMT_TRY(amt_arena_begin(ctx, 2 * amt_align((size_t)nplanes * n * 4) + amt_align(nlist * cap * 4) +
+                                     amt_align((size_t)nplanes * nblk * 4) + amt_align(nlist * 4)));
     int* L = arena_take_t<int>(ctx, (size_t)nplanes * n);
     int* T = arena_take_t<int>(ctx, (size_t)nplanes * n);
-    int* rootlist = arena_take_t<int>(ctx, (size_t)nplanes * cap);
+    int* rootlist = arena_take_t<int>(ctx, nlist * cap);
     int* blk = arena_take_t<int>(ctx, (size_t)nplanes * nblk);
-    int* nroots = arena_take_t<int>(ctx, nplanes);
+    int* nroots = arena_take_t<int>(ctx, nlist);
     AMT_HIP_CHECK(hipMemsetAsync(blk, 0, (size_t)nplanes * nblk * 4, ctx->stream));
-    AMT_HIP_CHECK(hipMemsetAsync(nroots, 0, (size_t)nplanes * 4, ctx->stream));
+    AMT_HIP_CHECK(hipMemsetAsync(nroots, 0, nlist * 4, ctx->stream));
     // tile-local union-find + seams; only the listed tile roots are compressed, pixels resolve in two hops
     if (in_dtype == AMT_U8) {
         if (connectivity == 2)
-            AMT_TRY((ccl_tileroots<uint8_t, true>(ctx, (const uint8_t*)in, L, rootlist, nroots, cap, nplanes, H, W)));
+            AMT_TRY((ccl_tileroots<uint8_t, true>(ctx, (const uint8_t*)in, L, rootlist, nroots, nplanes, H, W)));
         else
-            AMT_TRY((ccl_tileroots<uint8_t, false>(ctx, (const uint8_t*)in, L, rootlist, nroots, cap, nplanes, H, W)));
+            AMT_TRY((ccl_tileroots<uint8_t, false>(ctx, (const uint8_t*)in, L, rootlist, nroots, nplanes, H, W)));
     } else {
         if (connectivity == 2)
-            AMT_TRY((ccl_tileroots<int32_t, true>(ctx, (const int32_t*)in, L, rootlist, nroots, cap, nplanes, H, W)));
+            AMT_TRY((ccl_tileroots<int32_t, true>(ctx, (const int32_t*)in, L, rootlist, nroots, nplanes, H, W)));
         else
-            AMT_TRY((ccl_tileroots<int32_t, false>(ctx, (const int32_t*)in, L, rootlist, nroots, cap, nplanes, H, W)));
+            AMT_TRY((ccl_tileroots<int32_t, false>(ctx, (const int32_t*)in, L, rootlist, nroots, nplanes, H, W)));
     }
-    hipLaunchKernelGGL(roots_compress_count_kernel, dim3(32, nplanes), dim3(256), 0, ctx->stream, L, rootlist, nroots, blk,
-                       cap, n, nblk);
+    hipLaunchKernelGGL(roots_compress_count_kernel, dim3(4, trows, nplanes), dim3(256), 0, ctx->stream, L, rootlist,
+                       nroots, blk, cap, n, nblk);
     AMT_LAUNCH_CHECK();
     AMT_TRY(amt_i_rank_roots(ctx, L, T, blk, count_dev, nplanes, n));
     dim3 g1(amt_grid_for(n, 1024, 4096), nplanes);

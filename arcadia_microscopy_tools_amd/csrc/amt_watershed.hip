@@ -83,10 +83,11 @@ __global__ void __launch_bounds__(256) ws_seed_kernel(const int* __restrict__ ma
 __global__ void __launch_bounds__(256) ws_roots_kernel(int* __restrict__ Lall, int* __restrict__ Tall,
                                                        const int* __restrict__ rootlist, const int* __restrict__ nroots,
                                                        int* __restrict__ ncomp, size_t cap, size_t n) {
-    int* L = Lall + (size_t)blockIdx.y * n;
-    int* T = Tall + (size_t)blockIdx.y * n;
-    const int cnt = nroots[blockIdx.y] < (int)cap ? nroots[blockIdx.y] : (int)cap;
-    const int* lst = rootlist + (size_t)blockIdx.y * cap;
+    const int plane = blockIdx.z, shard = plane * gridDim.y + blockIdx.y;  // one list per tile row
+    int* L = Lall + (size_t)plane * n;
+    int* T = Tall + (size_t)plane * n;
+    const int cnt = nroots[shard] < (int)cap ? nroots[shard] : (int)cap;
+    const int* lst = rootlist + (size_t)shard * cap;
     for (int k = blockIdx.x * 256 + threadIdx.x; k < cnt; k += gridDim.x * 256) {
         const int t = lst[k];
         int r = L[t];
@@ -96,7 +97,7 @@ __global__ void __launch_bounds__(256) ws_roots_kernel(int* __restrict__ Lall, i
             p = L[r];
         }
         if (r != t) L[t] = r;
-        else T[t] = atomicAdd(&ncomp[blockIdx.y], 1) + 1;
+        else T[t] = atomicAdd(&ncomp[plane], 1) + 1;
     }
 }
 
@@ -656,8 +657,11 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     // HBM queues: bucket mode needs <= n + ncomp ints for head and tail each (only the used prefix is
     // initialised); the heap needs <= n elements per plane.
     const size_t bstride = use_d2 ? n + row_stride : n;
-    size_t need = 5 * amt_align(np * 4) + 6 * amt_align(nr * 4) + amt_align(nr * sizeof(comp_row)) +
-                  9 * amt_align(nplanes * 4 * 10);
+    const int trows = amt_i_tile_rows(H);
+    const size_t lcap = amt_i_rootlist_cap(W);
+    const size_t nlist = (size_t)nplanes * trows;
+    size_t need = 5 * amt_align(np * 4) + amt_align(nlist * lcap * 4) + amt_align(nlist * 4) + 6 * amt_align(nr * 4) + amt_align(nr * sizeof(comp_row)) +
+                  9 * amt_align(nplanes * 4 * 9);
     need += use_d2 ? 2 * amt_align((size_t)nplanes * bstride * 4) : amt_align((size_t)nplanes * bstride * sizeof(hp_elem));
     AMT_TRY(amt_arena_begin(ctx, need));
     int* L = arena_take_t<int>(ctx, np);
@@ -668,10 +672,12 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     int* mlist = arena_take_t<int>(ctx, np);
     int* next = arena_take_t<int>(ctx, np);
     int* F = arena_take_t<int>(ctx, np);  // per-root fill value (only root positions are used)
+    int* rootlist = arena_take_t<int>(ctx, nlist * lcap);  // tile-local roots, one list per tile row
+    int* nroots = arena_take_t<int>(ctx, nlist);
     comp_row* rows = arena_take_t<comp_row>(ctx, nr);
     int* btot = arena_take_t<int>(ctx, nplanes);
     int* mtot = arena_take_t<int>(ctx, nplanes);
-    int* counters = arena_take_t<int>(ctx, (size_t)nplanes * 10);
+    int* counters = arena_take_t<int>(ctx, (size_t)nplanes * 9);
     int* wl = arena_take_t<int>(ctx, 3 * nr);  // worklists of the three LDS classes
     int *head = nullptr, *tail = nullptr;
     hp_elem* heap = nullptr;
@@ -683,16 +689,15 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     }
 
     int* ncomp = counters + 8 * (size_t)nplanes;
-    hipLaunchKernelGGL(ws_zero_counters_kernel, dim3((nplanes * 10 + 63) / 64), dim3(64), 0, ctx->stream, counters,
-                       nplanes * 10);
+    hipLaunchKernelGGL(ws_zero_counters_kernel, dim3((nplanes * 9 + 63) / 64), dim3(64), 0, ctx->stream, counters,
+                       nplanes * 9);
     AMT_LAUNCH_CHECK();
     // components of the mask with dense ids in T (the order of the ids is irrelevant: components are
     // independent work items and nothing in the output depends on their numbering)
-    int* nroots = counters + 9 * (size_t)nplanes;
-    int* rootlist = mlist;  // the marker lists of the HBM path are built later: the space is free until then
-    AMT_TRY(amt_i_ccl_tileroots_u8(ctx, mask, L, rootlist, nroots, n, nplanes, H, W));
-    hipLaunchKernelGGL(ws_roots_kernel, dim3(32, nplanes), dim3(256), 0, ctx->stream, L, T, rootlist, nroots, ncomp, n,
-                       n);
+    AMT_HIP_CHECK(hipMemsetAsync(nroots, 0, nlist * 4, ctx->stream));
+    AMT_TRY(amt_i_ccl_tileroots_u8(ctx, mask, L, rootlist, nroots, nplanes, H, W));
+    hipLaunchKernelGGL(ws_roots_kernel, dim3(4, trows, nplanes), dim3(256), 0, ctx->stream, L, T, rootlist, nroots, ncomp,
+                       lcap, n);
     AMT_LAUNCH_CHECK();
     hipLaunchKernelGGL(ws_rows_init_kernel, dim3(64, nplanes), dim3(256), 0, ctx->stream, rows, ncomp, row_stride);
     AMT_LAUNCH_CHECK();
