@@ -59,7 +59,20 @@ __device__ __forceinline__ void uf_union(int* L, int a, int b) {
 // NW unless west matches (then west reaches NW as its own north), NE unless east matches.
 constexpr int STRIP_R = 16;            // rows per wave
 constexpr int TILE_R = 4 * STRIP_R;    // rows per block
-constexpr long long CCL_NOVAL = -(1ll << 40);  // outside the image: equals no pixel value
+// pixel values travel through shuffles / compares in the narrowest type that still has room for a sentinel
+// ("outside the image", equal to no pixel value): 32 bits for uint8 masks, 64 bits for int32 label images
+template <typename T>
+struct ccl_wide;
+template <>
+struct ccl_wide<uint8_t> {
+    typedef int type;
+    static constexpr int NOVAL = -1;
+};
+template <>
+struct ccl_wide<int32_t> {
+    typedef long long type;
+    static constexpr long long NOVAL = -(1ll << 40);
+};
 
 __device__ __forceinline__ int lds_find(int* S, int a) {
     int p = __hip_atomic_load(&S[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -88,17 +101,17 @@ __device__ __forceinline__ void lds_union(int* S, int a, int b) {
 
 // stitch row y (values v, index p) to row y-1 (values up) inside one 64-lane segment; executed by all lanes.
 // LDS = true: L is the tile's LDS array and `pitch` = 64; otherwise L is the plane in HBM and pitch = W.
-template <bool CONN8, bool LDS>
-__device__ __forceinline__ void ccl_stitch_rows(int* L, int p, int pitch, int lane, long long v, long long up) {
-    const long long w = __shfl_up(v, 1), upw = __shfl_up(up, 1);
+template <bool CONN8, bool LDS, typename V>
+__device__ __forceinline__ void ccl_stitch_rows(int* L, int p, int pitch, int lane, V v, V up, V noval) {
+    const V w = __shfl_up(v, 1), upw = __shfl_up(up, 1);
     const bool head = lane == 0 || w != v;
     const bool up_head = lane == 0 || upw != up;
-    long long e = 0, upe = 0;
+    V e = 0, upe = 0;
     if (CONN8) {
         e = __shfl_down(v, 1);
         upe = __shfl_down(up, 1);
     }
-    if (v == 0 || v == CCL_NOVAL) return;
+    if (v == 0 || v == noval) return;
     int q = -1;
     if (up == v) {
         if (head || up_head) q = p - pitch;
@@ -125,7 +138,9 @@ __global__ void __launch_bounds__(256) ccl_tile_kernel(const T* __restrict__ in,
                                                        int* __restrict__ rootlist, int* __restrict__ nroots,
                                                        size_t cap) {
     __shared__ int S[TILE_R * 64];
-    __shared__ long long vlast[4][64];
+    typedef typename ccl_wide<T>::type V;
+    constexpr V NOVAL = ccl_wide<T>::NOVAL;
+    __shared__ V vlast[4][64];
     const size_t n = (size_t)H * W;
     const T* img = in + (size_t)blockIdx.z * n;
     int* L = Lall + (size_t)blockIdx.z * n;
@@ -134,30 +149,30 @@ __global__ void __launch_bounds__(256) ccl_tile_kernel(const T* __restrict__ in,
     const int x = x0 + lane;
     const int xc = x < W ? x : W - 1;
     const int r0 = wave * STRIP_R;  // first tile row of this wave
-    long long v[STRIP_R];
+    V v[STRIP_R];
     unsigned fgrows = 0;
 #pragma unroll
     for (int k = 0; k < STRIP_R; ++k) {
         const int y = ty0 + r0 + k;
-        v[k] = (x < W && y < H) ? (long long)img[(size_t)y * W + xc] : CCL_NOVAL;
+        v[k] = (x < W && y < H) ? (V)img[(size_t)y * W + xc] : NOVAL;
     }
 #pragma unroll
     for (int k = 0; k < STRIP_R; ++k) {
-        const long long left = __shfl_up(v[k], 1);
+        const V left = __shfl_up(v[k], 1);
         const bool head = (lane == 0) || (left != v[k]);
         const unsigned long long heads = __ballot(head);
         const unsigned long long upto = heads & ((2ull << lane) - 1ull);
         const int start_lane = 63 - __clzll((long long)upto);
         S[(r0 + k) * 64 + lane] = (r0 + k) * 64 + start_lane;
-        if (__ballot(v[k] != 0 && v[k] != CCL_NOVAL)) fgrows |= 1u << k;  // uniform: rows holding foreground
+        if (__ballot(v[k] != 0 && v[k] != NOVAL)) fgrows |= 1u << k;  // uniform: rows holding foreground
     }
     vlast[wave][lane] = v[STRIP_R - 1];
     __syncthreads();
     // a row without foreground starts no union: most rows of a sparse mask are skipped here
 #pragma unroll
     for (int k = 1; k < STRIP_R; ++k)
-        if ((fgrows >> k) & 1u) ccl_stitch_rows<CONN8, true>(S, (r0 + k) * 64 + lane, 64, lane, v[k], v[k - 1]);
-    if (wave > 0 && (fgrows & 1u)) ccl_stitch_rows<CONN8, true>(S, r0 * 64 + lane, 64, lane, v[0], vlast[wave - 1][lane]);
+        if ((fgrows >> k) & 1u) ccl_stitch_rows<CONN8, true>(S, (r0 + k) * 64 + lane, 64, lane, v[k], v[k - 1], NOVAL);
+    if (wave > 0 && (fgrows & 1u)) ccl_stitch_rows<CONN8, true>(S, r0 * 64 + lane, 64, lane, v[0], vlast[wave - 1][lane], NOVAL);
     __syncthreads();
     // Phase A: every pixel finds its tile root and writes it back (path compression: phase B then needs one LDS
     // read); each wave counts its roots with ballots.  The block reserves its slice of the list with ONE atomic.
@@ -227,9 +242,11 @@ __global__ void __launch_bounds__(256) ccl_border_kernel(const T* __restrict__ i
         if (y >= H) return;
         const int x = blockIdx.x * 64 + lane;
         const int xc = x < W ? x : W - 1;
-        const long long v = x < W ? (long long)img[(size_t)y * W + xc] : CCL_NOVAL;
-        const long long up = x < W ? (long long)img[(size_t)(y - 1) * W + xc] : CCL_NOVAL;
-        ccl_stitch_rows<CONN8, false>(L, y * W + xc, W, lane, v, up);
+        typedef typename ccl_wide<T>::type V;
+        constexpr V NOVAL = ccl_wide<T>::NOVAL;
+        const V v = x < W ? (V)img[(size_t)y * W + xc] : NOVAL;
+        const V up = x < W ? (V)img[(size_t)(y - 1) * W + xc] : NOVAL;
+        ccl_stitch_rows<CONN8, false>(L, y * W + xc, W, lane, v, up, NOVAL);
     } else {
         // column pairs (x-1, x) with x a multiple of 64; one thread per (row, boundary)
         const int nbound = (W - 1) / 64;  // boundaries at x = 64, 128, ...
