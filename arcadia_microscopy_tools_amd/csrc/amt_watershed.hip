@@ -53,11 +53,9 @@ __global__ void __launch_bounds__(256) ws_seed_kernel(const int* __restrict__ ma
             int4 v = make_int4(0, 0, 0, 0);
             if (r.x >= 0 || r.y >= 0 || r.z >= 0 || r.w >= 0) {
                 const int4 m = *reinterpret_cast<const int4*>(markers + base + i0);
-                // pixel -> tile root -> component root (compressed by ws_roots_kernel) -> fill value
-                const int gx = r.x >= 0 ? L[base + r.x] : -1, gy = r.y >= 0 ? L[base + r.y] : -1;
-                const int gz = r.z >= 0 ? L[base + r.z] : -1, gw = r.w >= 0 ? L[base + r.w] : -1;
-                const int fx = gx >= 0 ? F[base + gx] : 0, fy = gy >= 0 ? F[base + gy] : 0;
-                const int fz = gz >= 0 ? F[base + gz] : 0, fw = gw >= 0 ? F[base + gw] : 0;
+                // pixel -> tile root, whose F entry was copied from the component root (ws_propagate_kernel)
+                const int fx = r.x >= 0 ? F[base + r.x] : 0, fy = r.y >= 0 ? F[base + r.y] : 0;
+                const int fz = r.z >= 0 ? F[base + r.z] : 0, fw = r.w >= 0 ? F[base + r.w] : 0;
                 v.x = r.x >= 0 ? (fx ? fx : m.x) : 0;
                 v.y = r.y >= 0 ? (fy ? fy : m.y) : 0;
                 v.z = r.z >= 0 ? (fz ? fz : m.z) : 0;
@@ -69,7 +67,7 @@ __global__ void __launch_bounds__(256) ws_seed_kernel(const int* __restrict__ ma
                 const int r = L[base + i];
                 int v = 0;
                 if (r >= 0) {
-                    const int f = F[base + L[base + r]];
+                    const int f = F[base + r];
                     v = f ? f : markers[base + i];
                 }
                 out[base + i] = v;
@@ -98,6 +96,22 @@ __global__ void __launch_bounds__(256) ws_roots_kernel(int* __restrict__ Lall, i
         }
         if (r != t) L[t] = r;
         else T[t] = atomicAdd(&ncomp[plane], 1) + 1;
+    }
+}
+
+// A[t] = A[component root of t] for every listed tile root t: afterwards a pixel reaches its component's entry of A
+// (component id, fill value) with ONE hop through its tile root
+__global__ void __launch_bounds__(256) ws_propagate_kernel(int* __restrict__ Aall, const int* __restrict__ Lall,
+                                                           const int* __restrict__ rootlist,
+                                                           const int* __restrict__ nroots, size_t cap, size_t n) {
+    const int plane = blockIdx.z, shard = plane * gridDim.y + blockIdx.y;
+    int* A = Aall + (size_t)plane * n;
+    const int* L = Lall + (size_t)plane * n;
+    const int cnt = nroots[shard] < (int)cap ? nroots[shard] : (int)cap;
+    const int* lst = rootlist + (size_t)shard * cap;
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < cnt; k += gridDim.x * 256) {
+        const int t = lst[k], r = L[t];
+        if (r != t) A[t] = A[r];
     }
 }
 
@@ -167,11 +181,10 @@ __global__ void __launch_bounds__(256) ws_stats_kernel(const int* __restrict__ d
                    (k == 0 || v >= vs[k > 0 ? k - 1 : 0]) && (k == 7 || v >= vs[k < 7 ? k + 1 : 7]);
         }
         const int lab = ms[k];
-        // r is the TILE root of the pixel (equal inside a run, since a run never leaves its tile); the component's
-        // root is one more hop away
-        const int gr = (head || cand || lab != 0) ? L[base + r] : -1;
+        // r is the TILE root of the pixel (equal inside a run, since a run never leaves its tile); its T entry was
+        // copied from the component root (ws_propagate_kernel)
         if (head || cand || lab != 0) {
-            comp_row* c = prow + (T[base + gr] - 1);
+            comp_row* c = prow + (T[base + r] - 1);
             if (cand) atomicMax(&c->cmax, v);
             if (lab != 0) {
                 atomicAdd(&c->mcnt, 1);
@@ -185,8 +198,9 @@ __global__ void __launch_bounds__(256) ws_stats_kernel(const int* __restrict__ d
             const unsigned long long later = hb & ~((2ull << lane) - 1ull);
             const int end_lane = later ? (__ffsll((long long)later) - 2) : 63;
             const int len = end_lane - lane + 1;
-            comp_row* c = prow + (T[base + gr] - 1);
-            if ((size_t)gr == (size_t)(yb + k) * W + x) c->root = gr;  // the run that starts at the root itself
+            comp_row* c = prow + (T[base + r] - 1);
+            // the run that starts at the component root itself (a tile root that is its own parent)
+            if ((size_t)r == (size_t)(yb + k) * W + x && L[base + r] == r) c->root = r;
             if (!use_d2) atomicAdd(&c->cmax, len);
             atomicMin(&c->x0, x);
             atomicMax(&c->x1, x + len - 1);
@@ -250,7 +264,7 @@ __global__ void __launch_bounds__(256) ws_fill_markers_kernel(const int* __restr
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const int r = L[base + i];
         if (r < 0 || out[base + i] == 0) continue;
-        const int cid = T[base + L[base + r]] - 1;
+        const int cid = T[base + r] - 1;
         if (rows[cb + cid].cls != CLS_G) continue;
         const int pos = atomicAdd(&cursor[cb + cid], 1);
         mlist[base + moff[cb + cid] + pos] = (int)i;
@@ -308,7 +322,7 @@ __global__ void __launch_bounds__(64) ws_flood_lds_kernel(const int* __restrict_
     const size_t n = (size_t)H * W;
     const int* d2 = d2all + (size_t)plane * n;
     const int* L = Lall + (size_t)plane * n;
-    (void)Tall;
+    const int* T = Tall + (size_t)plane * n;
     int* out = outall + (size_t)plane * n;
     const comp_row* rr = rows + (size_t)plane * row_stride;
     const int* mylist = wl + (size_t)plane * row_stride;
@@ -344,13 +358,13 @@ __global__ void __launch_bounds__(64) ws_flood_lds_kernel(const int* __restrict_
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) rr4[u] = rr4[u] >= 0 ? L[rr4[u]] : -1;  // tile root -> component root
+            for (int u = 0; u < 4; ++u) rr4[u] = rr4[u] >= 0 ? T[rr4[u]] : 0;  // tile root -> component id (1-based)
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int i = i0 + u * 64 + lane;
                 if (i < npx) {
                     unsigned cv = 0xFFFFu;
-                    if (rr4[u] == cr.root) {
+                    if (rr4[u] == c + 1) {
                         const int d = d4[u] < 0 ? 0 : d4[u];
                         cv = ((unsigned)o4[u] & 0xFFFFu) | ((unsigned)d << 16) | (o4[u] != 0 ? 0x80000000u : 0u);
                     }
@@ -699,6 +713,9 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     hipLaunchKernelGGL(ws_roots_kernel, dim3(4, trows, nplanes), dim3(256), 0, ctx->stream, L, T, rootlist, nroots, ncomp,
                        lcap, n);
     AMT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ws_propagate_kernel, dim3(4, trows, nplanes), dim3(256), 0, ctx->stream, T, L, rootlist, nroots,
+                       lcap, n);
+    AMT_LAUNCH_CHECK();
     hipLaunchKernelGGL(ws_rows_init_kernel, dim3(64, nplanes), dim3(256), 0, ctx->stream, rows, ncomp, row_stride);
     AMT_LAUNCH_CHECK();
     int* has_g = counters + 4 * nplanes;
@@ -709,6 +726,9 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     AMT_LAUNCH_CHECK();
     hipLaunchKernelGGL(ws_classify_kernel, dim3(64, nplanes), dim3(256), 0, ctx->stream, rows, ncomp, moff, boff, has_g,
                        wl, wl_count, F, n, nplanes, row_stride, use_d2 ? 1 : 0);
+    AMT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ws_propagate_kernel, dim3(4, trows, nplanes), dim3(256), 0, ctx->stream, F, L, rootlist, nroots,
+                       lcap, n);
     AMT_LAUNCH_CHECK();
     dim3 g1(amt_grid_for(n, 256, 4096), nplanes);
     hipLaunchKernelGGL(ws_seed_kernel, dim3(amt_grid_for(n, 1024, 4096), nplanes), dim3(256), 0, ctx->stream, markers, L, F,
