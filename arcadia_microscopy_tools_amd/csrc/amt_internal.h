@@ -85,6 +85,10 @@ int amt_i_tile_rows(int H);
 size_t amt_i_rootlist_cap(int W);
 int amt_i_ccl_tileroots_u8(amt_ctx* ctx, const uint8_t* in, int* L, int* rootlist, int* nroots, int nplanes, int H,
                            int W);
+// A[t] = A[L[t]] for every listed tile root t (lists compressed): a pixel then reaches its component's entry of A
+// with one hop through its tile root
+int amt_i_propagate_roots(amt_ctx* ctx, int* A, const int* L, const int* rootlist, const int* nroots, int nplanes, int H,
+                          int W);
 // T[plane][root] = 1-based rank of the root in raster order; count_dev[plane] = number of roots.
 // blk = scratch of nplanes * amt_i_rank_blocks(n) ints.
 int amt_i_rank_blocks(size_t n);

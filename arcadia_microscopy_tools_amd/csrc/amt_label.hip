@@ -407,6 +407,30 @@ int amt_i_ccl_tileroots_u8(amt_ctx* ctx, const uint8_t* in, int* L, int* rootlis
     return ccl_tileroots<uint8_t, false>(ctx, in, L, rootlist, nroots, nplanes, H, W);
 }
 
+// A[t] = A[component root of t] for every listed tile root t (the lists must be compressed already): afterwards a
+// pixel reaches its component's entry of A with ONE hop through its tile root
+__global__ void __launch_bounds__(256) roots_propagate_kernel(int* __restrict__ Aall, const int* __restrict__ Lall,
+                                                              const int* __restrict__ rootlist,
+                                                              const int* __restrict__ nroots, size_t cap, size_t n) {
+    const int plane = blockIdx.z, shard = plane * gridDim.y + blockIdx.y;
+    int* A = Aall + (size_t)plane * n;
+    const int* L = Lall + (size_t)plane * n;
+    const int cnt = nroots[shard] < (int)cap ? nroots[shard] : (int)cap;
+    const int* lst = rootlist + (size_t)shard * cap;
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < cnt; k += gridDim.x * 256) {
+        const int t = lst[k], r = L[t];
+        if (r != t) A[t] = A[r];
+    }
+}
+
+int amt_i_propagate_roots(amt_ctx* ctx, int* A, const int* L, const int* rootlist, const int* nroots, int nplanes, int H,
+                          int W) {
+    hipLaunchKernelGGL(roots_propagate_kernel, dim3(4, amt_i_tile_rows(H), nplanes), dim3(256), 0, ctx->stream, A, L,
+                       rootlist, nroots, amt_i_rootlist_cap(W), (size_t)H * W);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+
 // compress the listed tile roots and count the component roots of every RN_CHUNK-pixel chunk (what the raster
 // renumbering scans); blockcnt must be zero on entry
 __global__ void __launch_bounds__(256) roots_compress_count_kernel(int* __restrict__ Lall, const int* __restrict__ rootlist,
@@ -430,27 +454,23 @@ __global__ void __launch_bounds__(256) roots_compress_count_kernel(int* __restri
     }
 }
 
-// out = rank of the component root of every pixel: pixel -> tile root -> component root -> rank
-__global__ void __launch_bounds__(256) apply_rank2_kernel(const int* __restrict__ L, const int* __restrict__ T,
-                                                          int* __restrict__ out, size_t n) {
+// out = rank of the component of every pixel: pixel -> tile root, whose T entry was copied from the component root
+__global__ void __launch_bounds__(256) apply_rank_kernel(const int* __restrict__ L, const int* __restrict__ T,
+                                                         int* __restrict__ out, size_t n) {
     const size_t base = (size_t)blockIdx.y * n;
     for (size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i0 < n; i0 += (size_t)gridDim.x * 1024) {
         if (i0 + 3 < n && ((base + i0) & 3) == 0) {
             const int4 l = *reinterpret_cast<const int4*>(L + base + i0);
-            int4 g, o;
-            g.x = l.x >= 0 ? L[base + l.x] : -1;
-            g.y = l.y >= 0 ? L[base + l.y] : -1;
-            g.z = l.z >= 0 ? L[base + l.z] : -1;
-            g.w = l.w >= 0 ? L[base + l.w] : -1;
-            o.x = g.x >= 0 ? T[base + g.x] : 0;
-            o.y = g.y >= 0 ? T[base + g.y] : 0;
-            o.z = g.z >= 0 ? T[base + g.z] : 0;
-            o.w = g.w >= 0 ? T[base + g.w] : 0;
+            int4 o;
+            o.x = l.x >= 0 ? T[base + l.x] : 0;
+            o.y = l.y >= 0 ? T[base + l.y] : 0;
+            o.z = l.z >= 0 ? T[base + l.z] : 0;
+            o.w = l.w >= 0 ? T[base + l.w] : 0;
             *reinterpret_cast<int4*>(out + base + i0) = o;
         } else {
             for (size_t i = i0; i < n && i < i0 + 4; ++i) {
                 const int l = L[base + i];
-                out[base + i] = l >= 0 ? T[base + L[base + l]] : 0;
+                out[base + i] = l >= 0 ? T[base + l] : 0;
             }
         }
     }
@@ -507,8 +527,9 @@ extern "C" int amt_label(amt_ctx* ctx, const void* in, int in_dtype, int32_t* ou
                        nroots, blk, cap, n, nblk);
     AMT_LAUNCH_CHECK();
     AMT_TRY(amt_i_rank_roots(ctx, L, T, blk, count_dev, nplanes, n));
+    AMT_TRY(amt_i_propagate_roots(ctx, T, L, rootlist, nroots, nplanes, H, W));
     dim3 g1(amt_grid_for(n, 1024, 4096), nplanes);
-    hipLaunchKernelGGL(apply_rank2_kernel, g1, dim3(256), 0, ctx->stream, L, T, out, n);
+    hipLaunchKernelGGL(apply_rank_kernel, g1, dim3(256), 0, ctx->stream, L, T, out, n);
     AMT_LAUNCH_CHECK();
     return AMT_OK;
 }

@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(256) ws_seed_kernel(const int* __restrict__ ma
             int4 v = make_int4(0, 0, 0, 0);
             if (r.x >= 0 || r.y >= 0 || r.z >= 0 || r.w >= 0) {
                 const int4 m = *reinterpret_cast<const int4*>(markers + base + i0);
-                // pixel -> tile root, whose F entry was copied from the component root (ws_propagate_kernel)
+                // pixel -> tile root, whose F entry was copied from the component root (amt_i_propagate_roots)
                 const int fx = r.x >= 0 ? F[base + r.x] : 0, fy = r.y >= 0 ? F[base + r.y] : 0;
                 const int fz = r.z >= 0 ? F[base + r.z] : 0, fw = r.w >= 0 ? F[base + r.w] : 0;
                 v.x = r.x >= 0 ? (fx ? fx : m.x) : 0;
@@ -96,22 +96,6 @@ __global__ void __launch_bounds__(256) ws_roots_kernel(int* __restrict__ Lall, i
         }
         if (r != t) L[t] = r;
         else T[t] = atomicAdd(&ncomp[plane], 1) + 1;
-    }
-}
-
-// A[t] = A[component root of t] for every listed tile root t: afterwards a pixel reaches its component's entry of A
-// (component id, fill value) with ONE hop through its tile root
-__global__ void __launch_bounds__(256) ws_propagate_kernel(int* __restrict__ Aall, const int* __restrict__ Lall,
-                                                           const int* __restrict__ rootlist,
-                                                           const int* __restrict__ nroots, size_t cap, size_t n) {
-    const int plane = blockIdx.z, shard = plane * gridDim.y + blockIdx.y;
-    int* A = Aall + (size_t)plane * n;
-    const int* L = Lall + (size_t)plane * n;
-    const int cnt = nroots[shard] < (int)cap ? nroots[shard] : (int)cap;
-    const int* lst = rootlist + (size_t)shard * cap;
-    for (int k = blockIdx.x * 256 + threadIdx.x; k < cnt; k += gridDim.x * 256) {
-        const int t = lst[k], r = L[t];
-        if (r != t) A[t] = A[r];
     }
 }
 
@@ -182,7 +166,7 @@ __global__ void __launch_bounds__(256) ws_stats_kernel(const int* __restrict__ d
         }
         const int lab = ms[k];
         // r is the TILE root of the pixel (equal inside a run, since a run never leaves its tile); its T entry was
-        // copied from the component root (ws_propagate_kernel)
+        // copied from the component root (amt_i_propagate_roots)
         if (head || cand || lab != 0) {
             comp_row* c = prow + (T[base + r] - 1);
             if (cand) atomicMax(&c->cmax, v);
@@ -713,9 +697,7 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     hipLaunchKernelGGL(ws_roots_kernel, dim3(4, trows, nplanes), dim3(256), 0, ctx->stream, L, T, rootlist, nroots, ncomp,
                        lcap, n);
     AMT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ws_propagate_kernel, dim3(4, trows, nplanes), dim3(256), 0, ctx->stream, T, L, rootlist, nroots,
-                       lcap, n);
-    AMT_LAUNCH_CHECK();
+    AMT_TRY(amt_i_propagate_roots(ctx, T, L, rootlist, nroots, nplanes, H, W));
     hipLaunchKernelGGL(ws_rows_init_kernel, dim3(64, nplanes), dim3(256), 0, ctx->stream, rows, ncomp, row_stride);
     AMT_LAUNCH_CHECK();
     int* has_g = counters + 4 * nplanes;
@@ -727,9 +709,7 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     hipLaunchKernelGGL(ws_classify_kernel, dim3(64, nplanes), dim3(256), 0, ctx->stream, rows, ncomp, moff, boff, has_g,
                        wl, wl_count, F, n, nplanes, row_stride, use_d2 ? 1 : 0);
     AMT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ws_propagate_kernel, dim3(4, trows, nplanes), dim3(256), 0, ctx->stream, F, L, rootlist, nroots,
-                       lcap, n);
-    AMT_LAUNCH_CHECK();
+    AMT_TRY(amt_i_propagate_roots(ctx, F, L, rootlist, nroots, nplanes, H, W));
     dim3 g1(amt_grid_for(n, 256, 4096), nplanes);
     hipLaunchKernelGGL(ws_seed_kernel, dim3(amt_grid_for(n, 1024, 4096), nplanes), dim3(256), 0, ctx->stream, markers, L, F,
                        out, n);
