@@ -349,9 +349,172 @@ __global__ void __launch_bounds__(256) gauss_fused_kernel(const TIn* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same fused Gaussian for uint16 input with the INPUT side decoupled from the waves' registers: the raw
+// uint16 rows of the block's 256 columns go straight from HBM into an LDS ring with `global_load_lds_dwordx4`
+// (16 bytes per lane, no VGPRs, issued three row-groups ahead by two of the four waves), and every thread picks
+// its column's new samples out of LDS when a group starts.  HBM latency is then covered by three groups of
+// arithmetic instead of by occupancy.  Conditions (else the register-load kernel above runs): W a multiple of 8
+// and 16-byte aligned planes (so that tiles start on 16-byte chunks and no chunk straddles the image edge),
+// boundary modes nearest / reflect / mirror (the extension of a column is another column of the same tile).
+// Tile: 256 columns starting RP = roundup(R, 8) left of the first output; OUTW = 256 - 2 RP outputs.
+// ------------------------------------------------------------------------------------------------
+template <int R>
+__global__ void __launch_bounds__(256) gauss_lds_kernel(const uint16_t* __restrict__ in, double scale,
+                                                        double* __restrict__ out, int H, int W,
+                                                        const double* __restrict__ wts, int mode, size_t in_stride,
+                                                        int TH, unsigned long long* __restrict__ keys) {
+    constexpr int K = 2 * R + 1;
+    constexpr int RP = (R + 7) & ~7;
+    constexpr int OUTW = 256 - 2 * RP;
+    constexpr int NSEG = OUTW / 4;
+    constexpr int RING = 16;  // raw rows: four groups of four
+    __shared__ __attribute__((aligned(16))) double rowbuf[2][4][256 + 4];
+    __shared__ __attribute__((aligned(16))) unsigned short raw[RING][256];
+    __shared__ int ymap[256 + 2 * FR_MAX + 8];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int x0 = blockIdx.x * OUTW;
+    const int xt0 = x0 - RP;  // image column of tile column 0 (a multiple of 8)
+    const int y0 = blockIdx.y * TH;
+    const size_t plane = (size_t)blockIdx.z * H * W;
+    const uint16_t* src = in + (size_t)blockIdx.z * in_stride;
+    double w[R + 1];
+#pragma unroll
+    for (int j = 0; j <= R; ++j) w[j] = wts[R - j];
+    for (int k = t; k < TH + 2 * R + 8; k += 256) ymap[k] = amt_map_index(y0 - R + k, H, mode);
+    __syncthreads();
+    // this thread's column: tile column t; outside the image it reads the tile column of its boundary-mapped image
+    const int xm = amt_map_index(xt0 + t, W, mode);
+    int ti = xm - xt0;  // in [0, 256) for every column that an output needs; the others are clamped (never used)
+    ti = ti < 0 ? 0 : (ti > 255 ? 255 : ti);
+    const int rows = (y0 + TH <= H) ? TH : (H - y0);
+    const int ngroups = (rows + 3) >> 2;
+    // loader role (waves 0 and 1): lane l moves the 16-byte chunk (l & 31) of row (2 * wave + (l >> 5)) of a group
+    const int lrow = 2 * wave + (lane >> 5);
+    int lcol = xt0 + 8 * (lane & 31);
+    lcol = lcol < 0 ? 0 : (lcol > W - 8 ? W - 8 : lcol);  // chunks entirely outside the image are never read
+    auto issue_group = [&](int g) {  // window rows 2R + 4g .. + 3 -> ring slots (4g .. 4g + 3) & 15
+        if (wave < 2 && g < ngroups) {
+            const int yy = ymap[2 * R + 4 * g + lrow];
+            const uint16_t* gp = src + (size_t)yy * W + lcol;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                             (__attribute__((address_space(3))) void*)&raw[(4 * g + 2 * wave) & (RING - 1)][0],
+                                             16, 0, 0);
+        }
+    };
+    issue_group(0);
+    issue_group(1);
+    issue_group(2);
+    // initial window: rows -R .. R-1 of the first output row, ordinary loads (once per block)
+    double win[K + 3];
+#pragma unroll
+    for (int k = 0; k < K - 1; ++k) win[k] = (double)src[(size_t)ymap[k] * W + xm] * scale;
+    const int q = wave, seg = lane;
+    const int xo = x0 + 4 * seg;
+    double vlo = __builtin_huge_val(), vhi = -__builtin_huge_val();
+    __builtin_amdgcn_s_waitcnt(0x0F72);  // vmcnt(2): group 0 has landed (groups 1, 2 may be in flight)
+    __syncthreads();
+    for (int g = 0; g < ngroups; ++g) {
+        const int rg = g << 2;
+        issue_group(g + 3);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) win[K - 1 + i] = (double)raw[(rg + i) & (RING - 1)][ti] * scale;
+        const int buf = g & 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            double acc = win[R + i] * w[0];
+#pragma unroll
+            for (int j = R; j >= 1; --j) acc += (win[R + i - j] + win[R + i + j]) * w[j];
+            rowbuf[buf][i][t] = acc;
+        }
+        // Group g + 1 must have landed before the barrier that publishes it.  The vector-memory counter retires in
+        // order, so a loader wave may leave outstanding exactly what it issued AFTER that load: the loads of groups
+        // g+2 and g+3 and the two 16-byte stores of each of the groups g-2 and g-1 (waves 0 and 1 always own a row of a
+        // full group).  Near the end of the block, where fewer loads are issued, it simply drains.
+        if (wave < 2) {
+            if (g + 3 >= ngroups)
+                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+            else if (g >= 2)
+                __builtin_amdgcn_s_waitcnt(0x0F76);  // vmcnt(6)
+            else if (g == 1)
+                __builtin_amdgcn_s_waitcnt(0x0F74);  // vmcnt(4)
+            else
+                __builtin_amdgcn_s_waitcnt(0x0F72);  // vmcnt(2)
+        }
+        __syncthreads();
+        const int nrows = rows - rg < 4 ? rows - rg : 4;
+        if (q < nrows && seg < NSEG) {
+            const double* c0 = &rowbuf[buf][q][RP - R + 4 * seg];
+            double c[2 * R + 4];
+#pragma unroll
+            for (int i = 0; i < 2 * R + 4; ++i) c[i] = c0[i];
+            double a[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                double a2 = c[i + R] * w[0];
+#pragma unroll
+                for (int j = R; j >= 1; --j) a2 += (c[i + R - j] + c[i + R + j]) * w[j];
+                a[i] = a2;
+            }
+            // W and the tile origin are multiples of 8: the four outputs are inside the image together or not at
+            // all, and the destination is 16-byte aligned -> exactly two store instructions per row
+            double* dst = out + plane + (size_t)(y0 + rg + q) * W + xo;
+            if (xo < W) {
+                reinterpret_cast<double2*>(dst)[0] = make_double2(a[0], a[1]);
+                reinterpret_cast<double2*>(dst)[1] = make_double2(a[2], a[3]);
+                if (keys) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        vlo = vmin_f64(vlo, a[i]);
+                        vhi = vmax_f64(vhi, a[i]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < K - 1; ++k) win[k] = win[k + 4];
+    }
+    if (keys) {
+        unsigned long long klo = amt_f64_key(vlo), khi = amt_f64_key(vhi);
+        if (vlo > vhi) {
+            klo = ~0ull;
+            khi = 0ull;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const unsigned long long l2 = __shfl_xor(klo, off), h2 = __shfl_xor(khi, off);
+            klo = l2 < klo ? l2 : klo;
+            khi = h2 > khi ? h2 : khi;
+        }
+        if (lane == 0) {
+            atomicMin(&keys[2 * blockIdx.z], klo);
+            atomicMax(&keys[2 * blockIdx.z + 1], khi);
+        }
+    }
+}
+
 template <typename TIn, int R>
 static int launch_fused(amt_ctx* ctx, const TIn* in, double scale, double* out, int nplanes, int H, int W,
                         const double* wdev, int mode, double cval, size_t in_stride, unsigned long long* keys) {
+    if constexpr (sizeof(TIn) == 2) {
+        // direct-to-LDS input path (see gauss_lds_kernel): needs chunk-aligned rows and an in-tile boundary extension
+        const bool aligned = (W % 8 == 0) && W >= 256 && (in_stride % 8 == 0) && ((reinterpret_cast<uintptr_t>(in) & 15) == 0) &&
+                             ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+        const bool modeok = mode == AMT_MODE_NEAREST || mode == AMT_MODE_REFLECT || mode == AMT_MODE_MIRROR;
+        const char* off = getenv("AMT_GAUSS_LDS");
+        if (aligned && modeok && H > 2 * R && !(off && off[0] == '0')) {
+            constexpr int RP = (R + 7) & ~7;
+            constexpr int OUTW2 = 256 - 2 * RP;
+            const int gx2 = (W + OUTW2 - 1) / OUTW2;
+            int TH2 = 256;
+            while (TH2 > 32 && (long long)gx2 * ((H + TH2 - 1) / TH2) * nplanes < 4LL * ctx->num_cus) TH2 >>= 1;
+            dim3 grid2(gx2, (H + TH2 - 1) / TH2, nplanes);
+            hipLaunchKernelGGL((gauss_lds_kernel<R>), grid2, dim3(256), 0, ctx->stream, (const uint16_t*)in, scale, out, H,
+                               W, wdev, mode, in_stride, TH2, keys);
+            AMT_LAUNCH_CHECK();
+            return AMT_OK;
+        }
+    }
     constexpr int OUTW = 256 - 2 * R;
     const int gx = (W + OUTW - 1) / OUTW;
     // rows per block: long chunks amortise the 2R warm-up rows, but keep >= ~4 blocks per CU in flight

@@ -339,3 +339,28 @@ def test_threshold_open_close_fused(ctx, ops):
     thr_a = ops.threshold_otsu(ctx.asarray(g)).numpy()
     thr_b = ops.threshold_otsu(ctx.asarray(g), minmax=mm).numpy()
     assert np.array_equal(thr_a, thr_b)
+
+
+def test_gaussian_lds_path(ctx, ops):
+    """The direct-to-LDS Gaussian kernel (uint16 input, W a multiple of 8 and >= 256) against the oracle: several
+    radii (tile halo 8 and 16), the three supported boundary modes, heights below / above one row chunk, widths with a
+    partial last tile, a strided channel of a (C, Y, X) batch, and the fused min / max."""
+    from oracle import skops
+
+    rng = np.random.default_rng(17)
+    for (h, w), sigma in (((40, 256), 2.0), ((300, 264), 2.0), ((77, 512), 0.6), ((130, 496), 3.0), ((64, 1024), 1.0)):
+        u = rng.integers(0, 65535, (h, w)).astype(np.uint16)
+        d = ctx.asarray(u)
+        assert np.array_equal(ops.gaussian(d, sigma).numpy(), skops.gaussian(u, sigma)), (h, w, sigma)
+    u = rng.integers(0, 65535, (96, 320)).astype(np.uint16)
+    from scipy import ndimage as ndi
+
+    for mode in ("nearest", "reflect", "mirror", "constant", "wrap"):  # the last two take the register-load kernel
+        ref = ndi.gaussian_filter(u.astype(np.float64) * (1.0 / 65535), 2.0, mode=mode, cval=0.25)
+        assert np.array_equal(ops.gaussian(ctx.asarray(u), 2.0, mode=mode, cval=0.25).numpy(), ref), mode
+    batch = rng.integers(0, 65535, (3, 4, 72, 264)).astype(np.uint16)
+    mm = ctx.empty((3, 2), np.float64)
+    g = ops.gaussian(ctx.asarray(batch), 2.0, channel=2, minmax_out=mm).numpy()
+    for b in range(3):
+        assert np.array_equal(g[b], skops.gaussian(batch[b, 2], 2.0)), b
+    assert np.array_equal(mm.numpy(), np.stack([g.min(axis=(1, 2)), g.max(axis=(1, 2))], axis=1))
