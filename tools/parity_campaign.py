@@ -1,6 +1,6 @@
 """One-off parity campaign at BASELINE size: config 3 on 12 synthetic 4 x 2048 x 2048 fields of view (indices 2..13)
 through the HIP path and through the CPU oracle (12 threads); labels must be bit-identical, features within 1e-5.
-Run on the GPU box: python tools/parity_campaign.py  (takes ~40 s; last run: 12 / 12 identical)."""
+Run on the GPU box: python tools/parity_campaign.py  (CAMPAIGN_FIRST / CAMPAIGN_LAST select the FOV indices; last runs: 36 / 36 identical)."""
 import sys, time
 sys.path.insert(0, '.')
 import numpy as np
@@ -8,7 +8,8 @@ from concurrent.futures import ThreadPoolExecutor
 from arcadia_microscopy_tools_amd import synth
 from arcadia_microscopy_tools_amd.segment import segment_fovs
 from oracle import chains
-idx = list(range(2, 14))
+import os
+idx = list(range(int(os.environ.get("CAMPAIGN_FIRST", "2")), int(os.environ.get("CAMPAIGN_LAST", "14"))))
 fovs = np.stack([synth.synth_fov(i) for i in idx])
 t0 = time.time()
 res = segment_fovs(fovs, max_cells=2048)
