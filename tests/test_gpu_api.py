@@ -365,3 +365,22 @@ def test_overlay_against_matplotlib_golden(golden):
         create_overlay(np.zeros((2, 3, 4)), [])
     with pytest.raises(ValueError, match="but background has shape"):
         create_overlay(bg, [Layer(DAPI, dapi[:10])])
+
+
+def test_readme_flow(golden):
+    """The usage sketch of README.md end to end on the reference's ND2 fixture pixels."""
+    from arcadia_microscopy_tools_amd import ImageOperation, MicroscopyImage, Pipeline
+    from arcadia_microscopy_tools_amd.channels import BRIGHTFIELD, DAPI, FITC, TRITC
+    from arcadia_microscopy_tools_amd.masks import SegmentationMask
+    from arcadia_microscopy_tools_amd.model import SegmentationModel
+    from arcadia_microscopy_tools_amd.operations import rescale_by_percentile, subtract_background_dog
+
+    image = MicroscopyImage.from_array(golden("nd2_multichannel")["pixels"], [BRIGHTFIELD, DAPI, FITC, TRITC])
+    pipeline = Pipeline([ImageOperation(subtract_background_dog), ImageOperation(rescale_by_percentile)])
+    dapi = image.apply_pipeline(pipeline, channel=DAPI)
+    assert dapi.dtype == np.float64 and dapi.shape == (256, 256) and dapi.min() == 0.0 and dapi.max() == 1.0
+    labels = SegmentationModel(backend="classical").segment(dapi)
+    assert labels.dtype == np.int64 and labels.max() > 5
+    mask = SegmentationMask(labels, {DAPI: image.get_channel_intensities(DAPI)}, outline_extractor="skimage")
+    feats, outs = mask.cell_properties, mask.cell_outlines
+    assert len(outs) == mask.num_cells == len(feats["area"]) and "intensity_mean_dapi" in feats
