@@ -104,6 +104,8 @@ _SIGS = {
     "amt_label_bboxes": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int]),
     "amt_contours_find": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, c_size_t, _P]),
     "amt_contours_emit": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),
+    "amt_borders_find": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P]),
+    "amt_borders_emit": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),
     "amt_overlay": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_int]),
 }
 

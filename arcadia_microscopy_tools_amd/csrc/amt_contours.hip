@@ -241,3 +241,173 @@ extern "C" int amt_contours_emit(amt_ctx* ctx, const int32_t* labels, int H, int
     AMT_LAUNCH_CHECK();
     return AMT_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Pixel-border outlines: the "cellpose" extractor of the reference (R/masks.py:68-79).
+// cellpose.utils.outlines_list (4.0.8) runs, per label n, cv2.findContours(masks == n, RETR_EXTERNAL,
+// CHAIN_APPROX_NONE) (opencv-python-headless 4.11.0.86 in R's uv.lock) and keeps the contour with the most
+// points.  findContours is Suzuki-Abe border following; what is restated here is its published raster scan:
+//   * a pixel with a zero left neighbour that is still unmarked starts an OUTER border, unless the last border
+//     pixel passed on this row carries a positive mark (we are inside an already traced border: nested
+//     components are not external);
+//   * the border is followed from the start pixel i0: the first non-zero neighbour clockwise from "left" is i1;
+//     from then on the next pixel is the first non-zero neighbour counter-clockwise after the direction we came
+//     from; every visited pixel is one output point (CHAIN_APPROX_NONE); the walk ends when the current pixel is
+//     i1 and the next one is i0 again;
+//   * a visited pixel is marked -126 when its right neighbour was examined and found zero, else 2.
+// Directions: 0 = +x, then counter-clockwise on the screen (1 = +x -y, 2 = -y, ... 7 = +x +y).
+// One thread per label over its tight bounding box; marks live in one H x W byte plane (a pixel belongs to one
+// label).  Neither cv2 nor cellpose exists offline: parity unpinned (oracle/contours.py says the same).
+// ---------------------------------------------------------------------------------------------------------
+struct bbox_t {
+    const int* lab;
+    int W, label, r0, c0, r1, c1;  // half-open, tight
+};
+
+__device__ __forceinline__ bool bd_nz(const bbox_t& b, int y, int x) {
+    return y >= b.r0 && y < b.r1 && x >= b.c0 && x < b.c1 && b.lab[(size_t)y * b.W + x] == b.label;
+}
+
+__device__ __forceinline__ void bd_step(int s, int& dy, int& dx) {
+    // s & 7: 0 E, 1 NE, 2 N, 3 NW, 4 W, 5 SW, 6 S, 7 SE (y grows downwards)
+    const int k = s & 7;
+    dx = (k == 0 || k == 1 || k == 7) ? 1 : ((k >= 3 && k <= 5) ? -1 : 0);
+    dy = (k >= 1 && k <= 3) ? -1 : ((k >= 5) ? 1 : 0);
+}
+
+// Follows the outer border that starts at (y0, x0).  marks may be null (emit pass).  pts (y, x) int32 pairs may
+// be null (find pass).  Returns the number of points (0 if the step bound is hit: cannot happen for a
+// consistent image, it only guarantees termination).
+__device__ int bd_trace(const bbox_t& b, int y0, int x0, signed char* marks, int* pts, int max_steps) {
+    int s = 4, dy, dx;
+    const int s_stop = 4;
+    bool found = false;
+    do {
+        s = (s - 1) & 7;
+        bd_step(s, dy, dx);
+        if (bd_nz(b, y0 + dy, x0 + dx)) {
+            found = true;
+            break;
+        }
+    } while (s != s_stop);
+    if (!found) {  // isolated pixel
+        if (marks) marks[(size_t)y0 * b.W + x0] = (signed char)-126;
+        if (pts) {
+            pts[0] = y0;
+            pts[1] = x0;
+        }
+        return 1;
+    }
+    const int y1 = y0 + dy, x1 = x0 + dx;
+    int y3 = y0, x3 = x0, n = 0;
+    for (int step = 0; step < max_steps; ++step) {
+        const int s_end = s;
+        int y4 = y3, x4 = x3;
+        while (s < 15) {
+            ++s;
+            bd_step(s, dy, dx);
+            y4 = y3 + dy;
+            x4 = x3 + dx;
+            if (bd_nz(b, y4, x4)) break;
+        }
+        s &= 7;
+        if (marks) {
+            signed char* m = marks + (size_t)y3 * b.W + x3;
+            if ((unsigned)(s - 1) < (unsigned)s_end) *m = (signed char)-126;
+            else if (*m == 0) *m = 2;
+        }
+        if (pts) {
+            pts[2 * n] = y3;
+            pts[2 * n + 1] = x3;
+        }
+        ++n;
+        if (y4 == y0 && x4 == x0 && y3 == y1 && x3 == x1) return n;
+        y3 = y4;
+        x3 = x4;
+        s = (s + 4) & 7;
+    }
+    return 0;
+}
+
+// boxes: nlab x 5 ints {label, r0, c0, r1, c1} tight half-open; info: nlab x 3 ints {points, start y, start x}
+__global__ void __launch_bounds__(64) borders_find_kernel(const int* __restrict__ labels, int H, int W, int nlab,
+                                                          const int* __restrict__ boxes, signed char* marks,
+                                                          int* __restrict__ info) {
+    const int li = blockIdx.x * 64 + threadIdx.x;
+    if (li >= nlab) return;
+    const int* bx = boxes + (size_t)li * 5;
+    bbox_t b{labels, W, bx[0], bx[1], bx[2], bx[3], bx[4]};
+    int best_n = 0, best_y = 0, best_x = 0;
+    const bool ok = b.r0 >= 0 && b.c0 >= 0 && b.r1 <= H && b.c1 <= W && b.r0 < b.r1 && b.c0 < b.c1;
+    if (ok) {
+        const int max_steps = 8 * (b.r1 - b.r0) * (b.c1 - b.c0) + 16;
+        for (int y = b.r0; y < b.r1; ++y) {
+            int prev = 0, lnbd = 0;  // value of the previous pixel / of the last border pixel passed on this row
+            for (int x = b.c0; x < b.c1; ++x) {
+                int p = 0;
+                if (labels[(size_t)y * W + x] == b.label) {
+                    const int m = marks[(size_t)y * W + x];
+                    p = m ? m : 1;
+                }
+                if (prev == 0 && p == 1 && lnbd <= 0) {
+                    const int n = bd_trace(b, y, x, marks, nullptr, max_steps);
+                    // the contour list comes back newest first and argmax keeps the first maximum:
+                    // among equals the LAST border found in raster order wins
+                    if (n >= best_n && n > 0) {
+                        best_n = n;
+                        best_y = y;
+                        best_x = x;
+                    }
+                    p = marks[(size_t)y * W + x];
+                }
+                if (p != 0 && p != 1) lnbd = p;
+                prev = p;
+            }
+        }
+    }
+    info[(size_t)li * 3 + 0] = best_n;
+    info[(size_t)li * 3 + 1] = best_y;
+    info[(size_t)li * 3 + 2] = best_x;
+}
+
+// poff: nlab + 1 offsets (in points) into points_out = (y, x) int32 pairs; labels with fewer than five border
+// points have an empty slot (cellpose keeps only len(pix) > 4; the host passes poff accordingly)
+__global__ void __launch_bounds__(64) borders_emit_kernel(const int* __restrict__ labels, int H, int W, int nlab,
+                                                          const int* __restrict__ boxes, const int* __restrict__ info,
+                                                          const long long* __restrict__ poff,
+                                                          int* __restrict__ points_out) {
+    const int li = blockIdx.x * 64 + threadIdx.x;
+    if (li >= nlab) return;
+    const long long lo = poff[li], hi = poff[li + 1];
+    const int n = info[(size_t)li * 3];
+    if (hi - lo != n || n == 0) return;
+    const int* bx = boxes + (size_t)li * 5;
+    bbox_t b{labels, W, bx[0], bx[1], bx[2], bx[3], bx[4]};
+    if (!(b.r0 >= 0 && b.c0 >= 0 && b.r1 <= H && b.c1 <= W)) return;
+    bd_trace(b, info[(size_t)li * 3 + 1], info[(size_t)li * 3 + 2], nullptr, points_out + 2 * lo, n);
+}
+
+extern "C" int amt_borders_find(amt_ctx* ctx, const int32_t* labels, int H, int W, int nlab, const int32_t* boxes_dev,
+                                int8_t* marks_dev, int32_t* info_dev) {
+    AMT_TRY(amt_set_device(ctx));
+    AMT_REQUIRE(labels && H > 0 && W > 0 && nlab >= 0, "borders_find: bad arguments");
+    if (nlab == 0) return AMT_OK;
+    AMT_REQUIRE(boxes_dev && marks_dev && info_dev, "borders_find: null pointer");
+    AMT_HIP_CHECK(hipMemsetAsync(marks_dev, 0, (size_t)H * W, ctx->stream));
+    hipLaunchKernelGGL(borders_find_kernel, dim3((nlab + 63) / 64), dim3(64), 0, ctx->stream, labels, H, W, nlab,
+                       boxes_dev, (signed char*)marks_dev, info_dev);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+
+extern "C" int amt_borders_emit(amt_ctx* ctx, const int32_t* labels, int H, int W, int nlab, const int32_t* boxes_dev,
+                                const int32_t* info_dev, const int64_t* poff_dev, int32_t* points_dev) {
+    AMT_TRY(amt_set_device(ctx));
+    AMT_REQUIRE(labels && H > 0 && W > 0 && nlab >= 0, "borders_emit: bad arguments");
+    if (nlab == 0) return AMT_OK;
+    AMT_REQUIRE(boxes_dev && info_dev && poff_dev && points_dev, "borders_emit: null pointer");
+    hipLaunchKernelGGL(borders_emit_kernel, dim3((nlab + 63) / 64), dim3(64), 0, ctx->stream, labels, H, W, nlab,
+                       boxes_dev, info_dev, (const long long*)poff_dev, points_dev);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}

@@ -668,3 +668,53 @@ def cell_outlines(labels: DeviceArray, max_label: int) -> list[np.ndarray]:
     pts = d_pts.numpy()
     return [pts[poff[i]:poff[i + 1]].copy() if poff[i + 1] > poff[i] else np.array([]).reshape(0, 2)
             for i in range(nlab)]
+
+
+def cell_outlines_borders(labels: DeviceArray, max_label: int, skip_first_value: bool = True) -> list[np.ndarray]:
+    """Outline of every label of ONE int32 label plane as the reference's default "cellpose" extractor returns
+    them (R/masks.py:68-79): ``cellpose.utils.outlines_list`` = OpenCV ``findContours(masks == n, RETR_EXTERNAL,
+    CHAIN_APPROX_NONE)`` per label, contour with the most points, (y, x) int64 pixel coordinates after the
+    reference's column swap, ``np.zeros((0, 2))`` when the border has fewer than five points.  ``outlines_list``
+    iterates ``np.unique(masks)[1:]``, i.e. it drops the smallest value present whatever it is; with
+    ``skip_first_value`` the same happens here (label 1 is dropped when the plane has no background pixel).
+    Border following runs on the device.  Parity unpinned (no OpenCV offline), see oracle/contours.py."""
+    ctx = labels.ctx
+    if labels.ndim != 2 or labels.dtype != np.int32:
+        raise TypeError("cell_outlines_borders expects one (Y, X) int32 label plane")
+    H, W = labels.shape
+    bb = label_bboxes(labels, max(int(max_label), 1))[0]
+    present = np.nonzero(bb[:, 2] >= bb[:, 0])[0]
+    if skip_first_value and len(present):
+        area = (bb[present, 2] - bb[present, 0] + 1).astype(np.int64) * (bb[present, 3] - bb[present, 1] + 1)
+        # a background pixel exists unless the labels tile the plane; only then is it worth counting pixels
+        if area.sum() >= H * W:
+            cols = list(_hip.RP_COLS)
+            tab = regionprops(labels, max(int(max_label), 1)).numpy()[0]
+            if int(round(tab[:, cols.index("area")].sum())) >= H * W:
+                present = present[1:]
+    nlab = len(present)
+    if nlab == 0:
+        return []
+    boxes = np.empty((nlab, 5), dtype=np.int32)
+    boxes[:, 0] = present + 1
+    boxes[:, 1] = bb[present, 0]
+    boxes[:, 2] = bb[present, 1]
+    boxes[:, 3] = bb[present, 2] + 1
+    boxes[:, 4] = bb[present, 3] + 1
+    d_boxes = ctx.asarray(boxes)
+    d_marks = ctx.empty((H, W), np.int8)
+    d_info = ctx.empty((nlab, 3), np.int32)
+    _hip.check(_lib().amt_borders_find(ctx.handle, labels.ptr, H, W, nlab, d_boxes.ptr, d_marks.ptr, d_info.ptr),
+               "amt_borders_find")
+    info = d_info.numpy()
+    npts = np.where(info[:, 0] > 4, info[:, 0], 0).astype(np.int64)
+    poff = np.concatenate([[0], np.cumsum(npts)]).astype(np.int64)
+    total = int(poff[-1])
+    if total == 0:
+        return [np.zeros((0, 2)) for _ in range(nlab)]
+    d_poff = ctx.asarray(poff)
+    d_pts = ctx.empty((total, 2), np.int32)
+    _hip.check(_lib().amt_borders_emit(ctx.handle, labels.ptr, H, W, nlab, d_boxes.ptr, d_info.ptr, d_poff.ptr,
+                                       d_pts.ptr), "amt_borders_emit")
+    pts = d_pts.numpy().astype(np.int64)
+    return [pts[poff[i]:poff[i + 1]].copy() if poff[i + 1] > poff[i] else np.zeros((0, 2)) for i in range(nlab)]

@@ -158,20 +158,20 @@ class SegmentationMask:
     def cell_outlines(self) -> list[Float64Array]:
         """Per-cell outlines, one (n, 2) array of (y, x) vertices per cell (R/masks.py:229-245).
 
-        ``outline_extractor="skimage"`` runs on the device: marching squares at level 0.5 on each cell's padded
-        bounding box, longest contour, in scikit-image's vertex order (R/masks.py:82-115).
-        ``outline_extractor="cellpose"`` (``cellpose.utils.outlines_list`` -> OpenCV ``findContours``,
-        R/masks.py:68-79) has no pinned oracle in this environment (neither package is installed) and is refused
-        loudly rather than approximated."""
-        if self.outline_extractor == "cellpose":
-            raise NotImplementedError(
-                "outline_extractor='cellpose' (OpenCV findContours via cellpose.utils.outlines_list) is not "
-                "implemented on the MI355X path; use outline_extractor='skimage'"
-            )
+        Both extractors run on the device.  ``outline_extractor="skimage"``: marching squares at level 0.5 on each
+        cell's padded bounding box, longest contour, in scikit-image's vertex order, float64 (R/masks.py:82-115;
+        pinned by tests/golden/outlines_96.npz).  ``outline_extractor="cellpose"`` (the reference's default):
+        ``cellpose.utils.outlines_list`` = OpenCV ``findContours(RETR_EXTERNAL, CHAIN_APPROX_NONE)`` per cell, the
+        border with the most points, int64 pixel coordinates, empty when it has fewer than five points
+        (R/masks.py:68-79); restated from the published border-following algorithm, parity unpinned (neither
+        package exists offline, the reference's tests hold no vector for it)."""
         from . import hipops
 
         lab, k = self._labels_device
-        return hipops.cell_outlines(lab[0] if lab.ndim == 3 else lab, int(k))
+        plane = lab[0] if lab.ndim == 3 else lab
+        if self.outline_extractor == "cellpose":
+            return hipops.cell_outlines_borders(plane, int(k))
+        return hipops.cell_outlines(plane, int(k))
 
     @cached_property
     def cell_properties(self) -> dict[str, ScalarArray]:

@@ -283,6 +283,20 @@ int amt_contours_find(amt_ctx* ctx, const int32_t* labels, int H, int W, int nla
 int amt_contours_emit(amt_ctx* ctx, const int32_t* labels, int H, int W, int nlab, const int32_t* boxes_dev,
                       const int32_t* info_dev, const int64_t* poff_dev, double* points_dev);
 
+/* Pixel-border outlines, the reference's default extractor (R/masks.py:68-79: cellpose.utils.outlines_list ->
+ * cv2.findContours(masks == n, RETR_EXTERNAL, CHAIN_APPROX_NONE), contour with the most points, newest first among
+ * equals).  Suzuki-Abe border following on ONE int32 label plane, one walk per outer border.  Parity unpinned: no
+ * OpenCV / cellpose offline and no vector in the reference's tests (see oracle/contours.py).
+ *   boxes_dev   nlab x 5 ints {label, r_lo, c_lo, r_hi, c_hi}: the TIGHT bounding box, half-open
+ *   marks_dev   H x W scratch bytes (cleared by the call)
+ *   info_dev    nlab x 3 ints {points, start row, start col} of the selected border
+ *   poff_dev    nlab + 1 offsets (in points) into points_dev = (row, col) int32 pairs; a label whose slot is not
+ *               exactly its point count is skipped (the host drops borders of fewer than five points) */
+int amt_borders_find(amt_ctx* ctx, const int32_t* labels, int H, int W, int nlab, const int32_t* boxes_dev,
+                     int8_t* marks_dev, int32_t* info_dev);
+int amt_borders_emit(amt_ctx* ctx, const int32_t* labels, int H, int W, int nlab, const int32_t* boxes_dev,
+                     const int32_t* info_dev, const int64_t* poff_dev, int32_t* points_dev);
+
 /* ---- channel overlay: R/blending.py:116-226 (create_overlay / overlay_channels) ------------------------
  * out_rgb = H x W x 3 float64 (interleaved).  background and every layer are H x W float64 planes on the device
  * (values outside [0, 1] are clipped, as the reference does).  layers_host = nlayers device pointers;

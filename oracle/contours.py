@@ -124,3 +124,87 @@ def extract_outlines_skimage(label_image: np.ndarray):
         else:
             outlines.append(np.array([]).reshape(0, 2))
     return outlines
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The "cellpose" extractor (R/masks.py:68-79) -- PARITY UNPINNED.
+# ``cellpose.utils.outlines_list(masks, multiprocessing=False)`` (cellpose 4.0.8, R's uv.lock) is, per label n of
+# ``np.unique(masks)[1:]``: ``cv2.findContours((masks == n).astype(uint8), RETR_EXTERNAL, CHAIN_APPROX_NONE)``,
+# the contour with the most points (``np.argmax``: first maximum of the returned list), ``.astype(int).squeeze()``,
+# kept if ``len(pix) > 4`` else ``np.zeros((0, 2))``; the reference then swaps (x, y) -> (y, x).
+# Neither cellpose nor OpenCV (opencv-python-headless 4.11.0.86) can be imported here and the reference's tests hold
+# no vector for this extractor, so the functions below restate the published Suzuki-Abe border following the way
+# OpenCV's scanner runs it (raster scan, 8-neighbourhood, start pixel = first pixel of the border in raster order,
+# outer borders run counter-clockwise on the screen: a filled rectangle gives top-left, down the left side, along
+# the bottom, up the right side, back along the top) and nothing pins them to real OpenCV output.
+# ---------------------------------------------------------------------------------------------------------------
+_DX = (1, 1, 0, -1, -1, -1, 0, 1)
+_DY = (0, -1, -1, -1, 0, 1, 1, 1)
+
+
+def _follow_border(img: np.ndarray, y0: int, x0: int):
+    """Outer border from (y0, x0) on a zero-padded int8 image (1 = unvisited, 2 / -126 = visited); marks it."""
+    s = 4
+    while True:
+        s = (s - 1) & 7
+        if img[y0 + _DY[s], x0 + _DX[s]] != 0 or s == 4:
+            break
+    if img[y0 + _DY[s], x0 + _DX[s]] == 0:
+        img[y0, x0] = -126
+        return [(x0, y0)]
+    y1, x1 = y0 + _DY[s], x0 + _DX[s]
+    y3, x3 = y0, x0
+    pts = []
+    while True:
+        s_end = s
+        while True:
+            s += 1
+            y4, x4 = y3 + _DY[s & 7], x3 + _DX[s & 7]
+            if img[y4, x4] != 0:
+                break
+        s &= 7
+        if s != 0 and s - 1 < s_end:
+            img[y3, x3] = -126
+        elif img[y3, x3] == 1:
+            img[y3, x3] = 2
+        pts.append((x3, y3))
+        if (y4, x4) == (y0, x0) and (y3, x3) == (y1, x1):
+            return pts
+        y3, x3 = y4, x4
+        s = (s + 4) & 7
+
+
+def find_external_borders(binary: np.ndarray):
+    """``cv2.findContours(binary, RETR_EXTERNAL, CHAIN_APPROX_NONE)[-2]``: list of (N, 1, 2) int32 (x, y) arrays,
+    newest border first (OpenCV links every new contour at the head of its sibling list)."""
+    b = np.asarray(binary) != 0
+    h, w = b.shape
+    img = np.zeros((h + 2, w + 2), dtype=np.int8)
+    img[1:-1, 1:-1] = b
+    found = []
+    for y in range(1, h + 1):
+        prev, lnbd = 0, 0
+        for x in range(1, w + 1):
+            p = int(img[y, x])
+            if prev == 0 and p == 1 and lnbd <= 0:
+                pts = _follow_border(img, y, x)
+                found.append(np.array(pts, dtype=np.int32).reshape(-1, 1, 2) - 1)
+                p = int(img[y, x])
+            if p not in (0, 1):
+                lnbd = p
+            prev = p
+    return found[::-1]
+
+
+def extract_outlines_cellpose(label_image: np.ndarray):
+    """R/masks.py:68-79 with ``outlines_list`` inlined (see the note above: parity unpinned)."""
+    lab = np.asarray(label_image)
+    outlines = []
+    for n in np.unique(lab)[1:]:
+        mn = lab == n
+        if mn.sum() > 0:
+            contours = find_external_borders(mn)
+            cmax = int(np.argmax([c.shape[0] for c in contours]))
+            pix = contours[cmax].astype(int).squeeze()
+            outlines.append(pix if len(pix) > 4 else np.zeros((0, 2)))
+    return [o[:, [1, 0]] if len(o) > 0 else o for o in outlines]

@@ -174,9 +174,9 @@ def test_segmentation_mask_disks(golden):
         assert SegmentationMask(labels, property_names=["label", "area"]).centroids_yx.shape == (0, 2)
     sub = SegmentationMask(labels, property_names=["label", "circularity"]).cell_properties
     assert list(sub.keys()) == ["label", "circularity"]
-    with pytest.raises(NotImplementedError, match="cellpose"):
-        sm.cell_outlines  # default extractor = cellpose / OpenCV: refused loudly, never approximated
     from oracle import contours
+
+    assert len(sm.cell_outlines) == sm.num_cells  # default extractor = border following (test below)
 
     sk = SegmentationMask(labels, outline_extractor="skimage")
     outs = sk.cell_outlines
@@ -286,6 +286,50 @@ def test_cell_outlines_golden_and_random(golden):
         for a, b in zip(outs, ref):
             assert a.shape == b.shape and np.array_equal(a, b), t
     assert hipops.cell_outlines(ctx.asarray(np.zeros((8, 8), np.int32)), 1) == []
+
+
+def test_cell_outlines_border_following():
+    """The reference's default outline extractor (R/masks.py:68-79, cellpose.utils.outlines_list -> OpenCV
+    findContours) on the device against oracle/contours.py (PARITY UNPINNED there: no OpenCV offline): random
+    component labellings, labels with several components and holes, planes without background, and through
+    SegmentationMask with its default ``outline_extractor``."""
+    import scipy.ndimage as ndi
+
+    from arcadia_microscopy_tools_amd import hipops
+    from arcadia_microscopy_tools_amd.channels import DAPI
+    from arcadia_microscopy_tools_amd.device import get_context
+    from arcadia_microscopy_tools_amd.masks import SegmentationMask
+    from oracle import contours
+
+    ctx = get_context()
+    rng = np.random.default_rng(21)
+    for t in range(40):
+        h, w = rng.integers(3, 48, 2)
+        kind = t % 4
+        if kind == 0:
+            lab = ndi.label(rng.random((h, w)) < rng.uniform(0.2, 0.8), structure=np.ones((3, 3)))[0]
+        elif kind == 1:
+            lab = rng.integers(0, 4, (h, w))
+        elif kind == 2:
+            lab = rng.integers(1, 4, (h, w))
+        else:
+            lab = ndi.label(ndi.binary_opening(rng.random((h, w)) < 0.7))[0]
+        lab = lab.astype(np.int32)
+        outs = hipops.cell_outlines_borders(ctx.asarray(lab), max(int(lab.max()), 1))
+        ref = contours.extract_outlines_cellpose(lab)
+        assert len(outs) == len(ref), t
+        for a, b in zip(outs, ref):
+            assert a.shape == b.shape and a.dtype == b.dtype and np.array_equal(a, b), t
+    assert hipops.cell_outlines_borders(ctx.asarray(np.zeros((8, 8), np.int32)), 1) == []
+    yy, xx = np.mgrid[:64, :64]
+    lab = np.zeros((64, 64), np.int64)
+    lab[(yy - 20) ** 2 + (xx - 20) ** 2 < 64] = 1
+    lab[(yy - 44) ** 2 + (xx - 40) ** 2 < 100] = 2
+    mask = SegmentationMask(lab, {DAPI: np.zeros((64, 64), np.uint16)})
+    assert mask.outline_extractor == "cellpose"
+    outs, ref = mask.cell_outlines, contours.extract_outlines_cellpose(lab)
+    assert len(outs) == 2 and all(np.array_equal(a, b) for a, b in zip(outs, ref))
+    assert outs[0].dtype == np.int64 and outs[0].min() >= 0 and outs[0].max() < 64
 
 
 def test_fov_feeder_double_buffer():

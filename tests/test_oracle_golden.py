@@ -208,6 +208,43 @@ def test_contours_oracle_vs_skimage(golden):
             assert o.shape == ref.shape and np.array_equal(o, ref), (name, i)
 
 
+def test_border_outlines_oracle_known_answers():
+    """oracle/contours.py, the "cellpose" extractor (R/masks.py:68-79).  PARITY UNPINNED: OpenCV / cellpose are not
+    installable here and the reference's tests hold no vector; these are the documented behaviours of
+    cv2.findContours(RETR_EXTERNAL, CHAIN_APPROX_NONE) the restatement is held to: a filled rectangle starts at its
+    top-left pixel and runs down the left side first, a one-pixel line is walked there and back (2n - 2 points),
+    holes and components nested in them are not reported, borders of fewer than five points are dropped."""
+    from oracle import contours
+
+    a = np.zeros((5, 5), np.uint8)
+    a[1:4, 1:4] = 1
+    (c,) = contours.find_external_borders(a)
+    assert c.shape == (8, 1, 2) and c.dtype == np.int32
+    assert c.reshape(-1, 2).tolist() == [[1, 1], [1, 2], [1, 3], [2, 3], [3, 3], [3, 2], [3, 1], [2, 1]]
+    line = np.zeros((3, 7), np.uint8)
+    line[1, 1:6] = 1
+    assert contours.find_external_borders(line)[0].reshape(-1, 2)[:, 0].tolist() == [1, 2, 3, 4, 5, 4, 3, 2]
+    ring = np.zeros((9, 9), np.uint8)
+    ring[1:8, 1:8] = 1
+    ring[3:6, 3:6] = 0
+    ring[4, 4] = 1
+    assert [len(c) for c in contours.find_external_borders(ring)] == [24]
+    two = np.zeros((6, 12), np.uint8)
+    two[1:3, 1:3] = 1
+    two[2:5, 6:10] = 1
+    assert [len(c) for c in contours.find_external_borders(two)] == [10, 4]  # newest first
+    lab = np.zeros((12, 12), np.int64)
+    lab[1:3, 1:3] = 1  # four border points: dropped
+    lab[5:9, 4:9] = 2
+    lab[10, 10] = 3
+    outs = contours.extract_outlines_cellpose(lab)
+    assert [o.shape for o in outs] == [(0, 2), (14, 2), (0, 2)]
+    assert outs[1][0].tolist() == [5, 4] and outs[1][1].tolist() == [6, 4]  # (y, x), down the left side
+    full = np.ones((4, 4), np.int64)
+    full[:, 2:] = 2
+    assert len(contours.extract_outlines_cellpose(full)) == 1  # np.unique(masks)[1:] drops label 1 here
+
+
 def test_blending_oracle_vs_matplotlib(golden):
     """oracle/blending.py against matplotlib 3.10.8: colour tables and composited canvases."""
     from oracle import blending as ob
