@@ -150,3 +150,64 @@ class PlateTables:
         nc = g[:, self.n_table + self.n_itable: self.n_table + self.n_itable + n * 4].contiguous().view(
             torch.int32).view(world, n)
         return t, it, nc
+
+
+def well_id(fov_index: int, n_columns: int = 24, fovs_per_well: int = 1) -> str:
+    """Well of a field of view for row-major acquisition: FOV 0 -> "A01" ... FOV 383 -> "P24" on a 384-well
+    plate; same normalised form as the reference's ``Well.id`` (capital row letter + two-digit
+    column, R/microplate.py:24-45, columns 1..48, rows A..Z)."""
+    if fov_index < 0 or fovs_per_well <= 0 or not 1 <= n_columns <= 48:
+        raise ValueError(f"bad plate geometry: fov {fov_index}, {n_columns} columns, {fovs_per_well} FOVs per well")
+    row, col = divmod(int(fov_index) // fovs_per_well, n_columns)
+    if row >= 26:
+        raise ValueError(f"FOV {fov_index} is beyond row Z of a {n_columns}-column plate")
+    return f"{chr(ord('A') + row)}{col + 1:02d}"
+
+
+def plate_rows(table, itable, ncells, channel_names, fov_indices=None) -> np.ndarray:
+    """Dense per-plate blocks (``PlateTables.result()`` with the leading (rank, FOV) axes flattened) -> one packed
+    (total cells, ncols) float64 table in ``table_columns`` order, rows ordered by FOV then label; derived columns
+    (circularity, volume) exactly as ``cell_properties`` derives them (segment.assemble_cell_properties).
+
+    table (F, K, RP_NCOLS), itable (F, K, C, 4), ncells (F,): numpy arrays; fov_indices defaults to 0..F-1."""
+    from .segment import assemble_cell_properties
+
+    table, itable, ncells = np.asarray(table), np.asarray(itable), np.asarray(ncells)
+    F, K, ncol = table.shape
+    channel_names = list(channel_names)
+    if ncol != _hip.RP_NCOLS or itable.shape != (F, K, len(channel_names), 4) or ncells.shape != (F,):
+        raise ValueError("plate_rows: inconsistent block shapes")
+    if (ncells < 0).any() or (ncells > K).any():
+        raise ValueError("plate_rows: a field of view overflowed its max_cells slot")
+    fov_indices = list(range(F)) if fov_indices is None else [int(i) for i in fov_indices]
+    tables = [assemble_cell_properties(table[f, : ncells[f]], itable[f, : ncells[f]], channel_names)
+              for f in range(F)]
+    return pack_rows(fov_indices, tables, channel_names)
+
+
+def plate_dataframe(rows: np.ndarray, channel_names, n_columns: int = 24, fovs_per_well: int = 1, layout=None):
+    """Packed plate table -> pandas DataFrame keyed by well: columns ``well_id``, ``fov_index``, ``label``, the
+    morphology and per-channel intensity columns of ``table_columns``; with ``layout`` (any mapping
+    well id -> object with ``sample`` / ``properties``, e.g. the reference's ``MicroplateLayout``,
+    R/microplate.py:94-183) the well's sample and properties are joined as extra columns."""
+    import pandas as pd
+
+    cols = table_columns(channel_names)
+    rows = np.asarray(rows, dtype=np.float64)
+    if rows.ndim != 2 or rows.shape[1] != len(cols):
+        raise ValueError(f"expected a (rows, {len(cols)}) table, got {rows.shape}")
+    df = pd.DataFrame(rows, columns=cols)
+    df["fov_index"] = df["fov_index"].astype(np.int64)
+    df["label"] = df["label"].astype(np.int64)
+    df.insert(0, "well_id", [well_id(i, n_columns, fovs_per_well) for i in df["fov_index"]])
+    if layout is not None:
+        samples, props = [], {}
+        for n, w in enumerate(df["well_id"]):
+            well = layout[w] if w in layout else None
+            samples.append(getattr(well, "sample", "") if well is not None else "")
+            for k, v in (getattr(well, "properties", {}) or {}).items() if well is not None else ():
+                props.setdefault(k, [None] * len(df))[n] = v
+        df["sample"] = samples
+        for k, v in props.items():
+            df[k] = v
+    return df

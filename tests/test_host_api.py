@@ -297,3 +297,39 @@ def test_plate_sharding_and_packing():
     t = {c: np.arange(3, dtype=float) for c in cols[1:]}
     rows = plate.pack_rows([5], [t], ("DAPI", "FITC"))
     assert rows.shape == (3, len(cols)) and (rows[:, 0] == 5).all() and rows[2, 1] == 2
+
+
+def test_plate_well_keyed_export():
+    """Dense plate blocks -> packed rows -> well-keyed DataFrame (well ids in the
+    reference's normalised form, R/microplate.py:24-45)."""
+    from arcadia_microscopy_tools_amd import _hip, plate
+    from arcadia_microscopy_tools_amd.segment import assemble_cell_properties
+
+    assert [plate.well_id(i) for i in (0, 23, 24, 383)] == ["A01", "A24", "B01", "P24"]
+    assert plate.well_id(9, n_columns=12, fovs_per_well=4) == "A03"
+    with pytest.raises(ValueError):
+        plate.well_id(26 * 24)
+    rng = np.random.default_rng(0)
+    F, K, chans = 4, 6, ["DAPI", "FITC"]
+    table = rng.random((F, K, _hip.RP_NCOLS)) + 1.0
+    itable = rng.random((F, K, 2, 4))
+    ncells = np.array([3, 0, 6, 1])
+    rows = plate.plate_rows(table, itable, ncells, chans, fov_indices=[0, 1, 24, 383])
+    cols = plate.table_columns(chans)
+    assert rows.shape == (10, len(cols))
+    one = assemble_cell_properties(table[2, :6], itable[2, :6], chans)
+    blk = rows[rows[:, 0] == 24]
+    assert np.array_equal(blk[:, 1], np.arange(1, 7))
+    for name in ("area", "circularity", "volume", "intensity_std_fitc"):
+        assert np.array_equal(blk[:, cols.index(name)], one[name])
+    with pytest.raises(ValueError, match="overflowed"):
+        plate.plate_rows(table, itable, np.array([3, 0, 7, 1]), chans)
+
+    class _Well:
+        def __init__(self, sample, properties):
+            self.sample, self.properties = sample, properties
+
+    df = plate.plate_dataframe(rows, chans, layout={"A01": _Well("ctrl", {"dose": 1.0})})
+    assert list(df.columns[:3]) == ["well_id", "fov_index", "label"] and len(df) == 10
+    assert df["well_id"].tolist() == ["A01"] * 3 + ["B01"] * 6 + ["P24"]
+    assert df["sample"].tolist()[:4] == ["ctrl", "ctrl", "ctrl", ""] and df["dose"].iloc[0] == 1.0
