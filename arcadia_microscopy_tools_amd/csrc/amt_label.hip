@@ -431,16 +431,18 @@ int amt_i_propagate_roots(amt_ctx* ctx, int* A, const int* L, const int* rootlis
     return AMT_OK;
 }
 
-// compress the listed tile roots and count the component roots of every RN_CHUNK-pixel chunk (what the raster
-// renumbering scans); blockcnt must be zero on entry
+// compress the listed tile roots, count the component roots of every RN_CHUNK-pixel chunk (what the raster
+// renumbering scans) and set the root's bit in the plane's root bitmap; blockcnt and bitmap must be zero on entry
 __global__ void __launch_bounds__(256) roots_compress_count_kernel(int* __restrict__ Lall, const int* __restrict__ rootlist,
                                                                    const int* __restrict__ nroots,
-                                                                   int* __restrict__ blockcnt, size_t cap, size_t n,
-                                                                   int nblk) {
+                                                                   int* __restrict__ blockcnt,
+                                                                   unsigned long long* __restrict__ bitmap, size_t cap,
+                                                                   size_t n, int nblk) {
     const int plane = blockIdx.z, shard = plane * gridDim.y + blockIdx.y;
     int* L = Lall + (size_t)plane * n;
     const int cnt = nroots[shard] < (int)cap ? nroots[shard] : (int)cap;
     const int* lst = rootlist + (size_t)shard * cap;
+    unsigned long long* bm = bitmap + (size_t)plane * ((n + 63) / 64);
     for (int k = blockIdx.x * 256 + threadIdx.x; k < cnt; k += gridDim.x * 256) {
         const int t = lst[k];
         int r = L[t];
@@ -449,8 +451,36 @@ __global__ void __launch_bounds__(256) roots_compress_count_kernel(int* __restri
             r = p;
             p = L[r];
         }
-        if (r != t) L[t] = r;
-        else atomicAdd(&blockcnt[(size_t)plane * nblk + t / RN_CHUNK], 1);
+        if (r != t) {
+            L[t] = r;
+        } else {
+            atomicAdd(&blockcnt[(size_t)plane * nblk + t / RN_CHUNK], 1);
+            atomicOr(&bm[t >> 6], 1ull << (t & 63));
+        }
+    }
+}
+
+// T[t] = raster rank (1-based) of the component of every listed tile root t: roots before the root's chunk
+// (scanned counts) + set bits of the root bitmap before the root inside its chunk.  Only the lists are read, not
+// the label plane.
+__global__ void __launch_bounds__(256) roots_rank_kernel(int* __restrict__ Tall, const int* __restrict__ Lall,
+                                                         const int* __restrict__ rootlist, const int* __restrict__ nroots,
+                                                         const int* __restrict__ blockoff,
+                                                         const unsigned long long* __restrict__ bitmap, size_t cap,
+                                                         size_t n, int nblk) {
+    const int plane = blockIdx.z, shard = plane * gridDim.y + blockIdx.y;
+    int* T = Tall + (size_t)plane * n;
+    const int* L = Lall + (size_t)plane * n;
+    const int cnt = nroots[shard] < (int)cap ? nroots[shard] : (int)cap;
+    const int* lst = rootlist + (size_t)shard * cap;
+    const unsigned long long* bm = bitmap + (size_t)plane * ((n + 63) / 64);
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < cnt; k += gridDim.x * 256) {
+        const int t = lst[k], r = L[t];
+        const int chunk = r / RN_CHUNK, wr = r >> 6;
+        int rank = blockoff[(size_t)plane * nblk + chunk] + 1;
+        for (int w = chunk * (RN_CHUNK / 64); w < wr; ++w) rank += __popcll(bm[w]);
+        rank += __popcll(bm[wr] & ((1ull << (r & 63)) - 1ull));
+        T[t] = rank;
     }
 }
 
@@ -502,15 +532,19 @@ extern "C" int amt_label(amt_ctx* ctx, const void* in, int in_dtype, int32_t* ou
     const int trows = amt_i_tile_rows(H);
     const size_t cap = amt_i_rootlist_cap(W);
     const size_t nlist = (size_t)nplanes * trows;
+    const size_t nwords = (n + 63) / 64;
     AMT_TRY(amt_arena_begin(ctx, 2 * amt_align((size_t)nplanes * n * 4) + amt_align(nlist * cap * 4) +
-                                     amt_align((size_t)nplanes * nblk * 4) + amt_align(nlist * 4)));
+                                     amt_align((size_t)nplanes * nblk * 4) + amt_align(nlist * 4) +
+                                     amt_align((size_t)nplanes * nwords * 8)));
     int* L = arena_take_t<int>(ctx, (size_t)nplanes * n);
     int* T = arena_take_t<int>(ctx, (size_t)nplanes * n);
     int* rootlist = arena_take_t<int>(ctx, nlist * cap);
     int* blk = arena_take_t<int>(ctx, (size_t)nplanes * nblk);
     int* nroots = arena_take_t<int>(ctx, nlist);
+    unsigned long long* bitmap = arena_take_t<unsigned long long>(ctx, (size_t)nplanes * nwords);
     AMT_HIP_CHECK(hipMemsetAsync(blk, 0, (size_t)nplanes * nblk * 4, ctx->stream));
     AMT_HIP_CHECK(hipMemsetAsync(nroots, 0, nlist * 4, ctx->stream));
+    AMT_HIP_CHECK(hipMemsetAsync(bitmap, 0, (size_t)nplanes * nwords * 8, ctx->stream));
     // tile-local union-find + seams; only the listed tile roots are compressed, pixels resolve in two hops
     if (in_dtype == AMT_U8) {
         if (connectivity == 2)
@@ -524,10 +558,13 @@ extern "C" int amt_label(amt_ctx* ctx, const void* in, int in_dtype, int32_t* ou
             AMT_TRY((ccl_tileroots<int32_t, false>(ctx, (const int32_t*)in, L, rootlist, nroots, nplanes, H, W)));
     }
     hipLaunchKernelGGL(roots_compress_count_kernel, dim3(4, trows, nplanes), dim3(256), 0, ctx->stream, L, rootlist,
-                       nroots, blk, cap, n, nblk);
+                       nroots, blk, bitmap, cap, n, nblk);
     AMT_LAUNCH_CHECK();
-    AMT_TRY(amt_i_rank_roots(ctx, L, T, blk, count_dev, nplanes, n));
-    AMT_TRY(amt_i_propagate_roots(ctx, T, L, rootlist, nroots, nplanes, H, W));
+    // raster numbering from the lists alone: scan the per-chunk root counts, then rank every listed tile root
+    AMT_TRY(amt_scan_excl(ctx, blk, nblk, (size_t)nblk, count_dev, nplanes));
+    hipLaunchKernelGGL(roots_rank_kernel, dim3(4, trows, nplanes), dim3(256), 0, ctx->stream, T, L, rootlist, nroots,
+                       blk, bitmap, cap, n, nblk);
+    AMT_LAUNCH_CHECK();
     dim3 g1(amt_grid_for(n, 1024, 4096), nplanes);
     hipLaunchKernelGGL(apply_rank_kernel, g1, dim3(256), 0, ctx->stream, L, T, out, n);
     AMT_LAUNCH_CHECK();
