@@ -674,9 +674,22 @@ __global__ void __launch_bounds__(256) map_labels_kernel(const int* __restrict__
                                                          int* __restrict__ out, size_t n, int max_label) {
     const size_t base = (size_t)blockIdx.y * n;
     const int* M = map + (size_t)blockIdx.y * (max_label + 1);
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        int v = in[base + i];
-        out[base + i] = (v > 0 && v <= max_label) ? M[v] : 0;
+    const unsigned ml = (unsigned)max_label;
+    for (size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i0 < n; i0 += (size_t)gridDim.x * 1024) {
+        if (i0 + 3 < n && ((base + i0) & 3) == 0) {
+            const int4 v = *reinterpret_cast<const int4*>(in + base + i0);
+            int4 o;  // v - 1 < max_label as unsigned  <=>  1 <= v <= max_label
+            o.x = (unsigned)(v.x - 1) < ml ? M[v.x] : 0;
+            o.y = (unsigned)(v.y - 1) < ml ? M[v.y] : 0;
+            o.z = (unsigned)(v.z - 1) < ml ? M[v.z] : 0;
+            o.w = (unsigned)(v.w - 1) < ml ? M[v.w] : 0;
+            *reinterpret_cast<int4*>(out + base + i0) = o;
+        } else {
+            for (size_t i = i0; i < n && i < i0 + 4; ++i) {
+                const int v = in[base + i];
+                out[base + i] = (unsigned)(v - 1) < ml ? M[v] : 0;
+            }
+        }
     }
 }
 
