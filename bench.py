@@ -39,13 +39,14 @@ STAGE_BYTES_PER_PX = {
 
 # kernels (name prefixes in the rocprofv3 output) that make up each stage of the chain
 STAGE_KERNELS = {
-    "gaussian": ("gauss_fused_kernel", "conv_v8_kernel", "conv_h8_kernel"),
+    "gaussian": ("gauss_lds_kernel", "gauss_fused_kernel", "conv_v8_kernel", "conv_h8_kernel"),
     "otsu": ("hist_f64_kernel", "otsu_f64_kernel", "minmax_"),
     "threshold_open_close": ("pack_gt_kernel", "toc_fused_kernel", "packed_prim_kernel", "unpack_kernel"),
     "edt": ("edt_rows_kernel", "edt_cols_kernel"),
     "peaks": ("peaks_tile_kernel",),
     "markers": ("sp_",),
-    "watershed": ("ccl_", "ws_"),
+    "watershed": ("ccl_", "ws_", "roots_"),
+    "label8": ("ccl_", "roots_", "apply_rank_kernel"),
     "clear_border": ("presence_", "frame_mark_kernel", "drop_flagged_kernel", "map_labels_kernel"),
     "regionprops": ("rp_",),
 }
