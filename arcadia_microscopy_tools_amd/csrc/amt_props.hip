@@ -241,94 +241,102 @@ __global__ void __launch_bounds__(64) rp_label_kernel(const int* __restrict__ la
     }
 }
 
-// perimeter: border pixels (4-neighbourhood, outside = background) and their 3x3 weighted codes.
-constexpr int PT_H = 32, PT_W = 64;
-// With `bbox` the kernel also folds the bounding boxes (same per-run atomics as rp_bbox_kernel) from the tile it
-// has staged anyway, which spares the morphology path a separate pass over the label image.
-__global__ void __launch_bounds__(256) rp_perimeter_kernel(const int* __restrict__ labels, u64* __restrict__ acc, int H,
-                                                           int W, int max_label, int* __restrict__ bbox) {
-    __shared__ int lab[(PT_H + 4) * (PT_W + 4)];
-    __shared__ uint8_t bor[(PT_H + 2) * (PT_W + 2)];
-    const int x0 = blockIdx.x * PT_W, y0 = blockIdx.y * PT_H;
-    const size_t n = (size_t)H * W;
+// perimeter: border pixels (4-neighbourhood, outside = background) and their 3x3 weighted codes
+// (SK/measure/_regionprops_utils.py:186-249); with `bbox` the kernel also folds the bounding boxes (per-run
+// atomics, only for runs that can be an extreme of their label), which spares the morphology path a separate
+// pass over the label image.
+// No LDS and no barrier: a wave owns a strip of PR_IN columns (+ 2 halo columns on
+// either side = 64 lanes) and slides down PR_ROWS rows (+ 2 halo rows above / below) with a three-row window in
+// registers.  Horizontal neighbours come from DPP wave shifts, the "is a border pixel" flag rides in bit 31 of the
+// label (w = v | flag), so "neighbour is a border pixel of MY label" is one compare, w(q) == w(p).  Rows whose
+// whole window is background skip everything.  Loads are issued 17 rows ahead of their use.
+constexpr int PR_ROWS = 64, PR_IN = 60, PR_BATCH = 17, PR_NBATCH = (PR_ROWS + 4) / PR_BATCH;
+static_assert(PR_BATCH * PR_NBATCH == PR_ROWS + 4, "row batches must tile the strip");
+
+__device__ __forceinline__ int from_left(int v) {  // lane i <- lane i - 1 (lane 0 <- 0): DPP wave_shr:1
+    return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ int from_right(int v) {  // lane i <- lane i + 1 (lane 63 <- 0): DPP wave_shl:1
+    return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false);
+}
+
+__global__ void __launch_bounds__(256) rp_perimeter_rows_kernel(const int* __restrict__ labels, u64* __restrict__ acc,
+                                                                int H, int W, int max_label, int* __restrict__ bbox) {
+    const int lane = threadIdx.x & 63;
+    const int strip = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (strip * PR_IN >= W) return;  // whole wave; the kernel has no barrier
     const int plane = blockIdx.z;
+    const size_t n = (size_t)H * W;
     const int* L = labels + (size_t)plane * n;
-    constexpr int LP = PT_W + 4, BP = PT_W + 2;
-    {
-        // staging: wave w owns tile rows w, w + 4, ...: 64 centre columns + 4 halo columns; every load of the wave
-        // is issued before the first LDS store
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        constexpr int RPW = (PT_H + 4) / 4;
-        int vc[RPW], vh[RPW];
-        const int kxh = lane < 2 ? lane : PT_W + lane;  // halo column of lanes 0..3
-        const int xh = x0 - 2 + kxh, xc = x0 + lane;
+    const int x = strip * PR_IN - 2 + lane;
+    const int y0 = blockIdx.y * PR_ROWS;
+    const bool xin = x >= 0 && x < W;
+    const bool inner = xin && lane >= 2 && lane < 2 + PR_IN;
+    const unsigned ml = (unsigned)max_label;
+    u64* accp = acc + (size_t)plane * max_label * A_NACC;
+    int* bbp = bbox ? bbox + (size_t)plane * max_label * 4 : nullptr;
+
+    int cur[PR_BATCH], nxt[PR_BATCH];
 #pragma unroll
-        for (int j = 0; j < RPW; ++j) {
-            const int y = y0 - 2 + wave + 4 * j;
-            const bool yok = y >= 0 && y < H;
-            vc[j] = (yok && xc < W) ? L[(size_t)y * W + xc] : 0;
-            vh[j] = (yok && lane < 4 && xh >= 0 && xh < W) ? L[(size_t)y * W + xh] : 0;
-        }
-#pragma unroll
-        for (int j = 0; j < RPW; ++j) {
-            const int ky = wave + 4 * j;
-            lab[ky * LP + 2 + lane] = (vc[j] < 0 || vc[j] > max_label) ? 0 : vc[j];
-            if (lane < 4) lab[ky * LP + kxh] = (vh[j] < 0 || vh[j] > max_label) ? 0 : vh[j];
-        }
+    for (int j = 0; j < PR_BATCH; ++j) {
+        const int y = y0 - 2 + j;
+        cur[j] = (xin && y >= 0 && y < H) ? L[(size_t)y * W + x] : 0;
     }
-    __syncthreads();
-    if (bbox) {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // window: v1 / v2 = label rows r-1 / r-2 (+ their horizontal neighbours), wA / wB = flagged rows r-2 / r-3
+    int v1 = 0, v1l = 0, v1r = 0, v2 = 0, v2l = 0, v2r = 0;
+    int wA = 0, wAl = 0, wAr = 0, wB = 0, wBl = 0, wBr = 0;
+    for (int b = 0; b < PR_NBATCH; ++b) {
+        if (b + 1 < PR_NBATCH) {
 #pragma unroll
-        for (int j = 0; j < PT_H / 4; ++j) {
-            const int ky = wave + 4 * j;
-            const int y = y0 + ky, x = x0 + lane;
-            const int lv = (y < H && x < W) ? lab[(ky + 2) * LP + 2 + lane] : 0;
-            const int left = __shfl_up(lv, 1);
-            const bool head = (lane == 0) || (left != lv);
-            const u64 heads = __ballot(head);
-            if (lv != 0 && head) {
-                const u64 later = heads & ~((2ull << lane) - 1ull);
-                const int end_lane = later ? (__ffsll((long long)later) - 2) : 63;
-                int* B = bbox + ((size_t)plane * max_label + (lv - 1)) * 4;
-                // an end of the run is an extreme of the label only if no pixel of the label lies beyond it in the
-                // rows above / below (the tile's halo shows them): most runs of a blob touch no side of its box
-                const int* c = lab + (ky + 2) * LP + 2 + lane;       // head pixel
-                const int* e = c + (end_lane - lane);                 // last pixel of the run
-                if (c[-LP] != lv) atomicMin(&B[0], y);
-                if (c[LP] != lv) atomicMax(&B[2], y);
-                if (c[-LP - 1] != lv && c[LP - 1] != lv) atomicMin(&B[1], x);
-                if (e[-LP + 1] != lv && e[LP + 1] != lv) atomicMax(&B[3], x + (end_lane - lane));
+            for (int j = 0; j < PR_BATCH; ++j) {
+                const int y = y0 - 2 + (b + 1) * PR_BATCH + j;
+                nxt[j] = (xin && y >= 0 && y < H) ? L[(size_t)y * W + x] : 0;
             }
         }
-    }
-    for (int i = threadIdx.x; i < (PT_H + 2) * BP; i += 256) {
-        int ky = i / BP, kx = i - ky * BP;  // position (y0-1+ky, x0-1+kx) == lab index (ky+1, kx+1)
-        const int* c = lab + (ky + 1) * LP + (kx + 1);
-        int v = c[0];
-        bor[i] = (v != 0 && (c[-LP] != v || c[LP] != v || c[-1] != v || c[1] != v)) ? 1 : 0;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < PT_H * PT_W; i += 256) {
-        int ky = i / PT_W, kx = i - ky * PT_W;
-        int y = y0 + ky, x = x0 + kx;
-        if (y >= H || x >= W) continue;
-        const int v = lab[(ky + 2) * LP + (kx + 2)];
-        const uint8_t* b = bor + (ky + 1) * BP + (kx + 1);
-        if (v == 0 || !b[0]) continue;
-        const int* c = lab + (ky + 2) * LP + (kx + 2);
-        int code = 1;
-        code += 2 * ((b[-BP] && c[-LP] == v) + (b[BP] && c[LP] == v) + (b[-1] && c[-1] == v) + (b[1] && c[1] == v));
-        code += 10 * ((b[-BP - 1] && c[-LP - 1] == v) + (b[-BP + 1] && c[-LP + 1] == v) +
-                      (b[BP - 1] && c[LP - 1] == v) + (b[BP + 1] && c[LP + 1] == v));
-        int cls = -1;
-        switch (code) {
-            case 5: case 7: case 15: case 17: case 25: case 27: cls = A_C1; break;
-            case 21: case 33: cls = A_C2; break;
-            case 13: case 23: cls = A_C3; break;
-            default: break;
+#pragma unroll
+        for (int j = 0; j < PR_BATCH; ++j) {
+            const int r = y0 - 2 + b * PR_BATCH + j;  // row of v0
+            int v0 = cur[j];
+            v0 = (unsigned)(v0 - 1) < ml ? v0 : 0;
+            if (__ballot((v0 | v1 | v2 | wB) != 0) == 0ull) continue;  // uniform: the window stays all zero
+            const int v0l = from_left(v0), v0r = from_right(v0);
+            // flagged row r-1
+            const bool b1 = v1 != 0 && (v2 != v1 || v0 != v1 || v1l != v1 || v1r != v1);
+            const int w1 = b1 ? (v1 | (int)0x80000000) : v1;
+            const int w1l = from_left(w1), w1r = from_right(w1);
+            // bounding box: runs of row r-1 (above v2, below v0)
+            const int yb = r - 1;
+            if (bbp && inner && v1 != 0 && yb >= y0 && yb < y0 + PR_ROWS) {
+                int* B = bbp + (size_t)(v1 - 1) * 4;
+                if (v1l != v1) {  // head of a run
+                    if (v2 != v1) atomicMin(&B[0], yb);
+                    if (v0 != v1) atomicMax(&B[2], yb);
+                    if (v2l != v1 && v0l != v1) atomicMin(&B[1], x);
+                }
+                if (v1r != v1 && v2r != v1 && v0r != v1) atomicMax(&B[3], x);  // tail of a run
+            }
+            // perimeter code of row r-2 (centre wA, above wB, below w1)
+            const int yo = r - 2;
+            if (inner && wA < 0 && yo >= y0 && yo < y0 + PR_ROWS) {
+                const int key = wA;
+                const int code = 1 + 2 * ((wB == key) + (w1 == key) + (wAl == key) + (wAr == key)) +
+                                 10 * ((wBl == key) + (wBr == key) + (w1l == key) + (w1r == key));
+                int cls = -1;
+                switch (code) {
+                    case 5: case 7: case 15: case 17: case 25: case 27: cls = A_C1; break;
+                    case 21: case 33: cls = A_C2; break;
+                    case 13: case 23: cls = A_C3; break;
+                    default: break;
+                }
+                if (cls >= 0) atomicAdd(&accp[(size_t)((key & 0x7fffffff) - 1) * A_NACC + cls], 1ull);
+            }
+            wB = wA, wBl = wAl, wBr = wAr;
+            wA = w1, wAl = w1l, wAr = w1r;
+            v2 = v1, v2l = v1l, v2r = v1r;
+            v1 = v0, v1l = v0l, v1r = v0r;
         }
-        if (cls >= 0) atomicAdd(&acc[((size_t)plane * max_label + (v - 1)) * A_NACC + cls], 1ull);
+#pragma unroll
+        for (int j = 0; j < PR_BATCH; ++j) cur[j] = nxt[j];
     }
 }
 
@@ -544,8 +552,9 @@ static int regionprops_common(amt_ctx* ctx, const int32_t* labels, const uint16_
     hipLaunchKernelGGL(rp_init_kernel, dim3(amt_grid_for(nlab, 256, 1024)), dim3(256), 0, ctx->stream, acc, bbox, nlab);
     AMT_LAUNCH_CHECK();
     if (want_morph) {  // the perimeter pass stages every label tile anyway: it folds the bounding boxes too
-        dim3 gper((W + PT_W - 1) / PT_W, (H + PT_H - 1) / PT_H, nplanes);
-        hipLaunchKernelGGL(rp_perimeter_kernel, gper, dim3(256), 0, ctx->stream, labels, acc, H, W, max_label, bbox);
+        const int nstrips = (W + PR_IN - 1) / PR_IN;
+        dim3 gper((nstrips + 3) / 4, (H + PR_ROWS - 1) / PR_ROWS, nplanes);
+        hipLaunchKernelGGL(rp_perimeter_rows_kernel, gper, dim3(256), 0, ctx->stream, labels, acc, H, W, max_label, bbox);
     } else {
         hipLaunchKernelGGL(rp_bbox_kernel, dim3((W + 63) / 64, (H + 31) / 32, nplanes), dim3(256), 0, ctx->stream,
                            labels, bbox, H, W, max_label);
