@@ -132,79 +132,92 @@ extern "C" int amt_edt(amt_ctx* ctx, const uint8_t* mask, int32_t* d2_out, doubl
 // ---- peak mask ---------------------------------------------------------------------------------
 // peaks = (d2 == maximum_filter(d2, size=2m+1, mode='constant' (0))) & mask & (d2 > 0), border m cleared
 // (comparing the integer d2 is equivalent to comparing sqrt(d2)).
-// "d2 equals the window maximum" == "nothing in the window exceeds d2", so no maximum image is built:
-// one 256-thread block stages a 32 x 64 tile of d2 plus a halo of m in LDS; a pixel is first compared with
-// its 8 neighbours (which rejects all but a few percent of the foreground), and only the survivors scan the
-// full (2m+1)^2 window with early exit.  Tiles without any d2 > 0 exit after the staging pass.
-constexpr int PK_H = 64, PK_W = 64, PK_MAXM = 16;
-__global__ void __launch_bounds__(256) peaks_tile_kernel(const int* __restrict__ d2, const uint8_t* __restrict__ mask,
+// "d2 equals the window maximum" == "nothing in the window exceeds d2", so no maximum image is built: a pixel
+// is first compared with its 8 neighbours (which rejects all but a few per nucleus), and only the survivors look
+// at the full (2m+1)^2 window.
+constexpr int PK_MAXM = 16;
+// No LDS: a wave slides a three-row register window down a strip of PKR_IN columns (+ one halo
+// column on either side); the 8-neighbour pre-test uses DPP wave shifts, and the few survivors (a handful per
+// nucleus) are checked one at a time by the WHOLE wave: 64 lanes read the (2m+1)^2 window straight from global
+// memory (L2 hits: the strip has just streamed those rows) and vote.  The host clears `peaks` first; only peak
+// pixels are written.
+constexpr int PKR_ROWS = 64, PKR_IN = 62, PKR_BATCH = 22, PKR_NBATCH = (PKR_ROWS + 2) / PKR_BATCH;
+static_assert(PKR_BATCH * PKR_NBATCH == PKR_ROWS + 2, "row batches must tile the strip");
+
+__device__ __forceinline__ int pk_from_left(int v) {  // lane i <- lane i - 1 (lane 0 <- 0): DPP wave_shr:1
+    return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ int pk_from_right(int v) {  // lane i <- lane i + 1 (lane 63 <- 0): DPP wave_shl:1
+    return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false);
+}
+
+__global__ void __launch_bounds__(256) peaks_rows_kernel(const int* __restrict__ d2, const uint8_t* __restrict__ mask,
                                                          uint8_t* __restrict__ peaks, int H, int W, int m) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int TW = PK_W + 2 * m, TH = PK_H + 2 * m;
-    int* tile = reinterpret_cast<int*>(smem_raw);  // TH x TW
-    const int x0 = blockIdx.x * PK_W, y0 = blockIdx.y * PK_H;
+    const int lane = threadIdx.x & 63;
+    const int strip = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (strip * PKR_IN >= W) return;  // whole wave; the kernel has no barrier
     const size_t base = (size_t)blockIdx.z * H * W;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int local_any = 0;
-    // staging: wave w owns tile rows w, w + 4, ...: the 64 centre columns (aligned, coalesced) and the 2m halo
-    // columns; ALL loads of a wave are issued before the first LDS store (TH <= 64, i.e. <= 16 rows per wave)
-    constexpr int RPW = (PK_H + 2 * PK_MAXM + 3) / 4;
-    int vc[RPW], vh[RPW];
-    const int kxh = lane < m ? lane : PK_W + lane;  // halo column of lanes < 2m
-    const int xh = x0 - m + kxh;
+    const int* D = d2 + base;
+    const int x = strip * PKR_IN - 1 + lane;
+    const int y0 = blockIdx.y * PKR_ROWS;
+    const bool xin = x >= 0 && x < W;
+    const bool xok = xin && lane >= 1 && lane <= PKR_IN && x >= m && x < W - m;  // output lane inside the cleared frame
+    const int side = 2 * m + 1, wsize = side * side;
+
+    int cur[PKR_BATCH], nxt[PKR_BATCH];
 #pragma unroll
-    for (int j = 0; j < RPW; ++j) {
-        const int ky = wave + 4 * j;
-        const int y = y0 - m + ky;
-        const bool yok = ky < TH && y >= 0 && y < H;
-        const int x = x0 + lane;
-        vc[j] = (yok && x < W) ? d2[base + (size_t)y * W + x] : 0;  // constant 0 outside the image
-        vh[j] = (yok && lane < 2 * m && xh >= 0 && xh < W) ? d2[base + (size_t)y * W + xh] : 0;
+    for (int j = 0; j < PKR_BATCH; ++j) {
+        const int y = y0 - 1 + j;
+        cur[j] = (xin && y >= 0 && y < H) ? D[(size_t)y * W + x] : 0;  // constant 0 outside the image
     }
+    // window: v1 = row r-1 (the centre row of this step) with its neighbours, h2 = 3-wide maximum of row r-2
+    int v1 = 0, v1l = 0, v1r = 0, h1 = 0, h2 = 0;
+    for (int b = 0; b < PKR_NBATCH; ++b) {
+        if (b + 1 < PKR_NBATCH) {
 #pragma unroll
-    for (int j = 0; j < RPW; ++j) {
-        const int ky = wave + 4 * j;
-        if (ky < TH) {
-            tile[ky * TW + m + lane] = vc[j];
-            if (lane < 2 * m) tile[ky * TW + kxh] = vh[j];
-            if (vc[j] > 0 && ky >= m && ky < TH - m) local_any = 1;
-        }
-    }
-    const int any_fg = __syncthreads_or(local_any);
-    // each thread owns 4 consecutive pixels of a row: 16 threads per row, 16 rows per pass
-    const int kx4 = (threadIdx.x & 15) * 4;
-    for (int ky = threadIdx.x >> 4; ky < PK_H; ky += 16) {
-        const int y = y0 + ky;
-        if (y >= H) break;
-        unsigned packed = 0;
-        if (any_fg) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int kx = kx4 + i, x = x0 + kx;
-                const int* c = tile + (ky + m) * TW + (kx + m);
-                const int v = c[0];
-                if (v > 0 && y >= m && y < H - m && x >= m && x < W - m) {
-                    bool gt = false;
-                    if (m >= 1)
-                        gt = c[-1] > v || c[1] > v || c[-TW] > v || c[TW] > v || c[-TW - 1] > v || c[-TW + 1] > v ||
-                             c[TW - 1] > v || c[TW + 1] > v;
-                    if (!gt && mask[base + (size_t)y * W + x]) {
-                        for (int dy = -m; dy <= m && !gt; ++dy) {
-                            const int* row = c + dy * TW;
-                            for (int dx = -m; dx <= m; ++dx) gt |= row[dx] > v;
-                        }
-                        if (!gt) packed |= 1u << (8 * i);
-                    }
-                }
+            for (int j = 0; j < PKR_BATCH; ++j) {
+                const int y = y0 - 1 + (b + 1) * PKR_BATCH + j;
+                nxt[j] = (xin && y >= 0 && y < H) ? D[(size_t)y * W + x] : 0;
             }
         }
-        const int x = x0 + kx4;
-        uint8_t* o = peaks + base + (size_t)y * W + x;
-        if (x + 3 < W && ((reinterpret_cast<uintptr_t>(o) & 3) == 0)) {
-            *reinterpret_cast<unsigned*>(o) = packed;
-        } else {
-            for (int i = 0; i < 4 && x + i < W; ++i) o[i] = (packed >> (8 * i)) & 1u;
+#pragma unroll
+        for (int j = 0; j < PKR_BATCH; ++j) {
+            const int r = y0 - 1 + b * PKR_BATCH + j;  // row of v0
+            const int v0 = cur[j];
+            if (__ballot(v0 > 0 || v1 > 0) == 0ull) {  // uniform: no candidate in row r-1, nothing to carry from row r
+                h2 = h1, h1 = 0, v1 = 0, v1l = 0, v1r = 0;  // (non-positive values never beat a candidate)
+                continue;
+            }
+            const int v0l = pk_from_left(v0), v0r = pk_from_right(v0);
+            int h0 = v0 > v0l ? v0 : v0l;
+            h0 = h0 > v0r ? h0 : v0r;
+            const int yc = r - 1;  // centre row
+            bool cand = xok && v1 > 0 && yc >= y0 && yc < y0 + PKR_ROWS && yc >= m && yc < H - m;
+            if (m >= 1) {
+                int nb = h0 > h2 ? h0 : h2;
+                nb = nb > v1l ? nb : v1l;
+                nb = nb > v1r ? nb : v1r;
+                cand = cand && !(nb > v1);
+            }
+            unsigned long long todo = __ballot(cand);
+            while (todo) {  // uniform: one survivor at a time, the whole wave reads its window
+                const int sl = __ffsll((long long)todo) - 1;
+                todo &= todo - 1ull;
+                const int sv = __shfl(v1, sl);
+                const int sx = strip * PKR_IN - 1 + sl;
+                bool gt = false;
+                for (int k = lane; k < wsize; k += 64) {
+                    const int dy = k / side, dx = k - dy * side;
+                    gt |= D[(size_t)(yc - m + dy) * W + (sx - m + dx)] > sv;  // inside the image: the frame is cleared
+                }
+                if (__ballot(gt) == 0ull && lane == sl && mask[base + (size_t)yc * W + sx])
+                    peaks[base + (size_t)yc * W + sx] = 1;
+            }
+            h2 = h1, h1 = h0;
+            v1 = v0, v1l = v0l, v1r = v0r;
         }
+#pragma unroll
+        for (int j = 0; j < PKR_BATCH; ++j) cur[j] = nxt[j];
     }
 }
 
@@ -216,9 +229,10 @@ extern "C" int amt_peak_mask(amt_ctx* ctx, const int32_t* d2, const uint8_t* mas
                 min_distance, PK_MAXM);
     if (nplanes == 0) return AMT_OK;
     const int m = min_distance;
-    const size_t smem = (size_t)(PK_H + 2 * m) * (PK_W + 2 * m) * sizeof(int);
-    dim3 grid((W + PK_W - 1) / PK_W, (H + PK_H - 1) / PK_H, nplanes);
-    hipLaunchKernelGGL(peaks_tile_kernel, grid, dim3(256), smem, ctx->stream, d2, mask, peaks, H, W, m);
+    AMT_HIP_CHECK(hipMemsetAsync(peaks, 0, (size_t)nplanes * H * W, ctx->stream));
+    const int nstrips = (W + PKR_IN - 1) / PKR_IN;
+    dim3 grid((nstrips + 3) / 4, (H + PKR_ROWS - 1) / PKR_ROWS, nplanes);
+    hipLaunchKernelGGL(peaks_rows_kernel, grid, dim3(256), 0, ctx->stream, d2, mask, peaks, H, W, m);
     AMT_LAUNCH_CHECK();
     return AMT_OK;
 }

@@ -230,6 +230,32 @@ def test_edt_peaks(ctx, ops, golden):
         assert np.array_equal(e.numpy(), skops.distance_transform_edt(mm)), shape
 
 
+def test_peak_mask_random(ctx, ops):
+    """peak_mask against scipy's maximum_filter formulation (oracle/skops.py:peak_markers) on integer
+    reliefs with plateaus and ties, every strip / row-block boundary, m = 0, 1, 5, 16, masks unrelated to the
+    relief, two planes per call."""
+    import scipy.ndimage as ndi
+
+    rng = np.random.default_rng(77)
+    cases = [((70, 130), 5, 40), ((129, 63), 1, 6), ((64, 62), 0, 3), ((200, 190), 16, 1000), ((33, 300), 5, 3),
+             ((131, 125), 2, 2)]
+    for shape, m, hi in cases:
+        d2 = rng.integers(0, hi + 1, size=(2,) + shape).astype(np.int32)
+        d2[1] = (ndi.uniform_filter(d2[1].astype(np.float64), 5) * 3).astype(np.int32)  # smooth ridges and plateaus
+        d2[0][rng.random(shape) < 0.3] = 0
+        mask = rng.random((2,) + shape) < 0.8
+        pk = ops.peak_mask(ctx.asarray(d2), ctx.asarray(mask), m).numpy().astype(bool)
+        for b in range(2):
+            size = 2 * m + 1
+            ref = (d2[b] == ndi.maximum_filter(d2[b], size=size, mode="constant")) & mask[b] & (d2[b] > 0)
+            if m > 0:
+                ref[:m, :] = False
+                ref[-m:, :] = False
+                ref[:, :m] = False
+                ref[:, -m:] = False
+            assert np.array_equal(pk[b], ref), (shape, m, b)
+
+
 def test_watershed(ctx, ops, golden):
     from oracle import skops
     from oracle.watershed import watershed
