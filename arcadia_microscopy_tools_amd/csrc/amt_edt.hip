@@ -7,14 +7,14 @@
 //                     either side of a pixel is a clz / ffs on its own word, walking to further words only
 //                     across solid 64-pixel stretches.  g is stored as uint16 (sides are <= 32768).
 //   pass 2 (columns): d2(y,x) = min_k (k^2 + g(y+-k,x)^2), scanning k outward while k^2 < best.  A block
-//                     stages 64 columns x (32 + 2*24) rows of g in LDS; only searches deeper than the halo
+//                     stages 64 columns x (64 + 2*16) rows of g in LDS; only searches deeper than the halo
 //                     continue in HBM (coalesced: a wave reads 64 consecutive x of row y+-k).
 // Both searches are exact and cost O(distance) per pixel, which is what nuclei-sized objects need; they
 // degrade (never fail) on very large solid regions.
 #include "amt_internal.h"
 
 constexpr unsigned G_INF = 0xFFFFu;  // no zero pixel in this row
-constexpr int EC_ROWS = 32, EC_HALO = 24, EC_TROWS = EC_ROWS + 2 * EC_HALO;
+constexpr int EC_ROWS = 64, EC_HALO = 16, EC_TROWS = EC_ROWS + 2 * EC_HALO;
 
 __global__ void __launch_bounds__(256) edt_rows_kernel(const uint8_t* __restrict__ mask, unsigned short* __restrict__ g,
                                                        int H, int W) {
