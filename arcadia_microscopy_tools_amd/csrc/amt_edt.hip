@@ -51,6 +51,68 @@ __global__ void __launch_bounds__(256) edt_rows_kernel(const uint8_t* __restrict
     }
 }
 
+// Rows whose width is a multiple of 8 (and 16-byte aligned planes): a thread owns 8 consecutive pixels -- one
+// 8-byte load, the "is zero" flags of its bytes by carry arithmetic, one byte of the row's flag words in LDS; the
+// nearest zero left of the group (clz) and right of it (ffs) seed a forward and a backward sweep over the 8
+// pixels, and the 8 distances leave in one 16-byte store.
+__global__ void __launch_bounds__(256) edt_rows8_kernel(const uint8_t* __restrict__ mask, unsigned short* __restrict__ g,
+                                                        int H, int W) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    unsigned long long* zw = reinterpret_cast<unsigned long long*>(smem_raw);  // zero flags, 64 pixels per word
+    uint8_t* zb = reinterpret_cast<uint8_t*>(smem_raw);
+    const size_t base = ((size_t)blockIdx.y * H + blockIdx.x) * W;
+    const int nw = (W + 63) / 64, nb = W >> 3;
+    for (int b = nb + threadIdx.x; b < nw * 8; b += 256) zb[b] = 0;  // beyond W: "not zero"
+    for (int b = threadIdx.x; b < nb; b += 256) {
+        const unsigned long long v = *reinterpret_cast<const unsigned long long*>(mask + base + (size_t)b * 8);
+        unsigned long long t = (v & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full;
+        t = ~(t | v | 0x7f7f7f7f7f7f7f7full);                          // 0x80 in every zero byte
+        zb[b] = (uint8_t)(((t >> 7) * 0x0102040810204080ull) >> 56);   // bit i = byte i is zero
+    }
+    __syncthreads();
+    constexpr unsigned BIG = 0x20000u;  // > any distance inside a row (sides are <= 32768)
+    for (int b = threadIdx.x; b < nb; b += 256) {
+        const int x0 = b * 8, wi = x0 >> 6, bit0 = x0 & 63;
+        const unsigned long long own = zw[wi];
+        const unsigned z8 = (unsigned)(own >> bit0) & 0xffu;
+        uint4 out = make_uint4(0u, 0u, 0u, 0u);
+        if (z8 != 0xffu) {
+            unsigned dl = BIG, dr = BIG;  // distance of pixel x0 to the nearest zero left of the group / of x0+7 right
+            unsigned long long m = own & ((1ull << bit0) - 1ull);
+            int w = wi;
+            while (m == 0 && w > 0) m = zw[--w];
+            if (m) dl = (unsigned)(x0 - (w * 64 + 63 - __clzll((long long)m)));
+            const int sh = bit0 + 8;
+            m = sh == 64 ? 0ull : (own >> sh) << sh;
+            w = wi;
+            while (m == 0 && w + 1 < nw) m = zw[++w];
+            if (m) dr = (unsigned)(w * 64 + __ffsll((long long)m) - 1 - (x0 + 7));
+            unsigned L[8], R[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const unsigned prev = i == 0 ? dl : L[i - 1] + 1u;
+                L[i] = ((z8 >> i) & 1u) ? 0u : (prev < BIG ? prev : BIG);
+            }
+#pragma unroll
+            for (int i = 7; i >= 0; --i) {
+                const unsigned nxt = i == 7 ? dr : R[i + 1] + 1u;
+                R[i] = ((z8 >> i) & 1u) ? 0u : (nxt < BIG ? nxt : BIG);
+            }
+            unsigned d[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const unsigned mn = L[i] < R[i] ? L[i] : R[i];
+                d[i] = mn >= G_INF ? G_INF : mn;
+            }
+            out.x = d[0] | (d[1] << 16);
+            out.y = d[2] | (d[3] << 16);
+            out.z = d[4] | (d[5] << 16);
+            out.w = d[6] | (d[7] << 16);
+        }
+        *reinterpret_cast<uint4*>(g + base + x0) = out;
+    }
+}
+
 __global__ void __launch_bounds__(256) edt_cols_kernel(const unsigned short* __restrict__ g, int* __restrict__ d2_out,
                                                        double* __restrict__ edt_out, int H, int W) {
     __shared__ unsigned short tile[EC_TROWS][64];
@@ -120,8 +182,12 @@ extern "C" int amt_edt(amt_ctx* ctx, const uint8_t* mask, int32_t* d2_out, doubl
     const size_t n = (size_t)H * W;
     AMT_TRY(amt_arena_begin(ctx, amt_align((size_t)nplanes * n * 2)));
     unsigned short* g = arena_take_t<unsigned short>(ctx, (size_t)nplanes * n);
-    hipLaunchKernelGGL(edt_rows_kernel, dim3(H, nplanes), dim3(256), (size_t)((W + 63) / 64) * 8, ctx->stream, mask, g,
-                       H, W);
+    if ((W & 7) == 0 && (reinterpret_cast<uintptr_t>(mask) & 7) == 0)  // g comes from the arena: 256-byte aligned
+        hipLaunchKernelGGL(edt_rows8_kernel, dim3(H, nplanes), dim3(256), (size_t)((W + 63) / 64) * 8, ctx->stream, mask,
+                           g, H, W);
+    else
+        hipLaunchKernelGGL(edt_rows_kernel, dim3(H, nplanes), dim3(256), (size_t)((W + 63) / 64) * 8, ctx->stream, mask,
+                           g, H, W);
     AMT_LAUNCH_CHECK();
     hipLaunchKernelGGL(edt_cols_kernel, dim3((W + 63) / 64, (H + EC_ROWS - 1) / EC_ROWS, nplanes), dim3(256), 0,
                        ctx->stream, g, d2_out, edt_out, H, W);

@@ -223,7 +223,8 @@ def test_edt_peaks(ctx, ops, golden):
     assert np.array_equal(markers.numpy(), g["markers"])
     # random masks incl. rows/columns without background, thick blobs
     rng = np.random.default_rng(8)
-    for shape, p in (((50, 64), 0.9), ((97, 33), 0.97), ((40, 40), 0.5)):
+    for shape, p in (((50, 64), 0.9), ((97, 33), 0.97), ((40, 40), 0.5), ((60, 72), 0.995), ((31, 136), 0.9),
+                     ((20, 2056), 0.999)):
         mm = rng.random(shape) < p
         mm[0, 0] = False
         d2, e = ops.edt(ctx.asarray(mm))
