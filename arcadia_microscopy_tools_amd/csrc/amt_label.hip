@@ -74,6 +74,19 @@ struct ccl_wide<int32_t> {
     static constexpr long long NOVAL = -(1ll << 40);
 };
 
+// value of the neighbouring lane by DPP wave shift (VALU, no LDS crossbar): lane 0 / lane 63 receive 0, every
+// caller masks those lanes out itself
+__device__ __forceinline__ int lane_left(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ int lane_right(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false); }
+__device__ __forceinline__ long long lane_left(long long v) {
+    const unsigned lo = (unsigned)lane_left((int)(unsigned)v), hi = (unsigned)lane_left((int)(v >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ long long lane_right(long long v) {
+    const unsigned lo = (unsigned)lane_right((int)(unsigned)v), hi = (unsigned)lane_right((int)(v >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+
 __device__ __forceinline__ int lds_find(int* S, int a) {
     int p = __hip_atomic_load(&S[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     while (p != a) {
@@ -103,13 +116,13 @@ __device__ __forceinline__ void lds_union(int* S, int a, int b) {
 // LDS = true: L is the tile's LDS array and `pitch` = 64; otherwise L is the plane in HBM and pitch = W.
 template <bool CONN8, bool LDS, typename V>
 __device__ __forceinline__ void ccl_stitch_rows(int* L, int p, int pitch, int lane, V v, V up, V noval) {
-    const V w = __shfl_up(v, 1), upw = __shfl_up(up, 1);
+    const V w = lane_left(v), upw = lane_left(up);
     const bool head = lane == 0 || w != v;
     const bool up_head = lane == 0 || upw != up;
     V e = 0, upe = 0;
     if (CONN8) {
-        e = __shfl_down(v, 1);
-        upe = __shfl_down(up, 1);
+        e = lane_right(v);
+        upe = lane_right(up);
     }
     if (v == 0 || v == noval) return;
     int q = -1;
@@ -137,7 +150,7 @@ template <typename T, bool CONN8>
 __global__ void __launch_bounds__(256) ccl_tile_kernel(const T* __restrict__ in, int* __restrict__ Lall, int H, int W,
                                                        int* __restrict__ rootlist, int* __restrict__ nroots,
                                                        size_t cap) {
-    __shared__ int S[TILE_R * 64];
+    __shared__ __attribute__((aligned(16))) int S[TILE_R * 64];
     typedef typename ccl_wide<T>::type V;
     constexpr V NOVAL = ccl_wide<T>::NOVAL;
     __shared__ V vlast[4][64];
@@ -158,7 +171,7 @@ __global__ void __launch_bounds__(256) ccl_tile_kernel(const T* __restrict__ in,
     }
 #pragma unroll
     for (int k = 0; k < STRIP_R; ++k) {
-        const V left = __shfl_up(v[k], 1);
+        const V left = lane_left(v[k]);
         const bool head = (lane == 0) || (left != v[k]);
         const unsigned long long heads = __ballot(head);
         const unsigned long long upto = heads & ((2ull << lane) - 1ull);
@@ -187,6 +200,8 @@ __global__ void __launch_bounds__(256) ccl_tile_kernel(const T* __restrict__ in,
             const int r = lds_find(S, own);
             if (r != own) S[own] = r;
             is_root = r == own;
+        } else {
+            S[own] = -1;  // background / outside: no find ever walks through these slots
         }
         if (rootlist) wroots += __popcll(__ballot(is_root));
     }
@@ -199,31 +214,47 @@ __global__ void __launch_bounds__(256) ccl_tile_kernel(const T* __restrict__ in,
         }
     }
     __syncthreads();
-    // Phase B: write the labels (global index of the tile root) and append the roots in (wave, row, lane) order
+    // Phase B: write the labels (global index of the tile root) and append the roots.  A lane now owns FOUR
+    // consecutive pixels of a row of its wave's strip (one 16-byte LDS read, one 16-byte store); the roots are
+    // appended in (wave, row group, pixel-of-four, lane) order, which is as arbitrary as any other.
     int run = 0;
     if (rootlist) {
         run = s_base;
         for (int w2 = 0; w2 < wave; ++w2) run += s_wroots[w2];
     }
+    const int c4 = (lane & 15) * 4, rsub = lane >> 4;
+    const int xg = x0 + c4;
 #pragma unroll
-    for (int k = 0; k < STRIP_R; ++k) {
-        const int y = ty0 + r0 + k;
-        const int own = (r0 + k) * 64 + lane;
-        const bool inside = x < W && y < H;
-        int out = -1;
-        if (inside && v[k] != 0) {
-            const int r = S[own];
-            out = (ty0 + (r >> 6)) * W + x0 + (r & 63);
-        }
-        if (inside) L[(size_t)y * W + x] = out;
-        if (rootlist) {
-            const bool is_root = out >= 0 && S[own] == own;
-            const unsigned long long m = __ballot(is_root);
-            if (is_root) {
-                const size_t pos = (size_t)run + __popcll(m & ((1ull << lane) - 1ull));
-                if (pos < cap) rootlist[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * cap + pos] = out;
+    for (int j = 0; j < STRIP_R / 4; ++j) {
+        const int row = r0 + rsub + 4 * j;
+        const int y = ty0 + row;
+        const int own0 = row * 64 + c4;
+        const int4 r4 = *reinterpret_cast<const int4*>(&S[own0]);
+        const int rr[4] = {r4.x, r4.y, r4.z, r4.w};
+        int o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = rr[i] >= 0 ? (ty0 + (rr[i] >> 6)) * W + x0 + (rr[i] & 63) : -1;
+        if (y < H) {
+            const size_t idx = (size_t)y * W + xg;
+            if (xg + 3 < W && (((size_t)blockIdx.z * n + idx) & 3) == 0) {
+                *reinterpret_cast<int4*>(L + idx) = make_int4(o[0], o[1], o[2], o[3]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (xg + i < W) L[idx + i] = o[i];
             }
-            run += __popcll(m);
+        }
+        if (rootlist) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool is_root = rr[i] == own0 + i;  // only foreground pixels inside the image point at themselves
+                const unsigned long long m = __ballot(is_root);
+                if (is_root) {
+                    const size_t pos = (size_t)run + __popcll(m & ((1ull << lane) - 1ull));
+                    if (pos < cap) rootlist[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * cap + pos] = o[i];
+                }
+                run += __popcll(m);
+            }
         }
     }
 }
