@@ -210,13 +210,6 @@ constexpr int PK_MAXM = 16;
 constexpr int PKR_ROWS = 64, PKR_IN = 62, PKR_BATCH = 22, PKR_NBATCH = (PKR_ROWS + 2) / PKR_BATCH;
 static_assert(PKR_BATCH * PKR_NBATCH == PKR_ROWS + 2, "row batches must tile the strip");
 
-__device__ __forceinline__ int pk_from_left(int v) {  // lane i <- lane i - 1 (lane 0 <- 0): DPP wave_shr:1
-    return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false);
-}
-__device__ __forceinline__ int pk_from_right(int v) {  // lane i <- lane i + 1 (lane 63 <- 0): DPP wave_shl:1
-    return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false);
-}
-
 __global__ void __launch_bounds__(256) peaks_rows_kernel(const int* __restrict__ d2, const uint8_t* __restrict__ mask,
                                                          uint8_t* __restrict__ peaks, int H, int W, int m) {
     const int lane = threadIdx.x & 63;
@@ -254,7 +247,7 @@ __global__ void __launch_bounds__(256) peaks_rows_kernel(const int* __restrict__
                 h2 = h1, h1 = 0, v1 = 0, v1l = 0, v1r = 0;  // (non-positive values never beat a candidate)
                 continue;
             }
-            const int v0l = pk_from_left(v0), v0r = pk_from_right(v0);
+            const int v0l = amt_lane_left(v0), v0r = amt_lane_right(v0);
             int h0 = v0 > v0l ? v0 : v0l;
             h0 = h0 > v0r ? h0 : v0r;
             const int yc = r - 1;  // centre row

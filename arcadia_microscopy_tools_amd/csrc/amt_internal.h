@@ -93,3 +93,19 @@ int amt_i_propagate_roots(amt_ctx* ctx, int* A, const int* L, const int* rootlis
 // blk = scratch of nplanes * amt_i_rank_blocks(n) ints.
 int amt_i_rank_blocks(size_t n);
 int amt_i_rank_roots(amt_ctx* ctx, const int* L, int* T, int* blk, int* count_dev, int nplanes, size_t n);
+
+// Value of the neighbouring lane by DPP wave shift (a VALU move, no LDS crossbar as ds_bpermute needs): lane 0 of
+// amt_lane_left / lane 63 of amt_lane_right receive 0, every caller masks those lanes itself.  All 64 lanes must be
+// active (call from wave-uniform control flow only).
+#ifdef __HIPCC__
+__device__ __forceinline__ int amt_lane_left(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ int amt_lane_right(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false); }
+__device__ __forceinline__ long long amt_lane_left(long long v) {
+    const unsigned lo = (unsigned)amt_lane_left((int)(unsigned)v), hi = (unsigned)amt_lane_left((int)(v >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ long long amt_lane_right(long long v) {
+    const unsigned lo = (unsigned)amt_lane_right((int)(unsigned)v), hi = (unsigned)amt_lane_right((int)(v >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+#endif

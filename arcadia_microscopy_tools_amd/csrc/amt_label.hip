@@ -74,19 +74,6 @@ struct ccl_wide<int32_t> {
     static constexpr long long NOVAL = -(1ll << 40);
 };
 
-// value of the neighbouring lane by DPP wave shift (VALU, no LDS crossbar): lane 0 / lane 63 receive 0, every
-// caller masks those lanes out itself
-__device__ __forceinline__ int lane_left(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }
-__device__ __forceinline__ int lane_right(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false); }
-__device__ __forceinline__ long long lane_left(long long v) {
-    const unsigned lo = (unsigned)lane_left((int)(unsigned)v), hi = (unsigned)lane_left((int)(v >> 32));
-    return (long long)(((unsigned long long)hi << 32) | lo);
-}
-__device__ __forceinline__ long long lane_right(long long v) {
-    const unsigned lo = (unsigned)lane_right((int)(unsigned)v), hi = (unsigned)lane_right((int)(v >> 32));
-    return (long long)(((unsigned long long)hi << 32) | lo);
-}
-
 __device__ __forceinline__ int lds_find(int* S, int a) {
     int p = __hip_atomic_load(&S[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     while (p != a) {
@@ -116,13 +103,13 @@ __device__ __forceinline__ void lds_union(int* S, int a, int b) {
 // LDS = true: L is the tile's LDS array and `pitch` = 64; otherwise L is the plane in HBM and pitch = W.
 template <bool CONN8, bool LDS, typename V>
 __device__ __forceinline__ void ccl_stitch_rows(int* L, int p, int pitch, int lane, V v, V up, V noval) {
-    const V w = lane_left(v), upw = lane_left(up);
+    const V w = amt_lane_left(v), upw = amt_lane_left(up);
     const bool head = lane == 0 || w != v;
     const bool up_head = lane == 0 || upw != up;
     V e = 0, upe = 0;
     if (CONN8) {
-        e = lane_right(v);
-        upe = lane_right(up);
+        e = amt_lane_right(v);
+        upe = amt_lane_right(up);
     }
     if (v == 0 || v == noval) return;
     int q = -1;
@@ -171,7 +158,7 @@ __global__ void __launch_bounds__(256) ccl_tile_kernel(const T* __restrict__ in,
     }
 #pragma unroll
     for (int k = 0; k < STRIP_R; ++k) {
-        const V left = lane_left(v[k]);
+        const V left = amt_lane_left(v[k]);
         const bool head = (lane == 0) || (left != v[k]);
         const unsigned long long heads = __ballot(head);
         const unsigned long long upto = heads & ((2ull << lane) - 1ull);

@@ -253,13 +253,6 @@ __global__ void __launch_bounds__(64) rp_label_kernel(const int* __restrict__ la
 constexpr int PR_ROWS = 64, PR_IN = 60, PR_BATCH = 17, PR_NBATCH = (PR_ROWS + 4) / PR_BATCH;
 static_assert(PR_BATCH * PR_NBATCH == PR_ROWS + 4, "row batches must tile the strip");
 
-__device__ __forceinline__ int from_left(int v) {  // lane i <- lane i - 1 (lane 0 <- 0): DPP wave_shr:1
-    return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false);
-}
-__device__ __forceinline__ int from_right(int v) {  // lane i <- lane i + 1 (lane 63 <- 0): DPP wave_shl:1
-    return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false);
-}
-
 __global__ void __launch_bounds__(256) rp_perimeter_rows_kernel(const int* __restrict__ labels, u64* __restrict__ acc,
                                                                 int H, int W, int max_label, int* __restrict__ bbox) {
     const int lane = threadIdx.x & 63;
@@ -299,11 +292,11 @@ __global__ void __launch_bounds__(256) rp_perimeter_rows_kernel(const int* __res
             int v0 = cur[j];
             v0 = (unsigned)(v0 - 1) < ml ? v0 : 0;
             if (__ballot((v0 | v1 | v2 | wB) != 0) == 0ull) continue;  // uniform: the window stays all zero
-            const int v0l = from_left(v0), v0r = from_right(v0);
+            const int v0l = amt_lane_left(v0), v0r = amt_lane_right(v0);
             // flagged row r-1
             const bool b1 = v1 != 0 && (v2 != v1 || v0 != v1 || v1l != v1 || v1r != v1);
             const int w1 = b1 ? (v1 | (int)0x80000000) : v1;
-            const int w1l = from_left(w1), w1r = from_right(w1);
+            const int w1l = amt_lane_left(w1), w1r = amt_lane_right(w1);
             // bounding box: runs of row r-1 (above v2, below v0)
             const int yb = r - 1;
             if (bbp && inner && v1 != 0 && yb >= y0 && yb < y0 + PR_ROWS) {

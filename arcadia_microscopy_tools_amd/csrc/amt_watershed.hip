@@ -155,12 +155,12 @@ __global__ void __launch_bounds__(256) ws_stats_kernel(const int* __restrict__ d
         const int r = rs[k];
         const unsigned long long fg = __ballot(r >= 0);
         if (!fg) continue;  // uniform
-        const int left = __shfl_up(r, 1);
+        const int left = amt_lane_left(r);
         const bool head = r >= 0 && ((lane == 0) || (left != r));
         const int v = vs[k];
         bool cand = false;
         if (use_d2) {
-            const int vl = __shfl_up(v, 1), vr = __shfl_down(v, 1);
+            const int vl = amt_lane_left(v), vr = amt_lane_right(v);
             cand = r >= 0 && v > 0 && (lane == 0 || v >= vl) && (lane == 63 || v >= vr) &&
                    (k == 0 || v >= vs[k > 0 ? k - 1 : 0]) && (k == 7 || v >= vs[k < 7 ? k + 1 : 7]);
         }
