@@ -7,14 +7,15 @@
 //                     either side of a pixel is a clz / ffs on its own word, walking to further words only
 //                     across solid 64-pixel stretches.  g is stored as uint16 (sides are <= 32768).
 //   pass 2 (columns): d2(y,x) = min_k (k^2 + g(y+-k,x)^2), scanning k outward while k^2 < best.  A block
-//                     stages 64 columns x (64 + 2*16) rows of g in LDS; only searches deeper than the halo
+//                     stages 64 columns x (64 + 2*16) or (32 + 2*24) rows of g in LDS; only searches deeper than the halo
 //                     continue in HBM (coalesced: a wave reads 64 consecutive x of row y+-k).
 // Both searches are exact and cost O(distance) per pixel, which is what nuclei-sized objects need; they
 // degrade (never fail) on very large solid regions.
 #include "amt_internal.h"
 
 constexpr unsigned G_INF = 0xFFFFu;  // no zero pixel in this row
-constexpr int EC_ROWS = 64, EC_HALO = 16, EC_TROWS = EC_ROWS + 2 * EC_HALO;
+// column tiles: 64 rows + 2 x 16 halo rows for batches (least staging per output row), 32 + 2 x 24 when a call
+// has too few tiles to fill the chip (single planes)
 
 __global__ void __launch_bounds__(256) edt_rows_kernel(const uint8_t* __restrict__ mask, unsigned short* __restrict__ g,
                                                        int H, int W) {
@@ -113,8 +114,10 @@ __global__ void __launch_bounds__(256) edt_rows8_kernel(const uint8_t* __restric
     }
 }
 
+template <int EC_ROWS, int EC_HALO>
 __global__ void __launch_bounds__(256) edt_cols_kernel(const unsigned short* __restrict__ g, int* __restrict__ d2_out,
                                                        double* __restrict__ edt_out, int H, int W) {
+    constexpr int EC_TROWS = EC_ROWS + 2 * EC_HALO;
     __shared__ unsigned short tile[EC_TROWS][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x = blockIdx.x * 64 + lane;
@@ -189,8 +192,13 @@ extern "C" int amt_edt(amt_ctx* ctx, const uint8_t* mask, int32_t* d2_out, doubl
         hipLaunchKernelGGL(edt_rows_kernel, dim3(H, nplanes), dim3(256), (size_t)((W + 63) / 64) * 8, ctx->stream, mask,
                            g, H, W);
     AMT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(edt_cols_kernel, dim3((W + 63) / 64, (H + EC_ROWS - 1) / EC_ROWS, nplanes), dim3(256), 0,
-                       ctx->stream, g, d2_out, edt_out, H, W);
+    const size_t tiles64 = (size_t)((W + 63) / 64) * ((H + 63) / 64) * nplanes;
+    if (tiles64 >= 4096 && !edt_out)  // with the float64 output (sqrt + 8-byte stores) the shorter tiles measured faster
+        hipLaunchKernelGGL((edt_cols_kernel<64, 16>), dim3((W + 63) / 64, (H + 63) / 64, nplanes), dim3(256), 0,
+                           ctx->stream, g, d2_out, edt_out, H, W);
+    else
+        hipLaunchKernelGGL((edt_cols_kernel<32, 24>), dim3((W + 63) / 64, (H + 31) / 32, nplanes), dim3(256), 0,
+                           ctx->stream, g, d2_out, edt_out, H, W);
     AMT_LAUNCH_CHECK();
     return AMT_OK;
 }
