@@ -231,26 +231,28 @@ __global__ void __launch_bounds__(256) peaks_rows_kernel(const int* __restrict__
     const bool xok = xin && lane >= 1 && lane <= PKR_IN && x >= m && x < W - m;  // output lane inside the cleared frame
     const int side = 2 * m + 1, wsize = side * side;
 
+    // UNCONDITIONAL loads from clamped coordinates; positions outside the image become the constant 0 where the
+    // value is used (a select next to the load would be turned back into a branch around it, and the wait that
+    // comes with it serialises the loads)
+    const int xc = x < 0 ? 0 : (x < W ? x : W - 1);
+    auto load_row = [&](int y) -> int {
+        const int yc = y < 0 ? 0 : (y < H ? y : H - 1);
+        return D[(size_t)yc * W + xc];
+    };
     int cur[PKR_BATCH], nxt[PKR_BATCH];
 #pragma unroll
-    for (int j = 0; j < PKR_BATCH; ++j) {
-        const int y = y0 - 1 + j;
-        cur[j] = (xin && y >= 0 && y < H) ? D[(size_t)y * W + x] : 0;  // constant 0 outside the image
-    }
+    for (int j = 0; j < PKR_BATCH; ++j) cur[j] = load_row(y0 - 1 + j);
     // window: v1 = row r-1 (the centre row of this step) with its neighbours, h2 = 3-wide maximum of row r-2
     int v1 = 0, v1l = 0, v1r = 0, h1 = 0, h2 = 0;
     for (int b = 0; b < PKR_NBATCH; ++b) {
         if (b + 1 < PKR_NBATCH) {
 #pragma unroll
-            for (int j = 0; j < PKR_BATCH; ++j) {
-                const int y = y0 - 1 + (b + 1) * PKR_BATCH + j;
-                nxt[j] = (xin && y >= 0 && y < H) ? D[(size_t)y * W + x] : 0;
-            }
+            for (int j = 0; j < PKR_BATCH; ++j) nxt[j] = load_row(y0 - 1 + (b + 1) * PKR_BATCH + j);
         }
 #pragma unroll
         for (int j = 0; j < PKR_BATCH; ++j) {
             const int r = y0 - 1 + b * PKR_BATCH + j;  // row of v0
-            const int v0 = cur[j];
+            const int v0 = (xin && r >= 0 && r < H) ? cur[j] : 0;
             if (__ballot(v0 > 0 || v1 > 0) == 0ull) {  // uniform: no candidate in row r-1, nothing to carry from row r
                 h2 = h1, h1 = 0, v1 = 0, v1l = 0, v1r = 0;  // (non-positive values never beat a candidate)
                 continue;

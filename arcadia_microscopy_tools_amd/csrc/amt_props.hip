@@ -269,28 +269,30 @@ __global__ void __launch_bounds__(256) rp_perimeter_rows_kernel(const int* __res
     u64* accp = acc + (size_t)plane * max_label * A_NACC;
     int* bbp = bbox ? bbox + (size_t)plane * max_label * 4 : nullptr;
 
+    // UNCONDITIONAL loads from clamped coordinates; positions outside the image are zeroed where the value is
+    // used (a select next to the load would be turned back into a branch around it, and the wait that comes with
+    // it serialises the loads)
+    const int xc = x < 0 ? 0 : (x < W ? x : W - 1);
+    auto load_row = [&](int y) -> int {
+        const int yc = y < 0 ? 0 : (y < H ? y : H - 1);
+        return L[(size_t)yc * W + xc];
+    };
     int cur[PR_BATCH], nxt[PR_BATCH];
 #pragma unroll
-    for (int j = 0; j < PR_BATCH; ++j) {
-        const int y = y0 - 2 + j;
-        cur[j] = (xin && y >= 0 && y < H) ? L[(size_t)y * W + x] : 0;
-    }
+    for (int j = 0; j < PR_BATCH; ++j) cur[j] = load_row(y0 - 2 + j);
     // window: v1 / v2 = label rows r-1 / r-2 (+ their horizontal neighbours), wA / wB = flagged rows r-2 / r-3
     int v1 = 0, v1l = 0, v1r = 0, v2 = 0, v2l = 0, v2r = 0;
     int wA = 0, wAl = 0, wAr = 0, wB = 0, wBl = 0, wBr = 0;
     for (int b = 0; b < PR_NBATCH; ++b) {
         if (b + 1 < PR_NBATCH) {
 #pragma unroll
-            for (int j = 0; j < PR_BATCH; ++j) {
-                const int y = y0 - 2 + (b + 1) * PR_BATCH + j;
-                nxt[j] = (xin && y >= 0 && y < H) ? L[(size_t)y * W + x] : 0;
-            }
+            for (int j = 0; j < PR_BATCH; ++j) nxt[j] = load_row(y0 - 2 + (b + 1) * PR_BATCH + j);
         }
 #pragma unroll
         for (int j = 0; j < PR_BATCH; ++j) {
             const int r = y0 - 2 + b * PR_BATCH + j;  // row of v0
             int v0 = cur[j];
-            v0 = (unsigned)(v0 - 1) < ml ? v0 : 0;
+            v0 = (xin && r >= 0 && r < H && (unsigned)(v0 - 1) < ml) ? v0 : 0;
             if (__ballot((v0 | v1 | v2 | wB) != 0) == 0ull) continue;  // uniform: the window stays all zero
             const int v0l = amt_lane_left(v0), v0r = amt_lane_right(v0);
             // flagged row r-1
