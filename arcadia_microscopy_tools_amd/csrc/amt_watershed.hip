@@ -144,9 +144,15 @@ __global__ void __launch_bounds__(256) ws_stats_kernel(const int* __restrict__ d
         const size_t i = base + (size_t)(yb + k) * W + x;
         ms[k] = rs[k] >= 0 ? markers[i] : 0;
         vs[k] = 0;
-        if (use_d2 && rs[k] >= 0) {
-            const int d = d2[i];
-            vs[k] = d < 0 ? 0 : d;
+    }
+    if (use_d2) {
+        // raw values, nothing computed next to the loads (that would wait for each of them and serialise the
+        // rows); negative reliefs need no clamp: only v > 0 can be a candidate, and v >= neighbour holds for a
+        // negative neighbour exactly as it would for 0
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const size_t i = base + (size_t)(yb + k) * W + x;
+            vs[k] = rs[k] >= 0 ? d2[i] : 0;
         }
     }
     comp_row* prow = rows + (size_t)blockIdx.z * row_stride;
