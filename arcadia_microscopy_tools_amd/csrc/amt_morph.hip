@@ -18,31 +18,51 @@ constexpr int MAX_OFFS = 1024;
 
 constexpr int PACK_WORDS_PER_WAVE = 16;
 
-__global__ void __launch_bounds__(256) pack_kernel(const uint8_t* __restrict__ in, u64* __restrict__ packed, int H,
-                                                   int W, int WW) {
-    // a wave packs PACK_WORDS_PER_WAVE consecutive words of the (row-major) packed plane: lane i tests
-    // pixel word*64 + i of the word's row; the loads of all iterations are independent
+// A wave packs PACK_WORDS_PER_WAVE consecutive words of the (row-major) packed plane: lane i tests pixel
+// word * 64 + i of the word's row.  The word coordinates are wave-uniform and advance incrementally (no division per
+// word); every load is UNCONDITIONAL from clamped coordinates and nothing is computed from a value next to its load,
+// so all PACK_WORDS_PER_WAVE loads of a wave are in flight together (a test inside the bounds check would put a
+// wait behind each load).  TEST(value) decides the bit.
+template <typename T, typename TEST>
+__device__ __forceinline__ void pack_words(const T* __restrict__ src, u64* __restrict__ dst, int H, int W, int WW,
+                                           TEST test) {
     const int lane = threadIdx.x & 63;
-    const size_t plane = blockIdx.y;
-    const size_t nwords = (size_t)H * WW;
-    const size_t w0 = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * PACK_WORDS_PER_WAVE;
-    const uint8_t* src = in + plane * (size_t)H * W;
-    bool v[PACK_WORDS_PER_WAVE];
+    const unsigned nwords = (unsigned)H * (unsigned)WW;  // < 2^31: H, W <= 32768
+    const unsigned w0 = __builtin_amdgcn_readfirstlane((blockIdx.x * 4u + (threadIdx.x >> 6)) * PACK_WORDS_PER_WAVE);
+    if (w0 >= nwords) return;
+    const int y0 = (int)(w0 / (unsigned)WW), wx0 = (int)(w0 - (unsigned)y0 * (unsigned)WW);
+    T val[PACK_WORDS_PER_WAVE];
+    {
+        int y = y0, wx = wx0;
 #pragma unroll
-    for (int k = 0; k < PACK_WORDS_PER_WAVE; ++k) {
-        const size_t wi = w0 + k;
-        v[k] = false;
-        if (wi < nwords) {
-            const int y = (int)(wi / WW), wx = (int)(wi - (size_t)y * WW);
+        for (int k = 0; k < PACK_WORDS_PER_WAVE; ++k) {
+            const int yc = y < H ? y : H - 1;
             const int x = wx * 64 + lane;
-            v[k] = x < W && src[(size_t)y * W + x] != 0;
+            val[k] = src[(size_t)yc * W + (x < W ? x : W - 1)];
+            if (++wx == WW) {
+                wx = 0;
+                ++y;
+            }
         }
     }
+    int y = y0, wx = wx0;
 #pragma unroll
     for (int k = 0; k < PACK_WORDS_PER_WAVE; ++k) {
-        const u64 m = __ballot(v[k]);
-        if (lane == 0 && w0 + k < nwords) packed[plane * nwords + w0 + k] = m;
+        const bool inside = y < H && wx * 64 + lane < W;  // beyond W: bit 0
+        const u64 m = __ballot(inside && test(val[k]));
+        if (lane == 0 && y < H) dst[w0 + k] = m;
+        if (++wx == WW) {
+            wx = 0;
+            ++y;
+        }
     }
+}
+
+__global__ void __launch_bounds__(256) pack_kernel(const uint8_t* __restrict__ in, u64* __restrict__ packed, int H,
+                                                   int W, int WW) {
+    const size_t plane = blockIdx.y;
+    pack_words(in + plane * (size_t)H * W, packed + plane * (size_t)H * WW, H, W, WW,
+               [](uint8_t v) { return v != 0; });
 }
 
 // same packing, fused with the comparison `in > thr[plane]` (R/operations.py:216): the byte mask of the
@@ -50,28 +70,10 @@ __global__ void __launch_bounds__(256) pack_kernel(const uint8_t* __restrict__ i
 template <typename T>
 __global__ void __launch_bounds__(256) pack_gt_kernel(const T* __restrict__ in, const double* __restrict__ thr,
                                                       u64* __restrict__ packed, int H, int W, int WW) {
-    const int lane = threadIdx.x & 63;
     const size_t plane = blockIdx.y;
-    const size_t nwords = (size_t)H * WW;
-    const size_t w0 = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * PACK_WORDS_PER_WAVE;
-    const T* src = in + plane * (size_t)H * W;
     const double t = thr[plane];
-    bool v[PACK_WORDS_PER_WAVE];
-#pragma unroll
-    for (int k = 0; k < PACK_WORDS_PER_WAVE; ++k) {
-        const size_t wi = w0 + k;
-        v[k] = false;
-        if (wi < nwords) {
-            const int y = (int)(wi / WW), wx = (int)(wi - (size_t)y * WW);
-            const int x = wx * 64 + lane;
-            v[k] = x < W && (double)src[(size_t)y * W + x] > t;
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < PACK_WORDS_PER_WAVE; ++k) {
-        const u64 m = __ballot(v[k]);
-        if (lane == 0 && w0 + k < nwords) packed[plane * nwords + w0 + k] = m;
-    }
+    pack_words(in + plane * (size_t)H * W, packed + plane * (size_t)H * WW, H, W, WW,
+               [t](T v) { return (double)v > t; });
 }
 
 __device__ __forceinline__ unsigned spread4(unsigned nib) {
