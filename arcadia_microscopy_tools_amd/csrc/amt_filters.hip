@@ -259,10 +259,16 @@ __global__ void __launch_bounds__(256) gauss_fused_kernel(const TIn* __restrict_
     const int xm = amt_map_index(xg, W, mode);  // -1: outside in 'constant' mode
     for (int k = t; k < TH + 2 * R + 4; k += 256) ymap[k] = amt_map_index(y0 - R + k, H, mode);
     __syncthreads();
-    auto load_row = [&](int k) -> double {  // k = window row: image row y0 - R + k
+    // k = window row: image row y0 - R + k.  The load is UNCONDITIONAL from clamped coordinates and the conversion /
+    // cval substitution happens after the whole group has been issued (anything computed next to a conditional
+    // load puts a wait behind it and serialises the rows)
+    const int xmc = xm < 0 ? 0 : xm;
+    auto load_raw = [&](int k) -> TIn {
         const int yy = ymap[k];
-        if (yy < 0 || xm < 0) return cval;
-        return load_as_f64<TIn>(src, (size_t)yy * W + xm, scale);
+        return src[(size_t)(yy < 0 ? 0 : yy) * W + xmc];
+    };
+    auto to_sample = [&](TIn raw, int k) -> double {
+        return (ymap[k] < 0 || xm < 0) ? cval : load_as_f64<TIn>(&raw, 0, scale);
     };
     // axis-1 role of this thread: row q of a group, outputs 4 * seg .. 4 * seg + 3 of the block
     const int q = t >> 6, seg = t & 63;
@@ -309,12 +315,20 @@ __global__ void __launch_bounds__(256) gauss_fused_kernel(const TIn* __restrict_
     };
     // window of K + 3 samples: rows rg - R .. rg + R + 3 of the current group of four output rows
     double win[K + 3];
+    {
+        TIn raw[K - 1];
 #pragma unroll
-    for (int k = 0; k < K - 1; ++k) win[k] = load_row(k);
+        for (int k = 0; k < K - 1; ++k) raw[k] = load_raw(k);
+#pragma unroll
+        for (int k = 0; k < K - 1; ++k) win[k] = to_sample(raw[k], k);
+    }
     const int rows = (y0 + TH <= H) ? TH : (H - y0);
     for (int rg = 0; rg < rows; rg += 4) {
+        TIn raw4[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) win[K - 1 + i] = load_row(rg + 2 * R + i);  // four loads in flight
+        for (int i = 0; i < 4; ++i) raw4[i] = load_raw(rg + 2 * R + i);  // four loads in flight
+#pragma unroll
+        for (int i = 0; i < 4; ++i) win[K - 1 + i] = to_sample(raw4[i], rg + 2 * R + i);
         const int buf = (rg >> 2) & 1;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {

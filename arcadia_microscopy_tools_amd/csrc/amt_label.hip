@@ -151,10 +151,17 @@ __global__ void __launch_bounds__(256) ccl_tile_kernel(const T* __restrict__ in,
     const int r0 = wave * STRIP_R;  // first tile row of this wave
     V v[STRIP_R];
     unsigned fgrows = 0;
+    {
+        // unconditional loads from clamped coordinates, widened / invalidated afterwards: a conversion next to a
+        // conditional load would put a wait behind every one of them
+        T raw[STRIP_R];
 #pragma unroll
-    for (int k = 0; k < STRIP_R; ++k) {
-        const int y = ty0 + r0 + k;
-        v[k] = (x < W && y < H) ? (V)img[(size_t)y * W + xc] : NOVAL;
+        for (int k = 0; k < STRIP_R; ++k) {
+            const int y = ty0 + r0 + k;
+            raw[k] = img[(size_t)(y < H ? y : H - 1) * W + xc];
+        }
+#pragma unroll
+        for (int k = 0; k < STRIP_R; ++k) v[k] = (x < W && ty0 + r0 + k < H) ? (V)raw[k] : NOVAL;
     }
 #pragma unroll
     for (int k = 0; k < STRIP_R; ++k) {
