@@ -191,27 +191,45 @@ __global__ void __launch_bounds__(256) hist_f64_kernel(const double* __restrict_
         double v4[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) v4[u] = (i0 + (size_t)u * 256 < n) ? src[i0 + (size_t)u * 256] : __builtin_nan("");
+        // first guess of every bin and BOTH of its edges (eight LDS reads in flight, no dependent chain); the guess
+        // is exact unless the value sits within rounding distance of an edge -- only then the walk below runs
+        int b4[4];
+        double elo4[4], ehi4[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const double v = v4[u];
             const bool ok = v >= lo && v <= hi;  // NaN / out of range: not counted
-            int b = 0;
-            if (ok) {
-                const double f = (v - lo) * norm;
-                b = (int)f;
-                if (b < 0) b = 0;
-                if (b > nbins - 1) b = nbins - 1;
+            int b = ok ? (int)((v - lo) * norm) : 0;
+            b = b < 0 ? 0 : (b > nbins - 1 ? nbins - 1 : b);
+            b4[u] = b;
+            elo4[u] = edges[b];
+            ehi4[u] = edges[b + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double v = v4[u];
+            const bool ok = v >= lo && v <= hi;
+            int b = b4[u];
+            if (ok && (v < elo4[u] || (b < nbins - 1 && v >= ehi4[u]))) {
                 while (b > 0 && v < edges[b]) --b;
                 while (b < nbins - 1 && v >= edges[b + 1]) ++b;
             }
             const unsigned long long act = __ballot(ok);
             if (!act) continue;
-            const int b0 = __shfl(b, __ffsll((long long)act) - 1);
-            const unsigned long long same = __ballot(ok && b == b0);
-            if (same == act) {
-                if (lane == __ffsll((long long)act) - 1) atomicAdd(&mine[b0], (unsigned)__popcll(act));
-            } else if (ok) {
-                atomicAdd(&mine[b], 1u);
+            // two rounds of "first lane's bin, counted once for everyone who shares it" (64 same-address LDS atomics
+            // cost 64 slots; a smoothed background wave straddles at most one bin edge), then lane by lane
+            const int l0 = __ffsll((long long)act) - 1;
+            const int b0 = __shfl(b, l0);
+            const unsigned long long s0 = __ballot(ok && b == b0);
+            if (lane == l0) atomicAdd(&mine[b0], (unsigned)__popcll(s0));
+            unsigned long long rest = act & ~s0;
+            if (rest) {
+                const int l1 = __ffsll((long long)rest) - 1;
+                const int b1 = __shfl(b, l1);
+                const unsigned long long s1 = __ballot(ok && b == b1);
+                if (lane == l1) atomicAdd(&mine[b1], (unsigned)__popcll(s1));
+                rest &= ~s1;
+                if ((rest >> lane) & 1ull) atomicAdd(&mine[b], 1u);
             }
         }
     }
