@@ -696,11 +696,16 @@ __global__ void __launch_bounds__(256) sel_count_kernel(const double* __restrict
     for (size_t i0 = (size_t)blockIdx.x * 1024 + threadIdx.x; i0 < n; i0 += (size_t)gridDim.x * 1024) {
         unsigned long long k4[4];
         bool ok4[4];
+        double raw4[4];
+        // unconditional loads (clamped to the last element); keys are formed once all four are in flight
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            ok4[u] = i0 + (size_t)u * 256 < n;
-            k4[u] = ok4[u] ? amt_f64_key(src[i0 + (size_t)u * 256]) : 0ull;
+            const size_t i = i0 + (size_t)u * 256;
+            ok4[u] = i < n;
+            raw4[u] = src[ok4[u] ? i : n - 1];
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) k4[u] = amt_f64_key(raw4[u]);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const unsigned long long k = k4[u];
@@ -712,12 +717,19 @@ __global__ void __launch_bounds__(256) sel_count_kernel(const double* __restrict
             const int bin = slot >= 0 ? slot * 256 + (int)digit : -1;
             const unsigned long long act = __ballot(bin >= 0);
             if (!act) continue;
+            // two rounds of "first lane's bin, counted once for all lanes that share it", then lane by lane
             const int first = __ffsll((long long)act) - 1;
             const int bin0 = __shfl(bin, first);
-            if (__ballot(bin >= 0 && bin == bin0) == act) {
-                if (lane == first) atomicAdd(&lh[bin0], (unsigned)__popcll(act));
-            } else if (bin >= 0) {
-                atomicAdd(&lh[bin], 1u);
+            const unsigned long long s0 = __ballot(bin >= 0 && bin == bin0);
+            if (lane == first) atomicAdd(&lh[bin0], (unsigned)__popcll(s0));
+            unsigned long long rest = act & ~s0;
+            if (rest) {
+                const int l1 = __ffsll((long long)rest) - 1;
+                const int bin1 = __shfl(bin, l1);
+                const unsigned long long s1 = __ballot(bin >= 0 && bin == bin1);
+                if (lane == l1) atomicAdd(&lh[bin1], (unsigned)__popcll(s1));
+                rest &= ~s1;
+                if ((rest >> lane) & 1ull) atomicAdd(&lh[bin], 1u);
             }
             if (cand && slot >= 0) {
                 const unsigned pos = atomicAdd(&ncand[plane * nslots + slot], 1u);
