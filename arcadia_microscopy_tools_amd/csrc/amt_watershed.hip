@@ -145,6 +145,11 @@ __global__ void __launch_bounds__(256) ws_stats_kernel(const int* __restrict__ d
         ms[k] = rs[k] >= 0 ? markers[i] : 0;
         vs[k] = 0;
     }
+    // component row of every foreground pixel, gathered NOW with the marker / relief loads (a few hot lines: the
+    // tile roots) -- fetched where it is needed, it was a dependent round trip per row
+    int ts[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ts[k] = rs[k] >= 0 ? T[base + rs[k]] : 0;
     if (use_d2) {
         // raw values, nothing computed next to the loads (that would wait for each of them and serialise the
         // rows); negative reliefs need no clamp: only v > 0 can be a candidate, and v >= neighbour holds for a
@@ -174,7 +179,7 @@ __global__ void __launch_bounds__(256) ws_stats_kernel(const int* __restrict__ d
         // r is the TILE root of the pixel (equal inside a run, since a run never leaves its tile); its T entry was
         // copied from the component root (amt_i_propagate_roots)
         if (head || cand || lab != 0) {
-            comp_row* c = prow + (T[base + r] - 1);
+            comp_row* c = prow + (ts[k] - 1);
             if (cand) atomicMax(&c->cmax, v);
             if (lab != 0) {
                 atomicAdd(&c->mcnt, 1);
@@ -188,9 +193,9 @@ __global__ void __launch_bounds__(256) ws_stats_kernel(const int* __restrict__ d
             const unsigned long long later = hb & ~((2ull << lane) - 1ull);
             const int end_lane = later ? (__ffsll((long long)later) - 2) : 63;
             const int len = end_lane - lane + 1;
-            comp_row* c = prow + (T[base + r] - 1);
-            // the run that starts at the component root itself (a tile root that is its own parent)
-            if ((size_t)r == (size_t)(yb + k) * W + x && L[base + r] == r) c->root = r;
+            comp_row* c = prow + (ts[k] - 1);
+            // the run that starts at the component root itself: the one pixel that is its own parent (r = L[pixel])
+            if ((size_t)r == (size_t)(yb + k) * W + x) c->root = r;
             if (!use_d2) atomicAdd(&c->cmax, len);
             atomicMin(&c->x0, x);
             atomicMax(&c->x1, x + len - 1);
