@@ -102,8 +102,8 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=128, help="fields of view per GPU per step")
-    ap.add_argument("--streams", type=int, default=4,
+    ap.add_argument("--batch", type=int, default=192, help="fields of view per GPU per step")
+    ap.add_argument("--streams", type=int, default=6,
                     help="HIP streams per GPU; the batch is split over them so that the latency-bound flood of one "
                          "part overlaps the bandwidth-bound stages of the other")
     ap.add_argument("--size", type=int, default=2048)
