@@ -81,14 +81,16 @@ def all_gather_rows(local_rows, group=None):
 
 
 class PlateTables:
-    """The per-rank block of the per-plate feature table, and its ONE all-gather.
+    """The per-rank blocks of the per-plate feature tables, and the ONE all-gather each plate gets.
 
-    A rank processes its shard of the plate in `steps` batches.  Each batch's segmenters write their
-    morphology table, intensity table and cell counts straight into this rank's slice of one torch-allocated
-    byte buffer (no copies, no per-step collective); when the rank's shard is done a single
-    ``all_gather_into_tensor`` over RCCL exchanges the blocks (BASELINE.json north_star: "RCCL all-gather over
-    xGMI only for the final per-plate label/feature table").  Layout of a rank's block (bytes):
-    [S*B*K*14 float64 | S*B*K*C*4 float64 | S*B int32 (padded to 8 bytes)], S = steps, B = FOVs per step."""
+    A rank processes its shard in `steps` batches; a batch of all ranks together is one plate (world x B fields of
+    view: 384 at 2 GPUs with the bench's B = 192).  The batch's segmenters write their morphology table, intensity
+    table and cell counts straight into the batch's slice of one torch-allocated byte buffer (no copies); when the
+    batch's kernels have been enqueued, a single ``all_gather_into_tensor`` over RCCL for that plate is enqueued
+    on a side stream, ordered after the compute streams with events, so it travels over xGMI while the next batch
+    computes (BASELINE.json north_star: "RCCL all-gather over xGMI only for the final per-plate label/feature
+    table").  Layout of one batch block (bytes): [B*K*14 float64 | B*K*C*4 float64 | B int32 (padded to 8 bytes)];
+    the gathered buffer holds [step][rank][block]."""
 
     def __init__(self, segs, steps, torch_device, group=None):
         import torch
@@ -102,53 +104,69 @@ class PlateTables:
         B = sum(s.B for s in self.segs)
         K, C = self.segs[0].max_cells, self.segs[0].C
         self.B, self.K, self.C = B, K, C
-        n = self.steps * B
-        self.n_table = n * K * _hip.RP_NCOLS * 8
-        self.n_itable = n * K * C * 4 * 8
-        self.n_cells = (n * 4 + 7) // 8 * 8
-        self.local = torch.zeros(self.n_table + self.n_itable + self.n_cells, dtype=torch.uint8, device=torch_device)
-        self.gathered = None
+        self.n_table = B * K * _hip.RP_NCOLS * 8
+        self.n_itable = B * K * C * 4 * 8
+        self.n_cells = (B * 4 + 7) // 8 * 8
+        self.step_bytes = self.n_table + self.n_itable + self.n_cells
+        self.world = dist.get_world_size(group)
+        self.local = torch.zeros(self.steps * self.step_bytes, dtype=torch.uint8, device=torch_device)
+        self.gathered = torch.empty(self.steps * self.world * self.step_bytes, dtype=torch.uint8, device=torch_device)
+        self.done = [False] * self.steps
         # the collective's stream is one of the library's own HIP streams handed to torch as an external stream
         self.gctx = Context(self.segs[0].ctx.device)
         self.stream = torch.cuda.ExternalStream(self.gctx.stream_ptr, device=torch_device)
 
     def point(self, step: int):
-        """Make the segmenters write the tables of batch `step` (0-based, modulo `steps`) into the plate block."""
+        """Make the segmenters write the tables of batch `step` (0-based, modulo `steps`) into that batch's block."""
         from .device import DeviceArray
 
-        base = self.local.data_ptr()
+        slot = step % self.steps
+        base = self.local.data_ptr() + slot * self.step_bytes
         K, C = self.K, self.C
-        b0 = (step % self.steps) * self.B
+        b0 = 0
+        if self.done[slot]:  # an earlier exchange of this block may still be reading it
+            for s in self.segs:
+                s.ctx.wait_for(self.gctx)
         for s in self.segs:
             s.table = DeviceArray(s.ctx, base + b0 * K * _hip.RP_NCOLS * 8, (s.B, K, _hip.RP_NCOLS), np.float64)
             s.itable = DeviceArray(s.ctx, base + self.n_table + b0 * K * C * 4 * 8, (s.B, K, C, 4), np.float64)
             s.ncells = DeviceArray(s.ctx, base + self.n_table + self.n_itable + b0 * 4, (s.B,), np.int32)
             b0 += s.B
+        self.done[slot] = False
 
-    def all_gather(self):
-        """Enqueue the plate's single all-gather after everything the compute streams have been given."""
+    def gather_step(self, step: int):
+        """Enqueue the all-gather of batch `step` after everything the compute streams have been given so far."""
         torch, dist = self.torch, self.dist
-        world = dist.get_world_size(self.group)
-        if self.gathered is None:
-            self.gathered = torch.empty(world * self.local.numel(), dtype=torch.uint8, device=self.local.device)
+        slot = step % self.steps
         for s in self.segs:
             self.gctx.wait_for(s.ctx)
+        lo = slot * self.step_bytes
+        go = slot * self.world * self.step_bytes
         with torch.cuda.stream(self.stream):
-            dist.all_gather_into_tensor(self.gathered, self.local, group=self.group)
+            dist.all_gather_into_tensor(self.gathered[go: go + self.world * self.step_bytes],
+                                        self.local[lo: lo + self.step_bytes], group=self.group)
+        self.done[slot] = True
+
+    def all_gather(self):
+        """Enqueue the all-gather of every batch that has not been exchanged yet; returns the gathered buffer."""
+        for slot in range(self.steps):
+            if not self.done[slot]:
+                self.gather_step(slot)
         return self.gathered
 
     def result(self):
-        """(table, itable, ncells) of the whole plate: leading axes (rank, step * B + fov)."""
+        """(table, itable, ncells) of everything gathered: leading axes (rank, step * B + fov)."""
         torch = self.torch
-        world = self.dist.get_world_size(self.group)
         self.stream.synchronize()
-        n = self.steps * self.B
-        g = self.gathered.view(world, -1)
-        t = g[:, : self.n_table].contiguous().view(torch.float64).view(world, n, self.K, _hip.RP_NCOLS)
-        it = g[:, self.n_table: self.n_table + self.n_itable].contiguous().view(torch.float64).view(
-            world, n, self.K, self.C, 4)
-        nc = g[:, self.n_table + self.n_itable: self.n_table + self.n_itable + n * 4].contiguous().view(
-            torch.int32).view(world, n)
+        S, Wd, B, K, C = self.steps, self.world, self.B, self.K, self.C
+        g = self.gathered.view(S, Wd, self.step_bytes)
+        t = g[:, :, : self.n_table].contiguous().view(torch.float64).view(S, Wd, B, K, _hip.RP_NCOLS)
+        it = g[:, :, self.n_table: self.n_table + self.n_itable].contiguous().view(torch.float64).view(S, Wd, B, K, C, 4)
+        nc = g[:, :, self.n_table + self.n_itable: self.n_table + self.n_itable + B * 4].contiguous().view(
+            torch.int32).view(S, Wd, B)
+        t = t.permute(1, 0, 2, 3, 4).reshape(Wd, S * B, K, _hip.RP_NCOLS)
+        it = it.permute(1, 0, 2, 3, 4, 5).reshape(Wd, S * B, K, C, 4)
+        nc = nc.permute(1, 0, 2).reshape(Wd, S * B)
         return t, it, nc
 
 

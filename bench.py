@@ -19,9 +19,10 @@ import sys
 import time
 
 # Each context owns up to three HIP streams (main + two fork/join streams for the flood classes) and the
-# batch is split over several contexts; ROCm's default of 4 hardware queues per process would multiplex them.
+# batch is split over several contexts; ROCm's default of 4 hardware queues per process would multiplex them
+# (and with torch + RCCL in the process, 8 measured 14 % slower than 16).
 # Must be set before the HIP runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import numpy as np  # noqa: E402
 
@@ -213,10 +214,10 @@ def main():
     if distributed:
         from arcadia_microscopy_tools_amd.plate import PlateTables
 
-        # this rank's block of the per-plate feature table: every step writes its slice, ONE all-gather at the end
+        # this rank's blocks of the per-plate feature tables: one plate (= one step of all ranks), one all-gather
         packed = PlateTables(segs, args.steps, torch.device("cuda", local_rank))
 
-    gather = packed is not None and args.workload == "c3"
+    gather = packed is not None and args.workload == "c3" and os.environ.get("AMT_BENCH_NO_GATHER") != "1"
 
     def step(i=0):
         if gather:
@@ -226,6 +227,8 @@ def main():
                 sg.run_c3(part)
             else:
                 sg.run_c2(part)
+        if gather:
+            packed.gather_step(i)  # this plate's single RCCL all-gather; it overlaps the next step's compute
 
     def sync():
         if distributed:
@@ -245,7 +248,7 @@ def main():
     for i in range(args.steps):
         step(i)
     if gather:
-        packed.all_gather()  # the plate's single RCCL all-gather, inside the timed region
+        packed.all_gather()  # nothing left to exchange unless a step was skipped; all of it is inside the timed region
     sync()
     if distributed:
         dist.barrier()
@@ -256,6 +259,15 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+
+    if gather:  # outside the timed region: what arrived is what was written
+        t_all, it_all, nc_all = packed.result()
+        mine = nc_all[rank]
+        if int(mine.min()) < 0 or int(mine.max()) > args.max_cells or int(nc_all.sum()) <= 0:
+            raise RuntimeError("gathered plate tables are inconsistent (cell counts out of range)")
+        if world == 1 and not torch.equal(packed.gathered, packed.local):
+            raise RuntimeError("single-rank all-gather did not reproduce the local plate blocks")
+        log(f"plate tables gathered: {tuple(t_all.shape)} rows, {int(nc_all.sum())} cells over {world} rank(s)")
 
     # ---- per-stage device times (HIP events on the kernels' own stream), outside the timed region ----
     # one launch of the timed region covers the FOVs of ONE stream: profile that launch size
