@@ -80,6 +80,54 @@ def all_gather_rows(local_rows, group=None):
     return torch.cat(parts, dim=0), counts
 
 
+class PlateLayout:
+    """Byte layout of the per-plate feature blocks and of what the all-gather leaves behind (device independent,
+    so the world_size-2 gloo test on CPU exercises exactly what the RCCL path uses).
+
+    One block = one batch of B fields of view of one rank: [B*K*14 float64 | B*K*C*4 float64 | B int32, padded to
+    8 bytes].  A rank's buffer holds [step][block]; the gathered buffer holds [step][rank][block]."""
+
+    def __init__(self, steps: int, world: int, B: int, K: int, C: int):
+        self.steps, self.world, self.B, self.K, self.C = int(steps), int(world), int(B), int(K), int(C)
+        self.n_table = self.B * self.K * _hip.RP_NCOLS * 8
+        self.n_itable = self.B * self.K * self.C * 4 * 8
+        self.n_cells = (self.B * 4 + 7) // 8 * 8
+        self.step_bytes = self.n_table + self.n_itable + self.n_cells
+        self.local_bytes = self.steps * self.step_bytes
+        self.gathered_bytes = self.steps * self.world * self.step_bytes
+
+    def block_offsets(self, slot: int, b0: int = 0):
+        """Byte offsets, inside a rank's buffer, of the table / intensity table / cell counts of FOV b0 of a block."""
+        base = slot * self.step_bytes
+        return (base + b0 * self.K * _hip.RP_NCOLS * 8,
+                base + self.n_table + b0 * self.K * self.C * 4 * 8,
+                base + self.n_table + self.n_itable + b0 * 4)
+
+    def gather_step(self, local, gathered, slot: int, group=None):
+        """The plate's ONE collective: all-gather block `slot` of every rank (uint8 torch tensors)."""
+        import torch.distributed as dist
+
+        lo = slot * self.step_bytes
+        go = slot * self.world * self.step_bytes
+        dist.all_gather_into_tensor(gathered[go: go + self.world * self.step_bytes],
+                                    local[lo: lo + self.step_bytes], group=group)
+
+    def unpack(self, gathered):
+        """(table, itable, ncells) with leading axes (rank, step * B + fov) from a gathered uint8 tensor."""
+        import torch
+
+        S, Wd, B, K, C = self.steps, self.world, self.B, self.K, self.C
+        g = gathered.view(S, Wd, self.step_bytes)
+        t = g[:, :, : self.n_table].contiguous().view(torch.float64).view(S, Wd, B, K, _hip.RP_NCOLS)
+        it = g[:, :, self.n_table: self.n_table + self.n_itable].contiguous().view(torch.float64).view(S, Wd, B, K, C, 4)
+        nc = g[:, :, self.n_table + self.n_itable: self.n_table + self.n_itable + B * 4].contiguous().view(
+            torch.int32).view(S, Wd, B)
+        t = t.permute(1, 0, 2, 3, 4).reshape(Wd, S * B, K, _hip.RP_NCOLS)
+        it = it.permute(1, 0, 2, 3, 4, 5).reshape(Wd, S * B, K, C, 4)
+        nc = nc.permute(1, 0, 2).reshape(Wd, S * B)
+        return t, it, nc
+
+
 class PlateTables:
     """The per-rank blocks of the per-plate feature tables, and the ONE all-gather each plate gets.
 
@@ -104,13 +152,11 @@ class PlateTables:
         B = sum(s.B for s in self.segs)
         K, C = self.segs[0].max_cells, self.segs[0].C
         self.B, self.K, self.C = B, K, C
-        self.n_table = B * K * _hip.RP_NCOLS * 8
-        self.n_itable = B * K * C * 4 * 8
-        self.n_cells = (B * 4 + 7) // 8 * 8
-        self.step_bytes = self.n_table + self.n_itable + self.n_cells
         self.world = dist.get_world_size(group)
-        self.local = torch.zeros(self.steps * self.step_bytes, dtype=torch.uint8, device=torch_device)
-        self.gathered = torch.empty(self.steps * self.world * self.step_bytes, dtype=torch.uint8, device=torch_device)
+        self.layout = PlateLayout(self.steps, self.world, B, K, C)
+        self.step_bytes = self.layout.step_bytes
+        self.local = torch.zeros(self.layout.local_bytes, dtype=torch.uint8, device=torch_device)
+        self.gathered = torch.empty(self.layout.gathered_bytes, dtype=torch.uint8, device=torch_device)
         self.done = [False] * self.steps
         # the collective's stream is one of the library's own HIP streams handed to torch as an external stream
         self.gctx = Context(self.segs[0].ctx.device)
@@ -121,30 +167,27 @@ class PlateTables:
         from .device import DeviceArray
 
         slot = step % self.steps
-        base = self.local.data_ptr() + slot * self.step_bytes
+        ptr = self.local.data_ptr()
         K, C = self.K, self.C
-        b0 = 0
         if self.done[slot]:  # an earlier exchange of this block may still be reading it
             for s in self.segs:
                 s.ctx.wait_for(self.gctx)
+        b0 = 0
         for s in self.segs:
-            s.table = DeviceArray(s.ctx, base + b0 * K * _hip.RP_NCOLS * 8, (s.B, K, _hip.RP_NCOLS), np.float64)
-            s.itable = DeviceArray(s.ctx, base + self.n_table + b0 * K * C * 4 * 8, (s.B, K, C, 4), np.float64)
-            s.ncells = DeviceArray(s.ctx, base + self.n_table + self.n_itable + b0 * 4, (s.B,), np.int32)
+            o_t, o_i, o_c = self.layout.block_offsets(slot, b0)
+            s.table = DeviceArray(s.ctx, ptr + o_t, (s.B, K, _hip.RP_NCOLS), np.float64)
+            s.itable = DeviceArray(s.ctx, ptr + o_i, (s.B, K, C, 4), np.float64)
+            s.ncells = DeviceArray(s.ctx, ptr + o_c, (s.B,), np.int32)
             b0 += s.B
         self.done[slot] = False
 
     def gather_step(self, step: int):
         """Enqueue the all-gather of batch `step` after everything the compute streams have been given so far."""
-        torch, dist = self.torch, self.dist
         slot = step % self.steps
         for s in self.segs:
             self.gctx.wait_for(s.ctx)
-        lo = slot * self.step_bytes
-        go = slot * self.world * self.step_bytes
-        with torch.cuda.stream(self.stream):
-            dist.all_gather_into_tensor(self.gathered[go: go + self.world * self.step_bytes],
-                                        self.local[lo: lo + self.step_bytes], group=self.group)
+        with self.torch.cuda.stream(self.stream):
+            self.layout.gather_step(self.local, self.gathered, slot, self.group)
         self.done[slot] = True
 
     def all_gather(self):
@@ -156,18 +199,8 @@ class PlateTables:
 
     def result(self):
         """(table, itable, ncells) of everything gathered: leading axes (rank, step * B + fov)."""
-        torch = self.torch
         self.stream.synchronize()
-        S, Wd, B, K, C = self.steps, self.world, self.B, self.K, self.C
-        g = self.gathered.view(S, Wd, self.step_bytes)
-        t = g[:, :, : self.n_table].contiguous().view(torch.float64).view(S, Wd, B, K, _hip.RP_NCOLS)
-        it = g[:, :, self.n_table: self.n_table + self.n_itable].contiguous().view(torch.float64).view(S, Wd, B, K, C, 4)
-        nc = g[:, :, self.n_table + self.n_itable: self.n_table + self.n_itable + B * 4].contiguous().view(
-            torch.int32).view(S, Wd, B)
-        t = t.permute(1, 0, 2, 3, 4).reshape(Wd, S * B, K, _hip.RP_NCOLS)
-        it = it.permute(1, 0, 2, 3, 4, 5).reshape(Wd, S * B, K, C, 4)
-        nc = nc.permute(1, 0, 2).reshape(Wd, S * B)
-        return t, it, nc
+        return self.layout.unpack(self.gathered)
 
 
 def well_id(fov_index: int, n_columns: int = 24, fovs_per_well: int = 1) -> str:
