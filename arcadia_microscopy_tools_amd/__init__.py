@@ -13,17 +13,8 @@ from .pipeline import ImageOperation, Pipeline
 
 __version__ = "0.4.1+amd.1"
 
-__all__ = [
-    "BlendMode",
-    "Channel",
-    "HipError",
-    "HipUnavailableError",
-    "ImageOperation",
-    "Layer",
-    "MetadataWarning",
-    "MicroscopyImage",
-    "Pipeline",
-    "SegmentationWarning",
-    "create_overlay",
-    "overlay_channels",
-]
+# the reference's public names plus the two error types of the HIP boundary
+__all__ = sorted(
+    {"BlendMode", "Channel", "ImageOperation", "Layer", "MetadataWarning", "MicroscopyImage", "Pipeline",
+     "SegmentationWarning", "create_overlay", "overlay_channels"} | {"HipError", "HipUnavailableError"}
+)

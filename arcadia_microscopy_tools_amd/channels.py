@@ -30,19 +30,24 @@ class Channel:
             raise ValueError("emission_nm must be positive")
 
 
-BRIGHTFIELD = Channel("BRIGHTFIELD", "#FFFFFF")
-DIC = Channel("DIC", "#FFFFFF")
-PHASE = Channel("PHASE", "#DDDDDD")
-DAPI = Channel("DAPI", "#0033FF", excitation_nm=405, emission_nm=450)
-FITC = Channel("FITC", "#07FF00", excitation_nm=488, emission_nm=512)
-TRITC = Channel("TRITC", "#FFBF00", excitation_nm=561, emission_nm=595)
-CY5 = Channel("CY5", "#A30000", excitation_nm=640, emission_nm=665)
-SRS = Channel("SRS", "#E63535")
-E_CARS = Channel("E-CARS", "#AB1299")
-F_CARS = Channel("F-CARS", "#AB1299")
-E_SHG = Channel("E-SHG", "#F29B4F")
-F_SHG = Channel("F-SHG", "#F29B4F")
-
-CHANNELS: dict[str, Channel] = {
-    ch.name: ch for ch in [BRIGHTFIELD, DIC, PHASE, DAPI, FITC, TRITC, CY5, SRS, E_CARS, F_CARS, E_SHG, F_SHG]
-}
+# name, display colour, excitation / emission maximum in nm (values of R/channels.py:93-117)
+_PREDEFINED = (
+    ("BRIGHTFIELD", "#FFFFFF", None, None),
+    ("DIC", "#FFFFFF", None, None),
+    ("PHASE", "#DDDDDD", None, None),
+    ("DAPI", "#0033FF", 405, 450),
+    ("FITC", "#07FF00", 488, 512),
+    ("TRITC", "#FFBF00", 561, 595),
+    ("CY5", "#A30000", 640, 665),
+    ("SRS", "#E63535", None, None),
+    ("E-CARS", "#AB1299", None, None),
+    ("F-CARS", "#AB1299", None, None),
+    ("E-SHG", "#F29B4F", None, None),
+    ("F-SHG", "#F29B4F", None, None),
+)
+CHANNELS: dict[str, Channel] = {row[0]: Channel(*row) for row in _PREDEFINED}
+# module-level names as the reference has them (a dash in a channel name becomes an underscore)
+BRIGHTFIELD, DIC, PHASE = CHANNELS["BRIGHTFIELD"], CHANNELS["DIC"], CHANNELS["PHASE"]
+DAPI, FITC, TRITC, CY5 = CHANNELS["DAPI"], CHANNELS["FITC"], CHANNELS["TRITC"], CHANNELS["CY5"]
+SRS, E_CARS, F_CARS = CHANNELS["SRS"], CHANNELS["E-CARS"], CHANNELS["F-CARS"]
+E_SHG, F_SHG = CHANNELS["E-SHG"], CHANNELS["F-SHG"]

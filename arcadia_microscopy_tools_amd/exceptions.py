@@ -1,9 +1,9 @@
-"""Warning classes of the reference (R/exceptions.py:1-6)."""
+"""Warning categories under the reference's names (R/exceptions.py), so that callers' warning filters keep working."""
 
 
 class MetadataWarning(UserWarning):
-    """Metadata was incomplete or ambiguous; a fallback value was used."""
+    """Raised as a warning when acquisition metadata is missing or contradictory and a default stands in for it."""
 
 
 class SegmentationWarning(UserWarning):
-    """A segmentation step produced a degraded or missing result."""
+    """Raised as a warning when segmenting one image of a batch failed and its slot in the result is empty."""

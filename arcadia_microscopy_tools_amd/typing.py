@@ -1,12 +1,18 @@
-"""Array type aliases of the reference (R/typing.py:1-13): the dtype contract of the hot path."""
+"""Array type aliases under the names the reference exports (R/typing.py): the dtype contract of the hot path --
+bool masks, uint8 / uint16 intensities, int64 labels, float32 / float64 results."""
+from typing import Union
+
 import numpy as np
-from numpy.typing import NDArray
+import numpy.typing as npt
 
-BoolArray = NDArray[np.bool_]
-UByteArray = NDArray[np.uint8]
-UInt16Array = NDArray[np.uint16]
-Int64Array = NDArray[np.int64]
-Float32Array = NDArray[np.float32]
-Float64Array = NDArray[np.float64]
 
-ScalarArray = BoolArray | UByteArray | UInt16Array | Int64Array | Float32Array | Float64Array
+def _array_of(scalar_type):
+    return npt.NDArray[scalar_type]
+
+
+BoolArray, UByteArray, UInt16Array = _array_of(np.bool_), _array_of(np.uint8), _array_of(np.uint16)
+Int64Array = _array_of(np.int64)
+Float32Array, Float64Array = _array_of(np.float32), _array_of(np.float64)
+
+# whatever an ImageOperation may receive or return
+ScalarArray = Union[BoolArray, UByteArray, UInt16Array, Int64Array, Float32Array, Float64Array]
