@@ -9,37 +9,18 @@ from __future__ import annotations
 
 import warnings
 from collections.abc import Mapping
-from dataclasses import dataclass, field
 from functools import cached_property
-from typing import ClassVar, Literal
 
 import numpy as np
 
-from .channels import Channel
-from .typing import BoolArray, Float64Array, Int64Array, ScalarArray, UInt16Array
+from .typing import Float64Array, Int64Array, ScalarArray
 
-# property lists of the reference (R/masks.py:15-35)
-DEFAULT_CELL_PROPERTY_NAMES = [
-    "label",
-    "centroid",
-    "volume",
-    "area",
-    "area_convex",
-    "perimeter",
-    "eccentricity",
-    "circularity",
-    "solidity",
-    "axis_major_length",
-    "axis_minor_length",
-    "orientation",
-]
-
-DEFAULT_INTENSITY_PROPERTY_NAMES = [
-    "intensity_mean",
-    "intensity_max",
-    "intensity_min",
-    "intensity_std",
-]
+# columns of `cell_properties` when the caller names none (the reference's lists, R/masks.py:15-35)
+DEFAULT_CELL_PROPERTY_NAMES = (
+    "label centroid volume area area_convex perimeter eccentricity circularity solidity "
+    "axis_major_length axis_minor_length orientation"
+).split()
+DEFAULT_INTENSITY_PROPERTY_NAMES = ["intensity_" + stat for stat in ("mean", "max", "min", "std")]
 
 
 def _process_mask_device(mask_image, remove_edge_cells: bool):
@@ -75,69 +56,78 @@ def _process_mask_device(mask_image, remove_edge_cells: bool):
     return lab, int(cnt.numpy()[0])
 
 
-@dataclass
+def _check_label_plane(mask_image) -> None:
+    """Constructor checks of the mask, in the reference's order and wording (R/masks.py:169-176)."""
+    if not isinstance(mask_image, np.ndarray):
+        raise TypeError("mask_image must be a numpy array")
+    if mask_image.ndim != 2:
+        raise ValueError("mask_image must be a 2D array")
+    if (mask_image < 0).any():
+        raise ValueError("mask_image must have non-negative values")
+    if not mask_image.any():
+        raise ValueError("mask_image contains no cells (all values are 0)")
+
+
+def _checked_intensities(images, shape):
+    """None, or a NEW dict channel -> 2-D array of the mask's shape; the arrays themselves stay shared with the
+    caller (R/masks.py:178-194)."""
+    if images is None:
+        return None
+    if not isinstance(images, Mapping):
+        raise TypeError("intensity_image_dict must be a Mapping of channels to 2D arrays")
+    for channel, plane in images.items():
+        label = f"Intensity image for '{channel.name}'"
+        if not isinstance(plane, np.ndarray):
+            raise TypeError(f"{label} must be a numpy array")
+        if plane.ndim != 2:
+            raise ValueError(f"{label} must be 2D")
+        if plane.shape != shape:
+            raise ValueError(f"{label} must have same shape as mask_image")
+    return dict(images)
+
+
 class SegmentationMask:
-    """Segmentation mask plus feature extraction (constructor contract: R/masks.py:118-143)."""
+    """A label (or boolean) mask with the intensity images that belong to it, and the per-cell measurements derived
+    from them (constructor contract: R/masks.py:118-208).
 
-    mask_image: BoolArray | Int64Array
-    intensity_image_dict: Mapping[Channel, UInt16Array] | None = None
-    remove_edge_cells: bool = True
-    outline_extractor: Literal["cellpose", "skimage"] = "cellpose"
-    property_names: list[str] | None = field(default=None)
-    intensity_property_names: list[str] | None = field(default=None)
+    mask_image                bool (foreground) or integer (labels) 2-D array with at least one cell
+    intensity_image_dict      optional mapping Channel -> 2-D intensity image of the same shape
+    remove_edge_cells         drop cells that touch the image frame before numbering (default True)
+    outline_extractor         "cellpose" (pixel borders, the default) or "skimage" (sub-pixel contours)
+    property_names            columns of `cell_properties` (default DEFAULT_CELL_PROPERTY_NAMES)
+    intensity_property_names  per-channel intensity columns (default: all four when intensity images are given)
 
-    _IMMUTABLE_FIELDS: ClassVar[frozenset[str]] = frozenset(
-        {
-            "mask_image",
-            "intensity_image_dict",
-            "remove_edge_cells",
-            "outline_extractor",
-            "property_names",
-            "intensity_property_names",
-        }
-    )
+    The six constructor arguments cannot be reassigned afterwards; everything derived is computed on the GPU on
+    first access and cached.
+    """
 
-    def __setattr__(self, name: str, value: object) -> None:
-        if getattr(self, "_initialized", False) and name in self._IMMUTABLE_FIELDS:
+    _CTOR_FIELDS = ("mask_image", "intensity_image_dict", "remove_edge_cells", "outline_extractor", "property_names",
+                    "intensity_property_names")
+
+    def __init__(self, mask_image, intensity_image_dict=None, remove_edge_cells=True, outline_extractor="cellpose",
+                 property_names=None, intensity_property_names=None):
+        _check_label_plane(mask_image)
+        channels = _checked_intensities(intensity_image_dict, mask_image.shape)
+        if property_names is None:
+            property_names = list(DEFAULT_CELL_PROPERTY_NAMES)
+        if intensity_property_names is None:
+            intensity_property_names = list(DEFAULT_INTENSITY_PROPERTY_NAMES) if channels else []
+        given = (mask_image, channels, remove_edge_cells, outline_extractor, property_names, intensity_property_names)
+        for name, value in zip(self._CTOR_FIELDS, given):
+            object.__setattr__(self, name, value)
+        object.__setattr__(self, "_sealed", True)
+
+    def __setattr__(self, name, value):
+        if name in self._CTOR_FIELDS and self.__dict__.get("_sealed", False):
             raise AttributeError(
-                f"Cannot modify '{name}' after SegmentationMask is initialized. "
-                "Create a new instance instead."
+                f"Cannot modify '{name}' after SegmentationMask is initialized. Create a new instance instead."
             )
-        super().__setattr__(name, value)
+        object.__setattr__(self, name, value)
 
-    def __post_init__(self):
-        if not isinstance(self.mask_image, np.ndarray):
-            raise TypeError("mask_image must be a numpy array")
-        if self.mask_image.ndim != 2:
-            raise ValueError("mask_image must be a 2D array")
-        if np.any(self.mask_image < 0):
-            raise ValueError("mask_image must have non-negative values")
-        if self.mask_image.max() == 0:
-            raise ValueError("mask_image contains no cells (all values are 0)")
-
-        if self.intensity_image_dict is not None:
-            if not isinstance(self.intensity_image_dict, Mapping):
-                raise TypeError("intensity_image_dict must be a Mapping of channels to 2D arrays")
-            for channel, intensities in self.intensity_image_dict.items():
-                if not isinstance(intensities, np.ndarray):
-                    raise TypeError(f"Intensity image for '{channel.name}' must be a numpy array")
-                if intensities.ndim != 2:
-                    raise ValueError(f"Intensity image for '{channel.name}' must be 2D")
-                if intensities.shape != self.mask_image.shape:
-                    raise ValueError(
-                        f"Intensity image for '{channel.name}' must have same shape as mask_image"
-                    )
-            # shallow copy of the dict; the arrays stay shared (R/masks.py:191-194)
-            self.intensity_image_dict = dict(self.intensity_image_dict)
-
-        if self.property_names is None:
-            self.property_names = DEFAULT_CELL_PROPERTY_NAMES.copy()
-        if self.intensity_property_names is None:
-            if self.intensity_image_dict:
-                self.intensity_property_names = DEFAULT_INTENSITY_PROPERTY_NAMES.copy()
-            else:
-                self.intensity_property_names = []
-        object.__setattr__(self, "_initialized", True)
+    def __repr__(self):
+        chans = [c.name for c in self.intensity_image_dict] if self.intensity_image_dict else []
+        return (f"SegmentationMask(shape={self.mask_image.shape}, dtype={self.mask_image.dtype}, channels={chans}, "
+                f"remove_edge_cells={self.remove_edge_cells}, outline_extractor={self.outline_extractor!r})")
 
     # ---------------------------------------------------------------------------------------------
     @cached_property
@@ -211,16 +201,12 @@ class SegmentationMask:
         if self.property_names is None:
             raise ValueError("property_names cannot be None.")
         if "centroid" not in self.property_names:
-            warnings.warn(
-                "Centroid property not available. Include 'centroid' in property_names "
-                "to get centroid coordinates. Returning empty array.",
-                UserWarning,
-                stacklevel=2,
-            )
-            return np.array([]).reshape(0, 2)
-        yc = self.cell_properties["centroid_y"]
-        xc = self.cell_properties["centroid_x"]
-        return np.array([yc, xc], dtype=float).T
+            message = ("Centroid property not available. Include 'centroid' in property_names to get centroid "
+                       "coordinates. Returning empty array.")
+            warnings.warn(message, UserWarning, stacklevel=2)
+            return np.empty((0, 2), dtype=float)
+        table = self.cell_properties
+        return np.stack([table["centroid_y"], table["centroid_x"]], axis=1).astype(float)
 
     def filter(self, property_name: str, min_value: float | None = None,
                max_value: float | None = None) -> "SegmentationMask":
@@ -253,14 +239,12 @@ class SegmentationMask:
                 f"No cells remain after filtering '{property_name}' "
                 f"with min={min_value}, max={max_value}."
             )
-        return SegmentationMask(
-            mask_image=new_label_image,
-            intensity_image_dict=self.intensity_image_dict,
-            remove_edge_cells=False,
-            outline_extractor=self.outline_extractor,
-            property_names=list(self.property_names),
-            intensity_property_names=list(self.intensity_property_names),
-        )
+        # the survivors keep their pixels; numbering restarts at 1 and edge cells are NOT re-examined
+        settings = {name: getattr(self, name) for name in self._CTOR_FIELDS}
+        settings.update(mask_image=new_label_image, remove_edge_cells=False,
+                        property_names=list(self.property_names),
+                        intensity_property_names=list(self.intensity_property_names))
+        return SegmentationMask(**settings)
 
     def convert_properties_to_microns(self, pixel_size_um: float) -> dict[str, ScalarArray]:
         """Scale lengths / areas / volumes to microns with ``_um`` / ``_um2`` / ``_um3`` key suffixes

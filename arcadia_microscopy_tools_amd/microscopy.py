@@ -47,9 +47,8 @@ class InstrumentMetadata:
 
     @property
     def channel_axis(self) -> int | None:
-        if "C" in self.sizes:
-            return list(self.sizes.keys()).index("C")
-        return None
+        axes = list(self.sizes)
+        return axes.index("C") if "C" in axes else None
 
     @cached_property
     def dimensions(self) -> DimensionFlags:
@@ -69,9 +68,11 @@ class Metadata:
     sample: dict[str, Any] | None = None
 
     def __repr__(self) -> str:
-        channels = [cm.channel.name for cm in self.instrument.channel_metadata_list]
-        sample_str = f", sample={self.sample}" if self.sample else ""
-        return f"<Metadata sizes={self.instrument.sizes}, channels={channels}{sample_str}>"
+        shown = [f"sizes={self.instrument.sizes}",
+                 f"channels={[entry.channel.name for entry in self.instrument.channel_metadata_list]}"]
+        if self.sample:
+            shown.append(f"sample={self.sample}")
+        return "<Metadata " + ", ".join(shown) + ">"
 
 
 @dataclass
@@ -82,20 +83,14 @@ class MicroscopyImage:
     metadata: Metadata
 
     def __post_init__(self) -> None:
-        expected_shape = tuple(self.metadata.instrument.sizes.values())
-        if self.intensities.shape != expected_shape:
-            raise ValueError(
-                f"Intensities shape {self.intensities.shape} does not match "
-                f"metadata sizes {self.metadata.instrument.sizes} "
-                f"(expected shape {expected_shape})"
-            )
-        if self.intensities.dtype != uint16:
-            warnings.warn(
-                f"Expected uint16 intensities, got {self.intensities.dtype}. "
-                f"Some operations may behave unexpectedly.",
-                MetadataWarning,
-                stacklevel=2,
-            )
+        sizes = self.metadata.instrument.sizes
+        shape, wanted = self.intensities.shape, tuple(sizes.values())
+        if shape != wanted:  # the axes of `sizes` ARE the axes of the array, in order (R/microscopy.py:117-123)
+            raise ValueError(f"Intensities shape {shape} does not match metadata sizes {sizes} (expected shape {wanted})")
+        dtype = self.intensities.dtype
+        if dtype != uint16:  # uint16 is the canonical acquisition dtype (R/microscopy.py:125-131)
+            note = f"Expected uint16 intensities, got {dtype}. Some operations may behave unexpectedly."
+            warnings.warn(note, MetadataWarning, stacklevel=2)
 
     def __repr__(self) -> str:
         flat = self.intensities.reshape(-1)
@@ -157,7 +152,7 @@ class MicroscopyImage:
 
     @staticmethod
     def _resolve_channel_name(channel: str | Channel) -> str:
-        return channel if isinstance(channel, str) else channel.name
+        return getattr(channel, "name", channel)
 
     # -- channel access (R/microscopy.py:241-282) ---------------------------------------------------
     def _channel_index(self, channel: str | Channel) -> int:
