@@ -279,38 +279,65 @@ __device__ __forceinline__ u64 toc_fix(const toc_tile& t, int r, int wc, u64 v, 
     return v;
 }
 
-// buf points at logical (row 0, word 0); rows are PW words apart
-template <bool ERODE>
+// buf points at logical (row 0, word 0); rows are PW words apart.  Only tile rows [r_lo, r_hi) are produced: each
+// primitive of the chain needs ry fewer rows on either side than the one before it.  `inv` = ceil(2^20 / TW) turns
+// the row / column split of the flat index into a multiply (exact for idx < 2^11, TW <= 34).
+// DISK2: the footprint is disk(2) (the 13 cells |dy| + |dx| <= 2), unrolled with constant shifts; otherwise the
+// generic offset list is walked.
+template <bool ERODE, bool DISK2>
 __device__ __forceinline__ void toc_prim(const u64* src, u64* dst, const toc_tile& t, const int2* offs, int noffs,
-                                         u64 next_border) {
-    for (int idx = threadIdx.x; idx < t.TR * t.TW; idx += 256) {
-        const int r = idx / t.TW, wc = idx - r * t.TW;
-        u64 acc = ERODE ? ~0ull : 0ull;
-        int cur_dy = 0x7fffffff;
-        u64 p = 0, c = 0, nx = 0;
-        for (int k = 0; k < noffs; ++k) {
-            const int dy = ERODE ? offs[k].y : -offs[k].y;
-            const int dx = ERODE ? offs[k].x : -offs[k].x;
-            if (dy != cur_dy) {
-                cur_dy = dy;
-                const u64* row = src + (r + dy) * t.PW + wc;
-                p = row[-1];
-                c = row[0];
-                nx = row[1];
+                                         u64 next_border, int r_lo, int r_hi, unsigned inv) {
+    const int count = (r_hi - r_lo) * t.TW;
+    for (int idx = threadIdx.x; idx < count; idx += 256) {
+        const int rr = (int)(((unsigned)idx * inv) >> 20);
+        const int r = r_lo + rr, wc = idx - rr * t.TW;
+        u64 acc;
+        if (DISK2) {
+            const u64* s0 = src + r * t.PW + wc;
+            const u64 a2 = s0[-2 * t.PW], b2 = s0[2 * t.PW];
+            const u64 ap = s0[-t.PW - 1], ac = s0[-t.PW], an = s0[-t.PW + 1];
+            const u64 cp = s0[-1], cc = s0[0], cn = s0[1];
+            const u64 bp = s0[t.PW - 1], bc = s0[t.PW], bn = s0[t.PW + 1];
+#define TOC_L(c, p, d) (((c) << (d)) | ((p) >> (64 - (d))))  /* pixel x - d */
+#define TOC_R(c, n, d) (((c) >> (d)) | ((n) << (64 - (d))))  /* pixel x + d */
+            if (ERODE) {
+                acc = a2 & b2 & ac & TOC_L(ac, ap, 1) & TOC_R(ac, an, 1) & bc & TOC_L(bc, bp, 1) & TOC_R(bc, bn, 1) &
+                      cc & TOC_L(cc, cp, 1) & TOC_R(cc, cn, 1) & TOC_L(cc, cp, 2) & TOC_R(cc, cn, 2);
+            } else {
+                acc = a2 | b2 | ac | TOC_L(ac, ap, 1) | TOC_R(ac, an, 1) | bc | TOC_L(bc, bp, 1) | TOC_R(bc, bn, 1) |
+                      cc | TOC_L(cc, cp, 1) | TOC_R(cc, cn, 1) | TOC_L(cc, cp, 2) | TOC_R(cc, cn, 2);
             }
-            u64 v;
-            if (dx == 0)
-                v = c;
-            else if (dx > 0)
-                v = (c >> dx) | (nx << (64 - dx));
-            else
-                v = (c << (-dx)) | (p >> (64 + dx));
-            acc = ERODE ? (acc & v) : (acc | v);
+#undef TOC_L
+#undef TOC_R
+        } else {
+            acc = ERODE ? ~0ull : 0ull;
+            int cur_dy = 0x7fffffff;
+            u64 p = 0, c = 0, nx = 0;
+            for (int k = 0; k < noffs; ++k) {
+                const int dy = ERODE ? offs[k].y : -offs[k].y;
+                const int dx = ERODE ? offs[k].x : -offs[k].x;
+                if (dy != cur_dy) {
+                    cur_dy = dy;
+                    const u64* row = src + (r + dy) * t.PW + wc;
+                    p = row[-1];
+                    c = row[0];
+                    nx = row[1];
+                }
+                u64 v;
+                if (dx == 0)
+                    v = c;
+                else if (dx > 0)
+                    v = (c >> dx) | (nx << (64 - dx));
+                else
+                    v = (c << (-dx)) | (p >> (64 + dx));
+                acc = ERODE ? (acc & v) : (acc | v);
+            }
         }
         dst[r * t.PW + wc] = toc_fix(t, r, wc, acc, next_border);
     }
 }
 
+template <bool DISK2>
 __global__ void __launch_bounds__(256) toc_fused_kernel(const u64* __restrict__ packed, uint8_t* __restrict__ out,
                                                         int H, int W, int WW, const int2* __restrict__ offs_g,
                                                         int noffs, int HY) {
@@ -337,8 +364,9 @@ __global__ void __launch_bounds__(256) toc_fused_kernel(const u64* __restrict__ 
     const size_t plane = blockIdx.z;
     const u64* src = packed + plane * (size_t)H * WW;
     // ---- 1. copy the packed band + halo (outside the image: erosion's border, all ones) ----
+    const unsigned inv_tw = ((1u << 20) + (unsigned)t.TW - 1u) / (unsigned)t.TW;  // idx / TW as a multiply (idx < 2^11)
     for (int idx = threadIdx.x; idx < t.TR * t.TW; idx += 256) {
-        const int r = idx / t.TW, wc = idx - r * t.TW;
+        const int r = (int)(((unsigned)idx * inv_tw) >> 20), wc = idx - r * t.TW;
         const int y = t.y_top + r, wx = t.wx_left + wc;
         const u64 v = (y >= 0 && y < H && wx >= 0 && wx < WW) ? src[(size_t)y * WW + wx] : 0ull;
         bufA[r * t.PW + wc] = toc_fix(t, r, wc, v, ~0ull);
@@ -346,18 +374,21 @@ __global__ void __launch_bounds__(256) toc_fused_kernel(const u64* __restrict__ 
     __syncthreads();
     // ---- 2. opening = erosion, dilation; closing = dilation, erosion (skimage: erosion sees outside = 1,
     //         dilation sees outside = 0) ----
-    toc_prim<true>(bufA, bufB, t, offs, noffs, 0ull);
+    const int ry = HY / 4;
+    const unsigned inv = inv_tw;
+    toc_prim<true, DISK2>(bufA, bufB, t, offs, noffs, 0ull, ry, t.TR - ry, inv);
     __syncthreads();
-    toc_prim<false>(bufB, bufA, t, offs, noffs, 0ull);
+    toc_prim<false, DISK2>(bufB, bufA, t, offs, noffs, 0ull, 2 * ry, t.TR - 2 * ry, inv);
     __syncthreads();
-    toc_prim<false>(bufA, bufB, t, offs, noffs, ~0ull);
+    toc_prim<false, DISK2>(bufA, bufB, t, offs, noffs, ~0ull, 3 * ry, t.TR - 3 * ry, inv);
     __syncthreads();
-    toc_prim<true>(bufB, bufA, t, offs, noffs, 0ull);
+    toc_prim<true, DISK2>(bufB, bufA, t, offs, noffs, 0ull, 4 * ry, t.TR - 4 * ry, inv);
     __syncthreads();
     // ---- 3. unpack the band: 16 pixels per thread and step ----
     const int per_row = tww * 4;
+    const unsigned inv_pr = ((1u << 20) + (unsigned)per_row - 1u) / (unsigned)per_row;  // q < 2^12, per_row <= 128
     for (int q = threadIdx.x; q < TOC_BR * per_row; q += 256) {
-        const int r = q / per_row, rem = q - r * per_row;
+        const int r = (int)(((unsigned)q * inv_pr) >> 20), rem = q - r * per_row;
         const int wc = rem >> 2, part = rem & 3;
         const int y = (int)blockIdx.y * TOC_BR + r;
         const int x = ((int)blockIdx.x * TOC_TWW + wc) * 64 + part * 16;
@@ -412,7 +443,15 @@ extern "C" int amt_threshold_open_close(amt_ctx* ctx, const void* in, int in_dty
         const int tww = WW < TOC_TWW ? WW : TOC_TWW;
         const size_t smem = (size_t)2 * (TOC_BR + 2 * HY + 2 * TOC_PADR) * (tww + 4) * sizeof(u64);
         dim3 grid((WW + TOC_TWW - 1) / TOC_TWW, (H + TOC_BR - 1) / TOC_BR, nplanes);
-        hipLaunchKernelGGL(toc_fused_kernel, grid, dim3(256), smem, ctx->stream, pa, out, H, W, WW, offs, noffs, HY);
+        bool disk2 = fh == 5 && fw == 5 && noffs == 13;  // disk(2): the 13 cells with |dy| + |dx| <= 2
+        for (int k = 0; k < noffs && disk2; ++k)
+            disk2 = (host[k].x < 0 ? -host[k].x : host[k].x) + (host[k].y < 0 ? -host[k].y : host[k].y) <= 2;
+        if (disk2)
+            hipLaunchKernelGGL(toc_fused_kernel<true>, grid, dim3(256), smem, ctx->stream, pa, out, H, W, WW, offs,
+                               noffs, HY);
+        else
+            hipLaunchKernelGGL(toc_fused_kernel<false>, grid, dim3(256), smem, ctx->stream, pa, out, H, W, WW, offs,
+                               noffs, HY);
         AMT_LAUNCH_CHECK();
         return AMT_OK;
     }
