@@ -389,7 +389,7 @@ def main():
         }
         if pcie is not None:
             out["pcie_inclusive"] = pcie
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:  # the CPU baseline is a rank-0, N = 1 measurement
             out["cpu_baseline"] = cpu_baseline(fovs, args.workload, args.cpu_fovs)
             out["gpu_over_cpu_1thread"] = out["value"] / out["cpu_baseline"]["value"]
         os.write(json_fd, (json.dumps(out) + "\n").encode())
