@@ -165,13 +165,19 @@ __global__ void __launch_bounds__(256) ccl_tile_kernel(const T* __restrict__ in,
     }
 #pragma unroll
     for (int k = 0; k < STRIP_R; ++k) {
+        // uniform: a row segment without foreground takes no part in anything below -- its slots are marked
+        // "background" right away (what the write-out expects) and every later phase skips it
+        if (__ballot(v[k] != 0 && v[k] != NOVAL) == 0ull) {
+            S[(r0 + k) * 64 + lane] = -1;
+            continue;
+        }
+        fgrows |= 1u << k;
         const V left = amt_lane_left(v[k]);
         const bool head = (lane == 0) || (left != v[k]);
         const unsigned long long heads = __ballot(head);
         const unsigned long long upto = heads & ((2ull << lane) - 1ull);
         const int start_lane = 63 - __clzll((long long)upto);
         S[(r0 + k) * 64 + lane] = (r0 + k) * 64 + start_lane;
-        if (__ballot(v[k] != 0 && v[k] != NOVAL)) fgrows |= 1u << k;  // uniform: rows holding foreground
     }
     vlast[wave][lane] = v[STRIP_R - 1];
     __syncthreads();
@@ -187,6 +193,7 @@ __global__ void __launch_bounds__(256) ccl_tile_kernel(const T* __restrict__ in,
     int wroots = 0;
 #pragma unroll
     for (int k = 0; k < STRIP_R; ++k) {
+        if (!((fgrows >> k) & 1u)) continue;  // uniform: nothing but background, already marked
         const int y = ty0 + r0 + k;
         const int own = (r0 + k) * 64 + lane;
         bool is_root = false;
