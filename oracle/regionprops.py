@@ -153,6 +153,7 @@ def regionprops_table(label_image: np.ndarray, intensity_image=None, properties=
             T = inertia_tensor(mu)
             l1, l2 = inertia_tensor_eigvals(T)
         area = float(np.sum(img))
+        convex = None  # regionprops caches area_convex per region (SK/measure/_regionprops.py `_cached`)
         for p in props:
             if p == "label":
                 put("label", lab)
@@ -168,9 +169,11 @@ def regionprops_table(label_image: np.ndarray, intensity_image=None, properties=
                 put("bbox-2", sl[0].stop)
                 put("bbox-3", sl[1].stop)
             elif p == "area_convex":
-                put("area_convex", float(convex_area_exact(img)))
+                convex = float(convex_area_exact(img)) if convex is None else convex
+                put("area_convex", convex)
             elif p == "solidity":
-                put("solidity", area / float(convex_area_exact(img)))
+                convex = float(convex_area_exact(img)) if convex is None else convex
+                put("solidity", area / convex)
             elif p == "perimeter":
                 put("perimeter", perimeter(img))
             elif p == "eccentricity":
