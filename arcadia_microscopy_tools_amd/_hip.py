@@ -53,6 +53,10 @@ _SIGS = {
     "amt_memset": (c_int, [_P, _P, c_int, c_size_t]),
     "amt_sync": (c_int, [_P]),
     "amt_stream_wait": (c_int, [_P, _P]),
+    "amt_event_create": (c_int, [_P, POINTER(c_void_p)]),
+    "amt_event_record": (c_int, [_P, _P]),
+    "amt_event_wait": (c_int, [_P, _P]),
+    "amt_event_destroy": (c_int, [_P, _P]),
     "amt_host_alloc": (c_int, [c_size_t, POINTER(c_void_p)]),
     "amt_host_free": (c_int, [_P]),
     "amt_timer_create": (c_int, [_P, POINTER(c_void_p)]),
@@ -101,6 +105,7 @@ _SIGS = {
     "amt_regionprops_intensity_u16": (c_int, [_P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int]),
     "amt_regionprops_full_u16": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int]),
     "amt_max_i32": (c_int, [_P, _P, _P, c_int, c_size_t]),
+    "amt_pack_plate_rows": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_int, _P, c_size_t, _P]),
     "amt_label_bboxes": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int]),
     "amt_contours_find": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, c_size_t, _P]),
     "amt_contours_emit": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),
@@ -111,6 +116,44 @@ _SIGS = {
 
 _lib = None
 _lib_lock = threading.Lock()
+_runtime = None  # which HIP runtime the process ended up with: "torch" | "system"
+
+
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own ``libamdhip64.so`` (same SONAME as
+    /opt/rocm's).  If libamt_hip.so pulls in the system runtime first and torch is imported later, the process
+    holds TWO runtimes and torch's cannot open the GPU ("No HIP GPUs are available") -- and torch.distributed /
+    RCCL (plate.py) must see the memory and streams this library uses.  So when a torch wheel with a bundled
+    runtime is installed, that runtime is loaded first and libamt_hip.so binds to it; torch itself is NOT imported.
+    ``AMT_HIP_RUNTIME=system`` keeps the system runtime (single-GPU processes that never import torch)."""
+    global _runtime
+    import importlib.util
+    import sys
+
+    choice = os.environ.get("AMT_HIP_RUNTIME", "auto")
+    if choice == "system" and "torch" not in sys.modules:
+        _runtime = "system"
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is not None and spec.submodule_search_locations:
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            try:
+                ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+                _runtime = "torch"
+                return
+            except OSError:
+                pass
+    _runtime = "system"
+
+
+def hip_runtime() -> str:
+    """"torch" when the process shares PyTorch's bundled HIP runtime, "system" for /opt/rocm's."""
+    load_library()
+    return _runtime
 
 
 def load_library():
@@ -126,6 +169,7 @@ def load_library():
                 f"{LIB_PATH} not found: build the HIP extension first "
                 "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback"
             )
+        _share_hip_runtime_with_torch()
         try:
             lib = ctypes.CDLL(LIB_PATH)
         except OSError as e:  # missing ROCm runtime etc.

@@ -95,6 +95,17 @@ extern "C" int amt_device_name(amt_ctx* ctx, char* buf, int buflen) {
     return AMT_OK;
 }
 
+// AMT_DEBUG_POISON=1 (diagnostic): every allocation and, at the start of every op, the whole scratch arena are filled
+// with 0xCD bytes, so a kernel that relies on "fresh memory is zero" fails deterministically instead of once in a while.
+static bool poison_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("AMT_DEBUG_POISON");
+        v = (e && e[0] == '1') ? 1 : 0;
+    }
+    return v == 1;
+}
+
 int amt_arena_begin(amt_ctx* ctx, size_t total_bytes) {
     total_bytes = amt_align(total_bytes) + 4096;
     if (total_bytes > ctx->arena_cap) {
@@ -112,6 +123,7 @@ int amt_arena_begin(amt_ctx* ctx, size_t total_bytes) {
         ctx->arena_cap = cap;
     }
     ctx->arena_off = 0;
+    if (poison_enabled()) AMT_HIP_CHECK(hipMemsetAsync(ctx->arena, 0xCD, ctx->arena_cap, ctx->stream));
     return AMT_OK;
 }
 
@@ -187,6 +199,10 @@ extern "C" int amt_malloc(amt_ctx* ctx, size_t bytes, void** dptr) {
         amt_set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
         return AMT_ENOMEM;
     }
+    if (poison_enabled()) {
+        AMT_HIP_CHECK(hipMemsetAsync(*dptr, 0xCD, bytes, ctx->stream));
+        AMT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
     return AMT_OK;
 }
 
@@ -238,6 +254,34 @@ extern "C" int amt_stream_wait(amt_ctx* ctx, amt_ctx* other) {
     AMT_HIP_CHECK(hipEventRecord(ev, other->stream));
     AMT_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ev, 0));
     AMT_HIP_CHECK(hipEventDestroy(ev));  // destruction is deferred until the event has completed
+    return AMT_OK;
+}
+
+// ---- events: ordering between contexts at a RECORDED point (amt_stream_wait orders after everything so far) ----
+extern "C" int amt_event_create(amt_ctx* ctx, void** event) {
+    AMT_TRY(amt_set_device(ctx));
+    AMT_REQUIRE(event != nullptr, "amt_event_create: event is null");
+    hipEvent_t ev;
+    AMT_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    *event = (void*)ev;
+    return AMT_OK;
+}
+extern "C" int amt_event_record(amt_ctx* ctx, void* event) {
+    AMT_TRY(amt_set_device(ctx));
+    AMT_REQUIRE(event != nullptr, "amt_event_record: event is null");
+    AMT_HIP_CHECK(hipEventRecord((hipEvent_t)event, ctx->stream));
+    return AMT_OK;
+}
+extern "C" int amt_event_wait(amt_ctx* ctx, void* event) {
+    // what is enqueued next on ctx's stream happens after the event's last record (no-op if never recorded)
+    AMT_TRY(amt_set_device(ctx));
+    AMT_REQUIRE(event != nullptr, "amt_event_wait: event is null");
+    AMT_HIP_CHECK(hipStreamWaitEvent(ctx->stream, (hipEvent_t)event, 0));
+    return AMT_OK;
+}
+extern "C" int amt_event_destroy(amt_ctx* ctx, void* event) {
+    AMT_TRY(amt_set_device(ctx));
+    if (event) AMT_HIP_CHECK(hipEventDestroy((hipEvent_t)event));
     return AMT_OK;
 }
 

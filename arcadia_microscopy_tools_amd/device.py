@@ -111,6 +111,10 @@ class Context:
         """Order this context's stream after the work enqueued so far on ``other``'s stream (no host sync)."""
         _hip.check(self._lib.amt_stream_wait(self.handle, other.handle), "amt_stream_wait")
 
+    def event(self) -> "Event":
+        """A HIP event bound to this context's device (record on any context of the device, wait on any other)."""
+        return Event(self)
+
     def device_name(self) -> str:
         buf = ctypes.create_string_buffer(256)
         _hip.check(self._lib.amt_device_name(self.handle, buf, 256), "amt_device_name")
@@ -119,6 +123,31 @@ class Context:
     # -- timing (HIP events on this context's stream) ---------------------------------------------
     def timer(self) -> "Timer":
         return Timer(self)
+
+
+class Event:
+    """Ordering point between contexts: ``ev.record(a)`` marks a's stream, ``ev.wait(b)`` orders b's next work
+    after that mark (and not after what a's stream was given later, unlike ``Context.wait_for``)."""
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+        h = ctypes.c_void_p()
+        _hip.check(ctx._lib.amt_event_create(ctx.handle, ctypes.byref(h)), "amt_event_create")
+        self.h = h
+
+    def record(self, ctx: Context | None = None):
+        c = ctx or self.ctx
+        _hip.check(c._lib.amt_event_record(c.handle, self.h), "amt_event_record")
+
+    def wait(self, ctx: Context):
+        _hip.check(ctx._lib.amt_event_wait(ctx.handle, self.h), "amt_event_wait")
+
+    def __del__(self):
+        try:
+            if self.ctx.handle:
+                self.ctx._lib.amt_event_destroy(self.ctx.handle, self.h)
+        except Exception:
+            pass
 
 
 class Timer:
@@ -205,6 +234,19 @@ class DeviceArray:
                             base=self._base or self)
         else:
             raise IndexError("DeviceArray supports int or slice indexing of the leading axis only")
+        v.is_bool = self.is_bool
+        return v
+
+    def on(self, ctx: Context) -> "DeviceArray":
+        """The same memory as an array of another context of the same device.  Operators run on the stream of the
+        context their input belongs to, so a batch part that was uploaded by one context and is processed by
+        another (bench.py's stream split, the feeder's device buffers) must be re-bound, and ordered against its
+        producer with ``Context.wait_for`` / an ``Event`` if that producer may still be running."""
+        if ctx is self.ctx:
+            return self
+        if ctx.device != self.ctx.device:
+            raise ValueError(f"cannot bind an array of device {self.ctx.device} to a context of device {ctx.device}")
+        v = DeviceArray(ctx, self.ptr, self.shape, self.dtype, base=self._base or self)
         v.is_bool = self.is_bool
         return v
 

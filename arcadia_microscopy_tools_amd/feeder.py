@@ -39,6 +39,9 @@ class FovFeeder:
         self.copy_ctx.copy_from_host_async(self._dev[slot], self._pinned[slot].array)
 
     def acquire(self, slot: int, consumers) -> DeviceArray:
+        """The consumers' streams wait for the copy into ``slot``.  The returned array belongs to the COPY context;
+        operators run on the stream of their input's context, so bind it (or its parts) to the consuming context
+        with ``DeviceArray.on`` before use -- ``FovSegmenter`` does that itself."""
         for c in consumers:
             c.wait_for(self.copy_ctx)
         return self._dev[slot]

@@ -35,6 +35,10 @@ def _out(ctx: Context, out, shape, dtype) -> DeviceArray:
         return ctx.empty(shape, dtype)
     if tuple(out.shape) != tuple(shape) or out.dtype != np.dtype(dtype):
         raise ValueError(f"out has shape {out.shape} dtype {out.dtype}, need {tuple(shape)} {np.dtype(dtype)}")
+    if out.ctx is not ctx:
+        # the operator runs on the INPUT's stream: an output owned by another context would be written without any
+        # ordering against that context's work
+        raise ValueError("out belongs to another context than the input; bind the input with DeviceArray.on(ctx)")
     return out
 
 
@@ -596,6 +600,37 @@ def regionprops_full(labels: DeviceArray, intensity: DeviceArray, max_label: int
     _hip.check(_lib().amt_regionprops_full_u16(ctx.handle, labels.ptr, intensity.ptr, C, o.ptr, io.ptr, n, H, W,
                                                int(max_label)), "amt_regionprops_full_u16")
     return o, io
+
+
+def pack_plate_rows(table: DeviceArray, itable, ncells: DeviceArray, fov_index0: int = 0, fov_index=None,
+                    out=None, nrows_out=None):
+    """Dense per-FOV tables (B, K, RP_NCOLS) [+ (B, K, C, 4)] + cell counts (B,) -> one row per cell,
+    ``[fov index, label, morphology columns, C x {mean, max, min, std}]``: the block a rank contributes to the
+    plate's all-gather.  Returns (rows (B*K, 16 + 4C) float64 of which the first ``nrows`` are
+    written, nrows (1,) int64; -1 flags a field of view whose table overflowed)."""
+    ctx = table.ctx
+    if table.ndim != 3 or table.shape[2] != _hip.RP_NCOLS or table.dtype != np.float64:
+        raise ValueError(f"table must be (B, K, {_hip.RP_NCOLS}) float64, got {table.shape} {table.dtype}")
+    B, K = int(table.shape[0]), int(table.shape[1])
+    C = 0
+    if itable is not None:
+        if itable.ndim != 4 or itable.shape[:2] != (B, K) or itable.shape[3] != 4 or itable.dtype != np.float64:
+            raise ValueError(f"itable must be (B, K, C, 4) float64, got {itable.shape} {itable.dtype}")
+        C = int(itable.shape[2])
+    if ncells.dtype != np.int32 or ncells.size != B:
+        raise ValueError("ncells must be (B,) int32")
+    if fov_index is not None and (fov_index.dtype != np.int32 or fov_index.size != B):
+        raise ValueError("fov_index must be (B,) int32")
+    ncols = 2 + _hip.RP_NCOLS + 4 * C
+    if out is None:
+        out = ctx.empty((max(B * K, 1), ncols), np.float64)
+    elif out.dtype != np.float64 or out.ndim != 2 or out.shape[1] != ncols or out.shape[0] < B * K:
+        raise ValueError(f"out must be (>= {B * K}, {ncols}) float64, got {out.shape} {out.dtype}")
+    nr = _out(ctx, nrows_out, (1,), np.int64)
+    _hip.check(_lib().amt_pack_plate_rows(ctx.handle, table.ptr, None if itable is None else itable.ptr, ncells.ptr,
+                                          B, K, C, None if fov_index is None else fov_index.ptr, int(fov_index0),
+                                          out.ptr, int(out.shape[0]), nr.ptr), "amt_pack_plate_rows")
+    return out, nr
 
 
 def regionprops_intensity(labels: DeviceArray, intensity: DeviceArray, max_label: int, out=None) -> DeviceArray:

@@ -161,7 +161,12 @@ def read_frames_interleaved(path: Path):
     if at["bits"] != 16:
         raise NotImplementedError(f"only 16-bit ND2 frames are supported (got {at['bits']} bits)")
     W, H, C, N = at["width"], at["height"], at["components"], at["frames"]
-    frame_bytes = W * H * C * 2
+    # rows may be padded: uiWidthBytes is the row stride in bytes (the `nd2` reader honours it; R/nikon.py:41)
+    row_bytes = W * C * 2
+    stride = at["width_bytes"] or row_bytes
+    if stride < row_bytes or stride % 2:
+        raise ValueError(f"ND2 attributes are inconsistent: uiWidthBytes {stride} < {W} px x {C} components x 2 bytes")
+    frame_bytes = stride * (H - 1) + row_bytes if H > 0 else 0
     frames = np.empty((N, H, W, C), dtype="<u2")
     for i in range(N):
         key = b"ImageDataSeq|%d!" % i
@@ -169,8 +174,9 @@ def read_frames_interleaved(path: Path):
             raise ValueError(f"ND2 file has no chunk {key!r}")
         payload = chunk_payload(data, cmap[key])
         if len(payload) < 8 + frame_bytes:
-            raise NotImplementedError("compressed or padded ND2 frames are not supported")
-        frames[i] = np.frombuffer(payload, dtype="<u2", count=W * H * C, offset=8).reshape(H, W, C)
+            raise NotImplementedError("compressed ND2 frames are not supported")
+        rows = np.ndarray((H, W, C), dtype="<u2", buffer=payload, offset=8, strides=(stride, C * 2, 2))
+        frames[i] = rows
     return frames, at, read_channel_names(data, cmap, C)
 
 

@@ -80,127 +80,254 @@ def all_gather_rows(local_rows, group=None):
     return torch.cat(parts, dim=0), counts
 
 
-class PlateLayout:
-    """Byte layout of the per-plate feature blocks and of what the all-gather leaves behind (device independent,
-    so the world_size-2 gloo test on CPU exercises exactly what the RCCL path uses).
+def packed_ncols(C: int) -> int:
+    """Columns of a packed per-cell row: fov index, label, the RP_NCOLS morphology columns, C x {mean, max, min, std}."""
+    return 2 + _hip.RP_NCOLS + 4 * int(C)
 
-    One block = one batch of B fields of view of one rank: [B*K*14 float64 | B*K*C*4 float64 | B int32, padded to
-    8 bytes].  A rank's buffer holds [step][block]; the gathered buffer holds [step][rank][block]."""
 
-    def __init__(self, steps: int, world: int, B: int, K: int, C: int):
-        self.steps, self.world, self.B, self.K, self.C = int(steps), int(world), int(B), int(K), int(C)
-        self.n_table = self.B * self.K * _hip.RP_NCOLS * 8
-        self.n_itable = self.B * self.K * self.C * 4 * 8
-        self.n_cells = (self.B * 4 + 7) // 8 * 8
-        self.step_bytes = self.n_table + self.n_itable + self.n_cells
-        self.local_bytes = self.steps * self.step_bytes
-        self.gathered_bytes = self.steps * self.world * self.step_bytes
+class RowExchange:
+    """The plate's exchange, counts first, then rows -- an exact all-gather-v of the per-rank
+    blocks of packed feature rows, pipelined so that the host never waits for the step it has just enqueued.
 
-    def block_offsets(self, slot: int, b0: int = 0):
-        """Byte offsets, inside a rank's buffer, of the table / intensity table / cell counts of FOV b0 of a block."""
-        base = slot * self.step_bytes
+    ``submit(rows, nrows)`` enqueues the all-gather of the row COUNT of one block (world x int64) and its copy to
+    page-locked host memory; one block later (``lag``), when that small exchange has long finished, the host reads
+    the counts, and every rank enqueues ONE ``all_gather_into_tensor`` of ``max(counts)`` rows -- the bytes that
+    travel are the rows that exist (~1,360 of the 2,048 a field of view may hold), not the dense tables.
+    Device independent: the same code runs over RCCL on HIP streams (``stream`` = the side stream the collectives
+    are enqueued on) and over gloo on CPU tensors (tests/test_distributed_gloo.py, world_size 2)."""
+
+    def __init__(self, ncols: int, device, group=None, stream=None, lag: int = 1, keep: int | None = None):
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist, self.group = torch, dist, group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.ncols, self.device, self.stream, self.lag = int(ncols), torch.device(device), stream, int(lag)
+        self.on_gpu = self.device.type == "cuda"
+        # rehearsal on a single GPU: two ranks share the card and exchange through gloo, staged on the host
+        self.host_staged = self.on_gpu and dist.get_backend(group) == "gloo"
+        self.pending: list[dict] = []
+        # (gathered (world, max_rows, ncols), counts list) per block; `keep` bounds how many stay referenced (a
+        # consumer that writes each plate out as it arrives needs only the newest few; None keeps all)
+        self.finished: list[tuple] = []
+        self.keep = keep
+        self.n_finished = 0
+        # page-locked landing buffers for the counts, allocated once (hipHostMalloc / hipHostFree per step would
+        # stall the queues)
+        self._host_ring = ([torch.empty(self.world, dtype=torch.int64).pin_memory() for _ in range(self.lag + 2)]
+                           if self.on_gpu else None)
+        self._host_next = 0
+
+    def _stream_ctx(self):
+        import contextlib
+
+        if self.on_gpu and self.stream is not None:
+            return self.torch.cuda.stream(self.stream)
+        return contextlib.nullcontext()
+
+    def _all_gather(self, out, inp):
+        if self.host_staged:
+            if self.stream is not None:
+                self.stream.synchronize()
+            h_out = self.torch.empty(out.shape, dtype=out.dtype)
+            self.dist.all_gather_into_tensor(h_out, inp.cpu(), group=self.group)
+            out.copy_(h_out)
+        else:
+            self.dist.all_gather_into_tensor(out, inp, group=self.group)
+
+    def submit(self, rows, nrows):
+        """rows: (cap, ncols) float64 tensor of which the first ``nrows[0]`` rows are this rank's block;
+        nrows: (1,) int64 tensor on the same device (written by the pack kernel: the host does not know it yet)."""
+        torch = self.torch
+        if rows.dim() != 2 or rows.shape[1] != self.ncols or rows.dtype != torch.float64 or not rows.is_contiguous():
+            raise ValueError(f"rows must be a contiguous (cap, {self.ncols}) float64 tensor")
+        with self._stream_ctx():
+            counts = torch.empty(self.world, dtype=torch.int64, device=self.device)
+            self._all_gather(counts, nrows.reshape(1))
+            event = None
+            if self.on_gpu:
+                host = self._host_ring[self._host_next % len(self._host_ring)]
+                self._host_next += 1
+                host.copy_(counts, non_blocking=True)
+                event = torch.cuda.Event()
+                event.record(self.stream if self.stream is not None else torch.cuda.current_stream(self.device))
+            else:
+                host = counts
+        self.pending.append(dict(rows=rows, host=host, event=event, issued=False))
+        self.pump(self.lag)
+
+    def _issue(self, e):
+        torch = self.torch
+        if e["event"] is not None:
+            e["event"].synchronize()
+        counts = [int(v) for v in e["host"].tolist()]
+        if min(counts) < 0:
+            raise RuntimeError(f"a rank reported an overflowed feature table (row counts {counts}); raise max_cells")
+        max_rows = max(counts)
+        rows = e["rows"]
+        with self._stream_ctx():
+            if max_rows > rows.shape[0]:  # another rank holds more rows than this rank's buffer: pad a copy
+                padded = torch.zeros((max_rows, self.ncols), dtype=rows.dtype, device=rows.device)
+                padded[: rows.shape[0]] = rows
+                rows = padded
+            gathered = torch.empty((self.world, max_rows, self.ncols), dtype=torch.float64, device=self.device)
+            if max_rows > 0:
+                self._all_gather(gathered.view(-1), rows[:max_rows].reshape(-1))
+        self.finished.append((gathered, counts))
+        self.n_finished += 1
+        if self.keep is not None and len(self.finished) > self.keep:
+            del self.finished[: len(self.finished) - self.keep]
+        e["issued"] = True
+        e["rows"] = None
+
+    def pump(self, keep: int):
+        """Issue the row all-gather of every submitted block except the newest ``keep``."""
+        todo = [e for e in self.pending if not e["issued"]]
+        for e in todo[: max(0, len(todo) - keep)]:
+            self._issue(e)
+        self.pending = [e for e in self.pending if not e["issued"]]
+
+    def flush(self):
+        self.pump(0)
+
+    def results(self):
+        """[(rows (sum counts, ncols) tensor ordered by rank, counts list)] per submitted block, in order."""
+        self.flush()
+        if self.on_gpu and self.stream is not None:
+            self.stream.synchronize()
+        out = []
+        for gathered, counts in self.finished:
+            parts = [gathered[r, : counts[r]] for r in range(self.world)]
+            out.append((self.torch.cat(parts, dim=0) if parts else gathered.reshape(0, self.ncols), counts))
+        return out
+
+
+class PlateTables:
+    """The per-rank blocks of the per-plate feature tables, and the ONE row exchange each plate gets.
+
+    A rank processes its shard in steps; a step of all ranks together is one plate (BASELINE configs[3]: 384
+    fields of view, 48 per GPU at 8 GPUs).  The step's segmenters write their dense tables (B x K rows) and cell
+    counts straight into a staging block (a ring of ``slots`` blocks); when the step's kernels have been enqueued,
+    a side stream -- ordered after the compute streams with events -- compacts the block to one row per cell
+    (``amt_pack_plate_rows``) and hands it to ``RowExchange``: row counts first, then ONE RCCL all-gather of the rows
+    that exist, travelling over xGMI while the next step computes (BASELINE.json north_star: "RCCL all-gather over
+    xGMI only for the final per-plate label/feature table").  Ranks may hold different numbers of fields of view."""
+
+    def __init__(self, segs, torch_device, group=None, slots: int = 4, cap_fovs: int | None = None,
+                 keep: int | None = None):
+        import torch
+        import torch.distributed as dist
+
+        from .device import Context, DeviceArray
+
+        self.torch, self.dist, self.group = torch, dist, group
+        self.segs = list(segs)
+        B = sum(s.B for s in self.segs)
+        K, C = self.segs[0].max_cells, self.segs[0].C
+        if any(s.max_cells != K or s.C != C for s in self.segs):
+            raise ValueError("all segmenters of a rank must share max_cells and the channel count")
+        self.B, self.K, self.C = B, K, C
+        self.ncols = packed_ncols(C)
+        self.slots = max(2, int(slots))
+        cap_fovs = B if cap_fovs is None else max(int(cap_fovs), B)
+        # staging ring: [slot][B*K*RP_NCOLS f64 | B*K*C*4 f64 | B int32]
+        self.n_table = B * K * _hip.RP_NCOLS * 8
+        self.n_itable = B * K * C * 4 * 8
+        self.n_cells = (B * 4 + 7) // 8 * 8
+        self.slot_bytes = self.n_table + self.n_itable + self.n_cells
+        self.staging = torch.zeros(self.slots * self.slot_bytes, dtype=torch.uint8, device=torch_device)
+        # packed rows: one buffer per slot (a block's rows must stay put until its lagged all-gather has run)
+        self.rows = [torch.empty((max(cap_fovs * K, 1), self.ncols), dtype=torch.float64, device=torch_device)
+                     for _ in range(self.slots)]
+        self.nrows = [torch.zeros(1, dtype=torch.int64, device=torch_device) for _ in range(self.slots)]
+        # the side stream is one of the library's own HIP streams, handed to torch as an external stream
+        self.gctx = Context(self.segs[0].ctx.device)
+        self.stream = torch.cuda.ExternalStream(self.gctx.stream_ptr, device=torch_device)
+        self.exchange = RowExchange(self.ncols, torch_device, group, stream=self.stream, lag=1, keep=keep)
+        self._DeviceArray = DeviceArray
+        self.used = [False] * self.slots
+        self.packed_ev = [self.gctx.event() for _ in range(self.slots)]  # "the pack kernel has read this block"
+        torch.cuda.synchronize(torch_device)  # torch filled the buffers on ITS stream; the library's streams do not wait for it
+
+    def _offsets(self, slot: int, b0: int):
+        base = slot * self.slot_bytes
         return (base + b0 * self.K * _hip.RP_NCOLS * 8,
                 base + self.n_table + b0 * self.K * self.C * 4 * 8,
                 base + self.n_table + self.n_itable + b0 * 4)
 
-    def gather_step(self, local, gathered, slot: int, group=None):
-        """The plate's ONE collective: all-gather block `slot` of every rank (uint8 torch tensors)."""
-        import torch.distributed as dist
-
-        lo = slot * self.step_bytes
-        go = slot * self.world * self.step_bytes
-        dist.all_gather_into_tensor(gathered[go: go + self.world * self.step_bytes],
-                                    local[lo: lo + self.step_bytes], group=group)
-
-    def unpack(self, gathered):
-        """(table, itable, ncells) with leading axes (rank, step * B + fov) from a gathered uint8 tensor."""
-        import torch
-
-        S, Wd, B, K, C = self.steps, self.world, self.B, self.K, self.C
-        g = gathered.view(S, Wd, self.step_bytes)
-        t = g[:, :, : self.n_table].contiguous().view(torch.float64).view(S, Wd, B, K, _hip.RP_NCOLS)
-        it = g[:, :, self.n_table: self.n_table + self.n_itable].contiguous().view(torch.float64).view(S, Wd, B, K, C, 4)
-        nc = g[:, :, self.n_table + self.n_itable: self.n_table + self.n_itable + B * 4].contiguous().view(
-            torch.int32).view(S, Wd, B)
-        t = t.permute(1, 0, 2, 3, 4).reshape(Wd, S * B, K, _hip.RP_NCOLS)
-        it = it.permute(1, 0, 2, 3, 4, 5).reshape(Wd, S * B, K, C, 4)
-        nc = nc.permute(1, 0, 2).reshape(Wd, S * B)
-        return t, it, nc
-
-
-class PlateTables:
-    """The per-rank blocks of the per-plate feature tables, and the ONE all-gather each plate gets.
-
-    A rank processes its shard in `steps` batches; a batch of all ranks together is one plate (world x B fields of
-    view: 384 at 2 GPUs with the bench's B = 192).  The batch's segmenters write their morphology table, intensity
-    table and cell counts straight into the batch's slice of one torch-allocated byte buffer (no copies); when the
-    batch's kernels have been enqueued, a single ``all_gather_into_tensor`` over RCCL for that plate is enqueued
-    on a side stream, ordered after the compute streams with events, so it travels over xGMI while the next batch
-    computes (BASELINE.json north_star: "RCCL all-gather over xGMI only for the final per-plate label/feature
-    table").  Layout of one batch block (bytes): [B*K*14 float64 | B*K*C*4 float64 | B int32 (padded to 8 bytes)];
-    the gathered buffer holds [step][rank][block]."""
-
-    def __init__(self, segs, steps, torch_device, group=None):
-        import torch
-        import torch.distributed as dist
-
-        from .device import Context
-
-        self.torch, self.dist, self.group = torch, dist, group
-        self.segs = list(segs)
-        self.steps = int(steps)
-        B = sum(s.B for s in self.segs)
-        K, C = self.segs[0].max_cells, self.segs[0].C
-        self.B, self.K, self.C = B, K, C
-        self.world = dist.get_world_size(group)
-        self.layout = PlateLayout(self.steps, self.world, B, K, C)
-        self.step_bytes = self.layout.step_bytes
-        self.local = torch.zeros(self.layout.local_bytes, dtype=torch.uint8, device=torch_device)
-        self.gathered = torch.empty(self.layout.gathered_bytes, dtype=torch.uint8, device=torch_device)
-        self.done = [False] * self.steps
-        # the collective's stream is one of the library's own HIP streams handed to torch as an external stream
-        self.gctx = Context(self.segs[0].ctx.device)
-        self.stream = torch.cuda.ExternalStream(self.gctx.stream_ptr, device=torch_device)
-
     def point(self, step: int):
-        """Make the segmenters write the tables of batch `step` (0-based, modulo `steps`) into that batch's block."""
-        from .device import DeviceArray
-
-        slot = step % self.steps
-        ptr = self.local.data_ptr()
+        """Make the segmenters write the tables of step `step` into that step's staging block."""
+        DeviceArray = self._DeviceArray
+        slot = step % self.slots
+        ptr = self.staging.data_ptr()
         K, C = self.K, self.C
-        if self.done[slot]:  # an earlier exchange of this block may still be reading it
+        if self.used[slot]:  # the pack kernel of the block's previous use (`slots` steps ago) may still be reading it
             for s in self.segs:
-                s.ctx.wait_for(self.gctx)
+                self.packed_ev[slot].wait(s.ctx)
         b0 = 0
         for s in self.segs:
-            o_t, o_i, o_c = self.layout.block_offsets(slot, b0)
+            o_t, o_i, o_c = self._offsets(slot, b0)
             s.table = DeviceArray(s.ctx, ptr + o_t, (s.B, K, _hip.RP_NCOLS), np.float64)
             s.itable = DeviceArray(s.ctx, ptr + o_i, (s.B, K, C, 4), np.float64)
             s.ncells = DeviceArray(s.ctx, ptr + o_c, (s.B,), np.int32)
             b0 += s.B
-        self.done[slot] = False
+        self.used[slot] = True
 
-    def gather_step(self, step: int):
-        """Enqueue the all-gather of batch `step` after everything the compute streams have been given so far."""
-        slot = step % self.steps
+    def gather_step(self, step: int, fov_index0: int = 0):
+        """After everything the compute streams have been given so far: pack the step's block and submit it."""
+        from . import hipops
+
+        DeviceArray = self._DeviceArray
+        slot = step % self.slots
         for s in self.segs:
             self.gctx.wait_for(s.ctx)
-        with self.torch.cuda.stream(self.stream):
-            self.layout.gather_step(self.local, self.gathered, slot, self.group)
-        self.done[slot] = True
+        B, K, C = self.B, self.K, self.C
+        o_t, o_i, o_c = self._offsets(slot, 0)
+        ptr = self.staging.data_ptr()
+        g = self.gctx
+        hipops.pack_plate_rows(
+            DeviceArray(g, ptr + o_t, (B, K, _hip.RP_NCOLS), np.float64),
+            DeviceArray(g, ptr + o_i, (B, K, C, 4), np.float64),
+            DeviceArray(g, ptr + o_c, (B,), np.int32), fov_index0=fov_index0,
+            out=DeviceArray(g, self.rows[slot].data_ptr(), tuple(self.rows[slot].shape), np.float64),
+            nrows_out=DeviceArray(g, self.nrows[slot].data_ptr(), (1,), np.int64))
+        self.packed_ev[slot].record(g)
+        self.exchange.submit(self.rows[slot], self.nrows[slot])
 
     def all_gather(self):
-        """Enqueue the all-gather of every batch that has not been exchanged yet; returns the gathered buffer."""
-        for slot in range(self.steps):
-            if not self.done[slot]:
-                self.gather_step(slot)
-        return self.gathered
+        """Issue the row exchanges that are still held back by the one-step lag."""
+        self.exchange.flush()
 
     def result(self):
-        """(table, itable, ncells) of everything gathered: leading axes (rank, step * B + fov)."""
-        self.stream.synchronize()
-        return self.layout.unpack(self.gathered)
+        """[(rows (cells of all ranks, ncols) float64 numpy, counts per rank)] per step, in step order (the newest
+        ``keep`` steps when the exchange was built with a bound)."""
+        return [(r.cpu().numpy(), c) for r, c in self.exchange.results()]
+
+
+def rows_to_table(rows: np.ndarray, channel_names) -> np.ndarray:
+    """Packed rows ``[fov, label, RP columns, C x 4 intensity]`` (any order of fields of view) -> the plate table in
+    ``table_columns`` order, rows sorted by field of view then label, derived columns (circularity, volume) exactly
+    as ``cell_properties`` derives them (R/masks.py:292-305 via segment.assemble_cell_properties)."""
+    from .segment import assemble_cell_properties
+
+    rows = np.asarray(rows, dtype=np.float64)
+    channel_names = list(channel_names)
+    C = len(channel_names)
+    if rows.ndim != 2 or rows.shape[1] != packed_ncols(C):
+        raise ValueError(f"expected (rows, {packed_ncols(C)}) packed rows, got {rows.shape}")
+    order = np.lexsort((rows[:, 1], rows[:, 0]))
+    rows = rows[order]
+    fovs, starts = np.unique(rows[:, 0], return_index=True)
+    bounds = list(starts) + [len(rows)]
+    tables, idx = [], []
+    for i, f in enumerate(fovs):
+        blk = rows[bounds[i]: bounds[i + 1]]
+        morph = blk[:, 2: 2 + _hip.RP_NCOLS]
+        inten = blk[:, 2 + _hip.RP_NCOLS:].reshape(len(blk), C, 4)
+        tables.append(assemble_cell_properties(morph, inten, channel_names))
+        idx.append(int(f))
+    return pack_rows(idx, tables, channel_names)
 
 
 def well_id(fov_index: int, n_columns: int = 24, fovs_per_well: int = 1) -> str:

@@ -85,10 +85,14 @@ class FovSegmenter:
             self._open.stop()
             self._open = None
 
-    def _check_fovs(self, fovs: DeviceArray):
+    def _check_fovs(self, fovs: DeviceArray) -> DeviceArray:
+        """Validate the batch and bind it to THIS segmenter's context: operators run on the stream of their
+        input's context, and a batch part may have been uploaded by another context (bench.py's stream split, the
+        feeder's buffers) -- every kernel of the chain must be on self.ctx's stream."""
         if fovs.dtype != np.uint16 or fovs.shape != (self.B, self.C, self.H, self.W):
             raise ValueError(f"expected uint16 FOV batch of shape {(self.B, self.C, self.H, self.W)}, got "
                              f"{fovs.dtype} {fovs.shape}")
+        return fovs.on(self.ctx)
 
     def mask_chain(self, fovs: DeviceArray) -> DeviceArray:
         """Gaussian -> Otsu -> '>' -> opening -> closing on the DAPI channel of every FOV."""
@@ -103,7 +107,7 @@ class FovSegmenter:
 
     def run_c2(self, fovs: DeviceArray) -> DeviceArray:
         """BASELINE configs[1]: the mask chain + 8-connected labelling.  Returns int32 labels (B, H, W)."""
-        self._check_fovs(fovs)
+        fovs = self._check_fovs(fovs)
         if self.labels8 is None:
             self.labels8 = self.ctx.empty((self.B, self.H, self.W), np.int32)
         mask = self.mask_chain(fovs)
@@ -115,7 +119,7 @@ class FovSegmenter:
 
     def run_c3(self, fovs: DeviceArray) -> DeviceArray:
         """BASELINE configs[2]: nuclei watershed + morphology / intensity tables.  Returns int32 labels."""
-        self._check_fovs(fovs)
+        fovs = self._check_fovs(fovs)
         mask = self.mask_chain(fovs)
         self._stage("edt")
         hipops.edt(mask, want_edt=False, d2_out=self.d2)

@@ -1,20 +1,33 @@
 """bench.py -- fields-of-view/sec of the end-to-end segment + props hot path on MI355X.
 
-    python bench.py [--gpus N --steps K --warmup W --batch B]
+    python bench.py [--gpus N --steps K --warmup W --batch B] [--plate 384] [--workload c3|c2|prep|filters]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = the whole config-3 chain (BASELINE.json configs[2]: Gaussian -> Otsu -> threshold -> open ->
 close -> EDT -> peak markers -> watershed -> clear_border -> relabel -> morphology + 4-channel intensity
-tables) over one batch of B synthetic 4 x 2048 x 2048 uint16 fields of view that are ALREADY RESIDENT in
-HBM when the timed region starts.  For N > 1 every rank processes its own B fields of view (weak scaling)
-and each step ends with the RCCL all-gather of the per-rank feature tables (BASELINE configs[3]).
-Rank 0 prints ONE JSON line (contract in the task statement).
+tables) over one batch of synthetic 4 x 2048 x 2048 uint16 fields of view that are ALREADY RESIDENT in HBM when
+the timed region starts.
+
+N > 1: one process per GPU.  ``--gpus N`` without a launcher (WORLD_SIZE unset) starts the N ranks itself, as
+child processes of a parent that never touches HIP; under ``torch.distributed.run`` the ranks come from the
+environment and ``--gpus`` must agree with WORLD_SIZE.  Fields of view are independent: they are sharded with no
+collective on the data path, and each step (= one plate) ends with the plate's feature-table exchange over RCCL
+(row counts first, then ONE all-gather of the packed rows; arcadia_microscopy_tools_amd/plate.py).
+  default        weak scaling: every rank processes --batch fields of view per step (N x 192 per plate)
+  --plate 384    strong scaling: BASELINE configs[3], one step = one 384-FOV plate split over the ranks (48 per
+                 GPU at N = 8)
+
+Rank 0 prints ONE JSON line (contract in the task statement).  ``--workload prep`` / ``filters`` time the
+reference's canonical preprocessing (R/operations.py:57-97,10-54) and the north_star's filter set per stage, with
+a roofline per stage; their ``value`` is planes/s and they are supplementary lines, not the headline metric.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,31 +46,45 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (G/MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
 # algorithmic bytes per pixel per stage: narrowest dtypes, one read + one write
 STAGE_BYTES_PER_PX = {
-    "gaussian": 10, "otsu": 8, "threshold": 9, "opening": 4, "closing": 4, "threshold_open_close": 17, "label8": 5, "edt": 9, "peaks": 17,
-    "markers": 5, "watershed": 17, "clear_border": 8, "relabel": 4, "regionprops": 16, "intensity": 12,
+    "gaussian": 10, "otsu": 8, "threshold": 9, "opening": 4, "closing": 4, "threshold_open_close": 17, "label8": 5,
+    "edt": 9, "peaks": 17, "markers": 5, "watershed": 17, "clear_border": 8, "relabel": 4, "regionprops": 16,
+    "intensity": 12,
+    # reference-level preprocessing (R/operations.py) and the north_star's other filters, per SURVEY.md 8(d)
+    "dog": 10, "percentile_f64": 8, "sub_clip": 16, "rescale": 16,
+    "median_disk2": 4, "grey_open_disk2": 8, "grey_close_disk2": 8, "tophat_disk7": 14, "grey_erosion_disk2": 4,
 }
-
 
 # kernels (name prefixes in the rocprofv3 output) that make up each stage of the chain
 STAGE_KERNELS = {
     "gaussian": ("gauss_lds_kernel", "gauss_fused_kernel", "conv_v8_kernel", "conv_h8_kernel"),
     "otsu": ("hist_f64_kernel", "otsu_f64_kernel", "minmax_"),
     "threshold_open_close": ("pack_gt_kernel", "toc_fused_kernel", "packed_prim_kernel", "unpack_kernel"),
-    "edt": ("edt_rows_kernel", "edt_cols_kernel"),
-    "peaks": ("peaks_tile_kernel",),
+    "edt": ("edt_rows", "edt_cols"),
+    "peaks": ("peaks_",),
     "markers": ("sp_",),
     "watershed": ("ccl_", "ws_", "roots_"),
     "label8": ("ccl_", "roots_", "apply_rank_kernel"),
     "clear_border": ("presence_", "frame_mark_kernel", "drop_flagged_kernel", "map_labels_kernel"),
     "regionprops": ("rp_",),
 }
+# committed rocprofv3 summaries the `traffic` / `stage_kernels_rocprof_us` fields are read from (NOT measured in
+# this run: PMC collection needs separate rocprofv3 passes); the newest tag present wins
+PROFILE_TAGS = ("r02", "r01")
+
+
+def _profile_path(kind: str):
+    for tag in PROFILE_TAGS:
+        p = os.path.join(ROOT, "profiles", f"{tag}_{kind}.csv")
+        if os.path.exists(p):
+            return p
+    return None
 
 
 def pmc_traffic_bytes(stage: str):
-    """HBM bytes per 32-FOV launch of one stage from the committed PMC summary (profiles/r01_hbm_pmc.csv:
+    """HBM bytes per 32-FOV launch of one stage from the committed PMC summary (profiles/rNN_hbm_pmc.csv:
     FETCH_SIZE with the gfx950 x2 correction for wide reads + WRITE_SIZE), or None."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_hbm_pmc.csv")
-    if not os.path.exists(path) or stage not in STAGE_KERNELS:
+    path = _profile_path("hbm_pmc")
+    if path is None or stage not in STAGE_KERNELS:
         return None
     total = 0.0
     with open(path) as f:
@@ -75,9 +102,9 @@ def pmc_traffic_bytes(stage: str):
 
 def rocprof_kernel_us(stage: str):
     """Average duration (us per 32-FOV launch) of the kernels of one stage from the committed rocprofv3 summary
-    (profiles/r01_kernel_stats.csv), for comparison with the live HIP-event time of the stage."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_kernel_stats.csv")
-    if not os.path.exists(path) or stage not in STAGE_KERNELS:
+    (profiles/rNN_kernel_stats.csv), for comparison with the live HIP-event time of the stage."""
+    path = _profile_path("kernel_stats")
+    if path is None or stage not in STAGE_KERNELS:
         return None
     out = {}
     with open(path) as f:
@@ -103,23 +130,52 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=192, help="fields of view per GPU per step")
-    ap.add_argument("--streams", type=int, default=6,
+    ap.add_argument("--batch", type=int, default=192, help="fields of view per GPU per step (weak scaling)")
+    ap.add_argument("--plate", type=int, default=0,
+                    help="strong scaling: fields of view of ONE plate, split over the ranks; a step is one plate "
+                         "(384 = BASELINE configs[3]); 0 = weak scaling with --batch per GPU")
+    ap.add_argument("--streams", type=int, default=0,
                     help="HIP streams per GPU; the batch is split over them so that the latency-bound flood of one "
-                         "part overlaps the bandwidth-bound stages of the other")
+                         "part overlaps the bandwidth-bound stages of the others (0 = 6, fewer for small batches)")
     ap.add_argument("--size", type=int, default=2048)
     ap.add_argument("--max-cells", type=int, default=2048,
-                    help="row capacity of the per-FOV feature tables (the synthetic FOVs hold ~1,360 nuclei); it sizes "
-                         "the per-plate block that the ranks all-gather, and a FOV that exceeds it raises")
+                    help="row capacity of the per-FOV feature tables (the synthetic FOVs hold ~1,360 nuclei); a FOV "
+                         "that exceeds it raises")
     ap.add_argument("--unique", type=int, default=8,
                     help="distinct synthetic FOVs generated per GPU (host-side generation costs ~0.5 s each); the "
                          "batch cycles through them")
-    ap.add_argument("--workload", choices=["c3", "c2"], default="c3")
-    ap.add_argument("--cpu-fovs", type=int, default=2, help="FOVs timed through the single-thread CPU oracle")
+    ap.add_argument("--workload", choices=["c3", "c2", "prep", "filters"], default="c3")
+    ap.add_argument("--cpu-fovs", type=int, default=4, help="FOVs timed through the single-thread CPU oracle")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1 without the per-plate feature-table exchange")
     ap.add_argument("--no-h2d", action="store_true",
                     help="skip the extra host-fed run (FOVs streamed from pinned host memory over PCIe, N = 1 only)")
+    ap.add_argument("--tail-reps", type=int, default=0,
+                    help="c3: time the watershed stage of a 32-FOV launch this many times over rotating windows of "
+                         "the distinct FOVs and report p50 / p99 (flood time is set by the largest component)")
     return ap.parse_args()
+
+
+def launch_ranks_if_needed(args):
+    """``--gpus N`` without a launcher: start N ranks as fresh child processes BEFORE anything touches HIP (the
+    parent only waits for them), one rank per GPU over RCCL, rendezvous on 127.0.0.1."""
+    if "WORLD_SIZE" in os.environ:
+        world = int(os.environ["WORLD_SIZE"])
+        if world != args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with matching values",
+                  file=sys.stderr)
+            sys.exit(2)
+        return
+    if args.gpus <= 1:
+        return
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("launching: " + " ".join(cmd))
+    sys.exit(subprocess.call(cmd))
 
 
 def cpu_baseline(fovs: np.ndarray, workload: str, n_single: int):
@@ -128,9 +184,24 @@ def cpu_baseline(fovs: np.ndarray, workload: str, n_single: int):
     ThreadPoolExecutor mode (R/pipeline.py:145)."""
     from concurrent.futures import ThreadPoolExecutor
 
-    from oracle import chains
+    from oracle import chains, skops
 
-    fn = (lambda f: chains.c3_chain(f)) if workload == "c3" else (lambda f: chains.c2_chain(f[1]))
+    if workload == "c3":
+        fn = lambda f: chains.c3_chain(f)  # noqa: E731
+    elif workload == "c2":
+        fn = lambda f: chains.c2_chain(f[1])  # noqa: E731
+    elif workload == "prep":
+        def fn(f):
+            d = skops.difference_of_gaussians(f[1], 0.6, 16.0)
+            d = np.clip(d - np.percentile(d, 90), 0, None)
+            p = np.percentile(d, (1, 99))
+            return skops.rescale_intensity(d, p, (0, 1))
+    else:
+        def fn(f):
+            se2, se7 = skops.disk(2), skops.disk(7)
+            return (skops.median(f[1], se2), skops.opening(f[1], se2), skops.closing(f[1], se2),
+                    skops.white_tophat(f[1], se7))
+    unit = "FOV/s" if workload in ("c3", "c2") else "planes/s"
     n_single = max(1, min(n_single, len(fovs)))
     t0 = time.perf_counter()
     for i in range(n_single):
@@ -150,74 +221,236 @@ def cpu_baseline(fovs: np.ndarray, workload: str, n_single: int):
     tall = time.perf_counter() - t0
     return {
         "value": n_single / t1,
-        "unit": "FOV/s",
+        "unit": unit,
         "cores": 1,
         "kind": "port",
-        "sample": f"{n_single} synthetic 4x{fovs.shape[-1]}^2 FOVs through oracle/chains.py ({workload}), 1 thread",
+        "sample": f"{n_single} synthetic 4x{fovs.shape[-1]}^2 FOVs through the oracle ({workload}), 1 thread, "
+                  f"{t1:.1f} s",
         "all_cores": {"value": len(sample) / tall, "cores": cores,
-                      "sample": f"{len(sample)} FOVs, ThreadPoolExecutor(max_workers={cores})"},
+                      "sample": f"{len(sample)} FOVs, ThreadPoolExecutor(max_workers={cores}), {tall:.1f} s"},
     }
 
 
+def stage_roofline(stage_avg: dict, npx: int, PB: int):
+    """The `roofline` object: dominant stage vs the HBM peak, plus the whole chain and the filter+morphology chain."""
+    dom = max(stage_avg, key=stage_avg.get)
+    dom_bytes = STAGE_BYTES_PER_PX[dom] * npx
+    achieved = dom_bytes / (stage_avg[dom] * 1e-3) / 1e9
+    chain_bytes = sum(STAGE_BYTES_PER_PX[k] for k in stage_avg) * npx
+    chain_ms = sum(stage_avg.values())
+    traffic = pmc_traffic_bytes(dom)
+    roofline = {
+        "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS,
+        "frac_of_measured_peak": achieved / 6290.0,  # 6.29 TB/s = measured HBM3E streaming rate (MI355X_MICROARCH.md)
+        # PMC bytes of this stage's kernels for a 32-FOV launch from the COMMITTED profile (separate rocprofv3
+        # --pmc passes; not measured in this run), scaled to this run's launch size
+        "traffic": None if traffic is None else traffic * PB / 32.0,
+        "traffic_source": (os.path.relpath(_profile_path("hbm_pmc"), ROOT) + " (committed PMC passes, FETCH_SIZE x2 "
+                           "for wide reads + WRITE_SIZE)") if traffic is not None else None,
+        "algorithmic_bytes_per_launch": dom_bytes, "launch_ms": stage_avg[dom],
+        # the stage is one C-ABI call = several kernels (the flood classes run concurrently): their rocprofv3
+        # averages from the committed summary, per 32-FOV launch
+        "stage_kernels_rocprof_us": rocprof_kernel_us(dom),
+        "chain": {"achieved": chain_bytes / (chain_ms * 1e-3) / 1e9,
+                  "frac": chain_bytes / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms": chain_ms},
+        "stage_ms": stage_avg,
+        "stage_frac": {k: STAGE_BYTES_PER_PX[k] * npx / (v * 1e-3) / 1e9 / HBM_PEAK_GBS for k, v in stage_avg.items()},
+    }
+    # filter + morphology chain of the north_star: Gaussian (10 B/px) + open + close (8 B/px).  The '>' is
+    # fused into the packed open/close chain, so that stage's time is charged in full while only the
+    # morphology's 8 B/px are credited (conservative).
+    fm = [k for k in ("gaussian", "opening", "closing", "threshold_open_close") if k in stage_avg]
+    if fm:
+        fm_bytes = sum(8 if k == "threshold_open_close" else STAGE_BYTES_PER_PX[k] for k in fm) * npx
+        fm_ms = sum(stage_avg[k] for k in fm)
+        roofline["filter_morphology_chain"] = {"achieved": fm_bytes / (fm_ms * 1e-3) / 1e9,
+                                               "frac": fm_bytes / (fm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms": fm_ms}
+    return roofline
+
+
+# ------------------------------------------------------------------------------------------------------
+# reference-level operator chains on B resident planes (supplementary workloads)
+# ------------------------------------------------------------------------------------------------------
+def run_ops(args, json_fd):
+    from arcadia_microscopy_tools_amd import hipops, synth
+    from arcadia_microscopy_tools_amd.device import Context, set_default_device
+
+    set_default_device(0)
+    ctx = Context(0)
+    B, S = (args.batch if args.batch != 192 else 32), args.size
+    t0 = time.perf_counter()
+    nuniq = max(1, min(args.unique, B))
+    uniq = [synth.synth_fov(i, size=S) for i in range(nuniq)]
+    gen_s = time.perf_counter() - t0
+    planes = np.stack([uniq[i % nuniq][1] for i in range(B)])  # the DAPI plane of every FOV
+    d = ctx.asarray(planes)
+    log(f"{B} resident {S}^2 uint16 planes on {ctx.device_name()}")
+    f64 = lambda: ctx.empty((B, S, S), np.float64)  # noqa: E731
+    u16 = lambda: ctx.empty((B, S, S), np.uint16)  # noqa: E731
+    if args.workload == "prep":
+        # subtract_background_dog(percentile=90) -> rescale_by_percentile((1, 99)): the notebooks' fluorescence
+        # preprocessing (R/operations.py:57-97, 10-54; SURVEY.md 3.1)
+        dog, out = f64(), f64()
+        lvl = ctx.empty((B, 1), np.float64)
+        pr = ctx.empty((B, 2), np.float64)
+        stages = [
+            ("dog", lambda: hipops.difference_of_gaussians(d, 0.6, 16.0, out=dog)),
+            ("percentile_f64", lambda: hipops.percentile(dog, 90.0, out=lvl)),
+            ("sub_clip", lambda: hipops.sub_clip0(dog, lvl, out=dog)),
+            ("percentile_f64#2", lambda: hipops.percentile(dog, (1.0, 99.0), out=pr)),
+            ("rescale", lambda: hipops.rescale(dog, pr, (0.0, 1.0), out=out)),
+        ]
+        desc = ("reference preprocessing on DAPI planes: subtract_background_dog(0.6, 16, percentile=90) -> "
+                "rescale_by_percentile((1, 99)) (R/operations.py:57-97,10-54)")
+    else:
+        se2, se7 = hipops.disk(2), hipops.disk(7)
+        a, b, c = u16(), u16(), u16()
+        stages = [
+            ("median_disk2", lambda: hipops.median(d, se2, out=a)),
+            ("grey_erosion_disk2", lambda: hipops.erosion(d, se2, out=a)),
+            ("grey_open_disk2", lambda: hipops.dilation(hipops.erosion(d, se2, out=a), se2, out=b)),
+            ("grey_close_disk2", lambda: hipops.erosion(hipops.dilation(d, se2, out=a), se2, out=b)),
+            ("tophat_disk7", lambda: hipops.white_tophat(d, se7, out=c)),
+        ]
+        desc = "north_star filter set on uint16 planes: median disk(2), grey erosion / open / close disk(2), white top-hat disk(7)"
+
+    def step():
+        for _, fn in stages:
+            fn()
+
+    for _ in range(max(1, args.warmup)):
+        step()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.synchronize()
+    elapsed = time.perf_counter() - t0
+    timers = {name: ctx.timer() for name, _ in stages}
+    acc = {name: [] for name, _ in stages}
+    for _ in range(3):
+        for name, fn in stages:
+            timers[name].start()
+            fn()
+            timers[name].stop()
+        ctx.synchronize()
+        for name in acc:
+            acc[name].append(timers[name].elapsed_ms())
+    stage_avg = {k: float(np.mean(v)) for k, v in acc.items()}
+    log("stage ms: " + ", ".join(f"{k}={v:.3f}" for k, v in stage_avg.items()))
+    npx = B * S * S
+    per_stage = {}
+    for k, ms in stage_avg.items():
+        bpp = STAGE_BYTES_PER_PX[k.split("#")[0]]
+        gbs = bpp * npx / (ms * 1e-3) / 1e9
+        per_stage[k] = {"ms": ms, "bytes_per_px": bpp, "achieved_GBps": gbs, "frac": gbs / HBM_PEAK_GBS}
+    dom = max(stage_avg, key=stage_avg.get)
+    chain_bytes = sum(v["bytes_per_px"] for v in per_stage.values()) * npx
+    chain_ms = sum(stage_avg.values())
+    out = {
+        "metric": f"planes/sec (2048^2 uint16) through the {args.workload} operator chain", "value": B * args.steps / elapsed,
+        "unit": "planes/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64" if args.workload == "prep" else "u16", "data": "synthetic",
+        "config": {"workload": desc, "planes_per_step": B, "plane_shape": [S, S], "resident_in_hbm": True},
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": per_stage[dom]["achieved_GBps"], "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": per_stage[dom]["frac"], "traffic": None,
+                     "algorithmic_bytes_per_launch": per_stage[dom]["bytes_per_px"] * npx, "launch_ms": stage_avg[dom],
+                     "chain": {"achieved": chain_bytes / (chain_ms * 1e-3) / 1e9,
+                               "frac": chain_bytes / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms": chain_ms},
+                     "stages": per_stage},
+        "host_gen_s": gen_s,
+    }
+    if not args.no_cpu:
+        fovs = np.stack(uniq)
+        out["cpu_baseline"] = cpu_baseline(fovs, args.workload, min(args.cpu_fovs, 4))
+        out["gpu_over_cpu_1thread"] = out["value"] / out["cpu_baseline"]["value"]
+    os.write(json_fd, (json.dumps(out) + "\n").encode())
+
+
+# ------------------------------------------------------------------------------------------------------
 def main():
     args = parse_args()
+    launch_ranks_if_needed(args)
     # stdout must carry exactly ONE JSON line: RCCL / HIP runtime banners written to fd 1 by native code are
     # sent to stderr instead, and the JSON goes to the saved descriptor at the end.
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    if args.workload in ("prep", "filters"):
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            print("bench.py: --workload prep/filters are single-GPU lines", file=sys.stderr)
+            sys.exit(2)
+        return run_ops(args, json_fd)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    # AMT_BENCH_FORCE_DIST=1 exercises the RCCL path with a single rank (used to rehearse the N > 1 code)
+    # AMT_BENCH_FORCE_DIST=1 exercises the collective path with a single rank; AMT_BENCH_BACKEND=gloo +
+    # AMT_BENCH_SHARE_GPU=1 rehearse N ranks on ONE card (RCCL refuses two ranks on one device)
     distributed = world > 1 or os.environ.get("AMT_BENCH_FORCE_DIST") == "1"
+    backend = os.environ.get("AMT_BENCH_BACKEND", "nccl")
 
-    from arcadia_microscopy_tools_amd import synth
+    from arcadia_microscopy_tools_amd import _hip, synth
     from arcadia_microscopy_tools_amd.device import Context, set_default_device
+    from arcadia_microscopy_tools_amd.plate import shard_indices
     from arcadia_microscopy_tools_amd.segment import FovSegmenter
 
+    device = local_rank
+    if os.environ.get("AMT_BENCH_SHARE_GPU") == "1":
+        device = local_rank % max(1, _hip.load_library().amt_device_count())
     torch = dist = None
     if distributed:
         import torch
         import torch.distributed as dist
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        # compute runs on the library's own HIP streams (measured: compute placed on a torch-created stream
-        # ran ~30 % slower next to a second stream); only the collective uses a torch (side) stream,
-        # ordered against the compute streams with amt_stream_wait (plate.PlateGatherer)
-        set_default_device(local_rank)
-        ctx = Context(local_rank)
-    else:
-        set_default_device(local_rank)
-        ctx = Context(local_rank)
+        torch.cuda.set_device(device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend)
+    # compute runs on the library's own HIP streams (measured: compute placed on a torch-created stream ran ~30 %
+    # slower next to a second stream); only the collectives use a torch (side) stream, ordered against the compute
+    # streams with amt_stream_wait (plate.PlateTables)
+    set_default_device(device)
+    ctx = Context(device)
 
-    B, S = args.batch, args.size
-    # every rank owns B distinct FOV indices of the plate (weak scaling)
+    S = args.size
+    if args.plate > 0:  # strong scaling: this rank's contiguous block of the plate
+        mine = shard_indices(args.plate, rank, world)
+        B = len(mine)
+        fov0 = mine[0] if mine else 0
+        max_B = -(-args.plate // world)
+    else:               # weak scaling: every rank owns B FOV indices of an N x B plate
+        B = args.batch
+        fov0 = rank * B
+        max_B = B
+    if B <= 0:
+        raise SystemExit(f"rank {rank} has no field of view to process (plate {args.plate} over {world} ranks)")
     t0 = time.perf_counter()
     nuniq = max(1, min(args.unique, B))
-    uniq = [synth.synth_fov(rank * B + i, size=S) for i in range(nuniq)]
+    uniq = [synth.synth_fov(fov0 + i, size=S) for i in range(nuniq)]
     fovs = np.stack([uniq[i % nuniq] for i in range(B)])
     gen_s = time.perf_counter() - t0
     log(f"rank {rank}: generated {nuniq} distinct synthetic FOVs (batch {B}) in {gen_s:.1f}s; "
         f"device = {ctx.device_name()}")
     d_fovs = ctx.asarray(fovs)
     # split the batch over `streams` contexts (each = one HIP stream + arena); parts run concurrently
-    nstreams = max(1, min(args.streams, B))
+    nstreams = args.streams if args.streams > 0 else max(1, min(6, B // 12))
+    nstreams = max(1, min(nstreams, B))
     bounds = [round(i * B / nstreams) for i in range(nstreams + 1)]
-    ctxs = [ctx] + [Context(local_rank) for _ in range(nstreams - 1)]
+    ctxs = [ctx] + [Context(device) for _ in range(nstreams - 1)]
     parts = [d_fovs[bounds[i]:bounds[i + 1]] for i in range(nstreams)]
     segs = [FovSegmenter(bounds[i + 1] - bounds[i], 4, S, S, ctx=ctxs[i], max_cells=args.max_cells)
             for i in range(nstreams)]
-    seg = segs[0]
     packed = None
-    if distributed:
+    gather = distributed and args.workload == "c3" and not args.no_gather and os.environ.get("AMT_BENCH_NO_GATHER") != "1"
+    if gather:
         from arcadia_microscopy_tools_amd.plate import PlateTables
 
-        # this rank's blocks of the per-plate feature tables: one plate (= one step of all ranks), one all-gather
-        packed = PlateTables(segs, args.steps, torch.device("cuda", local_rank))
-
-    gather = packed is not None and args.workload == "c3" and os.environ.get("AMT_BENCH_NO_GATHER") != "1"
+        # this rank's staging ring + packed row blocks of the per-plate feature tables
+        packed = PlateTables(segs, torch.device("cuda", device), cap_fovs=max_B, keep=2)
 
     def step(i=0):
         if gather:
@@ -228,7 +461,9 @@ def main():
             else:
                 sg.run_c2(part)
         if gather:
-            packed.gather_step(i)  # this plate's single RCCL all-gather; it overlaps the next step's compute
+            # this plate's exchange: row counts now, the ONE all-gather of its rows when the next step has been
+            # enqueued (it overlaps that step's compute)
+            packed.gather_step(i, fov_index0=fov0)
 
     def sync():
         if distributed:
@@ -237,37 +472,60 @@ def main():
             for c in ctxs:
                 c.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    sync()
-    log("warmup done")
-    if distributed:
-        dist.barrier()
-        sync()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
+    def barrier():
+        if distributed:
+            dist.barrier()
+
+    for i in range(args.warmup):
         step(i)
     if gather:
-        packed.all_gather()  # nothing left to exchange unless a step was skipped; all of it is inside the timed region
+        packed.all_gather()
     sync()
-    if distributed:
-        dist.barrier()
-        sync()
+    log("warmup done")
+    n_warm_blocks = packed.exchange.n_finished if gather else 0
+    barrier()
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    if gather:
+        packed.all_gather()  # the last plate's rows: every exchange is inside the timed region
+    sync()
+    barrier()
+    sync()
     elapsed = time.perf_counter() - t0
     log(f"timed region: {args.steps} steps in {elapsed:.3f}s")
     if distributed:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    exchange_info = None
     if gather:  # outside the timed region: what arrived is what was written
-        t_all, it_all, nc_all = packed.result()
-        mine = nc_all[rank]
-        if int(mine.min()) < 0 or int(mine.max()) > args.max_cells or int(nc_all.sum()) <= 0:
-            raise RuntimeError("gathered plate tables are inconsistent (cell counts out of range)")
-        if world == 1 and not torch.equal(packed.gathered, packed.local):
-            raise RuntimeError("single-rank all-gather did not reproduce the local plate blocks")
-        log(f"plate tables gathered: {tuple(t_all.shape)} rows, {int(nc_all.sum())} cells over {world} rank(s)")
+        res = packed.result()
+        if packed.exchange.n_finished - n_warm_blocks != args.steps:
+            raise RuntimeError(f"{packed.exchange.n_finished - n_warm_blocks} plates were exchanged, expected {args.steps}")
+        rows_last, counts_last = res[-1]
+        ncols = packed.ncols
+        if rows_last.shape != (sum(counts_last), ncols) or min(counts_last) <= 0:
+            raise RuntimeError(f"gathered plate table is inconsistent: {rows_last.shape}, counts {counts_last}")
+        # this rank's own rows inside the gathered table are the rows its pack kernel wrote
+        own = packed.rows[(args.warmup + args.steps - 1) % packed.slots][: counts_last[rank]].cpu().numpy()
+        lo = sum(counts_last[:rank])
+        if not np.array_equal(rows_last[lo: lo + counts_last[rank]], own):
+            raise RuntimeError("the gathered plate table does not contain this rank's packed rows")
+        fcol = rows_last[:, 0]
+        expect_fovs = world * B if args.plate <= 0 else args.plate
+        if len(np.unique(fcol)) != expect_fovs:
+            raise RuntimeError(f"plate table holds {len(np.unique(fcol))} fields of view, expected {expect_fovs}")
+        exchange_info = {
+            "protocol": "row counts all-gather, then one all-gather of the packed rows (max count over ranks)",
+            "rows_per_plate": int(sum(counts_last)), "row_bytes": ncols * 8,
+            "bytes_sent_per_rank_per_plate": int(max(counts_last)) * ncols * 8,
+            "dense_block_bytes_per_rank": B * args.max_cells * (ncols - 2) * 8,
+            "backend": "rccl" if backend == "nccl" else backend,
+        }
+        log(f"plate tables exchanged: {rows_last.shape} rows in the last plate, counts {counts_last}")
 
     # ---- per-stage device times (HIP events on the kernels' own stream), outside the timed region ----
     # one launch of the timed region covers the FOVs of ONE stream: profile that launch size
@@ -278,7 +536,7 @@ def main():
     reps = 3
     for rep in range(reps + 1):
         (prof.run_c3 if args.workload == "c3" else prof.run_c2)(d_prof)
-        if rep == 0:  # warm-up: this segmenter's batch is larger than the timed ones, so the arena grows once
+        if rep == 0:  # warm-up: this segmenter's arena grows once
             ctx.synchronize()
             continue
         for k, v in prof.times.ms().items():
@@ -292,13 +550,32 @@ def main():
                 raise RuntimeError(f"a field of view produced {int(nm.max())} markers, above --max-cells {args.max_cells}")
     log("stage ms: " + ", ".join(f"{k}={v:.3f}" for k, v in stage_avg.items()))
 
+    # ---- flood tail: the watershed stage over rotating windows of the distinct FOVs (c3 only) ----
+    tail = None
+    if args.workload == "c3" and args.tail_reps > 0 and rank == 0:
+        ws_ms = []
+        for rep in range(args.tail_reps):
+            start = (rep * max(1, PB // 4)) % B
+            idx = [(start + j) % B for j in range(PB)]
+            if idx == list(range(idx[0], idx[0] + PB)):
+                window = d_fovs[idx[0]: idx[0] + PB]
+            else:  # wrap-around window: gather a copy (outside any timed region)
+                window = ctx.asarray(fovs[idx])
+            prof.run_c3(window)
+            ctx.synchronize()
+            ws_ms.append(prof.times.ms()["watershed"])
+        ws = np.sort(np.array(ws_ms))
+        tail = {"launch_fovs": PB, "distinct_fovs": nuniq, "reps": len(ws_ms), "p50_ms": float(np.percentile(ws, 50)),
+                "p99_ms": float(np.percentile(ws, 99)), "min_ms": float(ws[0]), "max_ms": float(ws[-1])}
+        log(f"watershed stage over {len(ws_ms)} windows: p50 {tail['p50_ms']:.3f} ms, p99 {tail['p99_ms']:.3f} ms")
+
     # ---- host-fed variant (never `value`): the same steps with every batch arriving from pinned host memory over
     # PCIe, double-buffered on a copy stream so that the transfer of batch i + 1 overlaps the segmentation of i ----
     pcie = None
     if not distributed and not args.no_h2d and args.workload == "c3":
         from arcadia_microscopy_tools_amd.feeder import FovFeeder
 
-        feeder = FovFeeder(fovs.shape, local_rank)
+        feeder = FovFeeder(fovs.shape, device)
         for slot in range(2):
             feeder.host(slot)[...] = fovs  # the file reader's job; done once here, outside the timed region
         fparts = [[feeder.device(slot)[bounds[i]:bounds[i + 1]] for i in range(nstreams)] for slot in range(2)]
@@ -332,34 +609,11 @@ def main():
 
     if rank == 0:
         npx = PB * S * S  # pixels per launch (one stream's share of the batch)
-        dom = max(stage_avg, key=stage_avg.get)
-        dom_bytes = STAGE_BYTES_PER_PX[dom] * npx
-        achieved = dom_bytes / (stage_avg[dom] * 1e-3) / 1e9
-        chain_bytes = sum(STAGE_BYTES_PER_PX[k] for k in stage_avg) * npx
-        chain_ms = sum(stage_avg.values())
-        # filter + morphology chain of the north_star: Gaussian (10 B/px) + open + close (8 B/px).  The '>' is
-        # fused into the packed open/close chain, so that stage's time is charged in full while only the
-        # morphology's 8 B/px are credited (conservative).
-        fm = [k for k in ("gaussian", "opening", "closing", "threshold_open_close") if k in stage_avg]
-        fm_bytes = sum(8 if k == "threshold_open_close" else STAGE_BYTES_PER_PX[k] for k in fm) * npx
-        fm_ms = sum(stage_avg[k] for k in fm)
-        roofline = {
-            "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS,
-            "frac_of_measured_peak": achieved / 6290.0,  # 6.29 TB/s = measured HBM3E streaming rate (MI355X_MICROARCH.md)
-            # PMC bytes of this stage's kernels for a 32-FOV launch, scaled to this run's launch size
-            "traffic": (lambda t: None if t is None else t * PB / 32.0)(pmc_traffic_bytes(dom)),
-            "algorithmic_bytes_per_launch": dom_bytes, "launch_ms": stage_avg[dom],
-            # the stage is one C-ABI call = several kernels (the flood classes run concurrently): their rocprofv3
-            # averages from the committed summary, per 32-FOV launch
-            "stage_kernels_rocprof_us": rocprof_kernel_us(dom),
-            "chain": {"achieved": chain_bytes / (chain_ms * 1e-3) / 1e9, "frac": chain_bytes / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                      "ms": chain_ms},
-            "filter_morphology_chain": {"achieved": fm_bytes / (fm_ms * 1e-3) / 1e9,
-                                        "frac": fm_bytes / (fm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms": fm_ms},
-            "stage_ms": stage_avg,
-        }
-        total_fovs = world * B * args.steps
+        roofline = stage_roofline(stage_avg, npx, PB)
+        if tail is not None:
+            roofline["watershed_tail"] = tail
+        fovs_per_step = args.plate if args.plate > 0 else world * B
+        total_fovs = fovs_per_step * args.steps
         out = {
             "metric": "fields-of-view/sec (4x2048^2 uint16) end-to-end segment+props",
             "value": total_fovs / elapsed,
@@ -369,7 +623,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.plate > 0 else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
@@ -378,11 +632,13 @@ def main():
                              "watershed nuclei + morphology and 4-channel intensity regionprops"
                              if args.workload == "c3" else
                              "configs[1]: synthetic 2048x2048 uint16 DAPI plane, Gaussian(2)+Otsu+open/close+CCL"),
-                "fovs_per_gpu_per_step": B, "streams_per_gpu": nstreams, "fovs_per_launch": PB,
-                "max_cells_per_fov": args.max_cells, "fov_shape": [4, S, S],
-                "resident_in_hbm": True,
+                "mode": (f"configs[3]: one step = one {args.plate}-FOV plate sharded over {world} GPU(s)"
+                         if args.plate > 0 else f"weak scaling, {B} FOVs per GPU per step"),
+                "fovs_per_step": fovs_per_step, "fovs_per_gpu_per_step": B, "streams_per_gpu": nstreams,
+                "fovs_per_launch": PB, "max_cells_per_fov": args.max_cells, "fov_shape": [4, S, S],
+                "distinct_fovs_per_gpu": nuniq, "resident_in_hbm": True,
                 "cells_per_fov_mean": float(np.mean(ncells)),
-                "feature_table_all_gather": bool(distributed and args.workload == "c3"),
+                "feature_table_exchange": exchange_info,
             },
             "roofline": roofline,
             "host_gen_s": gen_s,
@@ -390,8 +646,9 @@ def main():
         if pcie is not None:
             out["pcie_inclusive"] = pcie
         if not args.no_cpu and world == 1:  # the CPU baseline is a rank-0, N = 1 measurement
-            out["cpu_baseline"] = cpu_baseline(fovs, args.workload, args.cpu_fovs)
+            out["cpu_baseline"] = cpu_baseline(np.stack(uniq), args.workload, args.cpu_fovs)
             out["gpu_over_cpu_1thread"] = out["value"] / out["cpu_baseline"]["value"]
+            out["gpu_over_cpu_all_cores"] = out["value"] / out["cpu_baseline"]["all_cores"]["value"]
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if distributed:
         dist.barrier()

@@ -72,6 +72,13 @@ int amt_sync(amt_ctx* ctx);
 /* Order `ctx`'s stream after everything enqueued so far on `other`'s stream (same device), without
  * blocking the host: joins batch parts processed on separate streams before a collective. */
 int amt_stream_wait(amt_ctx* ctx, amt_ctx* other);
+/* Events: amt_event_record marks a point on ctx's stream; amt_event_wait orders what is enqueued next on ANOTHER
+ * context's stream after that point (not after everything the recording stream was given later).  Used by the
+ * plate's staging ring: a block is rewritten only after the pack kernel that read it (plate.PlateTables). */
+int amt_event_create(amt_ctx* ctx, void** event);
+int amt_event_record(amt_ctx* ctx, void* event);
+int amt_event_wait(amt_ctx* ctx, void* event);
+int amt_event_destroy(amt_ctx* ctx, void* event);
 /* pinned host staging buffers for the FOV feeder */
 int amt_host_alloc(size_t bytes, void** hptr);
 int amt_host_free(void* hptr);
@@ -265,6 +272,18 @@ int amt_regionprops_intensity_u16(amt_ctx* ctx, const int32_t* labels, const uin
 int amt_regionprops_full_u16(amt_ctx* ctx, const int32_t* labels, const uint16_t* intensity, int C, double* table_dev,
                              double* itable_dev, int nplanes, int H, int W, int max_label);
 int amt_max_i32(amt_ctx* ctx, const int32_t* in, int32_t* max_dev, int nplanes, size_t n);
+
+/* ---- per-plate feature rows (the reference's analogue is the list of cell_properties dicts a
+ * user collects per image, R/masks.py:247-328, R/pipeline.py:145-149) ------------------------------------------
+ * Compacts the dense tables of B fields of view (table_dev B x K x AMT_RP_NCOLS, itable_dev B x K x C x 4,
+ * ncells_dev B int32) into one row per cell, fields of view in order, labels 1..ncells[b] in order:
+ *   row = [fov index, label, the AMT_RP_NCOLS morphology columns, C x {mean, max, min, std}]  (16 + 4 C doubles)
+ * The fov index of plane b is fov_index_dev[b], or fov_index0 + b when fov_index_dev is NULL.  rows_cap (in rows)
+ * must be >= B * K.  *nrows_dev = total rows, or -1 when a field of view holds a count outside [0, K] (its table
+ * overflowed).  This block is what a rank contributes to the plate's all-gather: counts first, then rows. */
+int amt_pack_plate_rows(amt_ctx* ctx, const double* table_dev, const double* itable_dev, const int32_t* ncells_dev, int B,
+                        int K, int C, const int32_t* fov_index_dev, int fov_index0, double* rows_dev, size_t rows_cap,
+                        int64_t* nrows_dev);
 
 /* ---- cell outlines: R/masks.py:82-115 (_extract_outlines_skimage), SK/measure/_find_contours.py ------
  * bbox_dev = nplanes x max_label x 4 ints {min row, min col, max row, max col} INCLUSIVE; labels absent from a

@@ -59,55 +59,93 @@ def test_all_gather_rows_gloo_world2(tmp_path):
     assert a[-1, 2] == 100.0 * 4 + 1
 
 
-def _plate_worker(rank, world, port, out_dir):
+def _exchange_worker(rank, world, port, out_dir):
     import torch
     import torch.distributed as dist
 
-    from arcadia_microscopy_tools_amd import _hip, plate
+    from arcadia_microscopy_tools_amd import plate
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        S, B, K, C = 3, 2, 4, 2
-        lay = plate.PlateLayout(S, world, B, K, C)
-        local = torch.zeros(lay.local_bytes, dtype=torch.uint8)
-        gathered = torch.empty(lay.gathered_bytes, dtype=torch.uint8)
-        buf = local.numpy()
-        for step in range(S):
-            for b in range(B):  # what a segmenter would write through the pointers of PlateTables.point()
-                o_t, o_i, o_c = lay.block_offsets(step, b)
-                code = 1000.0 * rank + 100.0 * step + 10.0 * b
-                buf[o_t: o_t + K * _hip.RP_NCOLS * 8].view(np.float64)[:] = code + np.arange(K * _hip.RP_NCOLS) / 100.0
-                buf[o_i: o_i + K * C * 4 * 8].view(np.float64)[:] = -code - np.arange(K * C * 4) / 100.0
-                buf[o_c: o_c + 4].view(np.int32)[:] = 1 + rank + step + b
-            lay.gather_step(local, gathered, step)  # one collective per plate
-        t, it, nc = lay.unpack(gathered)
-        np.savez(os.path.join(out_dir, f"plate{rank}.npz"), t=t.numpy(), it=it.numpy(), nc=nc.numpy())
+        C = 2
+        ncols = plate.packed_ncols(C)
+        ex = plate.RowExchange(ncols, "cpu", lag=1)
+        steps = 4
+        # rank 0 owns 3 fields of view, rank 1 owns 2 (a 5-FOV plate): row capacities differ between the ranks,
+        # and in step 3 rank 0 holds MORE rows than rank 1's buffer can take (the padded-copy path)
+        cap = (3 if rank == 0 else 2) * 4
+        issued = []
+        for step in range(steps):
+            n = {0: [5, 0, 2, 12], 1: [3, 7, 8, 1]}[rank][step]
+            rows = torch.full((cap, ncols), -1.0, dtype=torch.float64)
+            for r in range(n):
+                rows[r, 0] = 10 * rank + step          # fov index
+                rows[r, 1] = r + 1                     # label
+                rows[r, 2:] = 1000.0 * rank + 100.0 * step + r + torch.arange(ncols - 2, dtype=torch.float64) / 100.0
+            ex.submit(rows, torch.tensor([n], dtype=torch.int64))
+            issued.append(len(ex.finished))
+        ex.flush()
+        res = ex.results()
+        np.savez(os.path.join(out_dir, f"ex{rank}.npz"), issued=np.array(issued),
+                 **{f"rows{i}": r.numpy() for i, (r, _) in enumerate(res)},
+                 **{f"counts{i}": np.array(c) for i, (_, c) in enumerate(res)})
     finally:
         dist.destroy_process_group()
 
 
-def test_plate_layout_all_gather_gloo_world2(tmp_path):
-    """The byte layout and the per-plate all-gather of plate.PlateLayout (what plate.PlateTables runs over RCCL),
-    world_size 2 with gloo: every rank ends with every rank's blocks, ordered (rank, step * B + fov)."""
+def test_row_exchange_gloo_world2(tmp_path):
+    """plate.RowExchange (what plate.PlateTables runs over RCCL on a side stream), world_size 2 with gloo: counts
+    first, rows one step later, ranks with different capacities and row counts, an empty block, and a block larger
+    than the other rank's buffer.  Every rank ends with every rank's rows of every step, ordered by rank."""
     import torch.multiprocessing as mp
 
-    from arcadia_microscopy_tools_amd import _hip
+    from arcadia_microscopy_tools_amd import plate
 
     port = _free_port()
-    mp.spawn(_plate_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    a, b = np.load(tmp_path / "plate0.npz"), np.load(tmp_path / "plate1.npz")
-    S, B, K, C = 3, 2, 4, 2
-    for key in ("t", "it", "nc"):
-        assert np.array_equal(a[key], b[key]), key
-    assert a["t"].shape == (2, S * B, K, _hip.RP_NCOLS) and a["it"].shape == (2, S * B, K, C, 4)
-    assert a["nc"].shape == (2, S * B)
-    for rank in range(2):
-        for step in range(S):
-            for fov in range(B):
-                code = 1000.0 * rank + 100.0 * step + 10.0 * fov
-                f = step * B + fov
-                assert np.array_equal(a["t"][rank, f].ravel(), code + np.arange(K * _hip.RP_NCOLS) / 100.0)
-                assert np.array_equal(a["it"][rank, f].ravel(), -code - np.arange(K * C * 4) / 100.0)
-                assert a["nc"][rank, f] == 1 + rank + step + fov
+    mp.spawn(_exchange_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = np.load(tmp_path / "ex0.npz"), np.load(tmp_path / "ex1.npz")
+    ncols = plate.packed_ncols(2)
+    expect = {0: [5, 0, 2, 12], 1: [3, 7, 8, 1]}
+    assert a["issued"].tolist() == [0, 1, 2, 3]  # the row all-gather of a step is issued one step later
+    for step in range(4):
+        ra, rb = a[f"rows{step}"], b[f"rows{step}"]
+        assert np.array_equal(ra, rb), f"step {step}: both ranks must hold the same table"
+        counts = a[f"counts{step}"].tolist()
+        assert counts == [expect[0][step], expect[1][step]]
+        assert ra.shape == (sum(counts), ncols)
+        off = 0
+        for rank in range(2):
+            for r in range(counts[rank]):
+                row = ra[off + r]
+                assert row[0] == 10 * rank + step and row[1] == r + 1
+                assert np.array_equal(row[2:], 1000.0 * rank + 100.0 * step + r + np.arange(ncols - 2) / 100.0)
+            off += counts[rank]
+
+
+def test_row_exchange_overflow_is_loud(tmp_path):
+    """A rank whose pack kernel flagged an overflowed table (count -1) makes every rank raise."""
+    import torch.multiprocessing as mp
+
+    port = _free_port()
+    mp.spawn(_overflow_worker, args=(2, port), nprocs=2, join=True)
+
+
+def _overflow_worker(rank, world, port):
+    import torch
+    import torch.distributed as dist
+
+    from arcadia_microscopy_tools_amd import plate
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ncols = plate.packed_ncols(1)
+        ex = plate.RowExchange(ncols, "cpu", lag=0)
+        rows = torch.zeros((4, ncols), dtype=torch.float64)
+        with pytest.raises(RuntimeError, match="overflowed feature table"):
+            ex.submit(rows, torch.tensor([-1 if rank == 1 else 2], dtype=torch.int64))
+    finally:
+        dist.destroy_process_group()

@@ -172,46 +172,21 @@ def test_channels():
 def test_nd2lite_reads_golden_fixture(golden, tmp_path):
     """The ND2 chunk walk + lite-variant attributes, on a synthetic file written here (the reference's
     fixture itself is not available on the GPU box; its pixels are pinned in tests/golden)."""
-    import struct
+    from conftest import write_synthetic_nd2
 
     from arcadia_microscopy_tools_amd import nd2lite
 
     px = golden("nd2_multichannel")["pixels"]  # (4, 256, 256)
-    frame = np.ascontiguousarray(px.transpose(1, 2, 0)).astype("<u2").tobytes()
-
-    def lv(typ, name, payload):
-        n = (name + "\x00").encode("utf-16-le")
-        return bytes([typ, len(n) // 2]) + n + payload
-
-    items = b"".join([
-        lv(3, "uiWidth", struct.pack("<I", 256)), lv(3, "uiWidthBytes", struct.pack("<I", 2048)),
-        lv(3, "uiHeight", struct.pack("<I", 256)), lv(3, "uiComp", struct.pack("<I", 4)),
-        lv(2, "uiBpcInMemory", struct.pack("<i", 16)), lv(3, "uiSequenceCount", struct.pack("<I", 1)),
-    ])
-    name = ("SLxImageAttributes" + "\x00").encode("utf-16-le")
-    head = bytes([11, len(name) // 2]) + name
-    attrs = head + struct.pack("<IQ", 6, len(head) + 12 + len(items)) + items + b"\x00" * (6 * 8)
-
-    def chunk(cname, payload):
-        nm = cname + b"\x00" * (32 - len(cname))
-        return struct.pack("<IIQ", 0x0ABECEDA, len(nm), len(payload)) + nm + payload
-
-    blob = b""
-    entries = []
-    for cname, payload in ((b"ImageAttributesLV!", attrs), (b"ImageDataSeq|0!", b"\x00" * 8 + frame)):
-        entries.append((cname, len(blob), len(payload)))
-        blob += chunk(cname, payload)
-    mp = b"".join(c + struct.pack("<QQ", off, size) for c, off, size in entries)
-    mp += b"ND2 CHUNK MAP SIGNATURE 0000001!" + struct.pack("<Q", len(blob))
-    map_off = len(blob)
-    blob += chunk(b"ND2 FILEMAP SIGNATURE NAME 0001!", mp)
-    blob += struct.pack("<Q", map_off)
-    f = tmp_path / "synthetic.nd2"
-    f.write_bytes(blob)
+    f = write_synthetic_nd2(tmp_path / "synthetic.nd2", px.transpose(1, 2, 0)[None])
     arr, meta = nd2lite.load_nd2(f, channels=[BRIGHTFIELD, DAPI, FITC, TRITC], use_device=False)
     assert arr.shape == (4, 256, 256) and arr.dtype == np.uint16 and np.array_equal(arr, px)
     assert meta.sizes == {"C": 4, "Y": 256, "X": 256}
-    im = MicroscopyImage.from_nd2_path(f, channels=[BRIGHTFIELD, DAPI, FITC, TRITC]) if False else None
+    # padded rows (uiWidthBytes > X * C * 2, e.g. odd widths): the row stride is honoured, not assumed
+    odd = px[:, :37, :45]
+    fp = write_synthetic_nd2(tmp_path / "padded.nd2", np.stack([odd, odd[:, ::-1]]).transpose(0, 2, 3, 1), row_pad_bytes=6)
+    arr2, meta2 = nd2lite.load_nd2(fp, channels=[BRIGHTFIELD, DAPI, FITC, TRITC], use_device=False)
+    assert arr2.shape == (2, 4, 37, 45) and np.array_equal(arr2[0], odd) and np.array_equal(arr2[1], odd[:, ::-1])
+    assert meta2.sizes == {"T": 2, "C": 4, "Y": 37, "X": 45}
     assert nd2lite.resolve_optical_config("Mono") is BRIGHTFIELD
     assert nd2lite.resolve_optical_config("GFP 488 nm") is FITC
     assert nd2lite.resolve_optical_config("FITC BP") is FITC and nd2lite.resolve_optical_config("zzz") is None
