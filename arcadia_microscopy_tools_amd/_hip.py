@@ -19,6 +19,7 @@ U8, U16, I32, F64, I64, F32 = 0, 1, 2, 3, 4, 5
 MODE_NEAREST, MODE_REFLECT, MODE_MIRROR, MODE_CONSTANT, MODE_WRAP = 0, 1, 2, 3, 4
 MODES = {"nearest": 0, "reflect": 1, "mirror": 2, "constant": 3, "wrap": 4}
 THR_OTSU = 0
+WS_TIES = {"exact": 0, "raster": 1, "report": 2, "refuse": 2}
 RP_COLS = (
     "area", "centroid-0", "centroid-1", "bbox-0", "bbox-1", "bbox-2", "bbox-3", "perimeter",
     "axis_major_length", "axis_minor_length", "eccentricity", "orientation", "area_convex", "solidity",
@@ -101,6 +102,8 @@ _SIGS = {
     "amt_peak_mask": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int]),
     "amt_watershed_edt": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int]),
     "amt_watershed_f64": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int]),
+    "amt_watershed_edt_ex": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "amt_watershed_f64_ex": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "amt_regionprops": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int]),
     "amt_regionprops_intensity_u16": (c_int, [_P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int]),
     "amt_regionprops_full_u16": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int]),

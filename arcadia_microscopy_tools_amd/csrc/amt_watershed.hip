@@ -7,9 +7,16 @@
 //
 // What is order-defining and what is not:
 //   * (value, age) is unique for every queued pixel except among the age-0 marker pixels.  scikit-image
-//     breaks those ties by the internal moves of its binary heap; this implementation breaks them by
-//     raster order (a stable queue).  The config-3 recipe gives marker pixels distinct, lowest values
-//     (oracle/skops.py:seeded_flood_image; here `seeds_first`), for which both definitions coincide.
+//     breaks those ties by the internal moves of its ONE binary heap over the whole image, so the order of two
+//     tied markers depends on every other element that passes through the heap -- other mask components
+//     included (measured with the oracle: flooding each component with its own heap of the same mechanics
+//     changes 20 of 6,458 labelled pixels of tests/golden/c2c3_256.npz).  Tied planes therefore have no parallel
+//     decomposition; the parallel flood below breaks such ties in raster order and REPORTS them (ties[plane]),
+//     and under AMT_WS_TIES_EXACT a tied plane is re-flooded by ws_global_kernel, a sequential emulation of
+//     scikit-image's heap (bit-identical, one lane).  Ties between markers of DIFFERENT components, or inside a
+//     component whose markers all carry one label, cannot change the result and are not reported.
+//     The config-3 recipe gives marker pixels distinct, lowest values (oracle/skops.py:seeded_flood_image; here
+//     `seeds_first`), for which ties cannot occur.
 //   * the flood never crosses between 4-connected components of the mask, and the relative order of two
 //     pixels of one component does not depend on the other components.  Components are therefore
 //     independent work items:
@@ -308,7 +315,7 @@ __global__ void __launch_bounds__(64) ws_flood_lds_kernel(const int* __restrict_
                                                           const comp_row* __restrict__ rows,
                                                           const int* __restrict__ wl, const int* __restrict__ wl_count,
                                                           int* __restrict__ counters, size_t row_stride, int H, int W,
-                                                          int seeds_first) {
+                                                          int seeds_first, int* __restrict__ ties) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     unsigned* cell = reinterpret_cast<unsigned*>(smem_raw);
     unsigned* ht = cell + TILE_PX;
@@ -421,7 +428,15 @@ __global__ void __launch_bounds__(64) ws_flood_lds_kernel(const int* __restrict_
                 const int b = __ffsll((long long)m) - 1;
                 m &= m - 1;
                 const int p = i0 + b;
-                if (seeds_first) spread(p, false); else push(p, (int)((uni(cell[p]) >> 16) & 0x7FFF));
+                if (seeds_first) {
+                    spread(p, false);
+                } else {
+                    const int bk = (int)((uni(cell[p]) >> 16) & 0x7FFF);
+                    // a second marker in one bucket = two age-0 entries of equal value in this component
+                    const bool occupied = bk == cur ? head != NONE : (uni(ht[bk]) & 0xFFFFu) != NONE;
+                    if (occupied && lane == 0) ties[plane] = 1;
+                    push(p, bk);
+                }
             }
         }
         {
@@ -476,7 +491,7 @@ __global__ void __launch_bounds__(64) ws_flood_edt_kernel(const int* __restrict_
                                                           const int* __restrict__ moffall, const int* __restrict__ boffall,
                                                           const int* __restrict__ ncomp, int* __restrict__ counters,
                                                           size_t row_stride, int H, int W, size_t n, size_t bstride,
-                                                          int seeds_first) {
+                                                          int seeds_first, int* __restrict__ ties) {
     const int plane = blockIdx.y;
     const size_t base = (size_t)plane * n;
     const size_t cb = (size_t)plane * row_stride;
@@ -530,7 +545,9 @@ __global__ void __launch_bounds__(64) ws_flood_edt_kernel(const int* __restrict_
         } else {
             for (int i = 0; i < nm; ++i) {
                 int b = d2[ml[i]];
-                push(ml[i], b < 0 ? 0 : b);
+                b = b < 0 ? 0 : b;
+                if (hd[b] >= 0) ties[plane] = 1;  // second marker of equal value in this component
+                push(ml[i], b);
             }
         }
         while (true) {
@@ -562,7 +579,8 @@ __global__ void __launch_bounds__(64) ws_flood_heap_kernel(const double* __restr
                                                            const comp_row* __restrict__ rows,
                                                            const int* __restrict__ moffall, const int* __restrict__ boffall,
                                                            const int* __restrict__ ncomp, int* __restrict__ counters,
-                                                           size_t row_stride, int H, int W, size_t n, size_t hstride) {
+                                                           size_t row_stride, int H, int W, size_t n, size_t hstride,
+                                                           int* __restrict__ ties) {
     const int plane = blockIdx.y;
     const size_t base = (size_t)plane * n;
     const size_t cb = (size_t)plane * row_stride;
@@ -625,9 +643,16 @@ __global__ void __launch_bounds__(64) ws_flood_heap_kernel(const double* __restr
             e.index = ml[i];
             hpush(e);
         }
+        bool have0 = false;
+        double last0 = 0.0;
         while (items > 0) {
             hp_elem e = hpop();
             const int p = e.index;
+            if (e.age == 0) {  // age-0 entries pop in non-decreasing value order: equal values are adjacent among them
+                if (have0 && e.value == last0) ties[plane] = 1;
+                have0 = true;
+                last0 = e.value;
+            }
             const int lab = out[p];
             const int py = p / W, px = p - py * W;
 #pragma unroll
@@ -650,15 +675,181 @@ __global__ void __launch_bounds__(64) ws_flood_heap_kernel(const double* __restr
     }
 }
 
+// ---- sequential emulation of scikit-image's flood (one heap per plane) --------------------------------------
+// markers are pushed in raster order with age 0; pop the smallest (value, age) -- STRICT comparisons,
+// so equal keys are ordered by the heap's own moves: push = append, then swap with the parent (child + 1) / 2 - 1
+// while strictly smaller; pop = move the last element to the root, then repeatedly take the right child if it is
+// strictly smaller than the left, and swap with the parent if strictly smaller.  Labels are assigned at push time;
+// neighbours in the order N, W, E, S (connectivity 1) or N, E, W, S, NW, NE, SW, SE (connectivity 2: the order
+// scikit-image 0.18.3's offset sort produces; version sensitive).  Only planes whose `run` flag is
+// set are touched.  One lane does the heap; the wave scans for marker pixels 64 at a time.
+__global__ void __launch_bounds__(256) ws_global_init_kernel(const int* __restrict__ markers,
+                                                             const uint8_t* __restrict__ mask, int* __restrict__ out,
+                                                             const int* __restrict__ run, size_t n) {
+    if (run && !run[blockIdx.y]) return;
+    const size_t base = (size_t)blockIdx.y * n;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        out[base + i] = mask[base + i] ? markers[base + i] : 0;  // markers.astype(int32) * mask
+}
+
+struct gh_less {
+    __device__ __forceinline__ bool operator()(const hp_elem& a, const hp_elem& b) const {
+        return a.value < b.value || (a.value == b.value && a.age < b.age);
+    }
+};
+
+template <bool USE_D2>
+__global__ void __launch_bounds__(64) ws_global_kernel(const void* __restrict__ reliefall,
+                                                       const uint8_t* __restrict__ maskall, int* __restrict__ outall,
+                                                       hp_elem* __restrict__ heapall, const int* __restrict__ run,
+                                                       int H, int W, size_t hstride, int conn) {
+    const int plane = blockIdx.x;
+    if (run && !run[plane]) return;
+    const size_t n = (size_t)H * W;
+    const uint8_t* mask = maskall + (size_t)plane * n;
+    int* out = outall + (size_t)plane * n;
+    hp_elem* hp = heapall + (size_t)plane * hstride;
+    const double* rel = USE_D2 ? nullptr : (const double*)reliefall + (size_t)plane * n;
+    const int* d2 = USE_D2 ? (const int*)reliefall + (size_t)plane * n : nullptr;
+    const int lane = threadIdx.x;
+    gh_less smaller;
+    // -sqrt(d2) orders exactly like -d2 (and ties exactly when d2 ties): the integer is the key
+    auto value_of = [&](int p) -> double {
+        if (USE_D2) {
+            const int d = d2[p];
+            return -(double)(d < 0 ? 0 : d);
+        }
+        return rel[p];
+    };
+    int items = 0;
+    auto push = [&](const hp_elem& e) {
+        int child = items++;
+        hp[child] = e;
+        while (child > 0) {
+            const int parent = (child + 1) / 2 - 1;
+            const hp_elem pe = hp[parent];
+            if (smaller(e, pe)) {
+                hp[child] = pe;
+                hp[parent] = e;
+                child = parent;
+            } else {
+                break;
+            }
+        }
+    };
+    auto pop = [&]() -> hp_elem {
+        const hp_elem top = hp[0];
+        hp_elem moved = hp[items - 1];
+        --items;
+        if (items > 0) {
+            hp[0] = moved;
+            int parent = 0, child = 1;
+            while (child < items) {
+                hp_elem ce = hp[child];
+                if (child + 1 < items) {
+                    const hp_elem c2 = hp[child + 1];
+                    if (smaller(c2, ce)) {
+                        ce = c2;
+                        ++child;
+                    }
+                }
+                if (smaller(ce, moved)) {
+                    hp[parent] = ce;
+                    hp[child] = moved;
+                    parent = child;
+                    child = 2 * child + 1;
+                } else {
+                    break;
+                }
+            }
+        }
+        return top;
+    };
+    // markers in raster order
+    for (size_t i0 = 0; i0 < n; i0 += 64) {
+        const size_t i = i0 + lane;
+        const int v = i < n ? out[i] : 0;
+        unsigned long long m = __ballot(v != 0);
+        if (lane == 0) {
+            while (m) {
+                const int b = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                hp_elem e;
+                e.index = (int)(i0 + b);
+                e.age = 0;
+                e.value = value_of(e.index);
+                push(e);
+            }
+        }
+    }
+    if (lane != 0) return;
+    const int dy1[4] = {-1, 0, 0, 1}, dx1[4] = {0, -1, 1, 0};
+    const int dy2[8] = {-1, 0, 0, 1, -1, -1, 1, 1}, dx2[8] = {0, 1, -1, 0, -1, 1, -1, 1};
+    const int nnb = conn == 1 ? 4 : 8;
+    int age = 0;
+    while (items > 0) {
+        const hp_elem e = pop();
+        const int p = e.index;
+        const int lab = out[p];
+        const int py = p / W, px = p - py * W;
+        for (int k = 0; k < nnb; ++k) {
+            const int qy = py + (conn == 1 ? dy1[k] : dy2[k]), qx = px + (conn == 1 ? dx1[k] : dx2[k]);
+            if (qy < 0 || qy >= H || qx < 0 || qx >= W) continue;
+            const int q = qy * W + qx;
+            if (!mask[q] || out[q] != 0) continue;
+            out[q] = lab;
+            hp_elem ne;
+            ne.value = value_of(q);
+            ne.age = ++age;
+            ne.index = q;
+            push(ne);
+        }
+    }
+}
+
+__global__ void ws_set_flags_kernel(int* f, int n, int v) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) f[i] = v;
+}
+
 static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const int32_t* markers,
-                            const uint8_t* mask, int32_t* out, int nplanes, int H, int W, int seeds_first) {
+                            const uint8_t* mask, int32_t* out, int nplanes, int H, int W, int seeds_first,
+                            int connectivity, int tie_policy, int32_t* ties_dev) {
     AMT_TRY(amt_set_device(ctx));
     AMT_REQUIRE(relief && markers && mask && out && nplanes >= 0 && H > 0 && W > 0, "watershed: bad arguments");
     AMT_REQUIRE((size_t)H * W < 0x3fffffffull, "watershed: plane too large");
     AMT_REQUIRE((const void*)markers != (const void*)out, "watershed: markers and out must not alias");
+    AMT_REQUIRE(connectivity == 1 || connectivity == 2, "watershed: connectivity must be 1 or 2, got %d", connectivity);
+    AMT_REQUIRE(tie_policy == AMT_WS_TIES_EXACT || tie_policy == AMT_WS_TIES_RASTER || tie_policy == AMT_WS_TIES_REPORT,
+                "watershed: unknown tie policy %d", tie_policy);
+    AMT_REQUIRE(connectivity == 1 || !seeds_first, "watershed: seeds_first is defined for connectivity 1 only");
+    AMT_REQUIRE(connectivity == 1 || tie_policy == AMT_WS_TIES_EXACT,
+                "watershed: connectivity 2 exists only as the sequential single-heap emulation (AMT_WS_TIES_EXACT)");
     if (nplanes == 0) return AMT_OK;
     const size_t n = (size_t)H * W;
     const size_t np = (size_t)nplanes * n;
+    // seeds_first cannot tie (marker pixels are spread first, in raster order, before anything is queued by value)
+    const bool exact = tie_policy == AMT_WS_TIES_EXACT && !seeds_first;
+    if (connectivity == 2) {
+        // 8-connected floods: no component decomposition here -- every plane goes through the sequential emulation
+        AMT_TRY(amt_arena_begin(ctx, amt_align(np * sizeof(hp_elem)) + amt_align((size_t)nplanes * 4)));
+        hp_elem* gheap = arena_take_t<hp_elem>(ctx, np);
+        if (ties_dev) {
+            hipLaunchKernelGGL(ws_set_flags_kernel, dim3((nplanes + 63) / 64), dim3(64), 0, ctx->stream, ties_dev, nplanes, 0);
+            AMT_LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(ws_global_init_kernel, dim3(amt_grid_for(n, 256, 1024), nplanes), dim3(256), 0, ctx->stream,
+                           markers, mask, out, (const int*)nullptr, n);
+        AMT_LAUNCH_CHECK();
+        if (use_d2)
+            hipLaunchKernelGGL((ws_global_kernel<true>), dim3(nplanes), dim3(64), 0, ctx->stream, relief, mask, out, gheap,
+                               (const int*)nullptr, H, W, n, 2);
+        else
+            hipLaunchKernelGGL((ws_global_kernel<false>), dim3(nplanes), dim3(64), 0, ctx->stream, relief, mask, out, gheap,
+                               (const int*)nullptr, H, W, n, 2);
+        AMT_LAUNCH_CHECK();
+        return AMT_OK;
+    }
     // per-component rows: a 4-connected component needs a background pixel between itself and the next one in
     // its row, so a plane has at most ceil(n / 2) components; only the first ncomp[plane] rows are touched
     const size_t row_stride = n / 2 + 1;
@@ -670,8 +861,11 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     const size_t lcap = amt_i_rootlist_cap(W);
     const size_t nlist = (size_t)nplanes * trows;
     size_t need = 5 * amt_align(np * 4) + amt_align(nlist * lcap * 4) + amt_align(nlist * 4) + 6 * amt_align(nr * 4) + amt_align(nr * sizeof(comp_row)) +
-                  9 * amt_align(nplanes * 4 * 9);
+                  9 * amt_align(nplanes * 4 * 9) + amt_align((size_t)nplanes * 4);
     need += use_d2 ? 2 * amt_align((size_t)nplanes * bstride * 4) : amt_align((size_t)nplanes * bstride * sizeof(hp_elem));
+    // the sequential emulation's heap (every pixel is pushed at most once): the float64 path reuses its per-component
+    // heap space, the bucket path needs it extra -- and only when ties are to be resolved exactly
+    if (exact && use_d2) need += amt_align(np * sizeof(hp_elem));
     AMT_TRY(amt_arena_begin(ctx, need));
     int* L = arena_take_t<int>(ctx, np);
     int* T = arena_take_t<int>(ctx, np);
@@ -688,18 +882,24 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     int* mtot = arena_take_t<int>(ctx, nplanes);
     int* counters = arena_take_t<int>(ctx, (size_t)nplanes * 9);
     int* wl = arena_take_t<int>(ctx, 3 * nr);  // worklists of the three LDS classes
+    int* ties = ties_dev ? ties_dev : arena_take_t<int>(ctx, nplanes);
     int *head = nullptr, *tail = nullptr;
     hp_elem* heap = nullptr;
+    hp_elem* gheap = nullptr;
     if (use_d2) {
         head = arena_take_t<int>(ctx, (size_t)nplanes * bstride);
         tail = arena_take_t<int>(ctx, (size_t)nplanes * bstride);
+        if (exact) gheap = arena_take_t<hp_elem>(ctx, np);
     } else {
         heap = arena_take_t<hp_elem>(ctx, (size_t)nplanes * bstride);
+        gheap = heap;  // bstride == n: the per-component heaps are dead when the emulation starts
     }
 
     int* ncomp = counters + 8 * (size_t)nplanes;
     hipLaunchKernelGGL(ws_zero_counters_kernel, dim3((nplanes * 9 + 63) / 64), dim3(64), 0, ctx->stream, counters,
                        nplanes * 9);
+    AMT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ws_set_flags_kernel, dim3((nplanes + 63) / 64), dim3(64), 0, ctx->stream, ties, nplanes, 0);
     AMT_LAUNCH_CHECK();
     // components of the mask with dense ids in T (the order of the ids is irrelevant: components are
     // independent work items and nothing in the output depends on their numbering)
@@ -744,36 +944,62 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
         AMT_TRY(amt_fork(ctx));
         hipLaunchKernelGGL((ws_flood_lds_kernel<L_PX, L_NB, CLS_L>), dim3(16, nplanes), dim3(64), ldsL, ctx->stream,
                            (const int*)relief, L, T, out, rows, wl + 2 * (size_t)nplanes * row_stride,
-                           wl_count + 2 * nplanes, counters + 0 * nplanes, row_stride, H, W, seeds_first);
+                           wl_count + 2 * nplanes, counters + 0 * nplanes, row_stride, H, W, seeds_first, ties);
         AMT_LAUNCH_CHECK();
         hipLaunchKernelGGL((ws_flood_lds_kernel<M_PX, M_NB, CLS_M>), dim3(64, nplanes), dim3(64), ldsM, ctx->aux[0],
                            (const int*)relief, L, T, out, rows, wl + 1 * (size_t)nplanes * row_stride,
-                           wl_count + 1 * nplanes, counters + 1 * nplanes, row_stride, H, W, seeds_first);
+                           wl_count + 1 * nplanes, counters + 1 * nplanes, row_stride, H, W, seeds_first, ties);
         AMT_LAUNCH_CHECK();
         hipLaunchKernelGGL((ws_flood_lds_kernel<S_PX, S_NB, CLS_S>), dim3(128, nplanes), dim3(64), ldsS, ctx->aux[1],
                            (const int*)relief, L, T, out, rows, wl + 0 * (size_t)nplanes * row_stride,
-                           wl_count + 0 * nplanes, counters + 2 * nplanes, row_stride, H, W, seeds_first);
+                           wl_count + 0 * nplanes, counters + 2 * nplanes, row_stride, H, W, seeds_first, ties);
         AMT_LAUNCH_CHECK();
         hipLaunchKernelGGL(ws_flood_edt_kernel, dim3(4, nplanes), dim3(64), 0, ctx->aux[1], (const int*)relief, mask, out,
                            next, head, tail, mlist, rows, moff, boff, ncomp, counters + 3 * nplanes, row_stride, H, W, n,
-                           bstride, seeds_first);
+                           bstride, seeds_first, ties);
         AMT_LAUNCH_CHECK();
         AMT_TRY(amt_join(ctx));
     } else {
         hipLaunchKernelGGL(ws_flood_heap_kernel, dim3(64, nplanes), dim3(64), 0, ctx->stream, (const double*)relief,
                            mask, out, heap, mlist, rows, moff, boff, ncomp, counters + 3 * nplanes, row_stride, H, W, n,
-                           bstride);
+                           bstride, ties);
     }
     AMT_LAUNCH_CHECK();
+    if (exact) {
+        // planes in which two markers of one component tied: scikit-image's answer comes from its single heap
+        hipLaunchKernelGGL(ws_global_init_kernel, dim3(amt_grid_for(n, 256, 1024), nplanes), dim3(256), 0, ctx->stream,
+                           markers, mask, out, (const int*)ties, n);
+        AMT_LAUNCH_CHECK();
+        if (use_d2)
+            hipLaunchKernelGGL((ws_global_kernel<true>), dim3(nplanes), dim3(64), 0, ctx->stream, relief, mask, out, gheap,
+                               (const int*)ties, H, W, n, 1);
+        else
+            hipLaunchKernelGGL((ws_global_kernel<false>), dim3(nplanes), dim3(64), 0, ctx->stream, relief, mask, out, gheap,
+                               (const int*)ties, H, W, n, 1);
+        AMT_LAUNCH_CHECK();
+    }
     return AMT_OK;
+}
+
+extern "C" int amt_watershed_edt_ex(amt_ctx* ctx, const int32_t* d2, const int32_t* markers, const uint8_t* mask,
+                                    int32_t* out, int nplanes, int H, int W, int seeds_first, int connectivity,
+                                    int tie_policy, int32_t* ties_dev) {
+    return watershed_common(ctx, d2, true, markers, mask, out, nplanes, H, W, seeds_first, connectivity, tie_policy,
+                            ties_dev);
+}
+
+extern "C" int amt_watershed_f64_ex(amt_ctx* ctx, const double* relief, const int32_t* markers, const uint8_t* mask,
+                                    int32_t* out, int nplanes, int H, int W, int connectivity, int tie_policy,
+                                    int32_t* ties_dev) {
+    return watershed_common(ctx, relief, false, markers, mask, out, nplanes, H, W, 0, connectivity, tie_policy, ties_dev);
 }
 
 extern "C" int amt_watershed_edt(amt_ctx* ctx, const int32_t* d2, const int32_t* markers, const uint8_t* mask,
                                  int32_t* out, int nplanes, int H, int W, int seeds_first) {
-    return watershed_common(ctx, d2, true, markers, mask, out, nplanes, H, W, seeds_first);
+    return watershed_common(ctx, d2, true, markers, mask, out, nplanes, H, W, seeds_first, 1, AMT_WS_TIES_EXACT, nullptr);
 }
 
 extern "C" int amt_watershed_f64(amt_ctx* ctx, const double* relief, const int32_t* markers, const uint8_t* mask,
                                  int32_t* out, int nplanes, int H, int W) {
-    return watershed_common(ctx, relief, false, markers, mask, out, nplanes, H, W, 0);
+    return watershed_common(ctx, relief, false, markers, mask, out, nplanes, H, W, 0, 1, AMT_WS_TIES_EXACT, nullptr);
 }

@@ -551,24 +551,57 @@ def peak_mask(d2: DeviceArray, mask: DeviceArray, min_distance: int = 5, out=Non
     return o
 
 
-def watershed_edt(d2: DeviceArray, markers: DeviceArray, mask: DeviceArray, seeds_first: bool = True, out=None):
-    """``skimage.segmentation.watershed(relief, markers, mask=mask)`` with relief = -sqrt(d2)
-    (seeds_first: the seeded relief of oracle/skops.py:seeded_flood_image)."""
+def _ws_ties(ctx, n: int, ties_policy: str, ties_out):
+    """The per-plane tie flags: the caller's array, a fresh one when the policy needs them, else none (the hot path
+    allocates nothing)."""
+    if ties_policy not in _hip.WS_TIES:
+        raise ValueError(f"ties must be one of {sorted(_hip.WS_TIES)}, got {ties_policy!r}")
+    if ties_out is not None:
+        return _out(ctx, ties_out, (n,), np.int32)
+    return ctx.empty((n,), np.int32) if ties_policy in ("report", "refuse") else None
+
+
+def _ws_finish(ctx, ties_policy: str, ties, what: str):
+    if ties_policy == "refuse":
+        t = ties.numpy()
+        if t.any():
+            raise ValueError(
+                f"{what}: equal-valued markers inside one mask component in plane(s) {np.flatnonzero(t).tolist()}: "
+                "scikit-image orders them by the moves of its binary heap; use ties='exact' (sequential emulation, "
+                "bit-identical, slow) or ties='raster'")
+
+
+def watershed_edt(d2: DeviceArray, markers: DeviceArray, mask: DeviceArray, seeds_first: bool = True, out=None,
+                  connectivity: int = 1, ties: str = "exact", ties_out: DeviceArray | None = None):
+    """``skimage.segmentation.watershed(-sqrt(d2), markers, connectivity, mask=mask)`` on the exact integer d2.
+    ``seeds_first``: the config-3 recipe (the seeded relief of oracle/skops.py:seeded_flood_image; no ties possible).
+    ``ties``: what to do with equal-valued markers inside one component (include/amt_hip.h): 'exact' (default;
+    bit-identical to scikit-image through a sequential emulation of its heap for the affected planes), 'raster'
+    (fast, documented deviation), 'report' (raster + per-plane flags in ``ties_out``), 'refuse' (raise)."""
     ctx = d2.ctx
     n, H, W = _planes(d2)
     o = _out(ctx, out, d2.shape, np.int32)
-    _hip.check(_lib().amt_watershed_edt(ctx.handle, d2.ptr, markers.ptr, mask.ptr, o.ptr, n, H, W,
-                                        1 if seeds_first else 0), "amt_watershed_edt")
+    t = _ws_ties(ctx, n, ties, ties_out)
+    _hip.check(_lib().amt_watershed_edt_ex(ctx.handle, d2.ptr, markers.ptr, mask.ptr, o.ptr, n, H, W,
+                                           1 if seeds_first else 0, int(connectivity), _hip.WS_TIES[ties],
+                                           None if t is None else t.ptr),
+               "amt_watershed_edt")
+    _ws_finish(ctx, ties, t, "watershed_edt")
     return o
 
 
-def watershed(relief: DeviceArray, markers: DeviceArray, mask: DeviceArray, out=None):
-    """``skimage.segmentation.watershed(relief, markers, connectivity=1, mask=mask)`` for float64 relief."""
+def watershed(relief: DeviceArray, markers: DeviceArray, mask: DeviceArray, out=None, connectivity: int = 1,
+              ties: str = "exact", ties_out: DeviceArray | None = None):
+    """``skimage.segmentation.watershed(relief, markers, connectivity, mask=mask)`` for float64 relief
+    (``ties`` as in ``watershed_edt``; connectivity 2 always runs the sequential emulation)."""
     ctx = relief.ctx
     n, H, W = _planes(relief)
     o = _out(ctx, out, relief.shape, np.int32)
-    _hip.check(_lib().amt_watershed_f64(ctx.handle, relief.ptr, markers.ptr, mask.ptr, o.ptr, n, H, W),
+    t = _ws_ties(ctx, n, ties, ties_out)
+    _hip.check(_lib().amt_watershed_f64_ex(ctx.handle, relief.ptr, markers.ptr, mask.ptr, o.ptr, n, H, W,
+                                           int(connectivity), _hip.WS_TIES[ties], None if t is None else t.ptr),
                "amt_watershed_f64")
+    _ws_finish(ctx, ties, t, "watershed")
     return o
 
 

@@ -230,18 +230,34 @@ int amt_edt(amt_ctx* ctx, const uint8_t* mask, int32_t* d2_out, double* edt_out,
 /* peaks = (d2 == maximum_filter(d2, (2m+1)^2, constant 0)) & mask & (d2 > 0), border of width m cleared */
 int amt_peak_mask(amt_ctx* ctx, const int32_t* d2, const uint8_t* mask, uint8_t* peaks, int nplanes, int H, int W,
                   int min_distance);
-/* Priority flood restricted to `mask` (skimage.segmentation.watershed, connectivity 1, no compactness,
- * no watershed line).  Priority = (value, insertion age); marker pixels enter with age 0 and equal-valued
- * age-0 markers pop in raster order (see DESIGN.md "watershed": scikit-image orders those by the
- * internals of its binary heap).
- *   amt_watershed_edt : relief = -sqrt(d2) given as the exact integer d2 (bucket queue);
- *                       seeds_first != 0 pops every marker pixel first, in raster order
- *                       (the config-3 recipe's seeded relief).
- *   amt_watershed_f64 : general float64 relief (per-component binary heap). */
+/* Priority flood restricted to `mask` (skimage.segmentation.watershed, no compactness, no watershed line;
+ * SURVEY.md A.1).  Priority = (value, insertion age); labels are assigned at push time.
+ *   amt_watershed_edt : relief = -sqrt(d2) given as the exact integer d2 (bucket queue).  seeds_first = 1 is the
+ *                       config-3 recipe (oracle/skops.py:seeded_flood_image): marker pixels are spread first, in
+ *                       raster order -- i.e. the relief with every marker pixel lowered to a distinct lowest value;
+ *   amt_watershed_f64 : general float64 relief (per-component binary heap).
+ * Equal-valued age-0 MARKER pixels: scikit-image orders them by the moves of its single binary heap, which depends
+ * on everything else in the image, so such planes cannot be flooded component by component.  tie_policy:
+ *   AMT_WS_TIES_EXACT   planes in which two markers of one mask component (with more than one label) tie are
+ *                       re-flooded by a sequential emulation of scikit-image's heap: bit-identical, one lane,
+ *                       ~seconds per 2048 x 2048 plane.  Untied planes keep the parallel result (also bit-identical).
+ *   AMT_WS_TIES_RASTER  ties are broken in raster order (fast; differs from scikit-image in tied planes).
+ *   AMT_WS_TIES_REPORT  as RASTER, and ties_dev[plane] = 1 marks every plane whose result may differ.
+ * ties_dev (nullable, nplanes ints) receives the per-plane tie flags under every policy.
+ * connectivity 2 (8 neighbours, visited N, E, W, S, NW, NE, SW, SE as scikit-image 0.18.3 does) runs
+ * the sequential emulation for every plane and requires AMT_WS_TIES_EXACT.  The two-argument-less entry points are
+ * connectivity 1 with AMT_WS_TIES_EXACT. */
+#define AMT_WS_TIES_EXACT 0
+#define AMT_WS_TIES_RASTER 1
+#define AMT_WS_TIES_REPORT 2
 int amt_watershed_edt(amt_ctx* ctx, const int32_t* d2, const int32_t* markers, const uint8_t* mask, int32_t* out,
                       int nplanes, int H, int W, int seeds_first);
 int amt_watershed_f64(amt_ctx* ctx, const double* relief, const int32_t* markers, const uint8_t* mask, int32_t* out,
                       int nplanes, int H, int W);
+int amt_watershed_edt_ex(amt_ctx* ctx, const int32_t* d2, const int32_t* markers, const uint8_t* mask, int32_t* out,
+                         int nplanes, int H, int W, int seeds_first, int connectivity, int tie_policy, int32_t* ties_dev);
+int amt_watershed_f64_ex(amt_ctx* ctx, const double* relief, const int32_t* markers, const uint8_t* mask, int32_t* out,
+                         int nplanes, int H, int W, int connectivity, int tie_policy, int32_t* ties_dev);
 
 /* ---- region properties: R/masks.py:286-326 (regionprops_table) ------------------------------- */
 /* Morphology columns per label 1..max_label (row = label-1), float64, column order: */

@@ -286,6 +286,67 @@ def test_watershed(ctx, ops, golden):
         assert np.array_equal(out, watershed(img, mk, mask=mask)), i
 
 
+def test_watershed_skimage_golden_cases(ctx, ops, golden):
+    """All 120 real scikit-image 0.18.3 cases of tests/golden/watershed_cases.npz (tie-heavy integer reliefs and
+    -EDT inputs, with / without mask, connectivity 1 and 2) through the C ABI: bit-identical under the default
+    tie policy ('exact'), and the cases in which 'raster' differs are exactly cases that were reported as tied."""
+    g = golden("watershed_cases")
+    n = int(g["n"])
+    assert n == 120
+    tied = differ = 0
+    for i in range(n):
+        img, mk, mask, conn = g[f"img_{i}"], g[f"markers_{i}"], g[f"mask_{i}"], int(g[f"conn_{i}"])
+        dimg, dmk, dmask = ctx.asarray(np.ascontiguousarray(img, np.float64)), ctx.asarray(mk), ctx.asarray(mask)
+        out = ops.watershed(dimg, dmk, dmask, connectivity=conn).numpy()
+        assert np.array_equal(out, g[f"out_{i}"]), f"case {i} (connectivity {conn})"
+        if conn == 1:
+            flags = ctx.empty((1,), np.int32)
+            fast = ops.watershed(dimg, dmk, dmask, ties="report", ties_out=flags).numpy()
+            t = int(flags.numpy()[0])
+            tied += t
+            if not np.array_equal(fast, g[f"out_{i}"]):
+                differ += 1
+                assert t == 1, f"case {i}: the raster-order flood differs from scikit-image but no tie was reported"
+                with pytest.raises(ValueError, match="equal-valued markers"):
+                    ops.watershed(dimg, dmk, dmask, ties="refuse")
+        else:
+            with pytest.raises(ValueError, match="connectivity 2"):
+                ops.watershed(dimg, dmk, dmask, connectivity=2, ties="raster")
+    assert tied > 0 and differ > 0  # the corpus does exercise the heap-order artefact
+
+
+def test_watershed_plain_edt_relief(ctx, ops, golden):
+    """watershed(-edt, markers, mask) as SURVEY.md A.8 writes it (equal-valued peak markers are ubiquitous on an EDT):
+    the bucket flood with the exact tie policy equals the real scikit-image output, in a batch with an untied plane."""
+    from oracle import skops
+
+    g = golden("c2c3_256")
+    m, markers = g["mask"], g["markers"]
+    # plane 1: the same mask with markers of ONE component only, distinct d2 -> no tie, the parallel result stands
+    edt = skops.distance_transform_edt(m)
+    m2 = np.zeros_like(markers)
+    ys, xs = np.nonzero(markers)
+    m2[ys[0], xs[0]] = 1
+    dm = ctx.asarray(np.stack([m, m]))
+    dmk = ctx.asarray(np.stack([markers, m2]))
+    d2, _ = ops.edt(dm)
+    flags = ctx.empty((2,), np.int32)
+    ws = ops.watershed_edt(d2, dmk, dm, seeds_first=False, ties_out=flags).numpy()
+    assert np.array_equal(ws[0], g["watershed_plain"])
+    from oracle.watershed import watershed
+
+    assert np.array_equal(ws[1], watershed(-edt, m2, mask=m))
+    assert flags.numpy().tolist() == [1, 0]
+    fast = ops.watershed_edt(d2, dmk, dm, seeds_first=False, ties="raster").numpy()
+    assert np.array_equal(fast[1], ws[1]) and not np.array_equal(fast[0], g["watershed_plain"])
+    # float64 relief entry point on the same input
+    ws64 = ops.watershed(ctx.asarray(np.stack([-edt, -edt])), dmk, dm).numpy()
+    assert np.array_equal(ws64[0], g["watershed_plain"]) and np.array_equal(ws64[1], ws[1])
+    # connectivity 2 through the bucket entry point (sequential emulation)
+    ws8 = ops.watershed_edt(d2[:1], dmk[:1], dm[:1], seeds_first=False, connectivity=2).numpy()[0]
+    assert np.array_equal(ws8, watershed(-edt, markers, mask=m, connectivity=2))
+
+
 def test_regionprops(ctx, ops, golden):
     from arcadia_microscopy_tools_amd import _hip
 
