@@ -346,6 +346,9 @@ __global__ void __launch_bounds__(256) rp_heights_kernel(const int* __restrict__
     }
 }
 
+// labels of at most HULL_HMAX rows and HULL_WMAX columns go to rp_hull_lds_kernel, the rest to rp_hull_kernel
+constexpr int HULL_HMAX = 48, HULL_WMAX = 250;
+
 __device__ __forceinline__ long long floor_div(long long a, long long b) {  // b > 0
     long long q = a / b;
     return (a % b != 0 && a < 0) ? q - 1 : q;
@@ -363,7 +366,7 @@ __device__ __forceinline__ long long ceil_div(long long a, long long b) {  // b 
 __global__ void __launch_bounds__(64) rp_hull_kernel(const int* __restrict__ bbox, const int* __restrict__ hoff,
                                                      const int* __restrict__ htot, const int2* __restrict__ rows,
                                                      int2* __restrict__ chainL, int2* __restrict__ chainR, size_t cap,
-                                                     double* __restrict__ table, int max_label) {
+                                                     double* __restrict__ table, int max_label, int skip_h) {
     const int plane = blockIdx.y;
     const int l = blockIdx.x * 64 + threadIdx.x;
     if (l >= max_label) return;
@@ -371,10 +374,11 @@ __global__ void __launch_bounds__(64) rp_hull_kernel(const int* __restrict__ bbo
     double* trow = table + li * AMT_RP_NCOLS;
     const int miny = bbox[li * 4 + 0], maxy = bbox[li * 4 + 2];
     if (maxy < miny) {
-        trow[AMT_RP_AREA_CONVEX] = 0.0;
+        if (skip_h == 0) trow[AMT_RP_AREA_CONVEX] = 0.0;
         return;
     }
     const int h = maxy - miny + 1;
+    if (h <= skip_h && bbox[li * 4 + 3] - bbox[li * 4 + 1] + 1 <= HULL_WMAX) return;  // done by rp_hull_lds_kernel
     const size_t off = (size_t)hoff[li];
     if ((size_t)htot[plane] > cap || off + (size_t)h > cap) {  // capacity exceeded (fragmented labels)
         trow[AMT_RP_AREA_CONVEX] = __longlong_as_double(0x7ff8000000000000ll);
@@ -461,6 +465,133 @@ __global__ void __launch_bounds__(64) rp_hull_kernel(const int* __restrict__ bbo
                 long long dY = p1.x - p0.x;
                 long long num = (long long)p0.y * dY + (long long)(p1.y - p0.y) * (Y - p0.x);
                 xmax = floor_div(num, 2 * dY);
+            }
+        }
+        if (xmax >= xmin) count += xmax - xmin + 1;
+    }
+    trow[AMT_RP_AREA_CONVEX] = (double)count;
+}
+
+// The same hull for labels that fit a small box (at most HULL_HMAX rows and HULL_WMAX columns: every nucleus-sized
+// label): one lane per label, row extents and both chains in LDS, interleaved over the wave ([word][lane]), all
+// arithmetic in 32 bits.  Coordinates are taken relative to the box (x - x0, Y - Y0), so a row is one 16-bit word
+// (min | max << 8), a chain vertex one 16-bit word ((Y - Y0) << 9 | (X - X0)) and 8 waves fit a CU; every product
+// stays below 2^20.  The HBM-scratch kernel above takes the labels that do not fit.
+constexpr int HULL_CH = 2 * HULL_HMAX + 1;
+__device__ __forceinline__ int floor_div32(int a, int b) {  // b > 0
+    const int q = a / b;
+    return (a % b != 0 && a < 0) ? q - 1 : q;
+}
+__device__ __forceinline__ int ceil_div32(int a, int b) {  // b > 0
+    const int q = a / b;
+    return (a % b != 0 && a > 0) ? q + 1 : q;
+}
+__global__ void __launch_bounds__(64) rp_hull_lds_kernel(const int* __restrict__ bbox, const int* __restrict__ hoff,
+                                                         const int* __restrict__ htot, const int2* __restrict__ rows,
+                                                         size_t cap, double* __restrict__ table, int max_label) {
+    __shared__ unsigned short s_rows[HULL_HMAX * 64];
+    __shared__ unsigned short s_cl[HULL_CH * 64];
+    __shared__ unsigned short s_cr[HULL_CH * 64];
+    const int plane = blockIdx.y;
+    const int lane = threadIdx.x;
+    const int l = blockIdx.x * 64 + lane;
+    if (l >= max_label) return;
+    const size_t li = (size_t)plane * max_label + l;
+    double* trow = table + li * AMT_RP_NCOLS;
+    const int miny = bbox[li * 4 + 0], x0 = bbox[li * 4 + 1], maxy = bbox[li * 4 + 2], x1 = bbox[li * 4 + 3];
+    if (maxy < miny) {
+        trow[AMT_RP_AREA_CONVEX] = 0.0;
+        return;
+    }
+    const int h = maxy - miny + 1;
+    if (h > HULL_HMAX || x1 - x0 + 1 > HULL_WMAX) return;  // rp_hull_kernel takes it
+    const size_t off = (size_t)hoff[li];
+    if ((size_t)htot[plane] > cap || off + (size_t)h > cap) {  // capacity exceeded (fragmented labels)
+        trow[AMT_RP_AREA_CONVEX] = __longlong_as_double(0x7ff8000000000000ll);
+        return;
+    }
+    const int2* r = rows + (size_t)plane * cap + off;
+    // eight row extents per round trip: loads from clamped indices, issued before the first of them is used (a
+    // load -> LDS store loop waits for every load in turn)
+    for (int k0 = 0; k0 < h; k0 += 8) {
+        int2 e[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) e[u] = r[min(k0 + u, h - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (k0 + u < h)  // an empty row (max < min) keeps that property: 255 | 0 << 8
+                s_rows[(k0 + u) * 64 + lane] =
+                    e[u].y >= e[u].x ? (unsigned short)((e[u].x - x0) | ((e[u].y - x0) << 8)) : (unsigned short)255;
+    }
+    // doubled, box-relative coordinates: Yr = Y - (2 miny - 1) in [0, 2h], Xr = X - (2 x0 - 1) in [0, 2w]
+    int nl = 0, nr = 0;
+    for (int Yr = 0; Yr <= 2 * h; ++Yr) {
+        int mn = 0x7fffffff, mx = -1;
+        if (!(Yr & 1)) {  // odd Y: shared by the rows above and below
+            const int ka = (Yr >> 1) - 1, kb = Yr >> 1;
+            if (ka >= 0) {
+                const unsigned e = s_rows[ka * 64 + lane];
+                if ((e >> 8) >= (e & 255)) {
+                    mn = min(mn, 2 * (int)(e & 255) + 1);
+                    mx = max(mx, 2 * (int)(e >> 8) + 1);
+                }
+            }
+            if (kb < h) {
+                const unsigned e = s_rows[kb * 64 + lane];
+                if ((e >> 8) >= (e & 255)) {
+                    mn = min(mn, 2 * (int)(e & 255) + 1);
+                    mx = max(mx, 2 * (int)(e >> 8) + 1);
+                }
+            }
+        } else {
+            const unsigned e = s_rows[(Yr >> 1) * 64 + lane];
+            if ((e >> 8) >= (e & 255)) {
+                mn = 2 * (int)(e & 255);
+                mx = 2 * (int)(e >> 8) + 2;
+            }
+        }
+        if (mx < mn) continue;  // no pixel of this label contributes at this Y
+        while (nl >= 2) {
+            const int v0 = s_cl[(nl - 2) * 64 + lane], v1 = s_cl[(nl - 1) * 64 + lane];
+            const int cr = ((v1 >> 9) - (v0 >> 9)) * (mn - (v0 & 511)) - ((v1 & 511) - (v0 & 511)) * (Yr - (v0 >> 9));
+            if (cr <= 0) --nl; else break;
+        }
+        s_cl[(nl++) * 64 + lane] = (unsigned short)((Yr << 9) | mn);
+        while (nr >= 2) {
+            const int v0 = s_cr[(nr - 2) * 64 + lane], v1 = s_cr[(nr - 1) * 64 + lane];
+            const int cr = ((v1 >> 9) - (v0 >> 9)) * (mx - (v0 & 511)) - ((v1 & 511) - (v0 & 511)) * (Yr - (v0 >> 9));
+            if (cr >= 0) --nr; else break;
+        }
+        s_cr[(nr++) * 64 + lane] = (unsigned short)((Yr << 9) | mx);
+    }
+    // count pixel centres: row k sits at Yr = 2k + 1; pixel x at Xr = 2 (x - x0) + 1
+    int count = 0;
+    int il = 0, ir = 0;
+    for (int k = 0; k < h; ++k) {
+        const int Yr = 2 * k + 1;
+        while (il + 1 < nl && (int)(s_cl[(il + 1) * 64 + lane] >> 9) <= Yr) ++il;
+        while (ir + 1 < nr && (int)(s_cr[(ir + 1) * 64 + lane] >> 9) <= Yr) ++ir;
+        int xmin, xmax;  // pixel index bounds: XL <= 2 x + 1 <= XR
+        {
+            const int v0 = s_cl[il * 64 + lane];
+            if ((v0 >> 9) == Yr || il + 1 >= nl) {
+                xmin = ceil_div32((v0 & 511) - 1, 2);
+            } else {
+                const int v1 = s_cl[(il + 1) * 64 + lane];
+                const int dY = (v1 >> 9) - (v0 >> 9);  // > 0
+                const int num = ((v0 & 511) - 1) * dY + ((v1 & 511) - (v0 & 511)) * (Yr - (v0 >> 9));  // (XL - 1) * dY
+                xmin = ceil_div32(num, 2 * dY);
+            }
+        }
+        {
+            const int v0 = s_cr[ir * 64 + lane];
+            if ((v0 >> 9) == Yr || ir + 1 >= nr) {
+                xmax = floor_div32((v0 & 511) - 1, 2);
+            } else {
+                const int v1 = s_cr[(ir + 1) * 64 + lane];
+                const int dY = (v1 >> 9) - (v0 >> 9);
+                const int num = ((v0 & 511) - 1) * dY + ((v1 & 511) - (v0 & 511)) * (Yr - (v0 >> 9));
+                xmax = floor_div32(num, 2 * dY);
             }
         }
         if (xmax >= xmin) count += xmax - xmin + 1;
@@ -573,8 +704,15 @@ static int regionprops_common(amt_ctx* ctx, const int32_t* labels, const uint16_
         hipLaunchKernelGGL(rp_final_kernel, dim3(amt_grid_for(nlab, 256, 1024)), dim3(256), 0, ctx->stream, acc, bbox,
                            table_dev, nlab);
         AMT_LAUNCH_CHECK();
+        const int skip_h = HULL_HMAX;
+        {
+            hipLaunchKernelGGL(rp_hull_lds_kernel, dim3((max_label + 63) / 64, nplanes), dim3(64), 0, ctx->stream, bbox,
+                               hoff, htot, rows, cap, table_dev, max_label);
+            AMT_LAUNCH_CHECK();
+        }
+        // labels taller than HULL_HMAX rows or wider than HULL_WMAX columns: chains in HBM scratch
         hipLaunchKernelGGL(rp_hull_kernel, dim3((max_label + 63) / 64, nplanes), dim3(64), 0, ctx->stream, bbox, hoff,
-                           htot, rows, chainL, chainR, cap, table_dev, max_label);
+                           htot, rows, chainL, chainR, cap, table_dev, max_label, skip_h);
         AMT_LAUNCH_CHECK();
         hipLaunchKernelGGL(rp_solidity_kernel, dim3(amt_grid_for(nlab, 256, 1024)), dim3(256), 0, ctx->stream,
                            table_dev, nlab);

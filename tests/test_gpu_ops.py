@@ -372,6 +372,43 @@ def test_regionprops(ctx, ops, golden):
         np.testing.assert_allclose(np.abs(cols["orientation"][sym]), np.pi / 4)
 
 
+def test_convex_area_all_heights(ctx, ops):
+    """area_convex for labels of every height class: both hull kernels (LDS chains for labels of <= 48 rows, HBM
+    chains above), labels touching row 0, one-pixel and one-row labels, concave and fragmented shapes -- against the
+    oracle's exact integer restatement of scikit-image's convex_hull_image (oracle/regionprops.py)."""
+    from arcadia_microscopy_tools_amd import _hip
+    from oracle.regionprops import convex_area_exact
+
+    rng = np.random.default_rng(17)
+    H, W = 300, 420
+    lab = np.zeros((H, W), np.int32)
+    yy, xx = np.mgrid[0:H, 0:W]
+    k = 0
+    shapes = [(20, 30, 9, 9), (0, 80, 14, 30), (60, 60, 24, 10), (70, 150, 25, 40), (150, 90, 49, 20),
+              (160, 260, 70, 60), (290, 300, 9, 50)]
+    for cy, cx, ry, rx in shapes:  # ellipses: 19 ... 141 rows tall; the second one is clipped by row 0
+        k += 1
+        lab[((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1] = k
+    k += 1
+    lab[5, 400] = k                      # one pixel
+    k += 1
+    lab[40, 330:415] = k                 # one row
+    k += 1
+    lab[100:230, 400] = k                # one column, 130 rows
+    k += 1
+    lab[240:290, 10:60][np.triu(np.ones((50, 50), bool))] = k   # triangle, 50 rows (just above the LDS limit)
+    k += 1
+    lab[200:248, 340:390][np.tril(np.ones((48, 50), bool))] = k  # 48 rows (exactly the LDS limit)
+    k += 1
+    m = rng.random((40, 40)) < 0.3       # fragmented label: convex hull of scattered pixels
+    lab[250:290, 100:140][m] = k
+    t = ops.regionprops(ctx.asarray(np.stack([lab, lab[::-1].copy()])), k).numpy()
+    col = _hip.RP_COLS.index("area_convex")
+    for b, L in enumerate((lab, lab[::-1])):
+        for l in range(1, k + 1):
+            assert t[b, l - 1, col] == convex_area_exact(L == l), (b, l)
+
+
 def test_regionprops_intensity(ctx, ops, golden):
     g = golden("c2c3_256")
     lab = g["labels"].astype(np.int32)
