@@ -34,11 +34,14 @@
 #include "amt_internal.h"
 
 // component classes
-enum { CLS_NONE = 0, CLS_UNIFORM = 1, CLS_S = 2, CLS_M = 3, CLS_L = 4, CLS_G = 5 };
-// LDS tile classes: max pixels of the bounding box, max d2 (bucket count - 1)
+enum { CLS_NONE = 0, CLS_UNIFORM = 1, CLS_S = 2, CLS_M = 3, CLS_L = 4, CLS_X = 5, CLS_G = 6 };
+// LDS tile classes: max pixels of the bounding box, max d2 (bucket count - 1).  S / M / L are flooded by
+// ws_flood_batch_kernel (6 bytes of LDS per pixel + 8 per bucket), X -- the few boxes between L and the 15-bit
+// index limit -- by the one-pop-at-a-time ws_flood_lds_kernel (4 bytes per pixel).
 constexpr int S_PX = 2048, S_NB = 512;
 constexpr int M_PX = 8192, M_NB = 1024;
-constexpr int L_PX = 32512, L_NB = 2048;  // pixel indices must fit the 15-bit link field
+constexpr int L_PX = 24576, L_NB = 2048;
+constexpr int X_PX = 32512, X_NB = 2048;  // pixel indices must fit the 15-bit link field
 
 struct comp_row {
     int cmax;            // max d2 (bucket mode) or pixel count (heap mode)
@@ -237,12 +240,13 @@ __global__ void __launch_bounds__(256) ws_classify_kernel(comp_row* __restrict__
             else if (area <= S_PX && c.cmax < S_NB) cls = CLS_S;
             else if (area <= M_PX && c.cmax < M_NB) cls = CLS_M;
             else if (area <= L_PX && c.cmax < L_NB) cls = CLS_L;
+            else if (area <= X_PX && c.cmax < X_NB) cls = CLS_X;
             else cls = CLS_G;
         }
         r[i].cls = cls;
         Fall[(size_t)blockIdx.y * n + c.root] = cls == CLS_UNIFORM ? c.labmin : 0;
         if (cls == CLS_G) has_g[blockIdx.y] = 1;
-        if (cls == CLS_S || cls == CLS_M || cls == CLS_L) {
+        if (cls == CLS_S || cls == CLS_M || cls == CLS_L || cls == CLS_X) {
             // per-class worklist of this plane (order is irrelevant: components are independent)
             const int k = cls - CLS_S;
             const int pos = atomicAdd(&wl_count[k * nplanes + blockIdx.y], 1);
@@ -469,6 +473,260 @@ __global__ void __launch_bounds__(64) ws_flood_lds_kernel(const int* __restrict_
                 }
                 spread((int)head, true);
             }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- write back ----
+        for (int i = lane; i < npx; i += 64) {
+            const unsigned lv = cell[i] & 0xFFFFu;
+            if (lv != 0xFFFFu) {
+                const int ty = (int)(((unsigned long long)(unsigned)i * inv_tw) >> 32), tx = i - ty * tw;
+                out[(size_t)(cr.y0 + ty - 1) * W + (cr.x0 + tx - 1)] = (int)lv;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---- LDS-tile flood, a whole FIFO at a time ------------------------------------------------------------------
+// The sequential flood pops ONE pixel per step; on an EDT relief a bucket (= one value of d2) of a cluster of nuclei
+// holds tens of pixels, and consecutive pops of one bucket interact only through (a) the cells they claim and (b) the
+// order of their pushes.  So a step takes up to 64 entries off the head of the current bucket, one per lane, and
+// reproduces the sequential outcome exactly:
+//   * every lane reads its four neighbour cells; a neighbour that is unlabelled at the start of the step is a target;
+//   * if a target lies in a HIGHER bucket than the current one, the sequential flood would continue there right after
+//     that pop: the step is cut after the first such lane (it certainly claims that cell -- an earlier claimant would
+//     itself be the first such lane), the later entries stay queued;
+//   * a cell targeted by several (lane, neighbour) pairs goes to the smallest (lane, N-W-E-S) pair, as when popped one
+//     by one: every pair does an LDS atomic max of a priority ticket into the label field, then re-reads it; the
+//     winner replaces the ticket with its label (targets were unlabelled, so tickets cannot be mistaken for labels);
+//   * winners are appended to the bucket of their cell in (lane, neighbour) order = sequential push order: for each
+//     distinct destination bucket the ranks come from ballots.
+// A pixel is pushed at most once and always into the bucket of its own d2, so a bucket's queue is an array segment
+// whose size is known up front: the staging pass histograms d2 over the component, a wave scan turns the counts into
+// segment offsets, and a bucket is two cursors -- no links to chase.
+//   cell[i]  (u32) = label (low 16; 0 = unclaimed, 0xFFFF = not in this component / ring) | d2 << 16 | marker << 31
+//   queue[i] (u16) = tile indices, bucket segments back to back
+//   off[b], hd[b], tl[b] (u16): segment start, next entry to pop, next free slot
+template <int TILE_PX, int NB>
+__global__ void __launch_bounds__(64) ws_flood_batch_kernel(const int* __restrict__ d2all, const int* __restrict__ Lall,
+                                                            const int* __restrict__ Tall, int* __restrict__ outall,
+                                                            const comp_row* __restrict__ rows,
+                                                            const int* __restrict__ wl, const int* __restrict__ wl_count,
+                                                            int* __restrict__ counters, size_t row_stride, int H, int W,
+                                                            int seeds_first, int* __restrict__ ties) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    unsigned* cell = reinterpret_cast<unsigned*>(smem_raw);
+    unsigned* cnt = cell + TILE_PX;                                       // NB words: histogram, then {hd | tl << 16}
+    unsigned short* offs = reinterpret_cast<unsigned short*>(cnt + NB);  // NB segment starts
+    unsigned short* queue = offs + NB;                                    // TILE_PX entries
+    const int plane = blockIdx.y;
+    const size_t n = (size_t)H * W;
+    const int* d2 = d2all + (size_t)plane * n;
+    const int* L = Lall + (size_t)plane * n;
+    const int* T = Tall + (size_t)plane * n;
+    int* out = outall + (size_t)plane * n;
+    const comp_row* rr = rows + (size_t)plane * row_stride;
+    const int* mylist = wl + (size_t)plane * row_stride;
+    const int nwork = wl_count[plane];
+    const int lane = threadIdx.x;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    auto uni = [&](unsigned v) -> unsigned { return __builtin_amdgcn_readfirstlane(v); };
+    while (true) {
+        int kk = 0;
+        if (lane == 0) kk = atomicAdd(&counters[plane], 1);
+        kk = __builtin_amdgcn_readfirstlane(kk);
+        if (kk >= nwork) break;
+        const int c = mylist[kk];
+        const comp_row cr = rr[c];
+        const int tw = cr.x1 - cr.x0 + 3, th = cr.y1 - cr.y0 + 3;  // padded tile
+        const int npx = tw * th;
+        const int nb = cr.cmax + 1;
+        const unsigned inv_tw = 0xFFFFFFFFu / (unsigned)tw + 1u;  // i / tw == (i * inv_tw) >> 32 for i < 65536
+        for (int i = lane; i < nb; i += 64) cnt[i] = 0;
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        // ---- stage the bounding box + ring, histogram d2 over the component ----
+        for (int i0 = 0; i0 < npx; i0 += 256) {
+            int rr4[4], o4[4], d4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * 64 + lane;
+                const int ty = (int)(((unsigned long long)(unsigned)i * inv_tw) >> 32), tx = i - ty * tw;
+                rr4[u] = -1;
+                o4[u] = 0;
+                d4[u] = 0;
+                if (i < npx && ty >= 1 && ty < th - 1 && tx >= 1 && tx < tw - 1) {
+                    const size_t g = (size_t)(cr.y0 + ty - 1) * W + (cr.x0 + tx - 1);
+                    rr4[u] = L[g];
+                    o4[u] = out[g];
+                    d4[u] = d2[g];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) rr4[u] = rr4[u] >= 0 ? T[rr4[u]] : 0;  // tile root -> component id (1-based)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * 64 + lane;
+                if (i < npx) {
+                    unsigned cv = 0xFFFFu;
+                    if (rr4[u] == c + 1) {
+                        const int d = d4[u] < 0 ? 0 : d4[u];
+                        cv = ((unsigned)o4[u] & 0xFFFFu) | ((unsigned)d << 16) | (o4[u] != 0 ? 0x80000000u : 0u);
+                        atomicAdd(&cnt[d], 1u);
+                    }
+                    cell[i] = cv;
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        // ---- counts -> segment offsets (each lane owns a contiguous run of buckets), cursors = segment start ----
+        {
+            const int per = (nb + 63) / 64;
+            const int b0 = lane * per;
+            int sum = 0;
+            for (int j = 0; j < per; ++j) sum += (b0 + j < nb) ? (int)cnt[b0 + j] : 0;
+            int incl = sum;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(incl, o);
+                if (lane >= o) incl += t;
+            }
+            int run = incl - sum;
+            for (int j = 0; j < per; ++j) {
+                if (b0 + j < nb) {
+                    const int cj = (int)cnt[b0 + j];
+                    offs[b0 + j] = (unsigned short)run;
+                    cnt[b0 + j] = (unsigned)run | ((unsigned)run << 16);  // hd = tl = segment start
+                    run += cj;
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        int cur = -1;    // current bucket (-1: none yet)
+        int raise = -1;  // highest bucket that received a push since the last switch
+        const int offN = -tw, offW = -1, offE = 1, offS = tw;
+        // One step over the pixels p (one per active lane, lane order = pop order).  `limit`: the bucket the pixels
+        // were popped from (a target above it cuts the step) or a value above every bucket (marker spreading).
+        // Returns the number of lanes that took part.
+        auto step = [&](int p, bool active, int limit, bool marker_push) -> int {
+            unsigned cN = 0xFFFFu, cW = 0xFFFFu, cE = 0xFFFFu, cS = 0xFFFFu, cp = 0;
+            const int pa = active ? p : 0;
+            if (!marker_push) {
+                cN = cell[pa + offN];
+                cW = cell[pa + offW];
+                cE = cell[pa + offE];
+                cS = cell[pa + offS];
+            }
+            cp = cell[pa];
+            bool tN = active && !marker_push && (cN & 0xFFFFu) == 0, tW = active && !marker_push && (cW & 0xFFFFu) == 0;
+            bool tE = active && !marker_push && (cE & 0xFFFFu) == 0, tS = active && !marker_push && (cS & 0xFFFFu) == 0;
+            const int bN = (int)((cN >> 16) & 0x7FFF), bW = (int)((cW >> 16) & 0x7FFF);
+            const int bE = (int)((cE >> 16) & 0x7FFF), bS = (int)((cS >> 16) & 0x7FFF);
+            const bool higher = (tN && bN > limit) || (tW && bW > limit) || (tE && bE > limit) || (tS && bS > limit);
+            const unsigned long long hm = __ballot(higher);
+            const unsigned long long am = __ballot(active);
+            int took = __popcll(am);
+            if (hm) {
+                const int first = __ffsll((long long)hm) - 1;
+                took = __popcll(am & ((2ull << first) - 1ull));
+                if (lane > first) tN = tW = tE = tS = false;
+            }
+            bool wN = false, wW = false, wE = false, wS = false;
+            int qN = pa + offN, qW = pa + offW, qE = pa + offE, qS = pa + offS;
+            int dN = bN, dW = bW, dE = bE, dS = bS;
+            if (marker_push) {  // the pixel itself is queued (markers entering by value): one "claim" per lane, slot N
+                wN = active;
+                qN = pa;
+                dN = (int)((cp >> 16) & 0x7FFF);
+            } else if (__ballot(tN || tW || tE || tS)) {
+                // tickets: the smallest (lane, neighbour) pair holds the largest ticket
+                const unsigned tk = 0x100u - (unsigned)(lane * 4);
+                if (tN) atomicMax(&cell[qN], (cN & 0xFFFF0000u) | (tk - 0));
+                if (tW) atomicMax(&cell[qW], (cW & 0xFFFF0000u) | (tk - 1));
+                if (tE) atomicMax(&cell[qE], (cE & 0xFFFF0000u) | (tk - 2));
+                if (tS) atomicMax(&cell[qS], (cS & 0xFFFF0000u) | (tk - 3));
+                const unsigned rN = tN ? cell[qN] : 0, rW = tW ? cell[qW] : 0, rE = tE ? cell[qE] : 0,
+                               rS = tS ? cell[qS] : 0;
+                wN = tN && (rN & 0xFFFFu) == tk - 0;
+                wW = tW && (rW & 0xFFFFu) == tk - 1;
+                wE = tE && (rE & 0xFFFFu) == tk - 2;
+                wS = tS && (rS & 0xFFFFu) == tk - 3;
+                const unsigned lab = cp & 0xFFFFu;
+                if (wN) cell[qN] = (cN & 0xFFFF0000u) | lab;
+                if (wW) cell[qW] = (cW & 0xFFFF0000u) | lab;
+                if (wE) cell[qE] = (cE & 0xFFFF0000u) | lab;
+                if (wS) cell[qS] = (cS & 0xFFFF0000u) | lab;
+            }
+            // append the winners, one destination bucket at a time, in (lane, N-W-E-S) order
+            unsigned long long pend = __ballot(wN || wW || wE || wS);
+            while (pend) {
+                const int l0 = __ffsll((long long)pend) - 1;
+                const int sel = wN ? dN : wW ? dW : wE ? dE : dS;  // this lane's first pending destination
+                const int bsel = __builtin_amdgcn_readlane(sel, l0);
+                const bool mN = wN && dN == bsel, mW = wW && dW == bsel, mE = wE && dE == bsel, mS = wS && dS == bsel;
+                const unsigned long long sN = __ballot(mN), sW = __ballot(mW), sE = __ballot(mE), sS = __ballot(mS);
+                const int before = __popcll(sN & lt_mask) + __popcll(sW & lt_mask) + __popcll(sE & lt_mask) +
+                                   __popcll(sS & lt_mask);
+                const int total = __popcll(sN) + __popcll(sW) + __popcll(sE) + __popcll(sS);
+                const unsigned ht = uni(cnt[bsel]);
+                const int base = (int)(ht >> 16);
+                if (marker_push && (ht >> 16) != (unsigned)offs[bsel] + 0u && lane == 0) ties[plane] = 1;
+                if (marker_push && total > 1 && lane == 0) ties[plane] = 1;
+                int r = base + before;
+                if (mN) queue[r++] = (unsigned short)qN;
+                if (mW) queue[r++] = (unsigned short)qW;
+                if (mE) queue[r++] = (unsigned short)qE;
+                if (mS) queue[r++] = (unsigned short)qS;
+                if (lane == 0) cnt[bsel] = (ht & 0xFFFFu) | ((unsigned)(base + total) << 16);
+                raise = bsel > raise ? bsel : raise;
+                wN = wN && !mN;
+                wW = wW && !mW;
+                wE = wE && !mE;
+                wS = wS && !mS;
+                pend = __ballot(wN || wW || wE || wS);
+            }
+            return took;
+        };
+        // ---- markers in raster order, 64 tile cells at a time ----
+        for (int i0 = 0; i0 < npx; i0 += 64) {
+            const int i = i0 + lane;
+            const bool ismk = i < npx && (cell[i] & 0x80000000u);
+            if (__ballot(ismk)) step(i, ismk, 0x7FFFFFFF, !seeds_first);
+        }
+        // ---- the flood ----
+        while (true) {
+            if (raise > cur) cur = raise;
+            raise = -1;
+            unsigned ht = cur >= 0 ? uni(cnt[cur]) : 0u;
+            if (cur < 0 || (ht & 0xFFFFu) == (ht >> 16)) {  // current bucket exhausted: walk down, 64 buckets a time
+                int found = -1;
+                int top = cur < 0 ? nb : cur;  // buckets below `top` are candidates
+                while (top > 0) {
+                    const int bi = top - 1 - lane;
+                    const unsigned h = bi >= 0 ? cnt[bi] : 0u;
+                    const unsigned long long m = __ballot(bi >= 0 && (h & 0xFFFFu) != (h >> 16));
+                    if (m) {
+                        found = top - 1 - (__ffsll((long long)m) - 1);
+                        break;
+                    }
+                    top -= 64;
+                }
+                if (found < 0) break;
+                cur = found;
+                ht = uni(cnt[cur]);
+            }
+            const int hd = (int)(ht & 0xFFFFu), tl = (int)(ht >> 16);
+            const int navail = tl - hd < 64 ? tl - hd : 64;
+            const bool active = lane < navail;
+            const int p = active ? (int)queue[hd + lane] : 0;
+            const int took = step(p, active, cur, false);  // pushes into the current bucket only move its tl
+            if (lane == 0) {
+                const unsigned now = cnt[cur];  // tl may have grown
+                cnt[cur] = (unsigned)(hd + took) | (now & 0xFFFF0000u);
+            }
+            __builtin_amdgcn_s_waitcnt(0);
         }
         __builtin_amdgcn_wave_barrier();
         // ---- write back ----
@@ -860,8 +1118,8 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     const int trows = amt_i_tile_rows(H);
     const size_t lcap = amt_i_rootlist_cap(W);
     const size_t nlist = (size_t)nplanes * trows;
-    size_t need = 5 * amt_align(np * 4) + amt_align(nlist * lcap * 4) + amt_align(nlist * 4) + 6 * amt_align(nr * 4) + amt_align(nr * sizeof(comp_row)) +
-                  9 * amt_align(nplanes * 4 * 9) + amt_align((size_t)nplanes * 4);
+    size_t need = 5 * amt_align(np * 4) + amt_align(nlist * lcap * 4) + amt_align(nlist * 4) + 7 * amt_align(nr * 4) + amt_align(nr * sizeof(comp_row)) +
+                  9 * amt_align(nplanes * 4 * 12) + amt_align((size_t)nplanes * 4);
     need += use_d2 ? 2 * amt_align((size_t)nplanes * bstride * 4) : amt_align((size_t)nplanes * bstride * sizeof(hp_elem));
     // the sequential emulation's heap (every pixel is pushed at most once): the float64 path reuses its per-component
     // heap space, the bucket path needs it extra -- and only when ties are to be resolved exactly
@@ -880,8 +1138,10 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     comp_row* rows = arena_take_t<comp_row>(ctx, nr);
     int* btot = arena_take_t<int>(ctx, nplanes);
     int* mtot = arena_take_t<int>(ctx, nplanes);
-    int* counters = arena_take_t<int>(ctx, (size_t)nplanes * 9);
-    int* wl = arena_take_t<int>(ctx, 3 * nr);  // worklists of the three LDS classes
+    // per plane: work counters of the L / M / S / G floods [0..4), has_g [4], worklist sizes S / M / L / X [5..9), work
+    // counter of the X flood [9], number of components [10]
+    int* counters = arena_take_t<int>(ctx, (size_t)nplanes * 12);
+    int* wl = arena_take_t<int>(ctx, 4 * nr);  // worklists of the four LDS classes
     int* ties = ties_dev ? ties_dev : arena_take_t<int>(ctx, nplanes);
     int *head = nullptr, *tail = nullptr;
     hp_elem* heap = nullptr;
@@ -895,9 +1155,9 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
         gheap = heap;  // bstride == n: the per-component heaps are dead when the emulation starts
     }
 
-    int* ncomp = counters + 8 * (size_t)nplanes;
-    hipLaunchKernelGGL(ws_zero_counters_kernel, dim3((nplanes * 9 + 63) / 64), dim3(64), 0, ctx->stream, counters,
-                       nplanes * 9);
+    int* ncomp = counters + 10 * (size_t)nplanes;
+    hipLaunchKernelGGL(ws_zero_counters_kernel, dim3((nplanes * 12 + 63) / 64), dim3(64), 0, ctx->stream, counters,
+                       nplanes * 12);
     AMT_LAUNCH_CHECK();
     hipLaunchKernelGGL(ws_set_flags_kernel, dim3((nplanes + 63) / 64), dim3(64), 0, ctx->stream, ties, nplanes, 0);
     AMT_LAUNCH_CHECK();
@@ -912,7 +1172,7 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     hipLaunchKernelGGL(ws_rows_init_kernel, dim3(64, nplanes), dim3(256), 0, ctx->stream, rows, ncomp, row_stride);
     AMT_LAUNCH_CHECK();
     int* has_g = counters + 4 * nplanes;
-    int* wl_count = counters + 5 * nplanes;  // [3][nplanes]
+    int* wl_count = counters + 5 * nplanes;  // [4][nplanes]
     hipLaunchKernelGGL(ws_stats_kernel, dim3((W + 63) / 64, (H + 31) / 32, nplanes), dim3(256), 0, ctx->stream,
                        use_d2 ? (const int*)relief : (const int*)nullptr, L, T, markers, rows, row_stride, H, W,
                        use_d2 ? 1 : 0);
@@ -934,23 +1194,28 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
                        has_g, row_stride, n);
     AMT_LAUNCH_CHECK();
     if (use_d2) {
-        const size_t ldsS = (size_t)S_PX * 4 + (size_t)S_NB * 4;
-        const size_t ldsM = (size_t)M_PX * 4 + (size_t)M_NB * 4;
-        const size_t ldsL = (size_t)L_PX * 4 + (size_t)L_NB * 4;
-        // the three LDS classes and the HBM path are independent, latency-bound and use few waves each:
+        const size_t ldsS = (size_t)S_PX * 6 + (size_t)S_NB * 6;
+        const size_t ldsM = (size_t)M_PX * 6 + (size_t)M_NB * 6;
+        const size_t ldsL = (size_t)L_PX * 6 + (size_t)L_NB * 6;
+        const size_t ldsX = (size_t)X_PX * 4 + (size_t)X_NB * 4;
+        // the LDS classes and the HBM path are independent, latency-bound and use few waves each:
         // run them side by side (fork / join on the context's auxiliary streams)
         hipLaunchKernelGGL(ws_fill_value_kernel, dim3(256, nplanes), dim3(256), 0, ctx->stream, head, btot, bstride, -1);
         AMT_LAUNCH_CHECK();
         AMT_TRY(amt_fork(ctx));
-        hipLaunchKernelGGL((ws_flood_lds_kernel<L_PX, L_NB, CLS_L>), dim3(16, nplanes), dim3(64), ldsL, ctx->stream,
+        hipLaunchKernelGGL((ws_flood_batch_kernel<L_PX, L_NB>), dim3(16, nplanes), dim3(64), ldsL, ctx->stream,
                            (const int*)relief, L, T, out, rows, wl + 2 * (size_t)nplanes * row_stride,
                            wl_count + 2 * nplanes, counters + 0 * nplanes, row_stride, H, W, seeds_first, ties);
         AMT_LAUNCH_CHECK();
-        hipLaunchKernelGGL((ws_flood_lds_kernel<M_PX, M_NB, CLS_M>), dim3(64, nplanes), dim3(64), ldsM, ctx->aux[0],
+        hipLaunchKernelGGL((ws_flood_lds_kernel<X_PX, X_NB, CLS_X>), dim3(8, nplanes), dim3(64), ldsX, ctx->stream,
+                           (const int*)relief, L, T, out, rows, wl + 3 * (size_t)nplanes * row_stride,
+                           wl_count + 3 * nplanes, counters + 9 * nplanes, row_stride, H, W, seeds_first, ties);
+        AMT_LAUNCH_CHECK();
+        hipLaunchKernelGGL((ws_flood_batch_kernel<M_PX, M_NB>), dim3(64, nplanes), dim3(64), ldsM, ctx->aux[0],
                            (const int*)relief, L, T, out, rows, wl + 1 * (size_t)nplanes * row_stride,
                            wl_count + 1 * nplanes, counters + 1 * nplanes, row_stride, H, W, seeds_first, ties);
         AMT_LAUNCH_CHECK();
-        hipLaunchKernelGGL((ws_flood_lds_kernel<S_PX, S_NB, CLS_S>), dim3(128, nplanes), dim3(64), ldsS, ctx->aux[1],
+        hipLaunchKernelGGL((ws_flood_batch_kernel<S_PX, S_NB>), dim3(128, nplanes), dim3(64), ldsS, ctx->aux[1],
                            (const int*)relief, L, T, out, rows, wl + 0 * (size_t)nplanes * row_stride,
                            wl_count + 0 * nplanes, counters + 2 * nplanes, row_stride, H, W, seeds_first, ties);
         AMT_LAUNCH_CHECK();
