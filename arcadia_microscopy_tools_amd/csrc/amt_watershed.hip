@@ -507,6 +507,16 @@ __global__ void __launch_bounds__(64) ws_flood_lds_kernel(const int* __restrict_
 //   cell[i]  (u32) = label (low 16; 0 = unclaimed, 0xFFFF = not in this component / ring) | d2 << 16 | marker << 31
 //   queue[i] (u16) = tile indices, bucket segments back to back
 //   off[b], hd[b], tl[b] (u16): segment start, next entry to pop, next free slot
+#ifdef WS_STATS
+__device__ unsigned long long ws_dbg[8];
+extern "C" int amt_ws_debug_read(unsigned long long* host8) {
+    return hipMemcpyFromSymbol(host8, HIP_SYMBOL(ws_dbg), 64) == hipSuccess ? 0 : -2;
+}
+extern "C" int amt_ws_debug_reset() {
+    unsigned long long z[8] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(ws_dbg), z, 64) == hipSuccess ? 0 : -2;
+}
+#endif
 template <int TILE_PX, int NB>
 __global__ void __launch_bounds__(64) ws_flood_batch_kernel(const int* __restrict__ d2all, const int* __restrict__ Lall,
                                                             const int* __restrict__ Tall, int* __restrict__ outall,
@@ -529,7 +539,6 @@ __global__ void __launch_bounds__(64) ws_flood_batch_kernel(const int* __restric
     const int* mylist = wl + (size_t)plane * row_stride;
     const int nwork = wl_count[plane];
     const int lane = threadIdx.x;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     auto uni = [&](unsigned v) -> unsigned { return __builtin_amdgcn_readfirstlane(v); };
     while (true) {
         int kk = 0;
@@ -541,6 +550,9 @@ __global__ void __launch_bounds__(64) ws_flood_batch_kernel(const int* __restric
         const int tw = cr.x1 - cr.x0 + 3, th = cr.y1 - cr.y0 + 3;  // padded tile
         const int npx = tw * th;
         const int nb = cr.cmax + 1;
+#ifdef WS_STATS
+        if (lane == 0) { atomicAdd(&ws_dbg[3], 1ull); atomicAdd(&ws_dbg[4], (unsigned long long)npx); atomicAdd(&ws_dbg[5], (unsigned long long)nb); }
+#endif
         const unsigned inv_tw = 0xFFFFFFFFu / (unsigned)tw + 1u;  // i / tw == (i * inv_tw) >> 32 for i < 65536
         for (int i = lane; i < nb; i += 64) cnt[i] = 0;
         __builtin_amdgcn_s_waitcnt(0);
@@ -659,27 +671,45 @@ __global__ void __launch_bounds__(64) ws_flood_batch_kernel(const int* __restric
                 if (wE) cell[qE] = (cE & 0xFFFF0000u) | lab;
                 if (wS) cell[qS] = (cS & 0xFFFF0000u) | lab;
             }
-            // append the winners, one destination bucket at a time, in (lane, N-W-E-S) order
+            // append the winners, one destination bucket at a time, in (lane, N-W-E-S) order.  Every bucket is handled
+            // once per step, so its cursor word is fetched for all claims up front (one LDS round trip, not one per
+            // bucket).  (Measured alternative: reserving slots with returning LDS atomics and ranking the tickets of a
+            // run afterwards was 3x slower -- the claims of a step go to FEW buckets, iso-distance contours, with many
+            // claims each.)
             unsigned long long pend = __ballot(wN || wW || wE || wS);
+            unsigned hN = 0, hW = 0, hE = 0, hS = 0;
+            if (pend) {
+                hN = wN ? cnt[dN] : 0u;
+                hW = wW ? cnt[dW] : 0u;
+                hE = wE ? cnt[dE] : 0u;
+                hS = wS ? cnt[dS] : 0u;
+            }
+            const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#ifdef WS_STATS
+            if (lane == 0 && !marker_push) { atomicAdd(&ws_dbg[0], 1ull); atomicAdd(&ws_dbg[1], (unsigned long long)took); }
+#endif
             while (pend) {
+#ifdef WS_STATS
+                if (lane == 0) atomicAdd(&ws_dbg[2], 1ull);
+#endif
                 const int l0 = __ffsll((long long)pend) - 1;
                 const int sel = wN ? dN : wW ? dW : wE ? dE : dS;  // this lane's first pending destination
+                const unsigned selh = wN ? hN : wW ? hW : wE ? hE : hS;
                 const int bsel = __builtin_amdgcn_readlane(sel, l0);
+                const unsigned ht = (unsigned)__builtin_amdgcn_readlane((int)selh, l0);
                 const bool mN = wN && dN == bsel, mW = wW && dW == bsel, mE = wE && dE == bsel, mS = wS && dS == bsel;
                 const unsigned long long sN = __ballot(mN), sW = __ballot(mW), sE = __ballot(mE), sS = __ballot(mS);
                 const int before = __popcll(sN & lt_mask) + __popcll(sW & lt_mask) + __popcll(sE & lt_mask) +
                                    __popcll(sS & lt_mask);
                 const int total = __popcll(sN) + __popcll(sW) + __popcll(sE) + __popcll(sS);
-                const unsigned ht = uni(cnt[bsel]);
                 const int base = (int)(ht >> 16);
-                if (marker_push && (ht >> 16) != (unsigned)offs[bsel] + 0u && lane == 0) ties[plane] = 1;
-                if (marker_push && total > 1 && lane == 0) ties[plane] = 1;
+                if (marker_push && ((ht >> 16) != (ht & 0xFFFFu) || total > 1) && lane == 0) ties[plane] = 1;
                 int r = base + before;
                 if (mN) queue[r++] = (unsigned short)qN;
                 if (mW) queue[r++] = (unsigned short)qW;
                 if (mE) queue[r++] = (unsigned short)qE;
                 if (mS) queue[r++] = (unsigned short)qS;
-                if (lane == 0) cnt[bsel] = (ht & 0xFFFFu) | ((unsigned)(base + total) << 16);
+                if (lane == l0) cnt[bsel] = (ht & 0xFFFFu) | ((unsigned)(base + total) << 16);
                 raise = bsel > raise ? bsel : raise;
                 wN = wN && !mN;
                 wW = wW && !mW;
