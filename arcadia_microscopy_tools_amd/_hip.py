@@ -102,6 +102,7 @@ _SIGS = {
     "amt_peak_mask": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int]),
     "amt_watershed_edt": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int]),
     "amt_watershed_f64": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int]),
+    "amt_watershed_edt_cleared": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "amt_watershed_edt_ex": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "amt_watershed_f64_ex": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "amt_regionprops": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int]),

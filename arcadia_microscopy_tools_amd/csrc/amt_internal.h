@@ -94,6 +94,10 @@ int amt_i_propagate_roots(amt_ctx* ctx, int* A, const int* L, const int* rootlis
 int amt_i_rank_blocks(size_t n);
 int amt_i_rank_roots(amt_ctx* ctx, const int* L, int* T, int* blk, int* count_dev, int nplanes, size_t n);
 
+// label map halves (amt_label.hip): see amt_i_presence_fill
+int amt_i_presence_fill(amt_ctx* ctx, int* P, const int* nlabels_dev, int max_label, int nplanes);
+int amt_i_drop_and_scan(amt_ctx* ctx, int* P, int max_label, int* count_dev, int nplanes);
+
 // Value of the neighbouring lane by DPP wave shift (a VALU move, no LDS crossbar as ds_bpermute needs): lane 0 of
 // amt_lane_left / lane 63 of amt_lane_right receive 0, every caller masks those lanes itself.  All 64 lanes must be
 // active (call from wave-uniform control flow only).

@@ -790,6 +790,24 @@ __global__ void __launch_bounds__(256) presence_fill_kernel(int* __restrict__ pr
     for (int l = blockIdx.x * 256 + threadIdx.x; l <= max_label; l += gridDim.x * 256) P[l] = (l >= 1 && l <= k) ? 1 : 0;
 }
 
+// the two halves of the label map for callers that find the frame-touching labels themselves (amt_watershed.hip's fused
+// watershed + clear_border + relabel): P = nplanes x (max_label + 1) ints; fill -> caller sets P[l] = 2 for every label
+// to drop -> drop_and_scan leaves P[l] = new label (0 = dropped) and the number of survivors in count_dev
+int amt_i_presence_fill(amt_ctx* ctx, int* P, const int* nlabels_dev, int max_label, int nplanes) {
+    hipLaunchKernelGGL(presence_fill_kernel, dim3(amt_grid_for((size_t)max_label + 1, 256, 64), nplanes), dim3(256), 0,
+                       ctx->stream, P, nlabels_dev, max_label);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+int amt_i_drop_and_scan(amt_ctx* ctx, int* P, int max_label, int* count_dev, int nplanes) {
+    hipLaunchKernelGGL(drop_flagged_kernel, dim3(amt_grid_for((size_t)max_label + 1, 256, 64), nplanes), dim3(256), 0,
+                       ctx->stream, P, max_label);
+    AMT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(presence_scan_kernel, dim3(nplanes), dim3(1024), 0, ctx->stream, P, max_label, count_dev);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+
 extern "C" int amt_clear_border_relabel(amt_ctx* ctx, const int32_t* in, int32_t* out, int32_t* count_dev, int nplanes,
                                         int H, int W, int max_label, const int32_t* nlabels_dev) {
     AMT_TRY(amt_set_device(ctx));

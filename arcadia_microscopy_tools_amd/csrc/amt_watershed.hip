@@ -54,8 +54,12 @@ struct comp_row {
 
 // out = label of the component for single-label components, markers * mask elsewhere.
 // F[root] = that label (0 for components that need a flood), written by ws_classify_kernel.
+// only_planes (nullable): planes whose flag is 0 are skipped (the fused path seeds only planes that hold a component for
+// the HBM flood, which works in `out` itself).
 __global__ void __launch_bounds__(256) ws_seed_kernel(const int* __restrict__ markers, const int* __restrict__ L,
-                                                      const int* __restrict__ F, int* __restrict__ out, size_t n) {
+                                                      const int* __restrict__ F, int* __restrict__ out, size_t n,
+                                                      const int* __restrict__ only_planes) {
+    if (only_planes && !only_planes[blockIdx.y]) return;
     const size_t base = (size_t)blockIdx.y * n;
     for (size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i0 < n; i0 += (size_t)gridDim.x * 1024) {
         if (i0 + 3 < n && ((base + i0) & 3) == 0) {
@@ -66,10 +70,10 @@ __global__ void __launch_bounds__(256) ws_seed_kernel(const int* __restrict__ ma
                 // pixel -> tile root, whose F entry was copied from the component root (amt_i_propagate_roots)
                 const int fx = r.x >= 0 ? F[base + r.x] : 0, fy = r.y >= 0 ? F[base + r.y] : 0;
                 const int fz = r.z >= 0 ? F[base + r.z] : 0, fw = r.w >= 0 ? F[base + r.w] : 0;
-                v.x = r.x >= 0 ? (fx ? fx : m.x) : 0;
-                v.y = r.y >= 0 ? (fy ? fy : m.y) : 0;
-                v.z = r.z >= 0 ? (fz ? fz : m.z) : 0;
-                v.w = r.w >= 0 ? (fw ? fw : m.w) : 0;
+                v.x = r.x >= 0 ? (fx > 0 ? fx : fx == 0 ? m.x : 0) : 0;
+                v.y = r.y >= 0 ? (fy > 0 ? fy : fy == 0 ? m.y : 0) : 0;
+                v.z = r.z >= 0 ? (fz > 0 ? fz : fz == 0 ? m.z : 0) : 0;
+                v.w = r.w >= 0 ? (fw > 0 ? fw : fw == 0 ? m.w : 0) : 0;
             }
             *reinterpret_cast<int4*>(out + base + i0) = v;
         } else {
@@ -78,7 +82,7 @@ __global__ void __launch_bounds__(256) ws_seed_kernel(const int* __restrict__ ma
                 int v = 0;
                 if (r >= 0) {
                     const int f = F[base + r];
-                    v = f ? f : markers[base + i];
+                    v = f > 0 ? f : (f == 0 ? markers[base + i] : 0);
                 }
                 out[base + i] = v;
             }
@@ -244,7 +248,9 @@ __global__ void __launch_bounds__(256) ws_classify_kernel(comp_row* __restrict__
             else cls = CLS_G;
         }
         r[i].cls = cls;
-        Fall[(size_t)blockIdx.y * n + c.root] = cls == CLS_UNIFORM ? c.labmin : 0;
+        // per-root fill value: the label of a single-label component, 0 = flooded (labels come from the flood),
+        // -1 = no marker at all (stays background)
+        Fall[(size_t)blockIdx.y * n + c.root] = cls == CLS_UNIFORM ? c.labmin : (cls == CLS_NONE ? -1 : 0);
         if (cls == CLS_G) has_g[blockIdx.y] = 1;
         if (cls == CLS_S || cls == CLS_M || cls == CLS_L || cls == CLS_X) {
             // per-class worklist of this plane (order is irrelevant: components are independent)
@@ -319,7 +325,8 @@ __global__ void __launch_bounds__(64) ws_flood_lds_kernel(const int* __restrict_
                                                           const comp_row* __restrict__ rows,
                                                           const int* __restrict__ wl, const int* __restrict__ wl_count,
                                                           int* __restrict__ counters, size_t row_stride, int H, int W,
-                                                          int seeds_first, int* __restrict__ ties) {
+                                                          int seeds_first, int* __restrict__ ties,
+                                                          const int* __restrict__ mkall) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     unsigned* cell = reinterpret_cast<unsigned*>(smem_raw);
     unsigned* ht = cell + TILE_PX;
@@ -330,6 +337,7 @@ __global__ void __launch_bounds__(64) ws_flood_lds_kernel(const int* __restrict_
     const int* L = Lall + (size_t)plane * n;
     const int* T = Tall + (size_t)plane * n;
     int* out = outall + (size_t)plane * n;
+    const int* mk = mkall + (size_t)plane * n;  // marker labels (the membership test keeps them inside the mask)
     const comp_row* rr = rows + (size_t)plane * row_stride;
     const int* mylist = wl + (size_t)plane * row_stride;
     const int nwork = wl_count[plane];
@@ -359,7 +367,7 @@ __global__ void __launch_bounds__(64) ws_flood_lds_kernel(const int* __restrict_
                 if (i < npx && ty >= 1 && ty < th - 1 && tx >= 1 && tx < tw - 1) {
                     const size_t g = (size_t)(cr.y0 + ty - 1) * W + (cr.x0 + tx - 1);
                     rr4[u] = L[g];
-                    o4[u] = out[g];
+                    o4[u] = mk[g];
                     d4[u] = d2[g];
                 }
             }
@@ -523,7 +531,8 @@ __global__ void __launch_bounds__(64) ws_flood_batch_kernel(const int* __restric
                                                             const comp_row* __restrict__ rows,
                                                             const int* __restrict__ wl, const int* __restrict__ wl_count,
                                                             int* __restrict__ counters, size_t row_stride, int H, int W,
-                                                            int seeds_first, int* __restrict__ ties) {
+                                                            int seeds_first, int* __restrict__ ties,
+                                                            const int* __restrict__ mkall) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     unsigned* cell = reinterpret_cast<unsigned*>(smem_raw);
     unsigned* cnt = cell + TILE_PX;                                       // NB words: histogram, then {hd | tl << 16}
@@ -535,6 +544,7 @@ __global__ void __launch_bounds__(64) ws_flood_batch_kernel(const int* __restric
     const int* L = Lall + (size_t)plane * n;
     const int* T = Tall + (size_t)plane * n;
     int* out = outall + (size_t)plane * n;
+    const int* mk = mkall + (size_t)plane * n;  // marker labels (the membership test keeps them inside the mask)
     const comp_row* rr = rows + (size_t)plane * row_stride;
     const int* mylist = wl + (size_t)plane * row_stride;
     const int nwork = wl_count[plane];
@@ -570,7 +580,7 @@ __global__ void __launch_bounds__(64) ws_flood_batch_kernel(const int* __restric
                 if (i < npx && ty >= 1 && ty < th - 1 && tx >= 1 && tx < tw - 1) {
                     const size_t g = (size_t)(cr.y0 + ty - 1) * W + (cr.x0 + tx - 1);
                     rr4[u] = L[g];
-                    o4[u] = out[g];
+                    o4[u] = mk[g];
                     d4[u] = d2[g];
                 }
             }
@@ -1100,9 +1110,85 @@ __global__ void ws_set_flags_kernel(int* f, int n, int v) {
     if (i < n) f[i] = v;
 }
 
+// ---- fused tail: clear_border + relabel_sequential on the flood's result (R/masks.py:56,65) ---------------------
+// A watershed label is ONE 4-connected region, so it is removed iff one of its pixels lies on the frame.  The label of
+// a pixel: F of its tile root (> 0: the single label of its component; 0: flooded -> the flood wrote it into ws;
+// < 0: component without markers).  P[l] = 2 marks frame-touching labels.
+__device__ __forceinline__ int ws_pixel_label(int r, const int* __restrict__ F, const int* __restrict__ ws, size_t base,
+                                              size_t i) {
+    if (r < 0) return 0;
+    const int f = F[base + r];
+    return f > 0 ? f : (f == 0 ? ws[base + i] : 0);
+}
+
+__global__ void __launch_bounds__(256) ws_frame_mark_kernel(const int* __restrict__ L, const int* __restrict__ F,
+                                                            const int* __restrict__ ws, int* __restrict__ present, int H,
+                                                            int W, int max_label) {
+    const size_t n = (size_t)H * W;
+    const size_t base = (size_t)blockIdx.y * n;
+    int* P = present + (size_t)blockIdx.y * (max_label + 1);
+    const int perim = 2 * W + 2 * H;
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < perim; k += gridDim.x * 256) {
+        int y, x;
+        if (k < W) {
+            y = 0;
+            x = k;
+        } else if (k < 2 * W) {
+            y = H - 1;
+            x = k - W;
+        } else if (k < 2 * W + H) {
+            y = k - 2 * W;
+            x = 0;
+        } else {
+            y = k - 2 * W - H;
+            x = W - 1;
+        }
+        const size_t i = (size_t)y * W + x;
+        const int v = ws_pixel_label(L[base + i], F, ws, base, i);
+        if (v > 0 && v <= max_label) P[v] = 2;
+    }
+}
+
+// labels_out = map[label of the pixel]: the ONE full-plane pass of the fused path (16-byte loads of the parent plane,
+// 16-byte stores); the flood's plane is read only at pixels of flooded components
+__global__ void __launch_bounds__(256) ws_final_kernel(const int* __restrict__ L, const int* __restrict__ F,
+                                                       const int* __restrict__ ws, const int* __restrict__ map,
+                                                       int* __restrict__ out, size_t n, int max_label) {
+    const size_t base = (size_t)blockIdx.y * n;
+    const int* M = map + (size_t)blockIdx.y * (max_label + 1);
+    const unsigned ml = (unsigned)max_label;
+    for (size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i0 < n; i0 += (size_t)gridDim.x * 1024) {
+        if (i0 + 3 < n && ((base + i0) & 3) == 0) {
+            const int4 r = *reinterpret_cast<const int4*>(L + base + i0);
+            int4 o = make_int4(0, 0, 0, 0);
+            if (r.x >= 0 || r.y >= 0 || r.z >= 0 || r.w >= 0) {
+                const int fx = r.x >= 0 ? F[base + r.x] : -1, fy = r.y >= 0 ? F[base + r.y] : -1;
+                const int fz = r.z >= 0 ? F[base + r.z] : -1, fw = r.w >= 0 ? F[base + r.w] : -1;
+                int4 w = make_int4(0, 0, 0, 0);
+                if (fx == 0 || fy == 0 || fz == 0 || fw == 0) w = *reinterpret_cast<const int4*>(ws + base + i0);
+                const int vx = fx > 0 ? fx : (fx == 0 ? w.x : 0), vy = fy > 0 ? fy : (fy == 0 ? w.y : 0);
+                const int vz = fz > 0 ? fz : (fz == 0 ? w.z : 0), vw = fw > 0 ? fw : (fw == 0 ? w.w : 0);
+                o.x = (unsigned)(vx - 1) < ml ? M[vx] : 0;
+                o.y = (unsigned)(vy - 1) < ml ? M[vy] : 0;
+                o.z = (unsigned)(vz - 1) < ml ? M[vz] : 0;
+                o.w = (unsigned)(vw - 1) < ml ? M[vw] : 0;
+            }
+            *reinterpret_cast<int4*>(out + base + i0) = o;
+        } else {
+            for (size_t i = i0; i < n && i < i0 + 4; ++i) {
+                const int v = ws_pixel_label(L[base + i], F, ws, base, i);
+                out[base + i] = (unsigned)(v - 1) < ml ? M[v] : 0;
+            }
+        }
+    }
+}
+
 static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const int32_t* markers,
                             const uint8_t* mask, int32_t* out, int nplanes, int H, int W, int seeds_first,
-                            int connectivity, int tie_policy, int32_t* ties_dev) {
+                            int connectivity, int tie_policy, int32_t* ties_dev, int32_t* fused_labels = nullptr,
+                            int32_t* fused_count = nullptr, const int32_t* nlabels_dev = nullptr, int max_label = 0) {
+    // fused_labels != nullptr: `out` is only the flood's scratch plane; the result is clear_border + relabel_sequential
+    // of the watershed, written to fused_labels / fused_count (connectivity 1 only)
     AMT_TRY(amt_set_device(ctx));
     AMT_REQUIRE(relief && markers && mask && out && nplanes >= 0 && H > 0 && W > 0, "watershed: bad arguments");
     AMT_REQUIRE((size_t)H * W < 0x3fffffffull, "watershed: plane too large");
@@ -1154,6 +1240,8 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     // the sequential emulation's heap (every pixel is pushed at most once): the float64 path reuses its per-component
     // heap space, the bucket path needs it extra -- and only when ties are to be resolved exactly
     if (exact && use_d2) need += amt_align(np * sizeof(hp_elem));
+    const size_t msz = (size_t)nplanes * ((size_t)max_label + 1);
+    if (fused_labels) need += amt_align(msz * 4);
     AMT_TRY(amt_arena_begin(ctx, need));
     int* L = arena_take_t<int>(ctx, np);
     int* T = arena_take_t<int>(ctx, np);
@@ -1173,6 +1261,7 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     int* counters = arena_take_t<int>(ctx, (size_t)nplanes * 12);
     int* wl = arena_take_t<int>(ctx, 4 * nr);  // worklists of the four LDS classes
     int* ties = ties_dev ? ties_dev : arena_take_t<int>(ctx, nplanes);
+    int* P = fused_labels ? arena_take_t<int>(ctx, msz) : nullptr;
     int *head = nullptr, *tail = nullptr;
     hp_elem* heap = nullptr;
     hp_elem* gheap = nullptr;
@@ -1212,8 +1301,11 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     AMT_LAUNCH_CHECK();
     AMT_TRY(amt_i_propagate_roots(ctx, F, L, rootlist, nroots, nplanes, H, W));
     dim3 g1(amt_grid_for(n, 256, 4096), nplanes);
+    // the seed pass gives `out` its final value everywhere except in flooded components.  The fused path needs no
+    // such plane (its final pass derives every pixel from F and the flood's sparse writes): it seeds only planes that
+    // hold a component for the HBM flood, which works in `out` itself
     hipLaunchKernelGGL(ws_seed_kernel, dim3(amt_grid_for(n, 1024, 4096), nplanes), dim3(256), 0, ctx->stream, markers, L, F,
-                       out, n);
+                       out, n, fused_labels ? (const int*)(counters + 4 * nplanes) : (const int*)nullptr);
     AMT_LAUNCH_CHECK();
     // ---- HBM-path bookkeeping (usually empty: only components too large for an LDS tile) ----
     AMT_TRY(amt_scan_excl_dev(ctx, moff, ncomp, row_stride, mtot, nplanes));
@@ -1235,19 +1327,19 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
         AMT_TRY(amt_fork(ctx));
         hipLaunchKernelGGL((ws_flood_batch_kernel<L_PX, L_NB>), dim3(16, nplanes), dim3(64), ldsL, ctx->stream,
                            (const int*)relief, L, T, out, rows, wl + 2 * (size_t)nplanes * row_stride,
-                           wl_count + 2 * nplanes, counters + 0 * nplanes, row_stride, H, W, seeds_first, ties);
+                           wl_count + 2 * nplanes, counters + 0 * nplanes, row_stride, H, W, seeds_first, ties, markers);
         AMT_LAUNCH_CHECK();
         hipLaunchKernelGGL((ws_flood_lds_kernel<X_PX, X_NB, CLS_X>), dim3(8, nplanes), dim3(64), ldsX, ctx->stream,
                            (const int*)relief, L, T, out, rows, wl + 3 * (size_t)nplanes * row_stride,
-                           wl_count + 3 * nplanes, counters + 9 * nplanes, row_stride, H, W, seeds_first, ties);
+                           wl_count + 3 * nplanes, counters + 9 * nplanes, row_stride, H, W, seeds_first, ties, markers);
         AMT_LAUNCH_CHECK();
         hipLaunchKernelGGL((ws_flood_batch_kernel<M_PX, M_NB>), dim3(64, nplanes), dim3(64), ldsM, ctx->aux[0],
                            (const int*)relief, L, T, out, rows, wl + 1 * (size_t)nplanes * row_stride,
-                           wl_count + 1 * nplanes, counters + 1 * nplanes, row_stride, H, W, seeds_first, ties);
+                           wl_count + 1 * nplanes, counters + 1 * nplanes, row_stride, H, W, seeds_first, ties, markers);
         AMT_LAUNCH_CHECK();
         hipLaunchKernelGGL((ws_flood_batch_kernel<S_PX, S_NB>), dim3(128, nplanes), dim3(64), ldsS, ctx->aux[1],
                            (const int*)relief, L, T, out, rows, wl + 0 * (size_t)nplanes * row_stride,
-                           wl_count + 0 * nplanes, counters + 2 * nplanes, row_stride, H, W, seeds_first, ties);
+                           wl_count + 0 * nplanes, counters + 2 * nplanes, row_stride, H, W, seeds_first, ties, markers);
         AMT_LAUNCH_CHECK();
         hipLaunchKernelGGL(ws_flood_edt_kernel, dim3(4, nplanes), dim3(64), 0, ctx->aux[1], (const int*)relief, mask, out,
                            next, head, tail, mlist, rows, moff, boff, ncomp, counters + 3 * nplanes, row_stride, H, W, n,
@@ -1273,7 +1365,27 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
                                (const int*)ties, H, W, n, 1);
         AMT_LAUNCH_CHECK();
     }
+    if (fused_labels) {
+        AMT_TRY(amt_i_presence_fill(ctx, P, nlabels_dev, max_label, nplanes));
+        hipLaunchKernelGGL(ws_frame_mark_kernel, dim3(amt_grid_for((size_t)2 * W + 2 * H, 256, 64), nplanes), dim3(256), 0,
+                           ctx->stream, L, F, out, P, H, W, max_label);
+        AMT_LAUNCH_CHECK();
+        AMT_TRY(amt_i_drop_and_scan(ctx, P, max_label, fused_count, nplanes));
+        hipLaunchKernelGGL(ws_final_kernel, dim3(amt_grid_for(n, 1024, 4096), nplanes), dim3(256), 0, ctx->stream, L, F, out,
+                           P, fused_labels, n, max_label);
+        AMT_LAUNCH_CHECK();
+    }
     return AMT_OK;
+}
+
+extern "C" int amt_watershed_edt_cleared(amt_ctx* ctx, const int32_t* d2, const int32_t* markers, const uint8_t* mask,
+                                         int32_t* ws_scratch, int32_t* labels_out, int32_t* count_dev, int nplanes,
+                                         int H, int W, int max_label, const int32_t* nlabels_dev) {
+    AMT_REQUIRE(ws_scratch && labels_out && count_dev && nlabels_dev && max_label >= 0,
+                "watershed_edt_cleared: bad arguments");
+    AMT_REQUIRE(ws_scratch != labels_out, "watershed_edt_cleared: scratch and output must not alias");
+    return watershed_common(ctx, d2, true, markers, mask, ws_scratch, nplanes, H, W, 1, 1, AMT_WS_TIES_EXACT, nullptr,
+                            labels_out, count_dev, nlabels_dev, max_label);
 }
 
 extern "C" int amt_watershed_edt_ex(amt_ctx* ctx, const int32_t* d2, const int32_t* markers, const uint8_t* mask,

@@ -590,6 +590,23 @@ def watershed_edt(d2: DeviceArray, markers: DeviceArray, mask: DeviceArray, seed
     return o
 
 
+def watershed_edt_cleared(d2: DeviceArray, markers: DeviceArray, mask: DeviceArray, nlabels: DeviceArray,
+                          max_label: int, scratch: DeviceArray, out=None, count=None):
+    """``relabel_sequential(clear_border(watershed(seeded relief, markers, mask=mask)))`` in one call (the tail of
+    config 3; R/masks.py:56,65): identical to ``watershed_edt(seeds_first=True)`` + ``clear_border_relabel`` but the
+    watershed image is never written out.  ``markers`` are numbered 1..nlabels[plane]; ``scratch`` is an int32 plane
+    batch the flood may use.  Returns (int32 labels, counts)."""
+    ctx = d2.ctx
+    n, H, W = _planes(d2)
+    o = _out(ctx, out, d2.shape, np.int32)
+    c = _out(ctx, count, (n,), np.int32)
+    if scratch.dtype != np.int32 or scratch.size != d2.size or scratch.ctx is not ctx:
+        raise ValueError("scratch must be an int32 array of the batch's size on the same context")
+    _hip.check(_lib().amt_watershed_edt_cleared(ctx.handle, d2.ptr, markers.ptr, mask.ptr, scratch.ptr, o.ptr, c.ptr, n, H,
+                                                W, int(max_label), nlabels.ptr), "amt_watershed_edt_cleared")
+    return o, c
+
+
 def watershed(relief: DeviceArray, markers: DeviceArray, mask: DeviceArray, out=None, connectivity: int = 1,
               ties: str = "exact", ties_out: DeviceArray | None = None):
     """``skimage.segmentation.watershed(relief, markers, connectivity, mask=mask)`` for float64 relief

@@ -46,11 +46,14 @@ class FovSegmenter:
 
     def __init__(self, batch: int, C: int, H: int, W: int, *, sigma: float = 2.0, radius: int = 2,
                  min_distance: int = 5, max_cells: int = 4096, dapi_index: int = 1, ctx: Context | None = None,
-                 props: bool = True, profile: bool = False):
+                 props: bool = True, profile: bool = False, fused: bool = True):
         self.ctx = ctx or get_context()
         self.B, self.C, self.H, self.W = int(batch), int(C), int(H), int(W)
         self.sigma, self.radius, self.min_distance = float(sigma), int(radius), int(min_distance)
         self.max_cells, self.dapi_index, self.props = int(max_cells), int(dapi_index), bool(props)
+        # fused = watershed + clear_border + relabel in one C-ABI call (self.ws is then only flood scratch: use
+        # fused=False to inspect the watershed image itself)
+        self.fused = bool(fused)
         self.footprint = hipops.disk(self.radius)
         c, B = self.ctx, self.B
         shp = (B, self.H, self.W)
@@ -127,14 +130,21 @@ class FovSegmenter:
         hipops.peak_mask(self.d2, mask, self.min_distance, out=self.peaks)
         self._stage("markers")
         hipops.label_sparse(self.peaks, 1, out=self.markers, count=self.nmarkers)  # peaks are a few thousand px
-        self._stage("watershed")
-        hipops.watershed_edt(self.d2, self.markers, mask, seeds_first=True, out=self.ws)
-        # every watershed label is one 4-connected region grown from one marker component, so
-        # clear_border + relabel_sequential (R/masks.py:56,65) collapse into one flag-and-renumber pass; the
-        # markers lie inside the mask, so exactly the labels 1..nmarkers occur in the result
-        self._stage("clear_border")
-        hipops.clear_border_relabel(self.ws, self.max_cells, out=self.labels, count=self.ncells,
-                                    nlabels=self.nmarkers)
+        if self.fused:
+            # watershed + clear_border + relabel_sequential in one call: the watershed image is never written out
+            # (self.ws only receives the pixels of flooded components)
+            self._stage("watershed_clear_relabel")
+            hipops.watershed_edt_cleared(self.d2, self.markers, mask, self.nmarkers, self.max_cells, scratch=self.ws,
+                                         out=self.labels, count=self.ncells)
+        else:
+            self._stage("watershed")
+            hipops.watershed_edt(self.d2, self.markers, mask, seeds_first=True, out=self.ws)
+            # every watershed label is one 4-connected region grown from one marker component, so
+            # clear_border + relabel_sequential (R/masks.py:56,65) collapse into one flag-and-renumber pass; the
+            # markers lie inside the mask, so exactly the labels 1..nmarkers occur in the result
+            self._stage("clear_border")
+            hipops.clear_border_relabel(self.ws, self.max_cells, out=self.labels, count=self.ncells,
+                                        nlabels=self.nmarkers)
         if self.props:
             self._stage("regionprops")
             hipops.regionprops_full(self.labels, fovs, self.max_cells, out=self.table, iout=self.itable)

@@ -48,6 +48,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (G/MI355X_MICROARCH.md: 8.0 TB/s
 STAGE_BYTES_PER_PX = {
     "gaussian": 10, "otsu": 8, "threshold": 9, "opening": 4, "closing": 4, "threshold_open_close": 17, "label8": 5,
     "edt": 9, "peaks": 17, "markers": 5, "watershed": 17, "clear_border": 8, "relabel": 4, "regionprops": 16,
+    "watershed_clear_relabel": 25,  # watershed 17 + clear_border / relabel 8, one C-ABI call
     "intensity": 12,
     # reference-level preprocessing (R/operations.py) and the north_star's other filters, per SURVEY.md 8(d)
     "dog": 10, "percentile_f64": 8, "sub_clip": 16, "rescale": 16,
@@ -63,6 +64,7 @@ STAGE_KERNELS = {
     "peaks": ("peaks_",),
     "markers": ("sp_",),
     "watershed": ("ccl_", "ws_", "roots_"),
+    "watershed_clear_relabel": ("ccl_", "ws_", "roots_", "presence_", "drop_flagged_kernel"),
     "label8": ("ccl_", "roots_", "apply_rank_kernel"),
     "clear_border": ("presence_", "frame_mark_kernel", "drop_flagged_kernel", "map_labels_kernel"),
     "regionprops": ("rp_",),
@@ -563,7 +565,7 @@ def main():
                 window = ctx.asarray(fovs[idx])
             prof.run_c3(window)
             ctx.synchronize()
-            ws_ms.append(prof.times.ms()["watershed"])
+            ws_ms.append(prof.times.ms()["watershed_clear_relabel"])
         ws = np.sort(np.array(ws_ms))
         tail = {"launch_fovs": PB, "distinct_fovs": nuniq, "reps": len(ws_ms), "p50_ms": float(np.percentile(ws, 50)),
                 "p99_ms": float(np.percentile(ws, 99)), "min_ms": float(ws[0]), "max_ms": float(ws[-1])}

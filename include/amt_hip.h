@@ -258,6 +258,14 @@ int amt_watershed_edt_ex(amt_ctx* ctx, const int32_t* d2, const int32_t* markers
                          int nplanes, int H, int W, int seeds_first, int connectivity, int tie_policy, int32_t* ties_dev);
 int amt_watershed_f64_ex(amt_ctx* ctx, const double* relief, const int32_t* markers, const uint8_t* mask, int32_t* out,
                          int nplanes, int H, int W, int connectivity, int tie_policy, int32_t* ties_dev);
+/* The config-3 tail in one call: amt_watershed_edt(seeds_first = 1) followed by amt_clear_border_relabel
+ * (R/masks.py:56 + :65 on the watershed of a mask from markers numbered 1..nlabels_dev[plane]; labels that touch the
+ * frame are dropped, the rest renumbered 1..count_dev[plane] in ascending order).  Same labels as the two calls, one
+ * full-plane write less: the watershed image itself is never materialised -- ws_scratch (nplanes x H x W ints) only
+ * receives the pixels of flooded components. */
+int amt_watershed_edt_cleared(amt_ctx* ctx, const int32_t* d2, const int32_t* markers, const uint8_t* mask,
+                              int32_t* ws_scratch, int32_t* labels_out, int32_t* count_dev, int nplanes, int H, int W,
+                              int max_label, const int32_t* nlabels_dev);
 
 /* ---- region properties: R/masks.py:286-326 (regionprops_table) ------------------------------- */
 /* Morphology columns per label 1..max_label (row = label-1), float64, column order: */

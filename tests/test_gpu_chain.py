@@ -41,8 +41,12 @@ def test_c2_c3_golden_256(ctx, golden):
     assert np.array_equal(lab8, g["labels8"])
     assert np.array_equal(seg.mask_a.numpy()[0], g["mask"])
     labels = seg.run_c3(d).numpy()[0]
-    assert np.array_equal(seg.ws.numpy()[0], g["watershed"])
     assert np.array_equal(labels, g["labels"])
+    # the same chain with the watershed image materialised (separate watershed / clear_border + relabel calls)
+    seg2 = FovSegmenter(1, 4, 256, 256, ctx=ctx, max_cells=64, fused=False)
+    labels2 = seg2.run_c3(d).numpy()[0]
+    assert np.array_equal(seg2.ws.numpy()[0], g["watershed"])
+    assert np.array_equal(labels2, g["labels"]) and np.array_equal(seg2.ncells.numpy(), seg.ncells.numpy())
     res = seg.result()
     from oracle import chains
 
@@ -198,3 +202,27 @@ def test_c3_small_and_non_tile_sizes(ctx):
         assert np.array_equal(res.labels_numpy()[0], ref_labels), (h, w)
         if ref_labels.max() > 0:
             _check_props(res.feature_tables()[0], ref_props)
+
+
+def test_fused_watershed_tail_equals_separate_calls(ctx):
+    """amt_watershed_edt_cleared (watershed + clear_border + relabel in one call, no watershed image) against the three
+    separate calls and the oracle, on windows cut out of larger fields of view so that nuclei DO touch the frame (the
+    synthetic generator keeps them away from it), plus a plane without any marker, at odd sizes."""
+    from arcadia_microscopy_tools_amd import synth
+    from arcadia_microscopy_tools_amd.segment import FovSegmenter
+    from oracle import chains
+
+    for size in (200, 333):
+        big = np.stack([synth.synth_fov(40 + i, size=size + 60) for i in range(3)])
+        fovs = np.ascontiguousarray(big[:, :, 25:25 + size, 31:31 + size])
+        fovs[2, 1] = 300  # constant DAPI plane: no mask, no markers, no cells
+        d = ctx.asarray(fovs)
+        a = FovSegmenter(3, 4, size, size, ctx=ctx, max_cells=256, fused=True)
+        b = FovSegmenter(3, 4, size, size, ctx=ctx, max_cells=256, fused=False)
+        la, lb = a.run_c3(d).numpy(), b.run_c3(d).numpy()
+        assert np.array_equal(la, lb)
+        assert np.array_equal(a.ncells.numpy(), b.ncells.numpy()) and a.ncells.numpy()[2] == 0
+        for k in range(2):
+            assert int(b.ws.numpy()[k].max()) > int(lb[k].max()) > 0  # clear_border did drop frame-touching nuclei
+            assert np.array_equal(la[k].astype(np.int64), chains.c3_labels(fovs[k, 1])[0])
+        np.testing.assert_array_equal(a.table.numpy()[:, :8], b.table.numpy()[:, :8])

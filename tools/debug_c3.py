@@ -11,7 +11,7 @@ size = int(sys.argv[1]); idxs = [int(v) for v in sys.argv[2:]]
 ctx = get_context()
 for i in idxs:
     fov = synth.synth_fov(i, size=size)
-    seg = FovSegmenter(1, 4, size, size, ctx=ctx, max_cells=512)
+    seg = FovSegmenter(1, 4, size, size, ctx=ctx, max_cells=512, fused=False)
     lab = seg.run_c3(ctx.asarray(fov[None])).numpy()[0].astype(np.int64)
     ref, inter = chains.c3_labels(fov[1])
     res = {

@@ -19,7 +19,7 @@ bad = 0
 t0 = time.time()
 for r in range(rounds):
     ctx = Context(0)
-    seg = FovSegmenter(2, 4, 192, 192, ctx=ctx, max_cells=128)
+    seg = FovSegmenter(2, 4, 192, 192, ctx=ctx, max_cells=128, fused=False)
     feeder = FovFeeder(batches[0].shape) if use_feeder else None
     if feeder:
         feeder.host(0)[...] = batches[0]
