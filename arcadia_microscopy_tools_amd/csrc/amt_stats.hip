@@ -671,11 +671,13 @@ __global__ void __launch_bounds__(256) sel_count_kernel(const double* __restrict
                                                         const sel_state* __restrict__ st,
                                                         uint32_t* __restrict__ counts, int nslots, int pass, size_t n,
                                                         unsigned long long* __restrict__ cand,
-                                                        unsigned* __restrict__ ncand, size_t cap) {
+                                                        unsigned* __restrict__ ncand, size_t cap,
+                                                        const int* __restrict__ only_planes) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     uint32_t* lh = reinterpret_cast<uint32_t*>(smem_raw);  // nslots x 256
     unsigned long long* pre = reinterpret_cast<unsigned long long*>(lh + nslots * 256);
     const int plane = blockIdx.y;
+    if (only_planes && !only_planes[plane]) return;  // passes 4..7 exist only for planes whose lists overflowed
     for (int i = threadIdx.x; i < nslots * 256; i += 256) lh[i] = 0;
     if (threadIdx.x < nslots) pre[threadIdx.x] = st[plane * nslots + threadIdx.x].prefix;
     __syncthreads();
@@ -731,9 +733,23 @@ __global__ void __launch_bounds__(256) sel_count_kernel(const double* __restrict
                 rest &= ~s1;
                 if ((rest >> lane) & 1ull) atomicAdd(&lh[bin], 1u);
             }
-            if (cand && slot >= 0) {
-                const unsigned pos = atomicAdd(&ncand[plane * nslots + slot], 1u);
-                if (pos < cap) cand[((size_t)plane * nslots + slot) * cap + pos] = k;
+            if (cand) {
+                // one atomic per wave and slot (massive ties -- a clipped image is mostly zeros -- would otherwise
+                // hammer ONE counter with millions of atomics); a list that has already overflowed is abandoned: the
+                // counter only has to end above `cap`
+                for (int sl = 0; sl < nslots; ++sl) {
+                    const unsigned long long m = __ballot(slot == sl);
+                    if (!m) continue;
+                    unsigned* ctr = &ncand[plane * nslots + sl];
+                    unsigned base = 0;
+                    const int leader = __ffsll((long long)m) - 1;
+                    if (lane == leader) base = (*ctr > cap) ? (unsigned)cap + 1u : atomicAdd(ctr, (unsigned)__popcll(m));
+                    base = __shfl(base, leader);
+                    if (slot == sl) {
+                        const unsigned pos = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+                        if (pos < cap) cand[((size_t)plane * nslots + sl) * cap + pos] = k;
+                    }
+                }
             }
         }
     }
@@ -750,10 +766,12 @@ __global__ void __launch_bounds__(256) sel_count_kernel(const double* __restrict
 __global__ void __launch_bounds__(256) sel_list_passes_kernel(const double* __restrict__ in, sel_state* __restrict__ st,
                                                               int nslots, size_t n,
                                                               const unsigned long long* __restrict__ cand,
-                                                              const unsigned* __restrict__ ncand, size_t cap) {
+                                                              const unsigned* __restrict__ ncand, size_t cap,
+                                                              const int* __restrict__ overflow) {
     __shared__ uint32_t lh[256];
     __shared__ unsigned long long s_prefix, s_rank;
     const int s = blockIdx.x, plane = blockIdx.y;
+    if (overflow[plane]) return;  // resolved by the full passes 4..7 instead
     sel_state* sp = st + (size_t)plane * nslots;
     if (threadIdx.x == 0) {
         s_prefix = sp[s].prefix;
@@ -811,10 +829,15 @@ __global__ void __launch_bounds__(256) sel_list_passes_kernel(const double* __re
 // one thread per (plane, slot): pick the digit from the counts of this pass.  State is double-buffered (read
 // st_in, write st_out) because slots of one plane read each other's prefixes to find their shared counts.
 __global__ void sel_pick_kernel(const sel_state* __restrict__ st_in, sel_state* __restrict__ st_out,
-                                const uint32_t* __restrict__ counts, int nslots, int pass, int nplanes) {
+                                const uint32_t* __restrict__ counts, int nslots, int pass, int nplanes,
+                                const int* __restrict__ only_planes) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nplanes * nslots) return;
     int plane = i / nslots, s = i - plane * nslots;
+    if (only_planes && !only_planes[plane]) {  // the plane's state passes through unchanged
+        st_out[i] = st_in[i];
+        return;
+    }
     // find the first slot with the same prefix (that is where the counts were accumulated)
     int src = s;
     for (int s2 = 0; s2 < s; ++s2)
@@ -836,6 +859,17 @@ __global__ void sel_pick_kernel(const sel_state* __restrict__ st_in, sel_state* 
     st_out[i].rank = rank - run;
 }
 
+// overflow[plane] = 1 if one of the plane's candidate lists did not hold all the keys that share its 24-bit prefix
+// (massive ties or near-ties): that plane is resolved by four more FULL passes on the whole chip instead of the lists
+__global__ void sel_overflow_kernel(const unsigned* __restrict__ ncand, int* __restrict__ overflow, int nslots,
+                                    int nplanes, unsigned cap) {
+    const int plane = blockIdx.x * blockDim.x + threadIdx.x;
+    if (plane >= nplanes) return;
+    int o = 0;
+    for (int s = 0; s < nslots; ++s) o |= ncand[plane * nslots + s] > cap;
+    overflow[plane] = o;
+}
+
 __global__ void sel_finish_kernel(const sel_state* st, const rank_req* reqs, int nq, int nplanes, double* out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nplanes * nq) return;
@@ -844,6 +878,386 @@ __global__ void sel_finish_kernel(const sel_state* st, const rank_req* reqs, int
     double b = amt_key_f64(st[(size_t)plane * 2 * nq + 2 * qi + 1].prefix);
     out[i] = np_lerp(a, b, reqs[qi].t);
 }
+
+// ---- float64 percentiles in ONE full pass: sampled splitters, exact selection ------------------------------------
+// For planes of >= PQ_MIN_N samples.  (1) pq_sample: PQ_M keys from hashed positions of the plane, sorted in LDS; for
+// every requested percentile a BRACKET [a, b] of two sample keys around its expected position, wide enough (+-4 sigma
+// of the sample rank + 8) that the wanted order statistics lie inside it except once in ~10^4 brackets.  (2) pq_classify:
+// the one full read -- per bracket the exact counts of keys < a, == a, == b and the list of keys strictly between.
+// (3) pq_resolve: a rank inside the "== a" / "== b" classes is that key (massive ties -- a clipped image is mostly
+// zeros -- cost nothing); a rank inside the list is found by a radix select over the list (a few per cent of the plane,
+// by the same idea one level down: a sorted sample of the LIST gives a sub-bracket, one pass over the list collects the
+// keys inside it into LDS, a sort of those gives the answer; a list of <= 16,384 keys is sorted outright).  A rank
+// outside a bracket, or a list / LDS buffer that overflowed, makes that one block fall back to an exact radix select
+// (over the list, or over the whole plane: slow, ~10 ms, about once in 10^4 brackets).  Every path returns exact order
+// statistics; np.percentile's lerp follows.
+constexpr int PQ_M = 8192;
+constexpr size_t PQ_MIN_N = 65536;
+
+// ascending bitonic sort of N (power of two) keys in LDS by a 1024-thread block
+template <int N>
+__device__ __forceinline__ void pq_block_sort(unsigned long long* S) {
+    const int t = threadIdx.x;
+    for (int size = 2; size <= N; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+#pragma unroll
+            for (int u = 0; u < N / 2048; ++u) {
+                const int i = t + u * 1024;  // pair index
+                const int lo = (i / stride) * 2 * stride + (i % stride);
+                const int hi = lo + stride;
+                const bool up = ((lo & size) == 0);
+                const unsigned long long x = S[lo], y = S[hi];
+                if ((x > y) == up) {
+                    S[lo] = y;
+                    S[hi] = x;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// bracket of sample positions around the expected positions plo..phi of the wanted ranks in a sorted sample of m keys
+__device__ __forceinline__ void pq_bracket_positions(double plo, double phi, double m, double sigmas, long long* ia,
+                                                     long long* ib) {
+    const double dlo = sigmas * sqrt(fmax(plo * (m - plo) / m, 0.0)) + 8.0;
+    const double dhi = sigmas * sqrt(fmax(phi * (m - phi) / m, 0.0)) + 8.0;
+    *ia = (long long)floor(plo - dlo);
+    *ib = (long long)ceil(phi + dhi);
+}
+struct pq_bracket {
+    unsigned long long a, b;  // sample keys; has_a / has_b = 0: open end
+    int has_a, has_b;
+    unsigned below, eq_a, eq_b, n_in;  // exact counts from the classify pass (n_in may exceed the list capacity)
+};
+
+__global__ void __launch_bounds__(1024) pq_sample_kernel(const double* __restrict__ in, const rank_req* __restrict__ reqs,
+                                                         int nq, pq_bracket* __restrict__ br, size_t n) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    unsigned long long* S = reinterpret_cast<unsigned long long*>(smem_raw);  // PQ_M keys
+    const int plane = blockIdx.x, t = threadIdx.x;
+    const double* src = in + (size_t)plane * n;
+#pragma unroll
+    for (int u = 0; u < PQ_M / 1024; ++u) {
+        const unsigned k = (unsigned)(t + u * 1024);
+        // multiplicative hashing spreads the sample over the plane without any period related to the image width
+        const size_t idx = (size_t)(((unsigned long long)k * 0x9E3779B97F4A7C15ull + 0x7F4A7C15ull * (unsigned)plane) % n);
+        S[k] = amt_f64_key(src[idx]);
+    }
+    __syncthreads();
+    pq_block_sort<PQ_M>(S);
+    if (t < nq) {
+        const double m = (double)PQ_M;
+        long long ia, ib;
+        pq_bracket_positions((double)reqs[t].lo / (double)n * m, (double)reqs[t].hi / (double)n * m, m, 4.0, &ia, &ib);
+        pq_bracket b;
+        b.has_a = ia >= 0;
+        b.has_b = ib < PQ_M;
+        b.a = b.has_a ? S[ia] : 0ull;
+        b.b = b.has_b ? S[ib] : ~0ull;
+        b.below = b.eq_a = b.eq_b = b.n_in = 0;
+        br[(size_t)plane * nq + t] = b;
+    }
+}
+
+// Keys inside a bracket are first collected in an LDS stage of the block (wave-aggregated LDS atomics) and flushed to
+// the bracket's list with ONE global atomic per flush: a per-wave global atomic on the list counter would serialise
+// ~50,000 atomics per plane on one address.  (Measured alternative: a stage per wave with the fill level in a register
+// and no block barriers ran 1.7x slower, 803 vs 476 us per 32 planes.)
+constexpr int PQ_STAGE = 2048;  // >= 2 x the 1024 keys a block can add between two flush checks
+constexpr int PQ_GROUP = 4;     // brackets per classify launch (LDS: PQ_GROUP x PQ_STAGE keys)
+__global__ void __launch_bounds__(256) pq_classify_kernel(const double* __restrict__ in, pq_bracket* __restrict__ br,
+                                                          int nq_all, int j0, unsigned long long* __restrict__ lists,
+                                                          size_t cap, size_t n) {
+    // brackets j0 .. j0 + nq - 1 of the plane's nq_all
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    unsigned long long* stage = reinterpret_cast<unsigned long long*>(smem_raw);  // nq x PQ_STAGE keys
+    const int nq = min(PQ_GROUP, nq_all - j0);
+    br += j0;
+    lists += (size_t)j0 * cap;
+    __shared__ pq_bracket sb[8];
+    __shared__ unsigned sc[8][3];
+    __shared__ unsigned s_fill[8], s_base[8];
+    const int plane = blockIdx.y;
+    if (threadIdx.x < nq) sb[threadIdx.x] = br[(size_t)plane * nq_all + threadIdx.x];
+    if (threadIdx.x < 24) sc[threadIdx.x / 3][threadIdx.x % 3] = 0;
+    if (threadIdx.x < 8) s_fill[threadIdx.x] = 0;
+    __syncthreads();
+    const double* src = in + (size_t)plane * n;
+    const int lane = threadIdx.x & 63;
+    unsigned c_below[8], c_eqa[8], c_eqb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) c_below[j] = c_eqa[j] = c_eqb[j] = 0;
+    const size_t per_iter = (size_t)gridDim.x * 1024;
+    const size_t iters = (n + per_iter - 1) / per_iter;  // the same for every thread: the flush needs block barriers
+    auto flush = [&](bool force) {
+        __syncthreads();
+        for (int j = 0; j < nq; ++j) {
+            const unsigned fill = s_fill[j];  // uniform
+            if (fill == 0 || (!force && fill <= PQ_STAGE - 1024)) continue;
+            if (threadIdx.x == 0) s_base[j] = atomicAdd(&br[(size_t)plane * nq_all + j].n_in, fill);
+            __syncthreads();
+            const size_t base = s_base[j];
+            for (unsigned i = threadIdx.x; i < fill; i += 256)
+                if (base + i < cap) lists[((size_t)plane * nq_all + j) * cap + base + i] = stage[(size_t)j * PQ_STAGE + i];
+            __syncthreads();
+            if (threadIdx.x == 0) s_fill[j] = 0;
+        }
+        __syncthreads();
+    };
+    for (size_t it = 0; it < iters; ++it) {
+        const size_t i0 = it * per_iter + (size_t)blockIdx.x * 1024 + threadIdx.x;
+        double raw4[4];
+        bool ok4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {  // unconditional loads from clamped indices, all in flight
+            const size_t i = i0 + (size_t)u * 256;
+            ok4[u] = i < n;
+            raw4[u] = src[ok4[u] ? i : n - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned long long k = amt_f64_key(raw4[u]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (j >= nq) break;
+                const unsigned long long a = sb[j].a, b = sb[j].b;
+                const bool ha = sb[j].has_a, hb = sb[j].has_b;
+                c_below[j] += ok4[u] && ha && k < a;
+                c_eqa[j] += ok4[u] && ha && k == a;
+                c_eqb[j] += ok4[u] && hb && k == b && !(ha && a == b);
+                const bool inside = ok4[u] && (!ha || k > a) && (!hb || k < b);
+                const unsigned long long m = __ballot(inside);
+                if (m) {
+                    unsigned base = 0;
+                    const int leader = __ffsll((long long)m) - 1;
+                    if (lane == leader) base = atomicAdd(&s_fill[j], (unsigned)__popcll(m));
+                    base = __shfl(base, leader);
+                    // a block adds at most 1024 keys per iteration and flushes above PQ_STAGE - 1024: the stage cannot
+                    // overflow, the bound is only a guard
+                    const unsigned pos = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+                    if (inside && pos < (unsigned)PQ_STAGE) stage[(size_t)j * PQ_STAGE + pos] = k;
+                }
+            }
+        }
+        flush(false);
+    }
+    flush(true);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (j >= nq) break;
+        unsigned v0 = c_below[j], v1 = c_eqa[j], v2 = c_eqb[j];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            v0 += __shfl_xor(v0, o);
+            v1 += __shfl_xor(v1, o);
+            v2 += __shfl_xor(v2, o);
+        }
+        if (lane == 0) {
+            atomicAdd(&sc[j][0], v0);
+            atomicAdd(&sc[j][1], v1);
+            atomicAdd(&sc[j][2], v2);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < nq) {
+        pq_bracket* g = &br[(size_t)plane * nq_all + threadIdx.x];
+        if (sc[threadIdx.x][0]) atomicAdd(&g->below, sc[threadIdx.x][0]);
+        if (sc[threadIdx.x][1]) atomicAdd(&g->eq_a, sc[threadIdx.x][1]);
+        if (sc[threadIdx.x][2]) atomicAdd(&g->eq_b, sc[threadIdx.x][2]);
+    }
+}
+
+// k-th smallest (0-based) of `cnt` keys produced by `key_at(i)`, all of which share the bits above byte `first_pass`;
+// one 1024-thread block, LDS histogram per byte
+template <typename KeyAt>
+__device__ unsigned long long pq_block_select(KeyAt key_at, size_t cnt, unsigned long long rank, unsigned long long prefix,
+                                              int first_pass, uint32_t* lh, unsigned long long* s_prefix,
+                                              unsigned long long* s_rank) {
+    if (threadIdx.x == 0) {
+        *s_prefix = prefix;
+        *s_rank = rank;
+    }
+    __syncthreads();
+    for (int pass = first_pass; pass < 8; ++pass) {
+        if (threadIdx.x < 256) lh[threadIdx.x] = 0;
+        __syncthreads();
+        const int shift = 56 - 8 * pass;
+        const unsigned long long himask = pass == 0 ? 0ull : (~0ull << (shift + 8));
+        const unsigned long long mine = *s_prefix;
+        for (size_t i = threadIdx.x; i < cnt; i += 1024) {
+            const unsigned long long k = key_at(i);
+            if ((k & himask) == mine) atomicAdd(&lh[(unsigned)(k >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long run = 0;
+            int d = 0;
+            for (; d < 256; ++d) {
+                const unsigned long long nxt = run + lh[d];
+                if (*s_rank < nxt) break;
+                run = nxt;
+            }
+            if (d == 256) d = 255;
+            *s_prefix = mine | ((unsigned long long)d << shift);
+            *s_rank -= run;
+        }
+        __syncthreads();
+    }
+    return *s_prefix;
+}
+
+constexpr int PQ_BUF = 16384;  // keys the resolve block can hold (and sort) in LDS
+constexpr int PQ_M2 = 4096;    // sample of a list
+
+// the (r0)-th and, if two, the (r0 + 1)-th smallest key of lst[0..c): see the header comment.  B = PQ_BUF keys of LDS.
+__device__ void pq_list_select(const unsigned long long* __restrict__ lst, size_t c, unsigned long long r0, int two,
+                               unsigned long long a1, unsigned long long b1, int has_ab, unsigned long long* B,
+                               uint32_t* lh, unsigned long long* sh64, unsigned* sh32, unsigned long long* out2) {
+    const int t = threadIdx.x;
+    auto radix = [&](unsigned long long r) -> unsigned long long {  // bytes above the first differing one are shared
+        int first = 0;
+        unsigned long long prefix = 0;
+        if (has_ab) {
+            const unsigned long long x = a1 ^ b1;
+            first = x ? (__clzll((long long)x) >> 3) : 7;
+            prefix = first ? (a1 & (~0ull << (64 - 8 * first))) : 0ull;
+        }
+        return pq_block_select([&](size_t i) { return lst[i]; }, c, r, prefix, first, lh, &sh64[0], &sh64[1]);
+    };
+    if (c <= (size_t)PQ_BUF) {  // sort the list outright
+        for (int i = t; i < PQ_BUF; i += 1024) B[i] = (size_t)i < c ? lst[i] : ~0ull;
+        __syncthreads();
+        pq_block_sort<PQ_BUF>(B);
+        out2[0] = B[r0];
+        out2[1] = two ? B[r0 + 1] : B[r0];
+        __syncthreads();
+        return;
+    }
+#pragma unroll
+    for (int u = 0; u < PQ_M2 / 1024; ++u) {
+        const unsigned k = (unsigned)(t + u * 1024);
+        B[k] = lst[(size_t)(((unsigned long long)k * 0x9E3779B97F4A7C15ull + 12345ull) % c)];
+    }
+    __syncthreads();
+    pq_block_sort<PQ_M2>(B);
+    long long ia, ib;
+    const double m2 = (double)PQ_M2;
+    pq_bracket_positions((double)r0 / (double)c * m2, (double)(r0 + (two ? 1 : 0)) / (double)c * m2, m2, 3.5, &ia, &ib);
+    const bool ha = ia >= 0, hb = ib < PQ_M2;
+    const unsigned long long a2 = ha ? B[ia] : 0ull, b2 = hb ? B[ib] : ~0ull;
+    __syncthreads();  // everybody has read the sample: B is free
+    if (t < 4) sh32[t] = 0;  // below, eq_a, eq_b, fill
+    __syncthreads();
+    const int lane = t & 63;
+    unsigned cb = 0, ca = 0, ce = 0;
+    const size_t iters = (c + 1023) / 1024;
+    for (size_t it = 0; it < iters; ++it) {
+        const size_t i = it * 1024 + t;
+        const bool ok = i < c;
+        const unsigned long long k = lst[ok ? i : c - 1];
+        cb += ok && ha && k < a2;
+        ca += ok && ha && k == a2;
+        ce += ok && hb && k == b2 && !(ha && a2 == b2);
+        const bool inside = ok && (!ha || k > a2) && (!hb || k < b2);
+        const unsigned long long m = __ballot(inside);
+        if (m) {
+            unsigned base = 0;
+            const int leader = __ffsll((long long)m) - 1;
+            if (lane == leader) base = atomicAdd(&sh32[3], (unsigned)__popcll(m));
+            base = __shfl(base, leader);
+            const unsigned pos = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+            if (inside && pos < (unsigned)PQ_BUF) B[pos] = k;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        cb += __shfl_xor(cb, o);
+        ca += __shfl_xor(ca, o);
+        ce += __shfl_xor(ce, o);
+    }
+    if (lane == 0) {
+        atomicAdd(&sh32[0], cb);
+        atomicAdd(&sh32[1], ca);
+        atomicAdd(&sh32[2], ce);
+    }
+    __syncthreads();
+    const unsigned long long e0 = sh32[0], e1 = e0 + sh32[1], fill = sh32[3], e2 = e1 + fill, e3 = e2 + sh32[2];
+    __syncthreads();
+    const bool sortable = fill <= (unsigned long long)PQ_BUF;
+    if (sortable) {
+        for (int i = t; i < PQ_BUF; i += 1024)
+            if ((unsigned long long)i >= fill) B[i] = ~0ull;
+        __syncthreads();
+        pq_block_sort<PQ_BUF>(B);
+    }
+    for (int w = 0; w < 2; ++w) {
+        const unsigned long long r = r0 + (unsigned long long)(w && two ? 1 : 0);
+        unsigned long long key;
+        if (ha && r >= e0 && r < e1) key = a2;
+        else if (sortable && r >= e1 && r < e2) key = B[r - e1];
+        else if (hb && r >= e2 && r < e3) key = b2;
+        else key = radix(r);  // outside the sub-bracket, or too many keys inside it
+        out2[w] = key;
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(1024) pq_resolve_kernel(const double* __restrict__ in, const rank_req* __restrict__ reqs,
+                                                          const pq_bracket* __restrict__ br, int nq,
+                                                          const unsigned long long* __restrict__ lists, size_t cap,
+                                                          sel_state* __restrict__ res, size_t n) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    unsigned long long* B = reinterpret_cast<unsigned long long*>(smem_raw);  // PQ_BUF keys
+    __shared__ uint32_t lh[256];
+    __shared__ unsigned long long sh64[2];
+    __shared__ unsigned sh32[4];
+    const int j = blockIdx.x, plane = blockIdx.y;
+    const pq_bracket b = br[(size_t)plane * nq + j];
+    const unsigned long long* lst = lists + ((size_t)plane * nq + j) * cap;
+    const double* src = in + (size_t)plane * n;
+    const unsigned long long rlo = (unsigned long long)reqs[j].lo, rhi = (unsigned long long)reqs[j].hi;
+    const unsigned long long e0 = b.below, e1 = e0 + b.eq_a, e2 = e1 + b.n_in, e3 = e2 + b.eq_b;
+    unsigned long long keys[2];
+    bool have[2] = {false, false};
+    // both ranks inside the list: one list selection serves both
+    if (b.n_in <= cap && rlo >= e1 && rhi < e2) {
+        unsigned long long out2[2];
+        pq_list_select(lst, (size_t)b.n_in, rlo - e1, rhi != rlo, b.a, b.b, b.has_a && b.has_b, B, lh, sh64, sh32, out2);
+        keys[0] = out2[0];
+        keys[1] = out2[1];
+        have[0] = have[1] = true;
+    }
+    for (int w = 0; w < 2; ++w) {
+        if (have[w]) continue;
+        const unsigned long long r = w ? rhi : rlo;
+        unsigned long long key;
+        if (w == 1 && rhi == rlo) {
+            key = keys[0];
+        } else if (b.has_a && r >= e0 && r < e1) {
+            key = b.a;
+        } else if (b.n_in <= cap && r >= e1 && r < e2) {
+            unsigned long long out2[2];
+            pq_list_select(lst, (size_t)b.n_in, r - e1, 0, b.a, b.b, b.has_a && b.has_b, B, lh, sh64, sh32, out2);
+            key = out2[0];
+        } else if (b.has_b && r >= e2 && r < e3) {
+            key = b.b;
+        } else {
+            // outside the bracket (or the list overflowed): exact select over the whole plane
+            key = pq_block_select([&](size_t i) { return amt_f64_key(src[i]); }, n, r, 0ull, 0, lh, &sh64[0], &sh64[1]);
+        }
+        keys[w] = key;
+    }
+    if (threadIdx.x == 0) {
+        for (int w = 0; w < 2; ++w) {
+            res[(size_t)plane * 2 * nq + 2 * j + w].prefix = keys[w];
+            res[(size_t)plane * 2 * nq + 2 * j + w].rank = 0;
+        }
+    }
+}
+
+static int percentile_f64_radix(amt_ctx* ctx, const double* in, const rank_req* reqs, int nq, double* out_dev, int nplanes,
+                                size_t n);
 
 extern "C" int amt_percentile_f64(amt_ctx* ctx, const double* in, const double* q_host, int nq, double* out_dev,
                                   int nplanes, size_t n) {
@@ -856,26 +1270,57 @@ extern "C" int amt_percentile_f64(amt_ctx* ctx, const double* in, const double* 
     if (nplanes == 0) return AMT_OK;
     rank_req reqs[8];
     make_rank_reqs(q_host, nq, n, reqs);
+    if (n < PQ_MIN_N) return percentile_f64_radix(ctx, in, reqs, nq, out_dev, nplanes, n);
+    const size_t cap = n / 8 + 4096;
+    const size_t nbr = (size_t)nplanes * nq;
+    AMT_TRY(amt_arena_begin(ctx, amt_align(sizeof(rank_req) * 8) + amt_align(sizeof(pq_bracket) * nbr) +
+                                     amt_align(nbr * cap * 8) + amt_align(sizeof(sel_state) * 2 * nbr)));
+    rank_req* rd = arena_take_t<rank_req>(ctx, 8);
+    pq_bracket* br = arena_take_t<pq_bracket>(ctx, nbr);
+    unsigned long long* lists = arena_take_t<unsigned long long>(ctx, nbr * cap);
+    sel_state* res = arena_take_t<sel_state>(ctx, 2 * nbr);
+    AMT_TRY(amt_param_upload(ctx, rd, reqs, sizeof(rank_req) * nq));
+    hipLaunchKernelGGL(pq_sample_kernel, dim3(nplanes), dim3(1024), (size_t)PQ_M * 8, ctx->stream, in, rd, nq, br, n);
+    AMT_LAUNCH_CHECK();
+    for (int j0 = 0; j0 < nq; j0 += PQ_GROUP) {  // one full read per group of four percentiles
+        const int nj = nq - j0 < PQ_GROUP ? nq - j0 : PQ_GROUP;
+        hipLaunchKernelGGL(pq_classify_kernel, dim3(amt_grid_for(n, 256 * 16, 512), nplanes), dim3(256),
+                           (size_t)nj * PQ_STAGE * 8, ctx->stream, in, br, nq, j0, lists, cap, n);
+        AMT_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(pq_resolve_kernel, dim3(nq, nplanes), dim3(1024), (size_t)PQ_BUF * 8, ctx->stream, in, rd, br, nq, lists,
+                       cap, res, n);
+    AMT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sel_finish_kernel, dim3((nplanes * nq + 63) / 64), dim3(64), 0, ctx->stream, res, rd, nq, nplanes,
+                       out_dev);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+
+// the 8-bit MSB radix select over the whole plane (four full passes + candidate lists): planes below PQ_MIN_N samples
+static int percentile_f64_radix(amt_ctx* ctx, const double* in, const rank_req* reqs, int nq, double* out_dev, int nplanes,
+                                size_t n) {
     const int nslots = 2 * nq;
     const int total = nplanes * nslots;
     // candidate lists: keys matching the first 24 resolved bits (a 1/4096 slice of the exponent / mantissa space);
     // n / 16 entries per slot cover everything but massive ties, which fall back to full scans
     const size_t cap = n / 16 + 1024;
     size_t need = amt_align(sizeof(rank_req) * 8) + amt_align(sizeof(sel_state) * 2 * total) +
-                  amt_align((size_t)(SEL_LIST_PASS + 1) * total * 256 * 4) + amt_align((size_t)total * cap * 8) +
-                  amt_align((size_t)total * 4);
+                  amt_align((size_t)8 * total * 256 * 4) + amt_align((size_t)total * cap * 8) +
+                  amt_align((size_t)total * 4) + amt_align((size_t)nplanes * 4);
     AMT_TRY(amt_arena_begin(ctx, need));
     rank_req* rd = arena_take_t<rank_req>(ctx, 8);
     sel_state* st = arena_take_t<sel_state>(ctx, 2 * (size_t)total);
-    uint32_t* counts = arena_take_t<uint32_t>(ctx, (size_t)(SEL_LIST_PASS + 1) * total * 256);
+    uint32_t* counts = arena_take_t<uint32_t>(ctx, (size_t)8 * total * 256);
     unsigned long long* cand = arena_take_t<unsigned long long>(ctx, (size_t)total * cap);
     unsigned* ncand = arena_take_t<unsigned>(ctx, (size_t)total);
+    int* overflow = arena_take_t<int>(ctx, nplanes);
     AMT_TRY(amt_param_upload(ctx, rd, reqs, sizeof(rank_req) * nq));
     hipLaunchKernelGGL(sel_init_kernel, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, st, rd, nq, nplanes);
     AMT_LAUNCH_CHECK();
     size_t smem = (size_t)nslots * 256 * 4 + (size_t)nslots * 8;
     // counts of the four full passes live side by side (one memset); the state ping-pongs between two buffers
-    AMT_HIP_CHECK(hipMemsetAsync(counts, 0, (size_t)(SEL_LIST_PASS + 1) * total * 256 * 4, ctx->stream));
+    AMT_HIP_CHECK(hipMemsetAsync(counts, 0, (size_t)8 * total * 256 * 4, ctx->stream));
     AMT_HIP_CHECK(hipMemsetAsync(ncand, 0, (size_t)total * 4, ctx->stream));
     sel_state* cur = st;
     sel_state* nxt = st + total;
@@ -883,17 +1328,35 @@ extern "C" int amt_percentile_f64(amt_ctx* ctx, const double* in, const double* 
         uint32_t* cnt = counts + (size_t)pass * total * 256;
         dim3 grid(amt_grid_for(n, 256 * 16, 512), nplanes);
         hipLaunchKernelGGL(sel_count_kernel, grid, dim3(256), smem, ctx->stream, in, cur, cnt, nslots, pass, n,
-                           pass == SEL_LIST_PASS ? cand : (unsigned long long*)nullptr, ncand, cap);
+                           pass == SEL_LIST_PASS ? cand : (unsigned long long*)nullptr, ncand, cap, (const int*)nullptr);
         AMT_LAUNCH_CHECK();
         hipLaunchKernelGGL(sel_pick_kernel, dim3((total + 63) / 64), dim3(64), 0, ctx->stream, cur, nxt, cnt, nslots, pass,
-                           nplanes);
+                           nplanes, (const int*)nullptr);
+        AMT_LAUNCH_CHECK();
+        sel_state* t = cur;
+        cur = nxt;
+        nxt = t;
+    }
+    hipLaunchKernelGGL(sel_overflow_kernel, dim3((nplanes + 63) / 64), dim3(64), 0, ctx->stream, ncand, overflow, nslots,
+                       nplanes, (unsigned)cap);
+    AMT_LAUNCH_CHECK();
+    // planes whose lists overflowed (massive ties): four more full passes, every block of the chip on them -- an even
+    // number, so the state ends in the buffer the list kernel works on; other planes' blocks exit at once
+    for (int pass = SEL_LIST_PASS + 1; pass < 8; ++pass) {
+        uint32_t* cnt = counts + (size_t)pass * total * 256;
+        dim3 grid(amt_grid_for(n, 256 * 16, 512), nplanes);
+        hipLaunchKernelGGL(sel_count_kernel, grid, dim3(256), smem, ctx->stream, in, cur, cnt, nslots, pass, n,
+                           (unsigned long long*)nullptr, ncand, cap, (const int*)overflow);
+        AMT_LAUNCH_CHECK();
+        hipLaunchKernelGGL(sel_pick_kernel, dim3((total + 63) / 64), dim3(64), 0, ctx->stream, cur, nxt, cnt, nslots, pass,
+                           nplanes, (const int*)overflow);
         AMT_LAUNCH_CHECK();
         sel_state* t = cur;
         cur = nxt;
         nxt = t;
     }
     hipLaunchKernelGGL(sel_list_passes_kernel, dim3(nslots, nplanes), dim3(256), 0, ctx->stream, in, cur, nslots, n, cand,
-                       ncand, cap);
+                       ncand, cap, (const int*)overflow);
     AMT_LAUNCH_CHECK();
     st = cur;
     hipLaunchKernelGGL(sel_finish_kernel, dim3((nplanes * nq + 63) / 64), dim3(64), 0, ctx->stream, st, rd, nq, nplanes,

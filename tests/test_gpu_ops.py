@@ -124,11 +124,39 @@ def test_percentile_rescale(ctx, ops, golden):
         rng.integers(0, 3, (128, 160)).astype(np.float64),
         rng.normal(0.0, 1e-3, (128, 160)),
         np.exp(rng.normal(0.0, 4.0, (128, 160))) * np.sign(rng.normal(size=(128, 160))),
+        np.clip(rng.normal(-1.2, 1.0, (128, 160)), 0, None),  # a clipped image: ~88 % exact zeros (R/operations.py:97)
     ])
     for q in ((0, 100), (1, 99), (50,), (12.5, 87.5, 99.99)):
         got = ops.percentile(ctx.asarray(planes), q).numpy()
         for b in range(planes.shape[0]):
             assert np.array_equal(got[b], np.atleast_1d(np.percentile(planes[b], q))), (b, q)
+
+
+def test_percentile_f64_sampled_path(ctx, ops):
+    """Planes of >= 65,536 samples take the one-pass path (sampled brackets + exact counts + list select): against
+    np.percentile, bit for bit, on smooth / heavy-tailed / constant / few-valued / mostly-zero (clipped) / sorted and
+    spatially structured planes, with up to six percentiles per call (two bracket groups) incl. 0 and 100."""
+    rng = np.random.default_rng(21)
+    H, W = 300, 352
+    yy, xx = np.mgrid[0:H, 0:W]
+    planes = np.stack([
+        rng.normal(0.3, 0.05, (H, W)),
+        np.exp(rng.normal(0.0, 3.0, (H, W))) * np.sign(rng.normal(size=(H, W))),
+        np.full((H, W), -7.5),
+        rng.integers(0, 4, (H, W)).astype(np.float64),
+        np.clip(rng.normal(-1.2, 1.0, (H, W)), 0, None),
+        np.arange(H * W, dtype=np.float64).reshape(H, W) / 7.0,
+        np.sin(xx / 9.0) * np.cos(yy / 13.0) + (xx // 64) * 0.5,      # stripes with the period of nothing in the hash
+        np.where((yy // 50 + xx // 50) % 2 == 0, 1.0, rng.random((H, W))),  # half the plane one value
+    ])
+    d = ctx.asarray(planes)
+    for q in ((1, 99), (90,), (0, 100), (50,), (0.01, 37.123, 50, 62.5, 99.9, 100), (0, 0.5, 99.5)):
+        got = ops.percentile(d, q).numpy()
+        for b in range(planes.shape[0]):
+            assert np.array_equal(got[b], np.atleast_1d(np.percentile(planes[b], q))), (b, q)
+    # one big plane at the benchmark size, heavy ties included
+    big = np.clip(rng.normal(-0.5, 1.0, (2048, 2048)), 0, None)
+    assert np.array_equal(ops.percentile(ctx.asarray(big), (1, 99)).numpy()[0], np.percentile(big, (1, 99)))
 
 
 def test_binary_morphology(ctx, ops, golden):
