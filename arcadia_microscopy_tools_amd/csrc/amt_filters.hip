@@ -143,9 +143,11 @@ __global__ void __launch_bounds__(256) conv_v8_kernel(const TIn* __restrict__ in
     }
 }
 
-__global__ void __launch_bounds__(256) conv_h8_kernel(const double* __restrict__ in, double* __restrict__ out, int H,
-                                                      int W, const double* __restrict__ wts, int r, int mode,
-                                                      double cval, int TW) {
+// `minuend` (nullable; may alias out): the kernel stores minuend - result instead of the result -- the second Gaussian
+// of a difference of Gaussians subtracts itself from the first in its own epilogue (no third pass over the planes)
+__global__ void __launch_bounds__(256) conv_h8_kernel(const double* __restrict__ in, double* out, int H, int W,
+                                                      const double* __restrict__ wts, int r, int mode, double cval,
+                                                      int TW, const double* minuend) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int cols = TW + 2 * r;
     const int pitch = cols | 1;  // odd number of doubles per row
@@ -190,13 +192,24 @@ __global__ void __launch_bounds__(256) conv_h8_kernel(const double* __restrict__
         const int x = x0 + c * 8;
         if (y < H && x < W) {
             double* dst = out + plane + (size_t)y * W + x;
+            const double* mn = minuend ? minuend + plane + (size_t)y * W + x : nullptr;
             if (x + 7 < W && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
+                if (mn) {
+                    double2 m2[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) m2[k] = *reinterpret_cast<const double2*>(mn + 2 * k);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        res[2 * k] = m2[k].x - res[2 * k];
+                        res[2 * k + 1] = m2[k].y - res[2 * k + 1];
+                    }
+                }
 #pragma unroll
                 for (int k = 0; k < 8; k += 2) *reinterpret_cast<double2*>(dst + k) = make_double2(res[k], res[k + 1]);
             } else {
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
-                    if (x + k < W) dst[k] = res[k];
+                    if (x + k < W) dst[k] = mn ? mn[k] - res[k] : res[k];
             }
         }
     }
@@ -544,7 +557,8 @@ static int launch_fused(amt_ctx* ctx, const TIn* in, double scale, double* out, 
 template <typename TIn>
 static int gaussian_typed(amt_ctx* ctx, const TIn* in, double scale, double* out, double* tmp, int nplanes, int H,
                           int W, const double* wdev, int r, int mode, double cval, size_t in_stride,
-                          unsigned long long* keys) {
+                          unsigned long long* keys, const double* minuend = nullptr) {
+    // minuend: only the two-pass path (r > FR_MAX) can subtract in its epilogue; callers check
     switch (r) {
 #define AMT_FUSED_CASE(RR) \
     case RR:               \
@@ -581,7 +595,8 @@ static int gaussian_typed(amt_ctx* ctx, const TIn* in, double scale, double* out
         const size_t smem1 = (size_t)64 * ((TW + 2 * r) | 1) * sizeof(double) + (size_t)(2 * r + 1) * 8 +
                              (size_t)(TW + 2 * r) * sizeof(int);
         dim3 g1((W + TW - 1) / TW, (H + 63) / 64, nplanes);
-        hipLaunchKernelGGL(conv_h8_kernel, g1, dim3(256), smem1, ctx->stream, tmp, out, H, W, wdev, r, mode, cval, TW);
+        hipLaunchKernelGGL(conv_h8_kernel, g1, dim3(256), smem1, ctx->stream, tmp, out, H, W, wdev, r, mode, cval, TW,
+                           minuend);
         AMT_LAUNCH_CHECK();
     }
     return AMT_OK;
@@ -598,13 +613,14 @@ static int check_gauss_args(const void* in, int in_dtype, double* out, int nplan
 
 static int gaussian_dispatch(amt_ctx* ctx, const void* in, int in_dtype, double scale, double* out, double* tmp,
                              int nplanes, int H, int W, const double* wdev, int r, int mode, double cval,
-                             size_t in_stride = 0, unsigned long long* keys = nullptr) {
+                             size_t in_stride = 0, unsigned long long* keys = nullptr,
+                             const double* minuend = nullptr) {
     if (in_stride == 0) in_stride = (size_t)H * W;
     if (in_dtype == AMT_U16)
         return gaussian_typed<uint16_t>(ctx, (const uint16_t*)in, scale, out, tmp, nplanes, H, W, wdev, r, mode, cval,
-                                        in_stride, keys);
+                                        in_stride, keys, minuend);
     return gaussian_typed<double>(ctx, (const double*)in, 1.0, out, tmp, nplanes, H, W, wdev, r, mode, cval, in_stride,
-                                  keys);
+                                  keys, minuend);
 }
 
 __global__ void convert_u16_f64_kernel(const uint16_t* __restrict__ in, double scale, double* __restrict__ out,
@@ -694,14 +710,22 @@ extern "C" int amt_dog(amt_ctx* ctx, const void* in, int in_dtype, double scale,
     size_t wl = amt_align((2 * r_lo + 1) * sizeof(double)), wh = amt_align((2 * r_hi + 1) * sizeof(double));
     size_t nb = amt_align(n * sizeof(double));
     bool need_tmp = (r_lo > FR_MAX) || (r_hi > FR_MAX);
-    AMT_TRY(amt_arena_begin(ctx, wl + wh + nb + (need_tmp ? nb : 0)));
+    // a wide second Gaussian (two-pass path) subtracts itself from the first in its horizontal pass: no ghi plane, no
+    // subtraction pass (the reference's default sigmas 0.6 / 16 take this route)
+    const bool fused_sub = r_hi > FR_MAX;
+    AMT_TRY(amt_arena_begin(ctx, wl + wh + (fused_sub ? 0 : nb) + (need_tmp ? nb : 0)));
     double* wlo_d = (double*)amt_arena_take(ctx, wl);
     double* whi_d = (double*)amt_arena_take(ctx, wh);
-    double* ghi = (double*)amt_arena_take(ctx, nb);
+    double* ghi = fused_sub ? nullptr : (double*)amt_arena_take(ctx, nb);
     double* tmp = need_tmp ? (double*)amt_arena_take(ctx, nb) : nullptr;
     AMT_TRY(amt_param_upload(ctx, wlo_d, w_lo, (2 * r_lo + 1) * sizeof(double)));
     AMT_TRY(amt_param_upload(ctx, whi_d, w_hi, (2 * r_hi + 1) * sizeof(double)));
     AMT_TRY(gaussian_dispatch(ctx, in, in_dtype, scale, out, tmp, nplanes, H, W, wlo_d, r_lo, mode, cval));
+    if (fused_sub) {
+        AMT_TRY(gaussian_dispatch(ctx, in, in_dtype, scale, out, tmp, nplanes, H, W, whi_d, r_hi, mode, cval, 0, nullptr,
+                                  out));
+        return AMT_OK;
+    }
     AMT_TRY(gaussian_dispatch(ctx, in, in_dtype, scale, ghi, tmp, nplanes, H, W, whi_d, r_hi, mode, cval));
     hipLaunchKernelGGL(sub_inplace_kernel, dim3(amt_grid_for(n, 256)), dim3(256), 0, ctx->stream, out, ghi, n);
     AMT_LAUNCH_CHECK();

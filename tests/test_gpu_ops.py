@@ -400,6 +400,47 @@ def test_regionprops(ctx, ops, golden):
         np.testing.assert_allclose(np.abs(cols["orientation"][sym]), np.pi / 4)
 
 
+def test_grey_morphology_u16_packed_kernel(ctx, ops):
+    """uint16 erosion / dilation / opening / closing / top-hat through the packed small-footprint kernel (symmetric run
+    footprints up to 15 x 15) against scipy (oracle/skops.py), on widths that are and are not multiples of 8, image
+    sizes smaller than a tile and not multiples of it, every boundary the halo has to reflect, and a footprint that
+    does NOT qualify (off-centre run) to make sure the generic kernel still takes it."""
+    from oracle import skops
+    from scipy import ndimage as ndi
+
+    rng = np.random.default_rng(41)
+    fps = {"cross": skops.cross3(), "sq3": np.ones((3, 3), np.uint8), "sq5": np.ones((5, 5), np.uint8),
+           "sq7x3": np.ones((7, 3), np.uint8), "col5": np.ones((5, 1), np.uint8), "row7": np.ones((1, 7), np.uint8)}
+    for r in (1, 2, 3, 5, 7):
+        fps[f"disk{r}"] = skops.disk(r)
+    diamond = (np.abs(np.arange(-4, 5))[:, None] + np.abs(np.arange(-4, 5))[None, :] <= 4).astype(np.uint8)
+    fps["diamond4"] = diamond
+    gap = skops.disk(3).copy()
+    gap[1] = 0  # a footprint with an empty row
+    fps["disk3_gap"] = gap
+    for shape in ((70, 200), (33, 131), (160, 264), (9, 20)):
+        img = rng.integers(0, 65536, (2,) + shape).astype(np.uint16)
+        img[1] = (ndi.gaussian_filter(img[1].astype(float), 3) ).astype(np.uint16)
+        d = ctx.asarray(img)
+        for name, fp in fps.items():
+            er, di = ops.erosion(d, fp).numpy(), ops.dilation(d, fp).numpy()
+            for b in range(2):
+                assert np.array_equal(er[b], skops.erosion(img[b], fp)), (shape, name, b, "erosion")
+                assert np.array_equal(di[b], skops.dilation(img[b], fp)), (shape, name, b, "dilation")
+        for fp in (skops.disk(2), skops.disk(7)):
+            assert np.array_equal(ops.opening(d, fp).numpy()[0], skops.opening(img[0], fp))
+            assert np.array_equal(ops.closing(d, fp).numpy()[1], skops.closing(img[1], fp))
+            assert np.array_equal(ops.white_tophat(d, fp).numpy()[1], skops.white_tophat(img[1], fp))
+    off = np.zeros((3, 5), np.uint8)
+    off[0, 0:3] = 1
+    off[1, 1:4] = 1
+    off[2, 2:5] = 1  # runs that are not centred: generic path
+    img = rng.integers(0, 65536, (40, 52)).astype(np.uint16)
+    assert np.array_equal(ops.erosion(ctx.asarray(img), off).numpy(), ndi.grey_erosion(img, footprint=off))
+    assert np.array_equal(ops.dilation(ctx.asarray(img), off).numpy(),
+                          ndi.grey_dilation(img, footprint=off[::-1, ::-1]))
+
+
 def test_convex_area_all_heights(ctx, ops):
     """area_convex for labels of every height class: both hull kernels (LDS chains for labels of <= 48 rows, HBM
     chains above), labels touching row 0, one-pixel and one-row labels, concave and fragmented shapes -- against the
