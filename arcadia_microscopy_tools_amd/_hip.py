@@ -115,6 +115,7 @@ _SIGS = {
     "amt_contours_emit": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),
     "amt_borders_find": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P]),
     "amt_borders_emit": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),
+    "amt_cellpose_masks": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, c_int, c_int, c_float, c_int]),
     "amt_overlay": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_int]),
 }
 

@@ -1,0 +1,187 @@
+"""The Cellpose path on MI355X (BASELINE configs[4]): network forward through PyTorch-ROCm (bf16, MFMA) and the
+flow -> mask post-processing in HIP (``amt_cellpose_masks``).
+
+The reference wraps ``cellpose.models.CellposeModel`` (R/model.py:160-169, :206-215, :270-290), whose weights are
+fetched from the network by name -- unobtainable offline, as is the package itself.  What can be built and measured
+here is (a) the post-processing, restated from the published algorithm (csrc/amt_dynamics.hip; oracle:
+oracle/cellpose_dynamics.py; **parity unpinned**), and (b) the forward pass of a network of Cellpose's published
+U-Net architecture (``CPnetStandIn``, RANDOM weights) to size the MFMA work: its output is meaningless as a
+segmentation and is never presented as one.  A real checkpoint is used by passing any ``torch.nn.Module`` that maps
+``(N, C, H, W)`` images to ``(N, 3, H, W)`` = (dY, dX, cellprob) as ``SegmentationModel(network=...)``.
+
+PyTorch is plumbing here (device memory, the conv stack on MFMA); the post-processing never touches torch kernels.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import hipops
+from .device import Context, DeviceArray, get_context
+
+
+def _torch():
+    import torch
+
+    return torch
+
+
+def make_standin(in_channels: int = 2, nbase=(32, 64, 128, 256), seed: int = 0):
+    """Cellpose's residual U-Net ("CPnet", Stringer et al. 2021, Fig. 1 / Methods): four scales of two residual
+    blocks (each two 3x3 convolutions with batch norm + ReLU in front), max-pool downsampling, a 256-d style vector
+    (global average of the deepest features, L2-normalised) added into every upsampling block, additive skips, and
+    a 1x1 output convolution to 3 maps.  RANDOM weights: an architectural stand-in to measure the forward pass."""
+    torch = _torch()
+    nn = torch.nn
+
+    def bconv(cin, cout, k):
+        return nn.Sequential(nn.BatchNorm2d(cin, eps=1e-5), nn.ReLU(inplace=True), nn.Conv2d(cin, cout, k, padding=k // 2))
+
+    class ResDown(nn.Module):
+        def __init__(self, cin, cout):
+            super().__init__()
+            self.proj = nn.Sequential(nn.BatchNorm2d(cin, eps=1e-5), nn.Conv2d(cin, cout, 1))
+            self.conv = nn.ModuleList([bconv(cin, cout, 3), bconv(cout, cout, 3), bconv(cout, cout, 3), bconv(cout, cout, 3)])
+
+        def forward(self, x):
+            x = self.proj(x) + self.conv[1](self.conv[0](x))
+            return x + self.conv[3](self.conv[2](x))
+
+    class ConvStyle(nn.Module):
+        def __init__(self, cin, cout, nstyle):
+            super().__init__()
+            self.conv = bconv(cin, cout, 3)
+            self.full = nn.Linear(nstyle, cout)
+
+        def forward(self, style, x, y=None):
+            if y is not None:
+                x = x + y
+            return self.conv(x + self.full(style)[:, :, None, None])
+
+    class ResUp(nn.Module):
+        def __init__(self, cin, cout, nstyle):
+            super().__init__()
+            self.conv0 = bconv(cin, cout, 3)
+            self.c1 = ConvStyle(cout, cout, nstyle)
+            self.c2 = ConvStyle(cout, cout, nstyle)
+            self.c3 = ConvStyle(cout, cout, nstyle)
+            self.proj = nn.Sequential(nn.BatchNorm2d(cin, eps=1e-5), nn.Conv2d(cin, cout, 1))
+
+        def forward(self, x, y, style):
+            x = self.proj(x) + self.c1(style, self.conv0(x), y=y)
+            return x + self.c3(style, self.c2(style, x))
+
+    class CPnetStandIn(nn.Module):
+        def __init__(self):
+            super().__init__()
+            chans = (in_channels,) + tuple(nbase)
+            self.down = nn.ModuleList([ResDown(chans[i], chans[i + 1]) for i in range(len(nbase))])
+            self.pool = nn.MaxPool2d(2, 2)
+            ups = []
+            for i in range(len(nbase) - 1, -1, -1):
+                cin = nbase[min(i + 1, len(nbase) - 1)]
+                ups.append(ResUp(cin, nbase[i], nbase[-1]))
+            self.up = nn.ModuleList(ups)
+            self.upsample = nn.Upsample(scale_factor=2, mode="nearest")
+            self.out = nn.Sequential(nn.BatchNorm2d(nbase[0], eps=1e-5), nn.ReLU(inplace=True), nn.Conv2d(nbase[0], 3, 1))
+
+        def forward(self, x):
+            feats = []
+            for i, blk in enumerate(self.down):
+                x = blk(self.pool(x) if i > 0 else x)
+                feats.append(x)
+            style = feats[-1].mean(dim=(2, 3))
+            style = style / (style.pow(2).sum(dim=1, keepdim=True).sqrt() + 1e-6)
+            x = self.up[0](feats[-1], feats[-1], style)
+            for j, blk in enumerate(self.up[1:], start=1):
+                x = blk(self.upsample(x), feats[-1 - j], style)
+            return self.out(x)
+
+    g = torch.Generator().manual_seed(seed)
+    net = CPnetStandIn()
+    with torch.no_grad():
+        for p in net.parameters():
+            if p.dim() > 1:
+                p.copy_(torch.randn(p.shape, generator=g) / float(np.sqrt(p[0].numel())))  # fan-in scaling
+    return net.eval()
+
+
+def prepare_network(net, device, dtype="bf16"):
+    """Move a flow network to the GPU in the compute dtype (bf16 unless told otherwise), channels-last."""
+    torch = _torch()
+    dt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[dtype]
+    return net.to(device=device, dtype=dt, memory_format=torch.channels_last).eval(), dt
+
+
+def forward_flops(net, x) -> int:
+    """FLOPs of one forward pass on ``x`` (torch.utils.flop_counter: 2 x multiply-accumulates of the convolutions and
+    linear layers -- the MFMA work; SURVEY.md 8(d) prescribes this counter)."""
+    torch = _torch()
+    from torch.utils.flop_counter import FlopCounterMode
+
+    with torch.no_grad(), FlopCounterMode(display=False) as fc:
+        net(x)
+    return int(fc.get_total_flops())
+
+
+def tensor_as_device_array(t, ctx: Context) -> DeviceArray:
+    """A contiguous CUDA tensor's memory as a DeviceArray of ``ctx`` (no copy; the tensor must outlive the view and
+    the caller orders the streams)."""
+    if not t.is_contiguous():
+        raise ValueError("tensor must be contiguous")
+    torch = _torch()
+    np_dtype = {torch.float32: np.float32, torch.int32: np.int32, torch.uint8: np.uint8, torch.float64: np.float64}[t.dtype]
+    return DeviceArray(ctx, t.data_ptr(), tuple(t.shape), np_dtype, base=t)
+
+
+def flows_to_masks(flows, cellprob_threshold: float = 0.0, niter: int | None = None, min_size: int = 15,
+                   ctx: Context | None = None, max_seeds: int = 16384):
+    """``(N, 3, H, W)`` float32 network output (dY, dX, cellprob) -- a CUDA tensor or a numpy array -- -> (int32
+    labels (N, H, W) DeviceArray, counts (N,) DeviceArray).  ``niter`` defaults to Cellpose's 200."""
+    ctx = ctx or get_context()
+    niter = 200 if niter is None else int(niter)
+    if isinstance(flows, np.ndarray):
+        f = np.ascontiguousarray(flows, dtype=np.float32)
+        d = ctx.asarray(f)
+        N, _, H, W = f.shape
+    else:
+        torch = _torch()
+        t = flows.detach().to(torch.float32).contiguous()
+        torch.cuda.current_stream(t.device).synchronize()  # the network ran on torch's stream, the kernels run on ctx's
+        d = tensor_as_device_array(t, ctx)
+        N, _, H, W = t.shape
+    if d.shape[1] != 3:
+        raise ValueError(f"expected (N, 3, H, W) flows, got {d.shape}")
+    # (N, 3, H, W): planes 0..1 of every image are the flows, plane 2 the probability -- two strided views cannot be
+    # expressed as DeviceArrays, so the three maps of each image are addressed per image
+    labels = ctx.empty((N, H, W), np.int32)
+    counts = ctx.empty((N,), np.int32)
+    for i in range(N):
+        img = d[i]
+        hipops.cellpose_masks(img[0:2], img[2], cellprob_threshold, niter, min_size, out=labels[i:i + 1].reshape(H, W),
+                              count=counts[i:i + 1], max_seeds=max_seeds)
+    return labels, counts
+
+
+def segment_image(net, image: np.ndarray, device, compute_dtype, *, cellprob_threshold=0.0, niter=None, batch_size=8,
+                  ctx: Context | None = None) -> np.ndarray:
+    """One ``([C], H, W)`` image -> int64 labels through ``net`` + the HIP post-processing.  The image is padded to a
+    multiple of 16 (four 2x poolings) by edge replication and the result cropped back."""
+    torch = _torch()
+    a = np.asarray(image, dtype=np.float32)
+    if a.ndim == 2:
+        a = a[None]
+    if a.ndim != 3:
+        raise ValueError(f"expected an image of shape ([channel], height, width), got {np.shape(image)}")
+    C, H, W = a.shape
+    ph, pw = (-H) % 16, (-W) % 16
+    if ph or pw:
+        a = np.pad(a, ((0, 0), (0, ph), (0, pw)), mode="edge")
+    x = torch.from_numpy(a[None]).to(device=device, dtype=compute_dtype).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        y = net(x)
+    y = y[:, :, :H, :W].to(torch.float32).contiguous()
+    labels, counts = flows_to_masks(y, cellprob_threshold, niter, ctx=ctx)
+    c = int(counts.numpy()[0])
+    if c < 0:
+        raise RuntimeError("the flow field produced more seeds than the post-processing's capacity")
+    return labels.numpy()[0].astype(np.int64)

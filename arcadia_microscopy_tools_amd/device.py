@@ -224,14 +224,14 @@ class DeviceArray:
                 i += self.shape[0]
             if not 0 <= i < self.shape[0]:
                 raise IndexError(idx)
-            v = DeviceArray(self.ctx, self.ptr + i * inner, self.shape[1:], self.dtype, base=self._base or self)
+            v = DeviceArray(self.ctx, self.ptr + i * inner, self.shape[1:], self.dtype, base=self._base if self._base is not None else self)
         elif isinstance(idx, slice):
             start, stop, step = idx.indices(self.shape[0])
             if step != 1:
                 raise IndexError("only contiguous slices of the leading axis are device views")
             n = max(0, stop - start)
             v = DeviceArray(self.ctx, self.ptr + start * inner, (n,) + self.shape[1:], self.dtype,
-                            base=self._base or self)
+                            base=self._base if self._base is not None else self)
         else:
             raise IndexError("DeviceArray supports int or slice indexing of the leading axis only")
         v.is_bool = self.is_bool
@@ -246,7 +246,7 @@ class DeviceArray:
             return self
         if ctx.device != self.ctx.device:
             raise ValueError(f"cannot bind an array of device {self.ctx.device} to a context of device {ctx.device}")
-        v = DeviceArray(ctx, self.ptr, self.shape, self.dtype, base=self._base or self)
+        v = DeviceArray(ctx, self.ptr, self.shape, self.dtype, base=self._base if self._base is not None else self)
         v.is_bool = self.is_bool
         return v
 
@@ -255,7 +255,7 @@ class DeviceArray:
             shape = tuple(shape[0])
         if int(np.prod(shape, dtype=np.int64)) != self.size:
             raise ValueError("cannot reshape DeviceArray: size mismatch")
-        v = DeviceArray(self.ctx, self.ptr, shape, self.dtype, base=self._base or self)
+        v = DeviceArray(self.ctx, self.ptr, shape, self.dtype, base=self._base if self._base is not None else self)
         v.is_bool = self.is_bool
         return v
 

@@ -701,6 +701,25 @@ def regionprops_intensity(labels: DeviceArray, intensity: DeviceArray, max_label
     return o
 
 
+def cellpose_masks(dP: DeviceArray, cellprob: DeviceArray, cellprob_threshold: float = 0.0, niter: int = 200,
+                   min_size: int = 15, max_size_fraction: float = 0.4, max_seeds: int = 16384, out=None, count=None):
+    """Cellpose's flow -> mask post-processing on the device (include/amt_hip.h ``amt_cellpose_masks``; parity
+    unpinned): ``dP`` (..., 2, Y, X) float32 flows (dY, dX), ``cellprob`` (..., Y, X) float32 -> (int32 labels, counts).
+    A plane that produces more than ``max_seeds`` seeds reports count -1."""
+    ctx = dP.ctx
+    if dP.dtype != np.float32 or cellprob.dtype != np.float32:
+        raise TypeError("cellpose_masks expects float32 flows and cell probabilities")
+    n, H, W = _planes(cellprob)
+    if dP.ndim < 3 or dP.shape[-3] != 2 or dP.shape[-2:] != cellprob.shape[-2:] or dP.size != 2 * cellprob.size:
+        raise ValueError(f"dP must be (..., 2, Y, X) matching cellprob (..., Y, X); got {dP.shape} and {cellprob.shape}")
+    o = _out(ctx, out, cellprob.shape, np.int32)
+    c = _out(ctx, count, (n,), np.int32)
+    _hip.check(_lib().amt_cellpose_masks(ctx.handle, dP.ptr, cellprob.ptr, o.ptr, c.ptr, n, H, W,
+                                         float(cellprob_threshold), int(niter), int(min_size), float(max_size_fraction),
+                                         int(max_seeds)), "amt_cellpose_masks")
+    return o, c
+
+
 def label_bboxes(labels: DeviceArray, max_label: int) -> np.ndarray:
     """(nplanes, max_label, 4) int32 {min row, min col, max row, max col}, inclusive; absent labels have max < min."""
     ctx = labels.ctx

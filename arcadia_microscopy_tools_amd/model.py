@@ -11,7 +11,14 @@ semantics of ``batch_segment`` (warning + ``None``), and adds a ``backend`` swit
       30 px); the Cellpose-specific thresholds are validated for API parity but do not apply.
   backend="cellpose": delegates to ``cellpose.models.CellposeModel`` exactly like the reference when that
       package and its weights are available (PyTorch-ROCm device selection is unchanged: ``torch.cuda`` is
-      the ROCm device); raises ``RuntimeError`` otherwise.
+      the ROCm device).  Without the package, a flow network given as ``network=`` (any ``torch.nn.Module`` mapping
+      (N, C, H, W) images to (N, 3, H, W) = dY, dX, cellprob -- e.g. a locally stored checkpoint) runs in bf16
+      through PyTorch-ROCm and its output goes through the HIP flow -> mask post-processing
+      (``cellpose_hip.flows_to_masks``; restated from the published algorithm, parity unpinned); with neither,
+      ``RuntimeError`` as before.
+  backend="cellpose-hip": always the ``network=`` + HIP post-processing route (``network="standin"`` builds the
+      random-weight architectural stand-in of ``cellpose_hip.make_standin`` -- for throughput measurements only,
+      its masks mean nothing).
 """
 from __future__ import annotations
 
@@ -52,12 +59,17 @@ class SegmentationModel:
     backend: str = "classical"
     sigma: float = 2.0
     opening_radius: int = 2
+    network: Any = field(default=None, repr=False)
+    compute_dtype: str = "bf16"
     _model: Any = field(default=None, init=False, repr=False)
+    _net: Any = field(default=None, init=False, repr=False)
 
     def __post_init__(self) -> None:
-        if self.backend not in ("classical", "cellpose"):
-            raise ValueError(f"backend must be 'classical' or 'cellpose', got '{self.backend}'")
-        if self.device is None and self.backend == "cellpose":
+        if self.backend not in ("classical", "cellpose", "cellpose-hip"):
+            raise ValueError(f"backend must be 'classical', 'cellpose' or 'cellpose-hip', got '{self.backend}'")
+        if self.backend == "cellpose-hip" and self.network is None:
+            raise ValueError("backend 'cellpose-hip' needs network= (a torch.nn.Module, or 'standin')")
+        if self.device is None and self.backend in ("cellpose", "cellpose-hip"):
             self.device = self.find_best_available_device()
 
     # -- parameters (R/model.py:80-132) ---------------------------------------------------------------
@@ -114,6 +126,33 @@ class SegmentationModel:
                 raise RuntimeError(f"Failed to load Cellpose model: {e}") from e
         return self._model
 
+    # -- flow network + HIP post-processing ---------------------------------------------------------------
+    def _use_network(self) -> bool:
+        """backend 'cellpose-hip', or backend 'cellpose' without the cellpose package but with a network."""
+        if self.backend == "cellpose-hip":
+            return True
+        if self.backend == "cellpose" and self.network is not None:
+            import importlib.util
+
+            return importlib.util.find_spec("cellpose") is None
+        return False
+
+    def _flow_network(self):
+        if self._net is None:
+            from . import cellpose_hip
+
+            net = cellpose_hip.make_standin() if isinstance(self.network, str) and self.network == "standin" else self.network
+            self._net = cellpose_hip.prepare_network(net, self.device, self.compute_dtype)
+        return self._net
+
+    def _segment_network(self, intensities: np.ndarray, params: CellposeParams) -> Int64Array:
+        from . import cellpose_hip
+
+        net, dt = self._flow_network()
+        return cellpose_hip.segment_image(net, intensities, self.device, dt,
+                                          cellprob_threshold=params["cellprob_threshold"], niter=params["niter"],
+                                          batch_size=params["batch_size"])
+
     # -- classical backend ------------------------------------------------------------------------------
     def _segment_classical(self, intensities: np.ndarray, params: CellposeParams) -> Int64Array:
         from . import hipops
@@ -157,13 +196,50 @@ class SegmentationModel:
             cell_diameter_px, flow_threshold, cellprob_threshold, num_iterations, batch_size
         )
         try:
-            if self.backend == "cellpose":
-                mask, *_ = self.cellpose_model.eval(x=intensities, **params, **cellpose_kwargs)
-            else:
-                mask = self._segment_classical(intensities, params)
+            mask = self._segment_one(intensities, params, cellpose_kwargs)
         except Exception as e:
             raise RuntimeError(f"Cellpose segmentation failed: {e}") from e
         return mask.astype(np.int64)
+
+    def _segment_one(self, intensities, params: CellposeParams, cellpose_kwargs) -> np.ndarray:
+        if self._use_network():
+            return self._segment_network(intensities, params)
+        if self.backend == "cellpose":
+            mask, *_ = self.cellpose_model.eval(x=intensities, **params, **cellpose_kwargs)
+            return mask
+        return self._segment_classical(intensities, params)
+
+    def _batch_classical(self, images, params: CellposeParams):
+        """All images of one shape through ``FovSegmenter`` in ONE batch of launches (the per-image loop costs a
+        host round trip per image); None if the batch does not qualify (mixed shapes / dtypes, 3-D inputs)."""
+        from .device import get_context
+        from .segment import FovSegmenter
+
+        arrs = []
+        for im in images:
+            a = np.asarray(im)
+            if a.ndim == 3:
+                a = a[0]
+            if a.ndim != 2 or a.dtype not in (np.uint8, np.uint16):
+                return None
+            arrs.append(a.astype(np.uint16, copy=False))
+        if not arrs or any(a.shape != arrs[0].shape for a in arrs):
+            return None
+        H, W = arrs[0].shape
+        ctx = get_context()
+        min_distance = max(1, int(round(params["diameter"] / 6.0)))
+        seg = FovSegmenter(len(arrs), 1, H, W, sigma=self.sigma, radius=self.opening_radius, min_distance=min_distance,
+                           max_cells=max(4096, (H * W) // 64), dapi_index=0, ctx=ctx, props=False, fused=False)
+        seg.run_c3(ctx.asarray(np.stack(arrs)[:, None]))
+        nm = seg.nmarkers.numpy()
+        if (nm < 0).any() or (nm > seg.max_cells).any():
+            return None
+        # segment() keeps edge cells (clear_border belongs to SegmentationMask): relabel the watershed image itself
+        from . import hipops
+
+        labels, _ = hipops.relabel_sequential(seg.ws, seg.max_cells)
+        out = labels.numpy().astype(np.int64)
+        return [out[i] for i in range(len(arrs))]
 
     def batch_segment(self, intensities_batch: Sequence[Float64Array], cell_diameter_px: float | None = None,
                       flow_threshold: float | None = None, cellprob_threshold: float | None = None,
@@ -175,6 +251,13 @@ class SegmentationModel:
             cell_diameter_px, flow_threshold, cellprob_threshold, num_iterations, batch_size
         )
         masks: list[Int64Array | None] = []
+        if self.backend == "classical" and len(intensities_batch) > 1:
+            try:
+                done = self._batch_classical(intensities_batch, params)
+            except Exception:
+                done = None  # fall back to the per-image loop, which reports failures image by image
+            if done is not None:
+                return done
         iterator = enumerate(intensities_batch)
         if show_progress:
             try:
@@ -185,10 +268,7 @@ class SegmentationModel:
                 pass
         for i, intensities in iterator:
             try:
-                if self.backend == "cellpose":
-                    mask, *_ = self.cellpose_model.eval(x=intensities, **params, **cellpose_kwargs)
-                else:
-                    mask = self._segment_classical(intensities, params)
+                mask = self._segment_one(intensities, params, cellpose_kwargs)
                 masks.append(mask.astype(np.int64))
             except Exception as e:
                 warnings.warn(

@@ -146,7 +146,8 @@ def parse_args():
     ap.add_argument("--unique", type=int, default=8,
                     help="distinct synthetic FOVs generated per GPU (host-side generation costs ~0.5 s each); the "
                          "batch cycles through them")
-    ap.add_argument("--workload", choices=["c3", "c2", "prep", "filters"], default="c3")
+    ap.add_argument("--workload", choices=["c3", "c2", "prep", "filters", "c5"], default="c3")
+    ap.add_argument("--tiles", type=int, default=8, help="c5: 2 x 1024 x 1024 tiles per step (the network's batch)")
     ap.add_argument("--cpu-fovs", type=int, default=4, help="FOVs timed through the single-thread CPU oracle")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N > 1 without the per-plate feature-table exchange")
@@ -372,6 +373,139 @@ def run_ops(args, json_fd):
 
 
 # ------------------------------------------------------------------------------------------------------
+# config 5: Cellpose-style network forward (bf16, MFMA, PyTorch-ROCm) + HIP flow -> mask post-processing
+# ------------------------------------------------------------------------------------------------------
+MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 (G/MI355X_MICROARCH.md: ~2.5 PF; the 5 PF headline includes 2:1 sparsity)
+
+
+def run_c5(args, json_fd):
+    """One step = forward pass of the RANDOM-WEIGHT architectural stand-in of Cellpose's published U-Net
+    (cellpose_hip.make_standin; the real weights are fetched from the network and are unobtainable offline) on
+    --tiles tiles of 2 x 1024 x 1024 in bf16, then the HIP post-processing of as many flow fields.  A random network's
+    output is not a flow field, so the post-processing runs on SYNTHETIC flow fields of the same shape
+    (oracle.cellpose_dynamics.synthetic_flows: disks with centre-pointing flows, ~1,200 per tile) that stay resident
+    on the device; both halves are inside the timed region.  The roofline object is the forward pass against the
+    dense bf16 MFMA peak (FLOPs from torch.utils.flop_counter, time from HIP events on torch's stream)."""
+    import torch
+
+    from arcadia_microscopy_tools_amd import cellpose_hip as ch
+    from arcadia_microscopy_tools_amd import hipops
+    from arcadia_microscopy_tools_amd.device import Context, set_default_device
+    from oracle import cellpose_dynamics as cd
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    set_default_device(local_rank)
+    ctx = Context(local_rank)
+    T, S = args.tiles, 1024
+    # let MIOpen time its convolution algorithms once per shape (the default heuristic pick was 1.5-2x slower here)
+    torch.backends.cudnn.benchmark = os.environ.get("AMT_C5_MIOPEN_FIND", "1") == "1"
+    net, dt = ch.prepare_network(ch.make_standin(), dev, "bf16")
+    x = torch.randn(T, 2, S, S, device=dev, dtype=dt)
+    if os.environ.get("AMT_C5_LAYOUT", "nhwc") == "nhwc":
+        x = x.contiguous(memory_format=torch.channels_last)
+    else:
+        net = net.to(memory_format=torch.contiguous_format)
+    flops = ch.forward_flops(net, x)
+    t0 = time.perf_counter()
+    nuniq = max(1, min(args.unique, T, 2))
+    syn = [cd.synthetic_flows((S, S), 1200, seed=100 * rank + i) for i in range(nuniq)]
+    dP = ctx.asarray(np.stack([syn[i % nuniq][0] for i in range(T)]))
+    pr = ctx.asarray(np.stack([syn[i % nuniq][1] for i in range(T)]))
+    gen_s = time.perf_counter() - t0
+    labels = ctx.empty((T, S, S), np.int32)
+    counts = ctx.empty((T,), np.int32)
+    log(f"rank {rank}: stand-in network {sum(p.numel() for p in net.parameters()) / 1e6:.2f} M parameters, "
+        f"{flops / T / 1e9:.1f} GFLOP per tile; {nuniq} synthetic flow fields in {gen_s:.1f}s")
+
+    def step():
+        with torch.no_grad():
+            y = net(x)
+        hipops.cellpose_masks(dP, pr, 0.0, 200, out=labels, count=counts)
+        return y
+
+    def sync():
+        torch.cuda.synchronize()
+        ctx.synchronize()
+
+    for _ in range(max(1, args.warmup)):
+        step()
+    sync()
+    if world > 1:
+        dist.barrier()
+        sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    if world > 1:
+        dist.barrier()
+        sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    # forward pass alone (HIP events on torch's current stream), post-processing alone (HIP events on ctx's stream)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fwd = []
+    for _ in range(5):
+        e0.record()
+        with torch.no_grad():
+            net(x)
+        e1.record()
+        e1.synchronize()
+        fwd.append(e0.elapsed_time(e1))
+    fwd_ms = float(np.median(fwd))
+    tm = ctx.timer()
+    post = []
+    for _ in range(3):
+        tm.start()
+        hipops.cellpose_masks(dP, pr, 0.0, 200, out=labels, count=counts)
+        tm.stop()
+        ctx.synchronize()
+        post.append(tm.elapsed_ms())
+    post_ms = float(np.median(post))
+    nmask = counts.numpy()
+    if (nmask < 0).any():
+        raise RuntimeError("the post-processing ran out of seed capacity")
+    if rank == 0:
+        achieved = flops / (fwd_ms * 1e-3) / 1e12
+        out = {
+            "metric": "tiles/sec (2x1024^2) Cellpose-style forward (bf16) + HIP flow->mask post-processing",
+            "value": world * T * args.steps / elapsed, "unit": "tiles/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {
+                "workload": "configs[4]: U-Net forward on 2-channel 1024x1024 tiles (bf16 MFMA, PyTorch-ROCm) + flow->mask "
+                            "post-processing in HIP",
+                "network": "random-weight stand-in of Cellpose's published residual U-Net (6.6 M parameters); real "
+                           "weights are unobtainable offline -- throughput only, no accuracy claim",
+                "tiles_per_gpu_per_step": T, "tile_shape": [2, S, S], "niter": 200,
+                "postprocessing_input": "synthetic flow fields (~1,200 disks per tile), resident on the device",
+                "masks_per_tile_mean": float(nmask.mean()),
+            },
+            "roofline": {"bound": "mfma", "kernel": "network forward (MIOpen / hipBLASLt convolutions via PyTorch-ROCm)",
+                         "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": None,
+                         "flops_per_launch": flops, "launch_ms": fwd_ms,
+                         "postprocessing_ms_per_step": post_ms, "postprocessing_ms_per_tile": post_ms / T},
+            "host_gen_s": gen_s,
+        }
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------------
 def main():
     args = parse_args()
     launch_ranks_if_needed(args)
@@ -385,6 +519,8 @@ def main():
             print("bench.py: --workload prep/filters are single-GPU lines", file=sys.stderr)
             sys.exit(2)
         return run_ops(args, json_fd)
+    if args.workload == "c5":
+        return run_c5(args, json_fd)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

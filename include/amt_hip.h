@@ -340,6 +340,19 @@ int amt_borders_find(amt_ctx* ctx, const int32_t* labels, int H, int W, int nlab
 int amt_borders_emit(amt_ctx* ctx, const int32_t* labels, int H, int W, int nlab, const int32_t* boxes_dev,
                      const int32_t* info_dev, const int64_t* poff_dev, int32_t* points_dev);
 
+/* ---- Cellpose post-processing: flows + cell probability -> labels (BASELINE configs[4]; the reference reaches it
+ * through CellposeModel.eval, R/model.py:206-215, :270-290).  Restated from the published algorithm (cellpose
+ * dynamics: follow the flow for niter Euler steps with bilinear sampling, histogram the end points, seeds = 5 x 5
+ * maxima with more than 10 pixels, five rounds of 3 x 3 growth over bins with more than 2 pixels, labels by end point,
+ * masks above max_size_fraction of the image or below min_size dropped, renumbered in raster order); the flow-error
+ * filter and hole filling are not part of this entry point.  PARITY UNPINNED: cellpose is not available offline and the
+ * reference holds no vector for it (oracle: oracle/cellpose_dynamics.py).
+ *   dP = nplanes x 2 x H x W float32 (dY, dX), cellprob = nplanes x H x W float32, labels_out = nplanes x H x W int32,
+ *   count_dev[plane] = number of masks, or -1 if the plane produced more than max_seeds seeds. */
+int amt_cellpose_masks(amt_ctx* ctx, const float* dP, const float* cellprob, int32_t* labels_out, int32_t* count_dev,
+                       int nplanes, int H, int W, float cellprob_threshold, int niter, int min_size,
+                       float max_size_fraction, int max_seeds);
+
 /* ---- channel overlay: R/blending.py:116-226 (create_overlay / overlay_channels) ------------------------
  * out_rgb = H x W x 3 float64 (interleaved).  background and every layer are H x W float64 planes on the device
  * (values outside [0, 1] are clipped, as the reference does).  layers_host = nlayers device pointers;
