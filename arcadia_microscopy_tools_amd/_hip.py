@@ -108,6 +108,8 @@ _SIGS = {
     "amt_regionprops": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int]),
     "amt_regionprops_intensity_u16": (c_int, [_P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int]),
     "amt_regionprops_full_u16": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int]),
+    "amt_regionprops_intensity_f64": (c_int, [_P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int]),
+    "amt_convolve_axis0": (c_int, [_P, _P, c_int, c_double, _P, c_int, c_int, c_int, _P, c_int, c_int, c_double]),
     "amt_max_i32": (c_int, [_P, _P, _P, c_int, c_size_t]),
     "amt_pack_plate_rows": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_int, _P, c_size_t, _P]),
     "amt_label_bboxes": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int]),

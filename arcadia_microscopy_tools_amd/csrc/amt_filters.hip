@@ -699,6 +699,35 @@ __global__ void sub_inplace_kernel(double* __restrict__ a, const double* __restr
     for (; i < n; i += stride) a[i] = a[i] - b[i];
 }
 
+// One axis of an n-D separable filter: the array is viewed as nplanes x L x inner, the filter runs along L (scipy
+// filters the axes of an n-D image one after the other, leading axes first; the last two axes go through amt_gaussian).
+extern "C" int amt_convolve_axis0(amt_ctx* ctx, const void* in, int in_dtype, double scale, double* out, int nplanes, int L,
+                                  int inner, const double* weights, int radius, int mode, double cval) {
+    AMT_TRY(amt_set_device(ctx));
+    AMT_TRY(check_gauss_args(in, in_dtype, out, nplanes, L, inner, weights, radius));
+    AMT_REQUIRE(radius >= 1, "convolve_axis0: radius must be >= 1");
+    AMT_REQUIRE((const void*)in != (const void*)out, "convolve_axis0: in-place operation is not supported");
+    if (nplanes == 0) return AMT_OK;
+    const int r = radius;
+    size_t wbytes = amt_align((2 * r + 1) * sizeof(double));
+    AMT_TRY(amt_arena_begin(ctx, wbytes));
+    double* wdev = (double*)amt_arena_take(ctx, wbytes);
+    AMT_TRY(amt_param_upload(ctx, wdev, weights, (2 * r + 1) * sizeof(double)));
+    const size_t esz = in_dtype == AMT_U16 ? 2 : 8;
+    int TH = 128;
+    while (TH > 32 && ((size_t)(TH + 2 * r) * 64 * esz + (size_t)(TH + 2 * r)) > 96 * 1024) TH >>= 1;
+    const size_t smem0 = (size_t)(TH + 2 * r) * 64 * esz + 8 + (size_t)(2 * r + 1) * 8 + (size_t)(TH + 2 * r);
+    dim3 g0((inner + 63) / 64, (L + TH - 1) / TH, nplanes);
+    if (in_dtype == AMT_U16)
+        hipLaunchKernelGGL((conv_v8_kernel<uint16_t>), g0, dim3(256), smem0, ctx->stream, (const uint16_t*)in, scale, out, L,
+                           inner, wdev, r, mode, cval, TH, (size_t)L * inner);
+    else
+        hipLaunchKernelGGL((conv_v8_kernel<double>), g0, dim3(256), smem0, ctx->stream, (const double*)in, 1.0, out, L, inner,
+                           wdev, r, mode, cval, TH, (size_t)L * inner);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+
 extern "C" int amt_dog(amt_ctx* ctx, const void* in, int in_dtype, double scale, double* out, int nplanes, int H,
                        int W, const double* w_lo, int r_lo, const double* w_hi, int r_hi, int mode, double cval) {
     AMT_TRY(amt_set_device(ctx));

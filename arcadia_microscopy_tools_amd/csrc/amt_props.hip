@@ -753,6 +753,86 @@ __global__ void __launch_bounds__(256) bbox_init_kernel(int* __restrict__ bbox, 
     }
 }
 
+// ---- intensity statistics of float64 images (R/masks.py:319-323 accepts any 2-D ndarray as intensity image) -------
+// One wave per label over its bounding box, two sweeps as np.mean / np.std make them: the mean first, then the mean
+// of the squared deviations (population std).  float64 sums depend on the order of addition: results
+// agree with numpy's pairwise sums to ~1e-15 relative, not bit for bit (the uint16 entry point is exact).
+__global__ void __launch_bounds__(64) rp_intensity_f64_kernel(const int* __restrict__ labels, const int* __restrict__ bbox,
+                                                              const double* __restrict__ inten, int C,
+                                                              double* __restrict__ itable, int H, int W, int max_label) {
+    const int plane = blockIdx.y, l = blockIdx.x, lane = threadIdx.x;
+    const size_t li = (size_t)plane * max_label + l;
+    const int y0 = bbox[li * 4 + 0], x0 = bbox[li * 4 + 1], y1 = bbox[li * 4 + 2], x1 = bbox[li * 4 + 3];
+    double* out = itable + li * (size_t)C * 4;
+    if (y1 < y0) {
+        for (int i = lane; i < C * 4; i += 64) out[i] = 0.0;
+        return;
+    }
+    const size_t n = (size_t)H * W;
+    const int* lab = labels + (size_t)plane * n;
+    auto wsum = [&](double v) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        return v;
+    };
+    for (int c = 0; c < C; ++c) {
+        const double* img = inten + ((size_t)plane * C + c) * n;
+        double s = 0.0, cnt = 0.0, mn = __longlong_as_double(0x7ff0000000000000ll), mx = -mn;
+        for (int y = y0; y <= y1; ++y)
+            for (int x = x0 + lane; x <= x1; x += 64)
+                if (lab[(size_t)y * W + x] == l + 1) {
+                    const double v = img[(size_t)y * W + x];
+                    s += v;
+                    cnt += 1.0;
+                    mn = v < mn ? v : mn;
+                    mx = v > mx ? v : mx;
+                }
+        s = wsum(s);
+        cnt = wsum(cnt);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double a = __shfl_xor(mn, o), b = __shfl_xor(mx, o);
+            mn = a < mn ? a : mn;
+            mx = b > mx ? b : mx;
+        }
+        const double mean = s / cnt;
+        double q = 0.0;
+        for (int y = y0; y <= y1; ++y)
+            for (int x = x0 + lane; x <= x1; x += 64)
+                if (lab[(size_t)y * W + x] == l + 1) {
+                    const double d = img[(size_t)y * W + x] - mean;
+                    q += d * d;
+                }
+        q = wsum(q);
+        if (lane == 0) {
+            out[c * 4 + 0] = mean;
+            out[c * 4 + 1] = mx;
+            out[c * 4 + 2] = mn;
+            out[c * 4 + 3] = sqrt(q / cnt);
+        }
+    }
+}
+
+extern "C" int amt_regionprops_intensity_f64(amt_ctx* ctx, const int32_t* labels, const double* intensity, int C,
+                                             double* table_dev, int nplanes, int H, int W, int max_label) {
+    AMT_TRY(amt_set_device(ctx));
+    AMT_REQUIRE(labels && intensity && table_dev && nplanes >= 0 && H > 0 && W > 0 && max_label >= 0 && C >= 1,
+                "regionprops_intensity_f64: bad arguments");
+    if (nplanes == 0 || max_label == 0) return AMT_OK;
+    const size_t nlab = (size_t)nplanes * max_label;
+    AMT_TRY(amt_arena_begin(ctx, amt_align(nlab * 16)));
+    int* bbox = arena_take_t<int>(ctx, nlab * 4);
+    hipLaunchKernelGGL(bbox_init_kernel, dim3(amt_grid_for(nlab, 256, 1024)), dim3(256), 0, ctx->stream, bbox, nlab);
+    AMT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(rp_bbox_kernel, dim3((W + 63) / 64, (H + 31) / 32, nplanes), dim3(256), 0, ctx->stream, labels, bbox,
+                       H, W, max_label);
+    AMT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(rp_intensity_f64_kernel, dim3(max_label, nplanes), dim3(64), 0, ctx->stream, labels, bbox, intensity, C,
+                       table_dev, H, W, max_label);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+
 extern "C" int amt_label_bboxes(amt_ctx* ctx, const int32_t* labels, int32_t* bbox_dev, int nplanes, int H, int W,
                                 int max_label) {
     AMT_TRY(amt_set_device(ctx));

@@ -99,10 +99,41 @@ def gaussian(a: DeviceArray, sigma: float, mode: str = "nearest", cval: float = 
     return o
 
 
+def gaussian_nd(a: DeviceArray, sigma: float, mode: str = "nearest", cval: float = 0.0, truncate: float = 4.0,
+                out: DeviceArray | None = None) -> DeviceArray:
+    """``skimage.filters.gaussian`` of an n-D array the way scikit-image / scipy filter it: EVERY axis, leading axes
+    first (SP/_filters.py:412-430), the intermediate kept in float64.  2-D arrays go straight to ``gaussian``."""
+    if a.ndim <= 2:
+        return gaussian(a, sigma, mode, cval, truncate, out=out)
+    ctx = a.ctx
+    if sigma <= 1e-15:
+        return gaussian(a, sigma, mode, cval, truncate, out=out)
+    w = gaussian_weights(sigma, truncate)
+    r = (len(w) - 1) // 2
+    wa, wp = _host_f64(w)
+    scale = 1.0 / 65535 if a.dtype == np.uint16 else 1.0
+    cur, cur_scale = a, scale
+    shape = a.shape
+    for k in range(a.ndim - 2):  # the leading axes, one 1-D pass each
+        outer = int(np.prod(shape[:k], dtype=np.int64)) if k else 1
+        L, inner = int(shape[k]), int(np.prod(shape[k + 1:], dtype=np.int64))
+        nxt = ctx.empty(shape, np.float64)
+        _hip.check(_lib().amt_convolve_axis0(ctx.handle, cur.ptr, _in_code(cur), float(cur_scale), nxt.ptr, outer, L, inner,
+                                             wp, r, _hip.MODES[mode], float(cval)), "amt_convolve_axis0")
+        cur, cur_scale = nxt, 1.0
+    return gaussian(cur, sigma, mode, cval, truncate, scale=cur_scale, out=out)
+
+
 def difference_of_gaussians(a: DeviceArray, low_sigma: float, high_sigma: float, mode: str = "nearest",
                             cval: float = 0.0, truncate: float = 4.0, out: DeviceArray | None = None) -> DeviceArray:
     """``skimage.filters.difference_of_gaussians`` (SK/filters/_gaussian.py:258-290; R/operations.py:91)."""
     ctx = a.ctx
+    if a.ndim > 2:  # n-D: both Gaussians filter every axis (SK/filters/_gaussian.py:284-290), then subtract
+        lo = gaussian_nd(a, low_sigma, mode, cval, truncate)
+        hi = gaussian_nd(a, high_sigma, mode, cval, truncate)
+        o = _out(ctx, out, a.shape, np.float64)
+        _hip.check(_lib().amt_subtract(ctx.handle, lo.ptr, hi.ptr, o.ptr, _hip.F64, a.size), "amt_subtract")
+        return o
     n, H, W = _planes(a)
     o = _out(ctx, out, a.shape, np.float64)
     wl, wh = gaussian_weights(low_sigma, truncate), gaussian_weights(high_sigma, truncate)
@@ -685,19 +716,23 @@ def pack_plate_rows(table: DeviceArray, itable, ncells: DeviceArray, fov_index0:
 
 def regionprops_intensity(labels: DeviceArray, intensity: DeviceArray, max_label: int, out=None) -> DeviceArray:
     """Intensity table (nplanes, max_label, C, 4) = {mean, max, min, std}; ``intensity`` is (..., C, Y, X)
-    uint16 with one (C, Y, X) stack per label plane."""
+    uint16 or float64 with one (C, Y, X) stack per label plane."""
     ctx = labels.ctx
     n, H, W = _planes(labels)
-    if intensity.dtype != np.uint16:
-        raise TypeError("intensity images must be uint16 on the device path")
+    if intensity.dtype not in (np.uint16, np.float64):
+        raise TypeError("intensity images must be uint16 or float64 on the device path")
     if intensity.ndim < 3 or intensity.shape[-2:] != labels.shape[-2:]:
         raise ValueError("intensity must be (..., C, Y, X) matching the label planes")
     C = int(intensity.shape[-3])
     if intensity.size != n * C * H * W:
         raise ValueError("intensity / labels plane count mismatch")
     o = _out(ctx, out, (n, max_label, C, 4), np.float64)
-    _hip.check(_lib().amt_regionprops_intensity_u16(ctx.handle, labels.ptr, intensity.ptr, C, o.ptr, n, H, W,
-                                                    int(max_label)), "amt_regionprops_intensity_u16")
+    if intensity.dtype == np.uint16:  # exact integer accumulation
+        _hip.check(_lib().amt_regionprops_intensity_u16(ctx.handle, labels.ptr, intensity.ptr, C, o.ptr, n, H, W,
+                                                        int(max_label)), "amt_regionprops_intensity_u16")
+    else:  # float64 images: two-sweep mean / std as numpy computes them
+        _hip.check(_lib().amt_regionprops_intensity_f64(ctx.handle, labels.ptr, intensity.ptr, C, o.ptr, n, H, W,
+                                                        int(max_label)), "amt_regionprops_intensity_f64")
     return o
 
 

@@ -181,16 +181,15 @@ class SegmentationMask:
         if self.intensity_image_dict and self.intensity_property_names:
             planes = []
             for channel, img in self.intensity_image_dict.items():
-                if img.dtype == np.uint8:
-                    img = img.astype(np.uint16)
-                if img.dtype != np.uint16:
-                    raise NotImplementedError(
-                        f"Intensity image for '{channel.name}' has dtype {img.dtype}; the device path takes "
-                        "uint8 / uint16 intensity images"
-                    )
-                planes.append(img)
+                planes.append(np.asarray(img))
                 names.append(channel.name)
-            stack = get_context().asarray(np.ascontiguousarray(np.stack(planes)))
+            # uint8 / uint16 images are accumulated exactly (integer sums); any other dtype the reference accepts
+            # (R/masks.py:178-190: "any 2-D ndarray") is measured in float64, as regionprops does
+            if all(p.dtype in (np.uint8, np.uint16) for p in planes):
+                stack = np.stack([p.astype(np.uint16, copy=False) for p in planes])
+            else:
+                stack = np.stack([p.astype(np.float64) for p in planes])
+            stack = get_context().asarray(np.ascontiguousarray(stack))
             inten = hipops.regionprops_intensity(lab, stack, max(k, 1)).numpy()[0][:k]
         return assemble_cell_properties(morph, inten, names, list(self.property_names),
                                         list(self.intensity_property_names))

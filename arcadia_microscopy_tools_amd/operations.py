@@ -6,9 +6,17 @@ reference's signatures, validation, error messages and edge-case results.  Each 
 of these functions makes one upload and one download).  All pixel-sized arithmetic runs in HIP kernels
 behind the C ABI; there is no CPU fallback.
 
-The device path processes 2-D images.  The reference calls scikit-image with whatever array it is given
-(an n-D array is filtered along ALL axes); to treat a (T, Y, X) / (Z, Y, X) stack plane by plane use
+n-D inputs follow the reference, which hands whatever array it is given to numpy / scikit-image: percentiles and
+global thresholds are taken over the WHOLE stack, a difference of Gaussians filters EVERY axis (leading axes first, as
+scipy does), ``crop_to_center`` crops the last two axes.  To treat a (T, Y, X) / (Z, Y, X) stack plane by plane use
 ``Pipeline(parallel=True)``, which maps the operations over axis 0 as the reference does (R/pipeline.py:139-149).
+Still refused for n-D input: the local thresholds (``local`` / ``niblack`` / ``sauvola``).
+
+dtypes: uint8 / uint16 / float64 are computed as the reference computes them (bit-exact).  Other integer
+types are converted on upload: to uint16 when the values fit (exact), otherwise to float64 (exact below 2^53; the
+histogram thresholds then bin like a float image and are refused instead, since scikit-image bins integers by value).
+float32 / float16 are computed in float64: numpy / scikit-image keep float32 arithmetic for them, so results agree
+to float32 rounding (~1e-7 relative), inside the 1e-5 bar for float outputs but not bit for bit.
 """
 from __future__ import annotations
 
@@ -24,27 +32,40 @@ from .typing import BoolArray, Float64Array, ScalarArray
 _SUPPORTED_METHODS = ("otsu", "li", "yen", "isodata", "mean", "minimum", "triangle", "local", "niblack", "sauvola")
 
 
-def _to_device(intensities, what: str):
-    """-> (DeviceArray, was_numpy).  uint8 is widened to uint16 (exact); other dtypes are refused loudly."""
+def _to_device(intensities, what: str, integer_histogram: bool = False):
+    """-> (DeviceArray, was_numpy).  See the module docstring for the dtype rules.  ``integer_histogram``: the caller
+    bins integer images by value (scikit-image's histogram), so integers beyond uint16 cannot be taken."""
     if isinstance(intensities, DeviceArray):
         d = intensities
-        was_numpy = False
-    else:
-        a = np.asarray(intensities)
-        if a.dtype == np.uint8:
-            a = a.astype(np.uint16)
-        elif a.dtype not in (np.uint16, np.float64):
-            raise TypeError(
-                f"{what}: dtype {a.dtype} is not supported on the MI355X path (uint8, uint16 and float64 are)"
+        if d.dtype not in (np.uint16, np.float64):
+            raise TypeError(f"{what}: device arrays must be uint16 or float64, got {d.dtype}")
+        return d, False
+    a = np.asarray(intensities)
+    if a.dtype == np.bool_:
+        a = a.astype(np.uint16)
+    elif a.dtype == np.uint8:
+        a = a.astype(np.uint16)
+    elif np.issubdtype(a.dtype, np.integer) and a.dtype != np.uint16:
+        lo, hi = (int(a.min()), int(a.max())) if a.size else (0, 0)
+        if lo >= 0 and hi <= 65535:
+            a = a.astype(np.uint16)  # exact: same values, same integer histogram
+        elif integer_histogram:
+            raise NotImplementedError(
+                f"{what}: integer image with values in [{lo}, {hi}]: scikit-image bins integers one bin per value, "
+                "which the device path does for the uint16 range only"
             )
-        d = get_context().asarray(a)
-        was_numpy = True
-    if d.ndim != 2:
-        raise NotImplementedError(
-            f"{what}: the device path filters 2-D images, got {d.ndim}-D; map a stack over its first axis with "
-            "Pipeline(parallel=True)"
-        )
-    return d, was_numpy
+        else:
+            a = a.astype(np.float64)
+    elif a.dtype in (np.float32, np.float16):
+        a = a.astype(np.float64)
+    elif a.dtype not in (np.uint16, np.float64):
+        raise TypeError(f"{what}: dtype {a.dtype} is not supported on the MI355X path")
+    return get_context().asarray(np.ascontiguousarray(a)), True
+
+
+def _flat(d: DeviceArray) -> DeviceArray:
+    """The whole array as ONE plane (1, size): statistics over a stack are statistics over all its samples."""
+    return d if d.ndim == 2 else d.reshape(1, d.size)
 
 
 def _result(d: DeviceArray, was_numpy: bool):
@@ -52,7 +73,7 @@ def _result(d: DeviceArray, was_numpy: bool):
 
 
 def _min_max(d: DeviceArray):
-    mm = hipops.percentile(d, (0.0, 100.0)).numpy()[0]
+    mm = hipops.percentile(_flat(d), (0.0, 100.0)).numpy()[0]
     return mm[0], mm[1]
 
 
@@ -76,8 +97,9 @@ def rescale_by_percentile(
     if lo == hi:  # constant image (R/operations.py:43-44)
         const = np.full(d.shape, out_range[0], dtype=float)
         return const if was_numpy else d.ctx.asarray(const)
-    p = hipops.percentile(d, percentile_range)
-    return _result(hipops.rescale(d, p, out_range), was_numpy)
+    f = _flat(d)
+    p = hipops.percentile(f, percentile_range)
+    return _result(hipops.rescale(f, p, out_range).reshape(d.shape), was_numpy)
 
 
 @device_operator
@@ -95,8 +117,10 @@ def subtract_background_dog(
         raise ValueError(f"low_sigma ({low_sigma}) must be smaller than high_sigma ({high_sigma})")
     d, was_numpy = _to_device(intensities, "subtract_background_dog")
     dog = hipops.difference_of_gaussians(d, low_sigma, high_sigma)
-    level = hipops.percentile(dog, percentile)
-    return _result(hipops.sub_clip0(dog, level, out=dog), was_numpy)
+    f = _flat(dog)
+    level = hipops.percentile(f, percentile)
+    hipops.sub_clip0(f, level, out=f)
+    return _result(dog, was_numpy)
 
 
 @device_operator
@@ -212,11 +236,21 @@ def apply_threshold(
             f"Unsupported thresholding method: '{method}'. "
             f"Supported methods: {', '.join(_SUPPORTED_METHODS)}"
         )
-    d, was_numpy = _to_device(intensities, "apply_threshold")
+    d, was_numpy = _to_device(intensities, "apply_threshold",
+                              integer_histogram=method_lower in ("otsu", "yen", "isodata", "triangle", "minimum",
+                                                                 "mean", "li"))
+    shape = d.shape
+    if d.ndim != 2:
+        if method_lower in ("local", "niblack", "sauvola"):
+            raise NotImplementedError(
+                f"apply_threshold: method '{method_lower}' filters every axis of an n-D image in scikit-image; the device "
+                "path does local thresholds on 2-D images -- map a stack over its first axis with Pipeline(parallel=True)"
+            )
+        d = _flat(d)  # global methods: ONE threshold from the histogram of the whole stack
     ctx = d.ctx
     lo, hi = _min_max(d)
     if lo == hi:  # constant image (R/operations.py:201-202)
-        z = np.zeros(d.shape, dtype=bool)
+        z = np.zeros(shape, dtype=bool)
         return z if was_numpy else ctx.asarray(z)
     kw = dict(kwargs)
     if method_lower == "otsu":
@@ -237,4 +271,8 @@ def apply_threshold(
         if isinstance(kw.get("window_size", 15), (tuple, list, np.ndarray)):
             raise NotImplementedError("per-axis window sizes are not supported on the device path")
         mask = hipops.greater_than_image(d, hipops.window_threshold(d, method=method_lower, **kw))
+    if mask.shape != shape:
+        is_bool = mask.is_bool
+        mask = mask.reshape(shape)
+        mask.is_bool = is_bool
     return _result(mask, was_numpy)

@@ -108,6 +108,10 @@ int amt_gaussian(amt_ctx* ctx, const void* in, int in_dtype, double scale, doubl
                  const double* weights, int radius, int mode, double cval, size_t in_plane_stride,
                  double* minmax_dev);
 /* out = G(w_lo) - G(w_hi) of the same converted input (SK/filters/_gaussian.py:284-290). */
+/* One leading axis of an n-D Gaussian (skimage filters EVERY axis of an n-D image, leading axes first,
+ * SP/_filters.py:423-427): the array is nplanes x L x inner, the 1-D filter runs along L; out is float64. */
+int amt_convolve_axis0(amt_ctx* ctx, const void* in, int in_dtype, double scale, double* out, int nplanes, int L, int inner,
+                       const double* weights, int radius, int mode, double cval);
 int amt_dog(amt_ctx* ctx, const void* in, int in_dtype, double scale, double* out, int nplanes, int H, int W,
             const double* w_lo, int r_lo, const double* w_hi, int r_hi, int mode, double cval);
 
@@ -295,6 +299,10 @@ int amt_regionprops_intensity_u16(amt_ctx* ctx, const int32_t* labels, const uin
  * SegmentationMask.cell_properties needs for a (C,Y,X) field of view (R/masks.py:286-326). */
 int amt_regionprops_full_u16(amt_ctx* ctx, const int32_t* labels, const uint16_t* intensity, int C, double* table_dev,
                              double* itable_dev, int nplanes, int H, int W, int max_label);
+/* The same {mean, max, min, std} for float64 intensity images (R/masks.py:178-190, :319-323 accept any 2-D ndarray):
+ * two sweeps per label as np.mean / np.std make them; float64 sums, so agreement with numpy is ~1e-15 relative. */
+int amt_regionprops_intensity_f64(amt_ctx* ctx, const int32_t* labels, const double* intensity, int C, double* table_dev,
+                                  int nplanes, int H, int W, int max_label);
 int amt_max_i32(amt_ctx* ctx, const int32_t* in, int32_t* max_dev, int nplanes, size_t n);
 
 /* ---- per-plate feature rows (the reference's analogue is the list of cell_properties dicts a

@@ -33,10 +33,12 @@ def test_operations_on_fixture(golden):
     # the reference's own range test (RT/test_pipeline.py:267-328): 0 <= result <= 1
     r = rescale_by_percentile(fitc, (2, 98), (0, 1))
     assert r.min() == 0.0 and r.max() == 1.0
-    with pytest.raises(NotImplementedError, match="2-D"):
-        rescale_by_percentile(g["pixels"])
-    with pytest.raises(TypeError, match="float32"):
-        rescale_by_percentile(fitc.astype(np.float32))
+    # a (C, Y, X) stack: ONE percentile pair over all four channels, as np.percentile gives it (R/operations.py:47)
+    px = g["pixels"]
+    p = np.percentile(px, (0, 100))
+    assert np.array_equal(rescale_by_percentile(px), skops.rescale_intensity(px, (p[0], p[1]), (0, 1)))
+    with pytest.raises(TypeError, match="complex"):
+        rescale_by_percentile(fitc.astype(np.complex64))
 
 
 def test_apply_threshold_methods(golden):
@@ -428,3 +430,68 @@ def test_readme_flow(golden):
     mask = SegmentationMask(labels, {DAPI: image.get_channel_intensities(DAPI)}, outline_extractor="skimage")
     feats, outs = mask.cell_properties, mask.cell_outlines
     assert len(outs) == mask.num_cells == len(feats["area"]) and "intensity_mean_dapi" in feats
+
+
+def test_operators_on_stacks_and_other_dtypes():
+    """The four reference operators on (T, Y, X) and (Z, C, Y, X) stacks -- global percentiles / thresholds over the
+    whole stack, Gaussians along every axis (R/operations.py:41-54, :91-97, :122-132, :199-216 hand the n-D array to
+    numpy / scikit-image) -- bit-exact against the oracle; float32 / int32 / int64 inputs; float64 intensity images in
+    cell_properties (R/masks.py:178-190, :319-323)."""
+    from scipy import ndimage as ndi
+
+    from arcadia_microscopy_tools_amd.channels import DAPI, FITC
+    from arcadia_microscopy_tools_amd.masks import SegmentationMask
+    from arcadia_microscopy_tools_amd.operations import (apply_threshold, crop_to_center, rescale_by_percentile,
+                                                        subtract_background_dog)
+    from oracle import regionprops as orp
+    from oracle import skops
+
+    rng = np.random.default_rng(12)
+    t3 = (ndi.gaussian_filter(rng.random((5, 64, 80)), (0.5, 3, 3)) * 40000 + 300).astype(np.uint16)
+    z4 = (ndi.gaussian_filter(rng.random((3, 2, 32, 40)), (0.0, 0.0, 2, 2)) * 20000 + 100).astype(np.uint16)
+    for x in (t3, z4, t3.astype(np.float64) / 7.0):
+        for q, o in (((1, 99), (0, 1)), ((0.1, 99.9), (0, 65535)), ((0, 100), (0, 1))):
+            p = np.percentile(x, q)
+            assert np.array_equal(rescale_by_percentile(x, q, o), skops.rescale_intensity(x, (p[0], p[1]), o)), (x.shape, q)
+        t = skops.threshold_otsu(x)
+        assert np.array_equal(apply_threshold(x, "otsu"), x > t), x.shape
+        assert np.array_equal(apply_threshold(x, "mean"), x > np.mean(x)) or x.dtype == np.float64
+        assert np.array_equal(crop_to_center(x, (20, 30)), x[..., (x.shape[-2] - 20) // 2:(x.shape[-2] - 20) // 2 + 20,
+                                                             (x.shape[-1] - 30) // 2:(x.shape[-1] - 30) // 2 + 30])
+    for x, (lo, hi) in ((t3, (0.6, 3.0)), (z4, (1.0, 2.5)), (t3.astype(np.float64), (0.6, 16.0))):
+        f = skops.img_as_float(x)
+        dog = (ndi.gaussian_filter(f, lo, mode="nearest", truncate=4.0)
+               - ndi.gaussian_filter(f, hi, mode="nearest", truncate=4.0))
+        for pct in (0, 90):
+            ref = np.clip(dog - np.percentile(dog, pct), 0, None)
+            got = subtract_background_dog(x, lo, hi, percentile=pct)
+            assert got.shape == x.shape and np.array_equal(got, ref), (x.shape, lo, hi, pct)
+    with pytest.raises(NotImplementedError, match="local thresholds on 2-D images"):
+        apply_threshold(t3, "sauvola")
+    # other dtypes
+    small = t3[0] // 4
+    for dt in (np.int32, np.int64, np.uint32):
+        assert np.array_equal(rescale_by_percentile(small.astype(dt), (2, 98)), rescale_by_percentile(small, (2, 98)))
+        assert np.array_equal(apply_threshold(small.astype(dt), "otsu"), apply_threshold(small, "otsu"))
+    wide = (t3[0].astype(np.int64) - 30000) * 1000
+    p = np.percentile(wide, (1, 99))
+    assert np.array_equal(rescale_by_percentile(wide, (1, 99)), skops.rescale_intensity(wide, (p[0], p[1]), (0, 1)))
+    with pytest.raises(NotImplementedError, match="one bin per value"):
+        apply_threshold(wide, "otsu")
+    f32 = (t3[1] / 65535.0).astype(np.float32)
+    p32 = np.percentile(f32, (1, 99))
+    ref32 = skops.rescale_intensity(f32.astype(np.float64), (float(p32[0]), float(p32[1])), (0, 1))
+    np.testing.assert_allclose(rescale_by_percentile(f32, (1, 99)), ref32, rtol=1e-5, atol=1e-6)
+    assert rescale_by_percentile(f32, (1, 99)).dtype == np.float64
+    # float64 / float32 intensity images in cell_properties
+    lab = np.zeros((64, 80), np.int64)
+    yy, xx = np.mgrid[0:64, 0:80]
+    lab[(yy - 20) ** 2 + (xx - 25) ** 2 < 90] = 1
+    lab[(yy - 44) ** 2 + (xx - 55) ** 2 < 140] = 2
+    fimg = rng.normal(3.0, 1.0, (64, 80))
+    mask = SegmentationMask(lab, {DAPI: fimg, FITC: fimg.astype(np.float32)})
+    props = mask.cell_properties
+    ref = orp.cell_properties(lab, {"DAPI": fimg, "FITC": fimg.astype(np.float32).astype(np.float64)})
+    for k in ("intensity_mean", "intensity_max", "intensity_min", "intensity_std"):
+        np.testing.assert_allclose(props[f"{k}_dapi"], ref[f"{k}_dapi"], rtol=1e-12, err_msg=k)
+        np.testing.assert_allclose(props[f"{k}_fitc"], ref[f"{k}_fitc"], rtol=1e-12, err_msg=k)
