@@ -101,8 +101,9 @@ def gaussian(a: DeviceArray, sigma: float, mode: str = "nearest", cval: float = 
 
 def gaussian_nd(a: DeviceArray, sigma: float, mode: str = "nearest", cval: float = 0.0, truncate: float = 4.0,
                 out: DeviceArray | None = None) -> DeviceArray:
-    """``skimage.filters.gaussian`` of an n-D array the way scikit-image / scipy filter it: EVERY axis, leading axes
-    first (SP/_filters.py:412-430), the intermediate kept in float64.  2-D arrays go straight to ``gaussian``."""
+    """``skimage.filters.gaussian`` of ONE n-D image the way scikit-image / scipy filter it: EVERY axis, leading axes
+    first (SP/_filters.py:412-430), the intermediate kept in float64 -- unlike ``gaussian``, whose leading axes are
+    independent planes.  2-D arrays go straight to ``gaussian``."""
     if a.ndim <= 2:
         return gaussian(a, sigma, mode, cval, truncate, out=out)
     ctx = a.ctx
@@ -128,12 +129,6 @@ def difference_of_gaussians(a: DeviceArray, low_sigma: float, high_sigma: float,
                             cval: float = 0.0, truncate: float = 4.0, out: DeviceArray | None = None) -> DeviceArray:
     """``skimage.filters.difference_of_gaussians`` (SK/filters/_gaussian.py:258-290; R/operations.py:91)."""
     ctx = a.ctx
-    if a.ndim > 2:  # n-D: both Gaussians filter every axis (SK/filters/_gaussian.py:284-290), then subtract
-        lo = gaussian_nd(a, low_sigma, mode, cval, truncate)
-        hi = gaussian_nd(a, high_sigma, mode, cval, truncate)
-        o = _out(ctx, out, a.shape, np.float64)
-        _hip.check(_lib().amt_subtract(ctx.handle, lo.ptr, hi.ptr, o.ptr, _hip.F64, a.size), "amt_subtract")
-        return o
     n, H, W = _planes(a)
     o = _out(ctx, out, a.shape, np.float64)
     wl, wh = gaussian_weights(low_sigma, truncate), gaussian_weights(high_sigma, truncate)
@@ -142,6 +137,18 @@ def difference_of_gaussians(a: DeviceArray, low_sigma: float, high_sigma: float,
     scale = 1.0 / 65535 if a.dtype == np.uint16 else 1.0
     _hip.check(_lib().amt_dog(ctx.handle, a.ptr, _in_code(a), scale, o.ptr, n, H, W, wlp, (len(wl) - 1) // 2, whp,
                               (len(wh) - 1) // 2, _hip.MODES[mode], float(cval)), "amt_dog")
+    return o
+
+
+def difference_of_gaussians_nd(a: DeviceArray, low_sigma: float, high_sigma: float, mode: str = "nearest",
+                               cval: float = 0.0, truncate: float = 4.0, out: DeviceArray | None = None) -> DeviceArray:
+    """``skimage.filters.difference_of_gaussians`` of ONE n-D image: both Gaussians filter EVERY axis
+    (SK/filters/_gaussian.py:284-290), unlike ``difference_of_gaussians``, whose leading axes are independent planes."""
+    ctx = a.ctx
+    lo = gaussian_nd(a, low_sigma, mode, cval, truncate)
+    hi = gaussian_nd(a, high_sigma, mode, cval, truncate)
+    o = _out(ctx, out, a.shape, np.float64)
+    _hip.check(_lib().amt_subtract(ctx.handle, lo.ptr, hi.ptr, o.ptr, _hip.F64, a.size), "amt_subtract")
     return o
 
 

@@ -116,7 +116,8 @@ def subtract_background_dog(
     if low_sigma >= high_sigma:
         raise ValueError(f"low_sigma ({low_sigma}) must be smaller than high_sigma ({high_sigma})")
     d, was_numpy = _to_device(intensities, "subtract_background_dog")
-    dog = hipops.difference_of_gaussians(d, low_sigma, high_sigma)
+    dog = (hipops.difference_of_gaussians(d, low_sigma, high_sigma) if d.ndim == 2 else
+           hipops.difference_of_gaussians_nd(d, low_sigma, high_sigma))
     f = _flat(dog)
     level = hipops.percentile(f, percentile)
     hipops.sub_clip0(f, level, out=f)
