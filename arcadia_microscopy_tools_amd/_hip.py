@@ -90,6 +90,8 @@ _SIGS = {
     "amt_binary_close": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_int, c_int]),
     "amt_threshold_open_close": (c_int, [_P, _P, c_int, _P, _P, c_int, c_int, c_int, _P, c_int, c_int]),
     "amt_rank_filter": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_double]),
+    "amt_rank_filter_sub": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, c_int,
+                                    c_double]),
     "amt_subtract": (c_int, [_P, _P, _P, _P, c_int, c_size_t]),
     "amt_label": (c_int, [_P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int]),
     "amt_label_sparse": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int]),

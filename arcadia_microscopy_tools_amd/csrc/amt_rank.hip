@@ -11,7 +11,7 @@
 //   median   out[p] = element of rank |S| // 2 of {in[p + s]}
 // Boundary: scipy's `mode` (reflect for grey morphology, nearest for skimage's median).
 // One 256-thread workgroup produces a 16 x 64 tile from an LDS-staged tile with halo.
-#include "amt_common.h"
+#include "amt_internal.h"
 
 constexpr int RT_H = 16, RT_W = 64;
 constexpr int RK_MAX_OFFS = 1024;
@@ -305,6 +305,7 @@ struct mm_params {
     // fields are scalar registers -- a search through hws[] per step was a chain of dependent scalar loads):
     int store_at[8];  // store_at[k] = LDS array (0 = first of arrs) that receives H_k, -1 = H_k is not needed
     int row_arr[15];  // row_arr[dy + ry] = -1 no cell, 0 = the input tile (half-width 0), a + 1 = arrs[a]
+    int row_h[15];    // row_h[dy + ry] = half-width of footprint row dy, -1 = no cell (register kernel)
 };
 
 template <bool ISMAX>
@@ -439,6 +440,191 @@ __global__ void __launch_bounds__(256) mm_u16_kernel(const uint16_t* __restrict_
     }
 }
 
+// ---- the same filter with NO LDS and no barrier: a wave slides down a strip of 62 x 8 columns -------------------
+// Each lane owns 8 consecutive pixels of the row (one 16-byte load; lanes 0 and 63 are halo), the neighbouring groups
+// come from the adjacent lanes by DPP wave shifts, the run minima H_k are built in registers, and every input row r
+// is folded straight into the 2 RY + 1 output rows it belongs to (out[y] gets H_{h(r - y)}[r]): the accumulators of
+// the pending output rows and the rows loaded ahead live in registers whose indices are compile-time constants
+// because the row loop is unrolled by 2 RY + 1.  Rows are requested 2 RY + 1 steps ahead, so a wave keeps ~(2 RY + 1)
+// KiB in flight -- the tile kernel above (load -> barrier -> LDS -> barrier -> store) kept ~15 KiB per CU and ran
+// at 2 TB/s whatever the footprint (tools/mm_probe.py: 244 us per 32 planes for a 1 x 1 footprint).
+__device__ __forceinline__ uint4 mm_lane_left(uint4 v) {
+    return make_uint4((unsigned)amt_lane_left((int)v.x), (unsigned)amt_lane_left((int)v.y),
+                      (unsigned)amt_lane_left((int)v.z), (unsigned)amt_lane_left((int)v.w));
+}
+__device__ __forceinline__ uint4 mm_lane_right(uint4 v) {
+    return make_uint4((unsigned)amt_lane_right((int)v.x), (unsigned)amt_lane_right((int)v.y),
+                      (unsigned)amt_lane_right((int)v.z), (unsigned)amt_lane_right((int)v.w));
+}
+
+// SHAPE: 0 = half-widths read from the kernel arguments (any centred-run footprint), 1 = disk(RY), 2 = rectangle
+// (2 RY + 1 rows of one half-width P.hmax, folded once after the horizontal loop):
+// for the disks every half-width is a compile-time constant, which keeps the 15-fold unrolled body of disk(7)
+// inside the instruction cache (the run-time form compares every footprint row against every k: 72 KiB of code and
+// 2.4 ms per 32 planes for disk(7); the constexpr form ~25 KiB).
+__host__ __device__ constexpr int mm_isqrt(int v) {
+    int r = 0;
+    while ((r + 1) * (r + 1) <= v) ++r;
+    return r;
+}
+__host__ __device__ constexpr int mm_shape_h(int shape, int ry, int dy) {
+    return shape == 1 ? mm_isqrt(ry * ry - dy * dy) : ry;  // disk: x^2 + dy^2 <= ry^2 ; square: ry
+}
+__host__ __device__ constexpr int mm_shape_hmax(int shape, int ry) { return ry; }
+
+__device__ __forceinline__ unsigned mm_swap16(unsigned a) { return __builtin_amdgcn_alignbit(a, a, 16); }
+// two uint16 differences (wrapping, as numpy's uint16 subtraction)
+__device__ __forceinline__ unsigned mm_pk_sub(unsigned a, unsigned b) {
+    mm_u16x2 x, y;
+    __builtin_memcpy(&x, &a, 4);
+    __builtin_memcpy(&y, &b, 4);
+    const mm_u16x2 r = x - y;
+    unsigned o;
+    __builtin_memcpy(&o, &r, 4);
+    return o;
+}
+
+// SUB: the stored value is minuend - result (white top-hat = image - dilation(erosion(image)): no separate subtraction
+// pass); the minuend's rows travel through a register ring of their own, requested as far ahead as the input rows.
+template <bool ISMAX, int RY, int SHAPE, bool SUB>
+__global__ void __launch_bounds__(256) mmr_u16_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int H,
+                                                      int W, mm_params P, int mode, uint16_t cval, int seg_rows,
+                                                      int nstrips, int nsegs, const uint16_t* __restrict__ minuend) {
+    // requires W % 8 == 0, H > 2 RY + 8 and mode in {reflect, nearest, constant} (the host checks): the groups beyond
+    // the left / right image edge are then functions of the neighbouring lane's group and need no loads of their own
+    constexpr int PER = 2 * RY + 1;               // pending output rows
+    constexpr int U = PER * ((8 + PER - 1) / PER);  // unroll factor: a multiple of PER that is >= 8
+    constexpr int D = 8;                          // rows requested ahead (8 KiB per wave in flight), D <= U
+    const int lane = threadIdx.x & 63;
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);  // wave id inside the plane
+    if (wid >= nstrips * nsegs) return;                   // whole waves only: the DPP shifts need all 64 lanes
+    const int strip = wid % nstrips, seg = wid / nstrips;
+    const size_t plane = (size_t)blockIdx.y * H * W;
+    const int xg = strip * 496 - 8 + 8 * lane;  // first column of this lane's group
+    const int y_begin = __builtin_amdgcn_readfirstlane(seg * seg_rows);
+    const int y_end = min(H, y_begin + seg_rows);
+    const bool inside = xg >= 0 && xg + 7 < W;
+    const bool halo_l = xg == -8, halo_r = xg == W;  // the groups just outside the image
+    const bool edge_wave = strip == 0 || strip == nstrips - 1;  // uniform
+    const unsigned ident = ISMAX ? 0u : 0xFFFFFFFFu;
+    const unsigned cv2 = (unsigned)cval | ((unsigned)cval << 16);
+    const unsigned lane_off = (unsigned)(inside ? xg : 0) * 2u;  // byte offset inside a row
+    const char* const in_plane = reinterpret_cast<const char*>(in + plane);
+    const int refl = mode == AMT_MODE_REFLECT;
+    // unconditional load from a boundary-mapped, clamped row (scalar arithmetic, no branches); rows outside the image in
+    // 'constant' mode and groups outside the image are replaced where the value is USED
+    auto load_row = [&](int r) -> uint4 {
+        const int lo = refl ? -r - 1 : 0, hi = refl ? 2 * H - 1 - r : H - 1;
+        int yy = r < 0 ? lo : (r >= H ? hi : r);
+        yy = min(max(yy, 0), H - 1);  // rows requested past the segment's last needed row are never used
+        const char* rowp = in_plane + (size_t)yy * W * 2;
+        return *reinterpret_cast<const uint4*>(rowp + lane_off);
+    };
+    uint4 inreg[U], acc[PER];
+#pragma unroll
+    for (int u = 0; u < D; ++u) inreg[u] = load_row(y_begin - RY + u);
+#pragma unroll
+    for (int u = 0; u < PER; ++u) acc[u] = make_uint4(ident, ident, ident, ident);
+    const bool can_store = lane >= 1 && lane <= 62 && inside;
+    uint16_t* const out_lane = out + plane + (inside ? xg : 0);
+    // minuend row of output row yo = r - RY, requested D steps before that row is stored
+    const char* const sub_plane = reinterpret_cast<const char*>(SUB ? minuend + plane : in);
+    auto load_sub = [&](int yo) -> uint4 {
+        const int yy = min(max(yo, 0), H - 1);
+        return *reinterpret_cast<const uint4*>(sub_plane + (size_t)yy * W * 2 + lane_off);
+    };
+    uint4 subreg[SUB ? U : 1];
+    if (SUB) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) subreg[u % (SUB ? U : 1)] = load_sub(y_begin - 2 * RY + u);
+    }
+    const int hmax = SHAPE == 1 ? mm_shape_hmax(SHAPE, RY) : P.hmax;
+    for (int base = y_begin - RY; base < y_end + RY; base += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = base + u;
+            uint4 cur = inreg[u];
+            inreg[(u + D) % U] = load_row(r + D);
+            uint4 subv = make_uint4(0, 0, 0, 0);
+            if (SUB) {
+                subv = subreg[u % (SUB ? U : 1)];
+                subreg[(u + D) % (SUB ? U : 1)] = load_sub(r - RY + D);
+            }
+            if (mode == AMT_MODE_CONSTANT && (r < 0 || r >= H)) cur = make_uint4(cv2, cv2, cv2, cv2);
+            if (edge_wave) {  // the group beyond the image edge from its inner neighbour
+                const uint4 nr = mm_lane_right(cur), nl = mm_lane_left(cur);
+                if (halo_l) {
+                    if (mode == AMT_MODE_REFLECT) cur = make_uint4(mm_swap16(nr.w), mm_swap16(nr.z), mm_swap16(nr.y), mm_swap16(nr.x));
+                    else if (mode == AMT_MODE_NEAREST) { const unsigned b = (nr.x & 0xFFFFu) | (nr.x << 16); cur = make_uint4(b, b, b, b); }
+                    else cur = make_uint4(cv2, cv2, cv2, cv2);
+                }
+                if (halo_r) {
+                    if (mode == AMT_MODE_REFLECT) cur = make_uint4(mm_swap16(nl.w), mm_swap16(nl.z), mm_swap16(nl.y), mm_swap16(nl.x));
+                    else if (mode == AMT_MODE_NEAREST) { const unsigned b = (nl.w >> 16) | (nl.w & 0xFFFF0000u); cur = make_uint4(b, b, b, b); }
+                    else cur = make_uint4(cv2, cv2, cv2, cv2);
+                }
+            }
+            unsigned p[12];
+            p[4] = cur.x, p[5] = cur.y, p[6] = cur.z, p[7] = cur.w;
+            if (hmax > 0) {
+                const uint4 lf = mm_lane_left(cur), rt = mm_lane_right(cur);
+                p[0] = lf.x, p[1] = lf.y, p[2] = lf.z, p[3] = lf.w;
+                p[8] = rt.x, p[9] = rt.y, p[10] = rt.z, p[11] = rt.w;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) p[i] = p[8 + i] = ident;
+            }
+            unsigned hk[4] = {p[4], p[5], p[6], p[7]};
+            // fold H_k of row r into the output rows y = r - dy whose footprint row dy has half-width k
+            auto fold = [&](int k) {
+#pragma unroll
+                for (int di = 0; di < PER; ++di) {
+                    const int hsel = SHAPE == 1 ? mm_shape_h(1, RY, di - RY) : (SHAPE == 2 ? -2 : P.row_h[di]);
+                    if (hsel != k) continue;
+                    const int j = ((u - (di - RY)) % PER + PER) % PER;
+                    acc[j].x = mm_pk<ISMAX>(acc[j].x, hk[0]);
+                    acc[j].y = mm_pk<ISMAX>(acc[j].y, hk[1]);
+                    acc[j].z = mm_pk<ISMAX>(acc[j].z, hk[2]);
+                    acc[j].w = mm_pk<ISMAX>(acc[j].w, hk[3]);
+                    // the accumulators feed only the (conditional) store: without this the compiler sinks every fold
+                    // into the store's branch and keeps the H_k of the last 2 RY + 1 rows alive instead (256 VGPRs)
+                    asm volatile("" : "+v"(acc[j].x), "+v"(acc[j].y), "+v"(acc[j].z), "+v"(acc[j].w));
+                }
+            };
+            if (SHAPE != 2) fold(0);
+#pragma unroll
+            for (int k = 1; k <= 7; ++k) {
+                if (k > hmax) break;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    unsigned lft, rgt;
+                    if (k & 1) {
+                        const int al = 4 + i - (k + 1) / 2, ar = 4 + i + (k - 1) / 2;
+                        lft = __builtin_amdgcn_alignbit(p[al + 1], p[al], 16);
+                        rgt = __builtin_amdgcn_alignbit(p[ar + 1], p[ar], 16);
+                    } else {
+                        lft = p[4 + i - k / 2];
+                        rgt = p[4 + i + k / 2];
+                    }
+                    hk[i] = mm_pk<ISMAX>(hk[i], mm_pk<ISMAX>(lft, rgt));
+                }
+                if (SHAPE != 2) fold(k);
+            }
+            if (SHAPE == 2) fold(-2);  // every row of a rectangle takes H_hmax
+            // output row r - RY has now seen all its input rows
+            const int yo = r - RY;
+            const int jo = ((u - RY) % PER + PER) % PER;
+            uint4 res = acc[jo];
+            if (SUB) {
+                res.x = mm_pk_sub(subv.x, res.x), res.y = mm_pk_sub(subv.y, res.y);
+                res.z = mm_pk_sub(subv.z, res.z), res.w = mm_pk_sub(subv.w, res.w);
+            }
+            if (yo >= y_begin && yo < y_end && can_store) *reinterpret_cast<uint4*>(out_lane + (size_t)yo * W) = res;
+            acc[jo] = make_uint4(ident, ident, ident, ident);
+        }
+    }
+}
+
 // host side: does the footprint qualify?  (rows are runs centred on the origin, ry <= 7, half-widths <= 7)
 static bool mm_plan(const uint8_t* footprint, int fh, int fw, mm_params* P) {
     const int ry = fh / 2, rx = fw / 2;
@@ -485,14 +671,39 @@ static bool mm_plan(const uint8_t* footprint, int fh, int fw, mm_params* P) {
     for (int k = 0; k < 8; ++k) P->store_at[k] = -1;
     for (int i = 0; i < P->ns; ++i)
         if (P->hws[i] > 0) P->store_at[P->hws[i]] = i - off0;
-    for (int y = 0; y < 15; ++y) P->row_arr[y] = -1;
+    for (int y = 0; y < 15; ++y) P->row_arr[y] = P->row_h[y] = -1;
     for (int y = 0; y < fh; ++y)
-        if (P->sel[y] >= 0) P->row_arr[y] = P->hws[P->sel[y]] == 0 ? 0 : P->sel[y] - off0 + 1;
+        if (P->sel[y] >= 0) {
+            P->row_arr[y] = P->hws[P->sel[y]] == 0 ? 0 : P->sel[y] - off0 + 1;
+            P->row_h[y] = P->hws[P->sel[y]];
+        }
     return P->ns > 0;
 }
 
+// 1 = the register kernel was launched and, if `minuend` was given, stored minuend - result; 0 = not applicable
+static int rank_filter_impl(amt_ctx* ctx, const void* in, void* out, int dtype, int nplanes, int H, int W,
+                            const uint8_t* footprint, int fh, int fw, int op, int mode, double cval,
+                            const void* minuend, int* fused);
+
 extern "C" int amt_rank_filter(amt_ctx* ctx, const void* in, void* out, int dtype, int nplanes, int H, int W,
                                const uint8_t* footprint, int fh, int fw, int op, int mode, double cval) {
+    int fused = 0;
+    return rank_filter_impl(ctx, in, out, dtype, nplanes, H, W, footprint, fh, fw, op, mode, cval, nullptr, &fused);
+}
+
+extern "C" int amt_rank_filter_sub(amt_ctx* ctx, const void* in, const void* minuend, void* out, int dtype, int nplanes,
+                                   int H, int W, const uint8_t* footprint, int fh, int fw, int op, int mode,
+                                   double cval) {
+    AMT_REQUIRE(minuend && minuend != out, "rank_filter_sub: minuend must be given and differ from out");
+    int fused = 0;
+    AMT_TRY(rank_filter_impl(ctx, in, out, dtype, nplanes, H, W, footprint, fh, fw, op, mode, cval, minuend, &fused));
+    if (fused) return AMT_OK;
+    return amt_subtract(ctx, minuend, out, out, dtype, (size_t)nplanes * H * W);  // elementwise: in place is fine
+}
+
+static int rank_filter_impl(amt_ctx* ctx, const void* in, void* out, int dtype, int nplanes, int H, int W,
+                            const uint8_t* footprint, int fh, int fw, int op, int mode, double cval,
+                            const void* minuend, int* fused) {
     AMT_TRY(amt_set_device(ctx));
     AMT_REQUIRE(in && out && footprint && nplanes >= 0 && H > 0 && W > 0, "rank_filter: bad arguments");
     AMT_REQUIRE(in != out, "rank_filter: in-place operation is not supported");
@@ -526,7 +737,73 @@ extern "C" int amt_rank_filter(amt_ctx* ctx, const void* in, void* out, int dtyp
                     const int t = P.row_arr[a];
                     P.row_arr[a] = P.row_arr[b];
                     P.row_arr[b] = t;
+                    const int t2 = P.row_h[a];
+                    P.row_h[a] = P.row_h[b];
+                    P.row_h[b] = t2;
                 }
+            // register kernel (no LDS, rows loaded 2 ry + 1 steps ahead): aligned widths and boundary modes whose
+            // out-of-image columns mirror the edge group (wrap / mirror keep the tile kernel)
+            if ((W & 7) == 0 && W >= 16 && H >= 16 && (mode == AMT_MODE_REFLECT || mode == AMT_MODE_NEAREST || mode == AMT_MODE_CONSTANT) &&
+                getenv("AMT_MM_TILE") == nullptr) {
+                // disks get compile-time half-widths, rectangles one run-time half-width; anything else (crosses,
+                // diamonds, gapped disks) the run-time table, up to 7 rows
+                int shape = 0;
+                {
+                    bool disk = fh == fw, rect = true;
+                    for (int y = 0; y < fh; ++y) {
+                        const int h = P.row_h[y];
+                        if (h != mm_shape_h(1, P.ry, y - P.ry)) disk = false;
+                        if (h != P.hmax) rect = false;
+                    }
+                    shape = rect ? 2 : (disk ? 1 : 0);
+                }
+                const bool sub = minuend != nullptr && op == 1;
+                const int seg_rows = P.ry <= 3 ? 64 : 128;
+                const int nstrips = (W + 495) / 496, nsegs = (H + seg_rows - 1) / seg_rows;
+                dim3 gridr((nstrips * nsegs + 3) / 4, nplanes);
+                bool launched = true;
+#define AMT_MMR_GO(RYV, SH)                                                                                            \
+    do {                                                                                                               \
+        if (op == 0)                                                                                                   \
+            hipLaunchKernelGGL((mmr_u16_kernel<false, RYV, SH, false>), gridr, dim3(256), 0, ctx->stream,              \
+                               (const uint16_t*)in, (uint16_t*)out, H, W, P, mode, (uint16_t)cval, seg_rows, nstrips,  \
+                               nsegs, (const uint16_t*)nullptr);                                                       \
+        else if (!sub)                                                                                                 \
+            hipLaunchKernelGGL((mmr_u16_kernel<true, RYV, SH, false>), gridr, dim3(256), 0, ctx->stream,               \
+                               (const uint16_t*)in, (uint16_t*)out, H, W, P, mode, (uint16_t)cval, seg_rows, nstrips,  \
+                               nsegs, (const uint16_t*)nullptr);                                                       \
+        else                                                                                                           \
+            hipLaunchKernelGGL((mmr_u16_kernel<true, RYV, SH, true>), gridr, dim3(256), 0, ctx->stream,                \
+                               (const uint16_t*)in, (uint16_t*)out, H, W, P, mode, (uint16_t)cval, seg_rows, nstrips,  \
+                               nsegs, (const uint16_t*)minuend);                                                       \
+    } while (0)
+#define AMT_MMR_CASE(RYV)                                       \
+    case RYV:                                                   \
+        if (shape == 1) AMT_MMR_GO(RYV, 1);                     \
+        else if (shape == 2) AMT_MMR_GO(RYV, 2);                \
+        else if (RYV <= 3) AMT_MMR_GO((RYV <= 3 ? RYV : 0), 0); \
+        else launched = false;                                  \
+        break;
+                switch (P.ry) {
+                    AMT_MMR_CASE(0)
+                    AMT_MMR_CASE(1)
+                    AMT_MMR_CASE(2)
+                    AMT_MMR_CASE(3)
+                    AMT_MMR_CASE(4)
+                    AMT_MMR_CASE(5)
+                    AMT_MMR_CASE(6)
+                    AMT_MMR_CASE(7)
+                    default:
+                        launched = false;
+                }
+#undef AMT_MMR_CASE
+#undef AMT_MMR_GO
+                if (launched) {
+                    AMT_LAUNCH_CHECK();
+                    *fused = sub ? 1 : 0;
+                    return AMT_OK;
+                }
+            }
             const int narr = P.ns - (P.hws[0] == 0 ? 1 : 0);
             // 16-row tiles for small footprints (more blocks per CU), 32-row tiles where the halo would dominate
             const int th = P.ry <= 3 ? 16 : 32, tw = 128;

@@ -455,9 +455,12 @@ def white_tophat(a, footprint=None, out=None):
     opening (grey_erosion then grey_dilation, both with the footprint as given; SK/morphology/grey.py:425)."""
     fp = _fp(footprint)
     er = _rank(a, fp, 0, "reflect", 0.0, None)
-    op = _rank(er, fp, 1, "reflect", 0.0, None)
+    n, H, W = _planes(a)
     o = _out(a.ctx, out, a.shape, a.dtype)
-    _hip.check(_lib().amt_subtract(a.ctx.handle, a.ptr, op.ptr, o.ptr, _in_code(a), a.size), "amt_subtract")
+    # the dilation stores image - dilation(erosion) directly (amt_rank_filter_sub)
+    _hip.check(_lib().amt_rank_filter_sub(a.ctx.handle, er.ptr, a.ptr, o.ptr, _in_code(a), n, H, W,
+                                          fp.ctypes.data_as(ctypes.c_void_p), fp.shape[0], fp.shape[1], 1,
+                                          _hip.MODES["reflect"], 0.0), "amt_rank_filter_sub")
     return o
 
 

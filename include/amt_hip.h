@@ -194,6 +194,11 @@ int amt_threshold_open_close(amt_ctx* ctx, const void* in, int in_dtype, const d
  * op: 0 = erosion (min), 1 = dilation (max, footprint already mirrored by the caller), 2 = median */
 int amt_rank_filter(amt_ctx* ctx, const void* in, void* out, int dtype, int nplanes, int H, int W,
                     const uint8_t* footprint, int fh, int fw, int op, int mode, double cval);
+/* out = minuend - rank_filter(in): the last step of ndi.white_tophat (R/ callers reach it through
+ * skimage.morphology.white_tophat, SK/morphology/grey.py:425) without a separate subtraction pass; uint16 run
+ * footprints subtract inside the filter kernel, everything else filters into `out` and subtracts in place. */
+int amt_rank_filter_sub(amt_ctx* ctx, const void* in, const void* minuend, void* out, int dtype, int nplanes, int H,
+                        int W, const uint8_t* footprint, int fh, int fw, int op, int mode, double cval);
 /* out = a - b (same dtype; white_tophat = image - opening) */
 int amt_subtract(amt_ctx* ctx, const void* a, const void* b, void* out, int dtype, size_t n);
 

@@ -431,6 +431,26 @@ def test_grey_morphology_u16_packed_kernel(ctx, ops):
             assert np.array_equal(ops.opening(d, fp).numpy()[0], skops.opening(img[0], fp))
             assert np.array_equal(ops.closing(d, fp).numpy()[1], skops.closing(img[1], fp))
             assert np.array_equal(ops.white_tophat(d, fp).numpy()[1], skops.white_tophat(img[1], fp))
+    # the register kernel's seams: strips of 496 columns (a width of exactly one / two strips, one group more, a last
+    # strip of a single group), row segments of 64 / 128 rows (heights around the segment length), and the three
+    # boundary modes it takes (grey morphology itself only uses 'reflect')
+    from arcadia_microscopy_tools_amd import hipops as _h
+    for shape in ((16, 496), (67, 992), (130, 504), (200, 1000), (129, 2048)):
+        img = rng.integers(0, 65536, shape).astype(np.uint16)
+        d = ctx.asarray(img)
+        fps["col15"], fps["r3x11"] = np.ones((15, 1), np.uint8), np.ones((3, 11), np.uint8)
+        for name in ("sq3", "col5", "row7", "sq7x3", "col15", "r3x11", "disk2", "disk5", "disk7", "diamond4", "disk3_gap"):
+            fp = fps[name]
+            assert np.array_equal(ops.erosion(d, fp).numpy(), skops.erosion(img, fp)), (shape, name, "erosion")
+            assert np.array_equal(ops.dilation(d, fp).numpy(), skops.dilation(img, fp)), (shape, name, "dilation")
+        for name in ("disk2", "disk7", "sq3"):  # the subtraction fused into the dilation
+            assert np.array_equal(ops.white_tophat(d, fps[name]).numpy(), skops.white_tophat(img, fps[name])), (shape, name)
+        for mode, cval in (("nearest", 0), ("constant", 0), ("constant", 40000)):
+            for fp in (fps["disk2"], fps["disk7"], fps["sq7x3"]):
+                got = _h._rank(d, fp, 0, mode, cval, None).numpy()
+                assert np.array_equal(got, ndi.minimum_filter(img, footprint=fp, mode=mode, cval=cval)), (shape, mode)
+                got = _h._rank(d, fp, 1, mode, cval, None).numpy()
+                assert np.array_equal(got, ndi.maximum_filter(img, footprint=fp, mode=mode, cval=cval)), (shape, mode)
     off = np.zeros((3, 5), np.uint8)
     off[0, 0:3] = 1
     off[1, 1:4] = 1
