@@ -625,6 +625,173 @@ __global__ void __launch_bounds__(256) mmr_u16_kernel(const uint16_t* __restrict
     }
 }
 
+// ---- median over a small footprint with the same register-strip skeleton -----------------------------------------
+// Footprints whose rows are centred runs, symmetric top / bottom, <= 5 x 5 (3 x 3, cross, disk(2), 5 x 5).  The last
+// 2 RY + 1 rows stay in a register ring (the lane's four pixel-pair words + one word of either neighbour lane), the
+// samples of an output pair are register moves (dx = +-2) or one v_alignbit (dx = +-1), and the median of the N samples
+// of each pixel pair is a packed forgetful selection (window of N / 2 + 2, min and max leave, the next sample enters):
+// 39 compare-exchanges = 78 v_pk_min / v_pk_max_u16 per two pixels for disk(2).
+__device__ __forceinline__ void med_ce(unsigned& a, unsigned& b) {
+    const unsigned lo = mm_pk<false>(a, b), hi = mm_pk<true>(a, b);
+    a = lo;
+    b = hi;
+}
+// minimum of v[LO .. LO + S - 1] to v[LO], maximum to v[LO + S - 1]
+template <int LO, int S, int NV>
+__device__ __forceinline__ void med_minmax(unsigned (&v)[NV]) {
+#pragma unroll
+    for (int i = 0; i < S / 2; ++i) med_ce(v[LO + i], v[LO + S - 1 - i]);
+    constexpr int HL = (S + 1) / 2;  // the middle element of an odd window belongs to both halves
+#pragma unroll
+    for (int i = 1; i < HL; ++i) med_ce(v[LO], v[LO + i]);
+#pragma unroll
+    for (int i = S - HL; i < S - 1; ++i) med_ce(v[LO + i], v[LO + S - 1]);
+}
+template <int LO, int S, int NEXT, int NV>
+__device__ __forceinline__ unsigned med_step(unsigned (&v)[NV]) {
+    if constexpr (S <= 1) {
+        return v[LO];
+    } else {
+        med_minmax<LO, S, NV>(v);
+        if constexpr (NEXT < NV) {
+            v[LO + S - 1] = v[NEXT];
+            return med_step<LO + 1, S - 1, NEXT + 1, NV>(v);
+        } else {
+            return med_step<LO + 1, S - 2, NEXT, NV>(v);
+        }
+    }
+}
+
+template <int RY, int H0, int H1, int H2>
+__global__ void __launch_bounds__(256) medr_u16_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int H,
+                                                       int W, int mode, uint16_t cval, int seg_rows, int nstrips,
+                                                       int nsegs) {
+    constexpr int PER = 2 * RY + 1;
+    constexpr int U = PER * ((8 + PER - 1) / PER);
+    constexpr int D = 8;
+    constexpr int N = (2 * H0 + 1) + (RY >= 1 ? 2 * (2 * H1 + 1) : 0) + (RY >= 2 ? 2 * (2 * H2 + 1) : 0);
+    const int lane = threadIdx.x & 63;
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= nstrips * nsegs) return;
+    const int strip = wid % nstrips, seg = wid / nstrips;
+    const size_t plane = (size_t)blockIdx.y * H * W;
+    const int xg = strip * 496 - 8 + 8 * lane;
+    const int y_begin = __builtin_amdgcn_readfirstlane(seg * seg_rows);
+    const int y_end = min(H, y_begin + seg_rows);
+    const bool inside = xg >= 0 && xg + 7 < W;
+    const bool halo_l = xg == -8, halo_r = xg == W;
+    const bool edge_wave = strip == 0 || strip == nstrips - 1;
+    const unsigned cv2 = (unsigned)cval | ((unsigned)cval << 16);
+    const unsigned lane_off = (unsigned)(inside ? xg : 0) * 2u;
+    const char* const in_plane = reinterpret_cast<const char*>(in + plane);
+    const int refl = mode == AMT_MODE_REFLECT;
+    auto load_row = [&](int r) -> uint4 {
+        const int lo = refl ? -r - 1 : 0, hi = refl ? 2 * H - 1 - r : H - 1;
+        int yy = r < 0 ? lo : (r >= H ? hi : r);
+        yy = min(max(yy, 0), H - 1);
+        return *reinterpret_cast<const uint4*>(in_plane + (size_t)yy * W * 2 + lane_off);
+    };
+    uint4 inreg[U];
+    unsigned ring[PER][6];
+#pragma unroll
+    for (int u = 0; u < D; ++u) inreg[u] = load_row(y_begin - RY + u);
+    const bool can_store = lane >= 1 && lane <= 62 && inside;
+    uint16_t* const out_lane = out + plane + (inside ? xg : 0);
+    for (int base = y_begin - RY; base < y_end + RY; base += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = base + u;
+            uint4 cur = inreg[u];
+            inreg[(u + D) % U] = load_row(r + D);
+            if (mode == AMT_MODE_CONSTANT && (r < 0 || r >= H)) cur = make_uint4(cv2, cv2, cv2, cv2);
+            if (edge_wave) {
+                const uint4 nr = mm_lane_right(cur), nl = mm_lane_left(cur);
+                if (halo_l) {
+                    if (mode == AMT_MODE_REFLECT) cur = make_uint4(mm_swap16(nr.w), mm_swap16(nr.z), mm_swap16(nr.y), mm_swap16(nr.x));
+                    else if (mode == AMT_MODE_NEAREST) { const unsigned b = (nr.x & 0xFFFFu) | (nr.x << 16); cur = make_uint4(b, b, b, b); }
+                    else cur = make_uint4(cv2, cv2, cv2, cv2);
+                }
+                if (halo_r) {
+                    if (mode == AMT_MODE_REFLECT) cur = make_uint4(mm_swap16(nl.w), mm_swap16(nl.z), mm_swap16(nl.y), mm_swap16(nl.x));
+                    else if (mode == AMT_MODE_NEAREST) { const unsigned b = (nl.w >> 16) | (nl.w & 0xFFFF0000u); cur = make_uint4(b, b, b, b); }
+                    else cur = make_uint4(cv2, cv2, cv2, cv2);
+                }
+            }
+            const int slot = u % PER;
+            ring[slot][0] = (unsigned)amt_lane_left((int)cur.w);
+            ring[slot][1] = cur.x, ring[slot][2] = cur.y, ring[slot][3] = cur.z, ring[slot][4] = cur.w;
+            ring[slot][5] = (unsigned)amt_lane_right((int)cur.x);
+            const int yo = r - RY;
+            if (yo >= y_begin && yo < y_end) {  // uniform: the warm-up rows of a segment skip the selection
+                unsigned res[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    unsigned v[N];
+                    int n = 0;
+#pragma unroll
+                    for (int dy = -RY; dy <= RY; ++dy) {
+                        const int s = ((u - RY + dy) % PER + PER) % PER;
+                        const int h = dy == 0 ? H0 : ((dy == 1 || dy == -1) ? H1 : H2);
+#pragma unroll
+                        for (int dx = -h; dx <= h; ++dx) {
+                            unsigned val;
+                            if (dx == 0) val = ring[s][1 + i];
+                            else if (dx == -2) val = ring[s][i];
+                            else if (dx == 2) val = ring[s][2 + i];
+                            else if (dx == -1) val = __builtin_amdgcn_alignbit(ring[s][1 + i], ring[s][i], 16);
+                            else val = __builtin_amdgcn_alignbit(ring[s][2 + i], ring[s][1 + i], 16);
+                            v[n++] = val;
+                        }
+                    }
+                    res[i] = med_step<0, N / 2 + 2, N / 2 + 2, N>(v);
+                }
+                if (can_store)
+                    *reinterpret_cast<uint4*>(out_lane + (size_t)yo * W) = make_uint4(res[0], res[1], res[2], res[3]);
+            }
+        }
+    }
+}
+
+// 1 = launched.  Qualifying footprints: see the kernel's comment.
+static int medr_try(amt_ctx* ctx, const uint16_t* in, uint16_t* out, int nplanes, int H, int W, const uint8_t* footprint,
+                    int fh, int fw, int mode, uint16_t cval) {
+    if ((W & 7) || W < 16 || H < 16 || fh > 5 || fw > 5) return 0;
+    if (!(mode == AMT_MODE_REFLECT || mode == AMT_MODE_NEAREST || mode == AMT_MODE_CONSTANT)) return 0;
+    if (getenv("AMT_MM_TILE") != nullptr) return 0;
+    const int ry = fh / 2, rx = fw / 2;
+    int hw[3] = {-1, -1, -1};
+    for (int y = 0; y < fh; ++y) {
+        int x0 = -1, x1 = -1, cnt = 0;
+        for (int x = 0; x < fw; ++x)
+            if (footprint[y * fw + x]) {
+                if (x0 < 0) x0 = x;
+                x1 = x;
+                ++cnt;
+            }
+        if (cnt == 0 || cnt != x1 - x0 + 1 || x0 + x1 != 2 * rx) return 0;  // one run, centred
+        const int h = (x1 - x0) / 2, a = y < ry ? ry - y : y - ry;
+        if (hw[a] >= 0 && hw[a] != h) return 0;  // top / bottom symmetric
+        hw[a] = h;
+    }
+    const int key = ry * 1000 + hw[0] * 100 + (ry >= 1 ? hw[1] : 0) * 10 + (ry >= 2 ? hw[2] : 0);
+    const int seg_rows = 64;
+    const int nstrips = (W + 495) / 496, nsegs = (H + seg_rows - 1) / seg_rows;
+    dim3 grid((nstrips * nsegs + 3) / 4, nplanes);
+#define AMT_MEDR(RYV, A, B, C)                                                                                       \
+    hipLaunchKernelGGL((medr_u16_kernel<RYV, A, B, C>), grid, dim3(256), 0, ctx->stream, in, out, H, W, mode, cval, \
+                       seg_rows, nstrips, nsegs)
+    switch (key) {
+        case 1110: AMT_MEDR(1, 1, 1, 0); break;  // 3 x 3
+        case 1100: AMT_MEDR(1, 1, 0, 0); break;  // cross = disk(1)
+        case 2210: AMT_MEDR(2, 2, 1, 0); break;  // disk(2)
+        case 2222: AMT_MEDR(2, 2, 2, 2); break;  // 5 x 5
+        case 2221: AMT_MEDR(2, 2, 2, 1); break;  // 5 x 5 without its corners
+        default: return 0;
+    }
+#undef AMT_MEDR
+    return 1;
+}
+
 // host side: does the footprint qualify?  (rows are runs centred on the origin, ry <= 7, half-widths <= 7)
 static bool mm_plan(const uint8_t* footprint, int fh, int fw, mm_params* P) {
     const int ry = fh / 2, rx = fw / 2;
@@ -876,6 +1043,11 @@ static int rank_filter_impl(amt_ctx* ctx, const void* in, void* out, int dtype, 
             AMT_LAUNCH_CHECK();
             return AMT_OK;
         }
+    }
+    if (op == 2 && dtype == AMT_U16 &&
+        medr_try(ctx, (const uint16_t*)in, (uint16_t*)out, nplanes, H, W, footprint, fh, fw, mode, (uint16_t)cval)) {
+        AMT_LAUNCH_CHECK();
+        return AMT_OK;
     }
     if (op == 2) {  // median over a small footprint: register selection
         const bool done = dtype == AMT_U16

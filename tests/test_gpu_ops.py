@@ -451,6 +451,20 @@ def test_grey_morphology_u16_packed_kernel(ctx, ops):
                 assert np.array_equal(got, ndi.minimum_filter(img, footprint=fp, mode=mode, cval=cval)), (shape, mode)
                 got = _h._rank(d, fp, 1, mode, cval, None).numpy()
                 assert np.array_equal(got, ndi.maximum_filter(img, footprint=fp, mode=mode, cval=cval)), (shape, mode)
+    # median through the register kernel (3 x 3, cross, disk(2), 5 x 5 with and without corners), images with many ties
+    oct5 = np.ones((5, 5), np.uint8)
+    oct5[0, 0] = oct5[0, 4] = oct5[4, 0] = oct5[4, 4] = 0
+    med_fps = {"sq3": fps["sq3"], "cross": fps["cross"], "disk2": fps["disk2"], "sq5": fps["sq5"], "oct5": oct5}
+    for shape in ((16, 496), (67, 992), (130, 504), (129, 2048)):
+        img = rng.integers(0, 65536, shape).astype(np.uint16)
+        few = rng.integers(0, 4, shape).astype(np.uint16) * 21845  # ties, and both ends of the uint16 range
+        for im in (img, few):
+            d = ctx.asarray(im)
+            for name, fp in med_fps.items():
+                assert np.array_equal(ops.median(d, fp).numpy(), skops.median(im, fp)), (shape, name, "median")
+            for mode, cval in (("reflect", 0), ("constant", 0), ("constant", 40000)):
+                got = ops.median(d, fps["disk2"], mode=mode, cval=cval).numpy()
+                assert np.array_equal(got, ndi.median_filter(im, footprint=fps["disk2"], mode=mode, cval=cval)), (shape, mode)
     off = np.zeros((3, 5), np.uint8)
     off[0, 0:3] = 1
     off[1, 1:4] = 1
