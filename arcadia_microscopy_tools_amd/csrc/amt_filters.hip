@@ -61,7 +61,10 @@ __device__ __forceinline__ void blocked8(F at, int o, const double* w, int r, do
         const int j = r - (st);                                                                    \
         const double nl = at(o + 9 - j), nr = at(o + j - 2); /* enter after the NEXT step */        \
         const double wj = w[st];                                                                   \
-        _Pragma("unroll") for (int k = 0; k < 8; ++k) acc[k] += (L[(k + (s)) & 7] + Rw[(k - (s)) & 7]) * wj; \
+        double t_[8];                                                                              \
+        _Pragma("unroll") for (int k = 0; k < 8; ++k) t_[k] = L[(k + (s)) & 7] + Rw[(k - (s)) & 7]; \
+        _Pragma("unroll") for (int k = 0; k < 8; ++k) t_[k] = t_[k] * wj;                          \
+        _Pragma("unroll") for (int k = 0; k < 8; ++k) acc[k] += t_[k];                             \
         L[(s) & 7] = pl;          /* the left window drops its first sample and gains x[o+8-j] */   \
         Rw[(7 - (s)) & 7] = pr;   /* the right window drops its last sample and gains x[o+j-1] */   \
         pl = nl;                                                                                   \
@@ -554,6 +557,169 @@ static int launch_fused(amt_ctx* ctx, const TIn* in, double scale, double* out, 
     return AMT_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same two passes with the tile staged by LDS-DMA (`global_load_lds_dwordx4`): a wave issues ALL its tile loads
+// back to back (no registers, nothing waits until the one vmcnt(0) in front of the barrier), and the horizontal tiles
+// are a quarter as tall so that four workgroups share a CU: one's staging overlaps the others' arithmetic.
+// Measured (32 planes of 2048^2, r = 64, rocprofv3): horizontal 1,990 -> 1,600 us, vertical 1,193 -> 1,109 us.  What is
+// left is arithmetic: tools/probes/fp64_probe.hip shows a SIMD retiring one fp64 instruction per 4.5 clocks at best
+// (4 waves x 8 independent chains; 6.7 with one wave) => 0.74 ms per pass for the 193 operations per sample; with the
+// staging removed the horizontal pass still takes ~1.05 ms (conflict-free LDS reads: -4 %, more ILP in the step: 0).
+//   horizontal: 16 rows x 256 tile columns (pitch 258 doubles = a multiple of 16 bytes; lane L reads row L & 15, the
+//               four lane groups of a wave work on different chunks), tile origin at an even column so that every lane moves an
+//               aligned pair; columns outside the image are loaded from clamped addresses and then replaced in LDS by
+//               their boundary image (reflect / mirror / nearest: another tile column; constant: cval).
+//   vertical  : (TH + 2r) rows x 64 columns of the RAW type; one instruction moves 1 KiB = 8 (uint16) or 2 (float64)
+//               boundary-mapped rows.
+// ------------------------------------------------------------------------------------------------
+constexpr int H8G_CP = 256, H8G_PITCH = 258;
+
+template <int H8G_ROWS>
+__global__ void __launch_bounds__(256) conv_h8g_kernel(const double* __restrict__ in, double* out, int H, int W,
+                                                       const double* __restrict__ wts, int r, int mode, double cval,
+                                                       int TW, const double* minuend, int remap) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* tile = reinterpret_cast<double*>(smem_raw);        // H8G_ROWS x H8G_PITCH
+    double* wl = tile + (size_t)H8G_ROWS * H8G_PITCH;          // 2r + 1
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // consecutive workgroups go to different XCDs (8, each with its own L2); tiles that are neighbours along x share
+    // their 2r halo columns, so the x-tiles of a band are given to ONE XCD, back to back
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (remap) {
+        const int nb = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+        const int per = nb >> 3;  // the host only asks for the remap when nb % 8 == 0
+        const int v = (lin & 7) * per + (lin >> 3);
+        bx = v % gridDim.x;
+        by = v / gridDim.x;
+    }
+    const int x0 = bx * TW;
+    const int y0 = by * H8G_ROWS;
+    const size_t plane = (size_t)blockIdx.z * H * W;
+    const int xs = (x0 - r) & ~1;  // even image column of tile column 0 (two's complement: rounds down)
+    const int delta = x0 - r - xs;
+    for (int i = threadIdx.x; i < 2 * r + 1; i += 256) wl[i] = wts[i];
+    // staging: wave w moves rows (ROWS / 4) w .. + ROWS / 4 - 1, two 1 KiB chunks (128 doubles) per row
+#pragma unroll
+    for (int rr = 0; rr < H8G_ROWS / 4; ++rr) {
+        const int row = wave * (H8G_ROWS / 4) + rr;
+        const int y = min(y0 + row, H - 1);
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            int col = xs + ch * 128 + 2 * lane;
+            col = col < 0 ? 0 : (col > W - 2 ? W - 2 : col);
+            const double* gp = in + plane + (size_t)y * W + col;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                             (__attribute__((address_space(3))) void*)(tile + row * H8G_PITCH + ch * 128),
+                                             16, 0, 0);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    __syncthreads();
+    if (xs < 0 || xs + H8G_CP > W) {  // uniform: a tile that reaches over the image edge
+        for (int idx = threadIdx.x; idx < H8G_ROWS * H8G_CP; idx += 256) {
+            const int row = idx >> 8, c = idx & 255;
+            const int gx = xs + c;
+            if (gx < 0 || gx >= W) {
+                const int m = amt_map_index(gx, W, mode);
+                int mi = m - xs;  // inside the tile for every column an output needs; the others are clamped
+                mi = mi < 0 ? 0 : (mi > H8G_CP - 1 ? H8G_CP - 1 : mi);
+                tile[row * H8G_PITCH + c] = m < 0 ? cval : tile[row * H8G_PITCH + mi];
+            }
+        }
+        __syncthreads();
+    }
+    constexpr int NG = 64 / H8G_ROWS;  // lane groups of a wave, each on a chunk of its own
+    const int rowl = lane & (H8G_ROWS - 1), half = lane / H8G_ROWS;
+    const double* myrow = tile + rowl * H8G_PITCH + delta;
+    auto at = [&](int i) -> double { return myrow[i]; };
+    const int nchunks = TW >> 3;
+    const int y = y0 + rowl;
+    for (int cb = wave * NG; cb < nchunks; cb += 4 * NG) {
+        const int cw = cb + half;                       // this lane group's chunk
+        const int c = cw < nchunks ? cw : nchunks - 1;  // an idle half recomputes the last chunk and stores nothing
+        double res[8];
+        blocked8(at, c * 8 + r, wl, r, res);
+        const int x = x0 + c * 8;
+        if (cw < nchunks && y < H && x < W) {
+            double* dst = out + plane + (size_t)y * W + x;
+            const double* mn = minuend ? minuend + plane + (size_t)y * W + x : nullptr;
+            if (x + 7 < W) {
+                if (mn) {
+                    double2 m2[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) m2[k] = *reinterpret_cast<const double2*>(mn + 2 * k);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        res[2 * k] = m2[k].x - res[2 * k];
+                        res[2 * k + 1] = m2[k].y - res[2 * k + 1];
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k += 2) *reinterpret_cast<double2*>(dst + k) = make_double2(res[k], res[k + 1]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (x + k < W) dst[k] = mn ? mn[k] - res[k] : res[k];
+            }
+        }
+    }
+}
+
+template <typename TIn>
+__global__ void __launch_bounds__(256) conv_v8g_kernel(const TIn* __restrict__ in, double scale,
+                                                       double* __restrict__ out, int H, int W,
+                                                       const double* __restrict__ wts, int r, int mode, double cval,
+                                                       int TH, size_t in_stride) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int RPI = 1024 / (64 * (int)sizeof(TIn));  // rows per instruction: 8 (uint16) or 2 (float64)
+    constexpr int LPR = 64 / RPI;                        // lanes per row
+    constexpr int EPL = 16 / (int)sizeof(TIn);           // elements per lane
+    const int rows = TH + 2 * r;
+    const int rows_pad = (rows + RPI - 1) / RPI * RPI;
+    TIn* tile = reinterpret_cast<TIn*>(smem_raw);  // rows_pad x 64
+    double* wl = reinterpret_cast<double*>(smem_raw + (size_t)rows_pad * 64 * sizeof(TIn));  // 2r + 1
+    unsigned char* inside = reinterpret_cast<unsigned char*>(wl + 2 * r + 1);                // rows: 0 = cval row
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int xb = blockIdx.x * 64;  // W is a multiple of 64 (the host checks)
+    const int x = xb + lane;
+    const int y0 = blockIdx.y * TH;
+    const size_t plane = (size_t)blockIdx.z * H * W;
+    const TIn* src = in + (size_t)blockIdx.z * in_stride;
+    for (int i = threadIdx.x; i < 2 * r + 1; i += 256) wl[i] = wts[i];
+    int any_out = 0;
+    for (int k = threadIdx.x; k < rows; k += 256) {
+        const int yy = amt_map_index(y0 - r + k, H, mode);
+        inside[k] = yy >= 0 ? 1 : 0;
+        any_out |= yy < 0 ? 1 : 0;
+    }
+    // staging: one instruction = RPI consecutive tile rows; the row of a lane is mapped by that lane
+    const int lrow = lane / LPR, lcol = (lane % LPR) * EPL;
+    for (int k0 = wave * RPI; k0 < rows_pad; k0 += 4 * RPI) {
+        const int k = k0 + lrow;
+        int yy = amt_map_index(y0 - r + (k < rows ? k : rows - 1), H, mode);
+        yy = yy < 0 ? 0 : yy;  // 'constant' rows are replaced where they are read
+        const TIn* gp = src + (size_t)yy * W + xb + lcol;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                         (__attribute__((address_space(3))) void*)(tile + (size_t)k0 * 64), 16, 0, 0);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    const int has_out = __syncthreads_or(any_out);
+    auto at = [&](int i) -> double { return inside[i] ? cvt_f64<TIn>(tile[i * 64 + lane], scale) : cval; };
+    auto at_in = [&](int i) -> double { return cvt_f64<TIn>(tile[i * 64 + lane], scale); };
+    for (int c = wave; c * 8 < TH; c += 4) {
+        const int q0 = c * 8;
+        if (y0 + q0 >= H) break;
+        double acc[8];
+        if (has_out)
+            blocked8(at, q0 + r, wl, r, acc);
+        else
+            blocked8(at_in, q0 + r, wl, r, acc);
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (y0 + q0 + k < H) out[plane + (size_t)(y0 + q0 + k) * W + x] = acc[k];
+    }
+}
+
 template <typename TIn>
 static int gaussian_typed(amt_ctx* ctx, const TIn* in, double scale, double* out, double* tmp, int nplanes, int H,
                           int W, const double* wdev, int r, int mode, double cval, size_t in_stride,
@@ -580,7 +746,20 @@ static int gaussian_typed(amt_ctx* ctx, const TIn* in, double scale, double* out
             break;
     }
     // register-blocked two-pass path
-    {
+    const bool aligned = (reinterpret_cast<uintptr_t>(in) & 15) == 0 && (reinterpret_cast<uintptr_t>(tmp) & 15) == 0 &&
+                         (in_stride * sizeof(TIn)) % 16 == 0 && getenv("AMT_GAUSS_NO_GLDS") == nullptr;
+    bool v_done = false, h_done = false;
+    if (aligned && W % 64 == 0 && H > 2 * r) {  // vertical pass, LDS-DMA staging
+        int TH = sizeof(TIn) == 2 ? 128 : 64;
+        const int rows_pad = (TH + 2 * r + 7) & ~7;
+        const size_t smem0 = (size_t)rows_pad * 64 * sizeof(TIn) + (size_t)(2 * r + 1) * 8 + (size_t)(TH + 2 * r);
+        dim3 g0(W / 64, (H + TH - 1) / TH, nplanes);
+        hipLaunchKernelGGL((conv_v8g_kernel<TIn>), g0, dim3(256), smem0, ctx->stream, in, scale, tmp, H, W, wdev, r, mode,
+                           cval, TH, in_stride);
+        AMT_LAUNCH_CHECK();
+        v_done = true;
+    }
+    if (!v_done) {
         // vertical: rows per block chosen so that the raw-type tile stays within ~96 KB
         int TH = 128;
         while (TH > 32 && ((size_t)(TH + 2 * r) * 64 * sizeof(TIn) + (size_t)(TH + 2 * r)) > 96 * 1024) TH >>= 1;
@@ -589,6 +768,24 @@ static int gaussian_typed(amt_ctx* ctx, const TIn* in, double scale, double* out
         hipLaunchKernelGGL((conv_v8_kernel<TIn>), g0, dim3(256), smem0, ctx->stream, in, scale, tmp, H, W, wdev, r, mode,
                            cval, TH, in_stride);
         AMT_LAUNCH_CHECK();
+    }
+    // horizontal pass, LDS-DMA staging: the tile (TW outputs + 2r halo + the alignment column) must fit 256 columns,
+    // and an out-of-image column must have its boundary image inside the tile
+    const int tw_g = ((H8G_CP - 2 * r - 1) / 8) * 8;
+    const bool h_ok = aligned && W % 2 == 0 && tw_g >= 64 && W >= H8G_CP + 2 * r && mode != AMT_MODE_WRAP;
+    if (h_ok) {
+        const int TW = tw_g > 128 ? 128 : tw_g;
+        // 16-row tiles: four workgroups (16 waves) per CU; measured 4 % faster than 32-row tiles (two per CU)
+        constexpr int ROWS = 16;
+        const size_t smem1 = (size_t)ROWS * H8G_PITCH * sizeof(double) + (size_t)(2 * r + 1) * 8;
+        dim3 g1((W + TW - 1) / TW, (H + ROWS - 1) / ROWS, nplanes);
+        const int remap = (g1.x * g1.y) % 8 == 0;
+        hipLaunchKernelGGL(conv_h8g_kernel<ROWS>, g1, dim3(256), smem1, ctx->stream, tmp, out, H, W, wdev, r, mode, cval,
+                           TW, minuend, remap);
+        AMT_LAUNCH_CHECK();
+        h_done = true;
+    }
+    if (!h_done) {
         // horizontal: 64 rows x TW columns per block; wide tiles amortise the 2r halo columns
         int TW = 128;
         while (TW > 32 && (size_t)64 * ((TW + 2 * r) | 1) * sizeof(double) > 136 * 1024) TW >>= 1;
