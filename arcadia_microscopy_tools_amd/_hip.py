@@ -12,7 +12,8 @@ import threading
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libamt_hip.so")
+# AMT_HIP_LIB: another build of the same library (instrumented / experimental variants made by tools/), never a fallback
+LIB_PATH = os.environ.get("AMT_HIP_LIB") or os.path.join(_HERE, "libamt_hip.so")
 
 # element type codes (amt_hip.h)
 U8, U16, I32, F64, I64, F32 = 0, 1, 2, 3, 4, 5
@@ -90,6 +91,9 @@ _SIGS = {
     "amt_binary_close": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_int, c_int]),
     "amt_threshold_open_close": (c_int, [_P, _P, c_int, _P, _P, c_int, c_int, c_int, _P, c_int, c_int]),
     "amt_rank_filter": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_double]),
+    "amt_gaussian_otsu_codes_supported": (c_int, [c_int, c_int, c_int, c_int, c_size_t]),
+    "amt_gaussian_otsu_codes": (c_int, [_P, _P, c_double, c_int, c_int, c_int, _P, c_int, c_int, c_size_t, _P, _P, _P, _P,
+                                        _P]),
     "amt_rank_filter_sub": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, c_int,
                                     c_double]),
     "amt_subtract": (c_int, [_P, _P, _P, _P, c_int, c_size_t]),

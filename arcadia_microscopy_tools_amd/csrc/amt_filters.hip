@@ -389,19 +389,38 @@ __global__ void __launch_bounds__(256) gauss_fused_kernel(const TIn* __restrict_
 // boundary modes nearest / reflect / mirror (the extension of a column is another column of the same tile).
 // Tile: 256 columns starting RP = roundup(R, 8) left of the first output; OUTW = 256 - 2 RP outputs.
 // ------------------------------------------------------------------------------------------------
-template <int R>
+// EPI selects what happens to the finished samples (the arithmetic in front of it is the same code, so every variant
+// produces the same float64 values bit for bit):
+//   0  store them (and fold min / max into `keys` when given) -- amt_gaussian;
+//   1  fold min / max into `keys` only -- first pass of amt_gaussian_otsu_codes: the float64 plane never exists;
+//   2  second pass of amt_gaussian_otsu_codes: np.histogram bin b of every sample (edges = np.linspace(min, max, 257),
+//      repaired against both edges exactly like hist_f64_kernel) counted into `hist`, and the uint16 code
+//      2 b + (sample > centre of bin b) stored: for the Otsu threshold t = centre of bin k,
+//      sample > t  <=>  code > 2 k  (a sample of a bin above k is >= its lower edge > centre_k, one of a bin below is
+//      < centre_k, and inside bin k the low bit IS the comparison), so the mask chain continues from 2 bytes per pixel.
+constexpr int GL_NBINS = 256;
+template <int R, int EPI>
 __global__ void __launch_bounds__(256) gauss_lds_kernel(const uint16_t* __restrict__ in, double scale,
                                                         double* __restrict__ out, int H, int W,
                                                         const double* __restrict__ wts, int mode, size_t in_stride,
-                                                        int TH, unsigned long long* __restrict__ keys) {
+                                                        int TH, unsigned long long* __restrict__ keys,
+                                                        const double* __restrict__ minmax, uint32_t* __restrict__ hist,
+                                                        uint16_t* __restrict__ codes) {
     constexpr int K = 2 * R + 1;
     constexpr int RP = (R + 7) & ~7;
     constexpr int OUTW = 256 - 2 * RP;
     constexpr int NSEG = OUTW / 4;
     constexpr int RING = 16;  // raw rows: four groups of four
-    __shared__ __attribute__((aligned(16))) double rowbuf[2][4][256 + 4];
-    __shared__ __attribute__((aligned(16))) unsigned short raw[RING][256];
-    __shared__ int ymap[256 + 2 * FR_MAX + 8];
+    // ONE LDS object, carved by hand: with several __shared__ arrays the compiler cannot tell the LDS-DMA writes into
+    // the ring from reads of the other arrays and drains the ring (vmcnt(0)) in front of every LDS read
+    constexpr int ROWBUF_B = 2 * 4 * (256 + 4) * 8, RAW_B = RING * 256 * 2, YMAP_B = (256 + 2 * FR_MAX + 8) * 4;
+    constexpr int EDGES_B = EPI == 2 ? ((GL_NBINS + 1) * 8 + 8) : 0, LH_B = EPI == 2 ? 4 * GL_NBINS * 4 : 0;
+    __shared__ __attribute__((aligned(16))) char lds[ROWBUF_B + RAW_B + YMAP_B + EDGES_B + LH_B];
+    double(*rowbuf)[4][256 + 4] = reinterpret_cast<double(*)[4][256 + 4]>(lds);
+    unsigned short(*raw)[256] = reinterpret_cast<unsigned short(*)[256]>(lds + ROWBUF_B);
+    int* ymap = reinterpret_cast<int*>(lds + ROWBUF_B + RAW_B);
+    double* edges = reinterpret_cast<double*>(lds + ROWBUF_B + RAW_B + YMAP_B);
+    uint32_t* lh = reinterpret_cast<uint32_t*>(lds + ROWBUF_B + RAW_B + YMAP_B + EDGES_B);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int x0 = blockIdx.x * OUTW;
     const int xt0 = x0 - RP;  // image column of tile column 0 (a multiple of 8)
@@ -412,6 +431,15 @@ __global__ void __launch_bounds__(256) gauss_lds_kernel(const uint16_t* __restri
 #pragma unroll
     for (int j = 0; j <= R; ++j) w[j] = wts[R - j];
     for (int k = t; k < TH + 2 * R + 8; k += 256) ymap[k] = amt_map_index(y0 - R + k, H, mode);
+    double h_lo = 0.0, h_hi = 0.0, h_norm = 0.0;
+    if (EPI == 2) {
+        h_lo = minmax[2 * blockIdx.z];
+        h_hi = minmax[2 * blockIdx.z + 1];
+        const double step = (h_hi - h_lo) / (double)GL_NBINS;
+        h_norm = (double)GL_NBINS / (h_hi - h_lo);
+        for (int i = t; i <= GL_NBINS; i += 256) edges[i] = i == GL_NBINS ? h_hi : (double)i * step + h_lo;
+        for (int i = t; i < 4 * GL_NBINS; i += 256) lh[i] = 0;
+    }
     __syncthreads();
     // this thread's column: tile column t; outside the image it reads the tile column of its boundary-mapped image
     const int xm = amt_map_index(xt0 + t, W, mode);
@@ -488,23 +516,78 @@ __global__ void __launch_bounds__(256) gauss_lds_kernel(const uint16_t* __restri
             }
             // W and the tile origin are multiples of 8: the four outputs are inside the image together or not at
             // all, and the destination is 16-byte aligned -> exactly two store instructions per row
-            double* dst = out + plane + (size_t)(y0 + rg + q) * W + xo;
-            if (xo < W) {
-                reinterpret_cast<double2*>(dst)[0] = make_double2(a[0], a[1]);
-                reinterpret_cast<double2*>(dst)[1] = make_double2(a[2], a[3]);
-                if (keys) {
+            if (EPI == 0) {
+                double* dst = out + plane + (size_t)(y0 + rg + q) * W + xo;
+                if (xo < W) {
+                    reinterpret_cast<double2*>(dst)[0] = make_double2(a[0], a[1]);
+                    reinterpret_cast<double2*>(dst)[1] = make_double2(a[2], a[3]);
+                }
+            }
+            if (EPI <= 1 && keys && xo < W) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    vlo = vmin_f64(vlo, a[i]);
+                    vhi = vmax_f64(vhi, a[i]);
+                }
+            }
+            if (EPI == 2 && xo < W) {
+                unsigned cd[4];
+                if (!(h_lo < h_hi)) {  // constant plane: every code 0, the threshold code is 0, the mask empty
+                    cd[0] = cd[1] = cd[2] = cd[3] = 0;
+                } else {
+                    uint32_t* mine = lh + wave * GL_NBINS;
+                    int b4[4];
+                    double e0[4], e1[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        vlo = vmin_f64(vlo, a[i]);
-                        vhi = vmax_f64(vhi, a[i]);
+                        int b = (int)((a[i] - h_lo) * h_norm);
+                        b = b < 0 ? 0 : (b > GL_NBINS - 1 ? GL_NBINS - 1 : b);
+                        b4[i] = b;
+                        e0[i] = edges[b];
+                        e1[i] = edges[b + 1];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const double v = a[i];
+                        int b = b4[i];
+                        if (v < e0[i] || (b < GL_NBINS - 1 && v >= e1[i])) {  // within rounding distance of an edge
+                            while (b > 0 && v < edges[b]) --b;
+                            while (b < GL_NBINS - 1 && v >= edges[b + 1]) ++b;
+                            e0[i] = edges[b];
+                            e1[i] = edges[b + 1];
+                        }
+                        cd[i] = ((unsigned)b << 1) | (v > (e0[i] + e1[i]) / 2.0 ? 1u : 0u);
+                        b4[i] = b;
+                    }
+                    // count: a smoothed background wave sits in one or two bins -- the first lane's bin is counted once
+                    // for every lane that shares it, twice in a row, the rest lane by lane (as hist_f64_kernel)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int b = b4[i];
+                        const unsigned long long act = __ballot(1);
+                        const int l0 = __ffsll((long long)act) - 1;
+                        const int b0 = __shfl(b, l0);
+                        const unsigned long long s0 = __ballot(b == b0);
+                        if (lane == l0) atomicAdd(&mine[b0], (unsigned)__popcll(s0));
+                        unsigned long long rest = act & ~s0;
+                        if (rest) {
+                            const int l1 = __ffsll((long long)rest) - 1;
+                            const int b1 = __shfl(b, l1);
+                            const unsigned long long s1 = __ballot(b == b1);
+                            if (lane == l1) atomicAdd(&mine[b1], (unsigned)__popcll(s1));
+                            rest &= ~s1;
+                            if ((rest >> lane) & 1ull) atomicAdd(&mine[b], 1u);
+                        }
                     }
                 }
+                uint16_t* cdst = codes + plane + (size_t)(y0 + rg + q) * W + xo;
+                *reinterpret_cast<uint2*>(cdst) = make_uint2(cd[0] | (cd[1] << 16), cd[2] | (cd[3] << 16));
             }
         }
 #pragma unroll
         for (int k = 0; k < K - 1; ++k) win[k] = win[k + 4];
     }
-    if (keys) {
+    if (EPI <= 1 && keys) {
         unsigned long long klo = amt_f64_key(vlo), khi = amt_f64_key(vhi);
         if (vlo > vhi) {
             klo = ~0ull;
@@ -519,6 +602,14 @@ __global__ void __launch_bounds__(256) gauss_lds_kernel(const uint16_t* __restri
         if (lane == 0) {
             atomicMin(&keys[2 * blockIdx.z], klo);
             atomicMax(&keys[2 * blockIdx.z + 1], khi);
+        }
+    }
+    if (EPI == 2) {
+        __syncthreads();
+        uint32_t* gh = hist + (size_t)blockIdx.z * GL_NBINS;
+        for (int i = t; i < GL_NBINS; i += 256) {
+            const uint32_t c = lh[i] + lh[GL_NBINS + i] + lh[2 * GL_NBINS + i] + lh[3 * GL_NBINS + i];
+            if (c) atomicAdd(&gh[i], c);
         }
     }
 }
@@ -539,8 +630,9 @@ static int launch_fused(amt_ctx* ctx, const TIn* in, double scale, double* out, 
             int TH2 = 256;
             while (TH2 > 32 && (long long)gx2 * ((H + TH2 - 1) / TH2) * nplanes < 4LL * ctx->num_cus) TH2 >>= 1;
             dim3 grid2(gx2, (H + TH2 - 1) / TH2, nplanes);
-            hipLaunchKernelGGL((gauss_lds_kernel<R>), grid2, dim3(256), 0, ctx->stream, (const uint16_t*)in, scale, out, H,
-                               W, wdev, mode, in_stride, TH2, keys);
+            hipLaunchKernelGGL((gauss_lds_kernel<R, 0>), grid2, dim3(256), 0, ctx->stream, (const uint16_t*)in, scale, out,
+                               H, W, wdev, mode, in_stride, TH2, keys, (const double*)nullptr, (uint32_t*)nullptr,
+                               (uint16_t*)nullptr);
             AMT_LAUNCH_CHECK();
             return AMT_OK;
         }
@@ -888,6 +980,84 @@ extern "C" int amt_gaussian(amt_ctx* ctx, const void* in, int in_dtype, double s
     AMT_TRY(gaussian_dispatch(ctx, in, in_dtype, scale, out, tmp, nplanes, H, W, wdev, radius, mode, cval,
                               in_plane_stride, keys));
     return amt_i_minmax_finish(ctx, keys, minmax_dev, nplanes);
+}
+
+// ---- Gaussian -> Otsu without the float64 plane (the mask chain of BASELINE configs[1] / [2]) ------------------------
+// R/ callers: ski.filters.gaussian -> ski.filters.threshold_otsu -> `>` (SURVEY.md A.7/A.8 recipes through
+// R/pipeline.py:25-45).  Two passes of the fused uint16 Gaussian over the input: the first folds min / max, the second
+// recomputes the samples, counts np.histogram's 256 bins and stores 2-byte codes; Otsu runs on the histogram and the
+// threshold comparison continues on the codes (amt_threshold_open_close / amt_threshold_gt on the uint16 code plane
+// with thr_code).  26 bytes of HBM traffic per pixel (write + two reads of a float64 plane, read uint16) become 8.
+template <int R>
+static int launch_codes(amt_ctx* ctx, const uint16_t* in, double scale, int nplanes, int H, int W, const double* wdev,
+                        int mode, size_t in_stride, unsigned long long* keys, double* mm, uint32_t* hist,
+                        uint16_t* codes) {
+    constexpr int RP = (R + 7) & ~7;
+    constexpr int OUTW2 = 256 - 2 * RP;
+    const int gx2 = (W + OUTW2 - 1) / OUTW2;
+    int TH2 = 256;
+    while (TH2 > 32 && (long long)gx2 * ((H + TH2 - 1) / TH2) * nplanes < 4LL * ctx->num_cus) TH2 >>= 1;
+    dim3 grid2(gx2, (H + TH2 - 1) / TH2, nplanes);
+    AMT_TRY(amt_i_minmax_init(ctx, keys, nplanes));
+    hipLaunchKernelGGL((gauss_lds_kernel<R, 1>), grid2, dim3(256), 0, ctx->stream, in, scale, (double*)nullptr, H, W,
+                       wdev, mode, in_stride, TH2, keys, (const double*)nullptr, (uint32_t*)nullptr, (uint16_t*)nullptr);
+    AMT_LAUNCH_CHECK();
+    AMT_TRY(amt_i_minmax_finish(ctx, keys, mm, nplanes));
+    AMT_HIP_CHECK(hipMemsetAsync(hist, 0, (size_t)nplanes * GL_NBINS * sizeof(uint32_t), ctx->stream));
+    hipLaunchKernelGGL((gauss_lds_kernel<R, 2>), grid2, dim3(256), 0, ctx->stream, in, scale, (double*)nullptr, H, W,
+                       wdev, mode, in_stride, TH2, (unsigned long long*)nullptr, (const double*)mm, hist, codes);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+
+extern "C" int amt_gaussian_otsu_codes_supported(int H, int W, int radius, int mode, size_t in_plane_stride) {
+    const bool modeok = mode == AMT_MODE_NEAREST || mode == AMT_MODE_REFLECT || mode == AMT_MODE_MIRROR;
+    return radius >= 1 && radius <= FR_MAX && modeok && W % 8 == 0 && W >= 256 && H > 2 * radius &&
+           (in_plane_stride == 0 || in_plane_stride % 8 == 0);
+}
+
+extern "C" int amt_gaussian_otsu_codes(amt_ctx* ctx, const uint16_t* in, double scale, int nplanes, int H, int W,
+                                       const double* weights, int radius, int mode, size_t in_plane_stride,
+                                       double* minmax_dev, uint32_t* hist_dev, double* thr_dev, double* thr_code_dev,
+                                       uint16_t* codes) {
+    AMT_TRY(amt_set_device(ctx));
+    AMT_REQUIRE(in && weights && minmax_dev && hist_dev && thr_dev && thr_code_dev && codes && nplanes >= 0,
+                "gaussian_otsu_codes: bad arguments");
+    AMT_REQUIRE(amt_gaussian_otsu_codes_supported(H, W, radius, mode, in_plane_stride) &&
+                    (reinterpret_cast<uintptr_t>(in) & 15) == 0 && (reinterpret_cast<uintptr_t>(codes) & 15) == 0,
+                "gaussian_otsu_codes: unsupported shape / radius / mode / alignment (ask "
+                "amt_gaussian_otsu_codes_supported; the separate operators handle every case)");
+    if (nplanes == 0) return AMT_OK;
+    if (in_plane_stride == 0) in_plane_stride = (size_t)H * W;
+    const size_t wbytes = amt_align((2 * radius + 1) * sizeof(double)), kbytes = amt_align((size_t)2 * nplanes * 8);
+    AMT_TRY(amt_arena_begin(ctx, wbytes + kbytes));
+    double* wdev = (double*)amt_arena_take(ctx, wbytes);
+    unsigned long long* keys = (unsigned long long*)amt_arena_take(ctx, kbytes);
+    AMT_TRY(amt_param_upload(ctx, wdev, weights, (2 * radius + 1) * sizeof(double)));
+    switch (radius) {
+#define AMT_CODES_CASE(RR)                                                                                            \
+    case RR:                                                                                                          \
+        AMT_TRY(launch_codes<RR>(ctx, in, scale, nplanes, H, W, wdev, mode, in_plane_stride, keys, minmax_dev, hist_dev, \
+                                 codes));                                                                             \
+        break;
+        AMT_CODES_CASE(1)
+        AMT_CODES_CASE(2)
+        AMT_CODES_CASE(3)
+        AMT_CODES_CASE(4)
+        AMT_CODES_CASE(5)
+        AMT_CODES_CASE(6)
+        AMT_CODES_CASE(7)
+        AMT_CODES_CASE(8)
+        AMT_CODES_CASE(9)
+        AMT_CODES_CASE(10)
+        AMT_CODES_CASE(11)
+        AMT_CODES_CASE(12)
+#undef AMT_CODES_CASE
+        default:
+            amt_set_error("gaussian_otsu_codes: radius %d", radius);
+            return AMT_EINVAL;
+    }
+    return amt_i_otsu_from_hist(ctx, hist_dev, minmax_dev, GL_NBINS, thr_dev, thr_code_dev, nplanes);
 }
 
 __global__ void sub_inplace_kernel(double* __restrict__ a, const double* __restrict__ b, size_t n) {

@@ -70,6 +70,9 @@ static inline int amt_scan_excl_dev(amt_ctx* ctx, int* data, const int* len_dev,
 int amt_i_minmax_init(amt_ctx* ctx, unsigned long long* keys, int nplanes);
 int amt_i_minmax_finish(amt_ctx* ctx, const unsigned long long* keys, double* out, int nplanes);
 int amt_i_minmax_f64(amt_ctx* ctx, const double* in, unsigned long long* keys, double* out, int nplanes, size_t n);
+// Otsu threshold of float64 histograms (np.histogram edges from minmax); thr_code (nullable) = 2 * bin index
+int amt_i_otsu_from_hist(amt_ctx* ctx, const uint32_t* hist, const double* minmax, int nbins, double* thr,
+                         double* thr_code, int nplanes);
 
 // ---- connected components (amt_label.hip) -------------------------------------------------------
 // L[plane][p] = flat index of the component's first pixel (its union-find root), -1 for background.

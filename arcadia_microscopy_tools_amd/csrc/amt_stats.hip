@@ -382,9 +382,10 @@ __global__ void __launch_bounds__(1024) otsu_u16_kernel(const uint32_t* __restri
     if (t == 0) thr[plane] = (double)bi;
 }
 
+// thr_code (nullable): 2 * (index of the threshold's bin), the threshold in the code space of amt_gaussian_otsu_codes
 __global__ void __launch_bounds__(256) otsu_f64_kernel(const uint32_t* __restrict__ hist,
                                                        const double* __restrict__ minmax, int nbins,
-                                                       double* __restrict__ thr) {
+                                                       double* __restrict__ thr, double* __restrict__ thr_code) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* ctr = reinterpret_cast<double*>(smem_raw);  // nbins
     double* w1 = ctr + nbins;
@@ -397,7 +398,10 @@ __global__ void __launch_bounds__(256) otsu_f64_kernel(const uint32_t* __restric
     const uint32_t* h = hist + (size_t)plane * nbins;
     const double lo = minmax[2 * plane], hi = minmax[2 * plane + 1];
     if (!(lo < hi)) {  // constant image (or NaN): skimage returns the first pixel
-        if (threadIdx.x == 0) thr[plane] = lo;
+        if (threadIdx.x == 0) {
+            thr[plane] = lo;
+            if (thr_code) thr_code[plane] = 0.0;
+        }
         return;
     }
     const double step = (hi - lo) / (double)nbins;
@@ -437,7 +441,18 @@ __global__ void __launch_bounds__(256) otsu_f64_kernel(const uint32_t* __restric
     double bv;
     int bi;
     block_argmax_first(best, best_idx, s_val, s_idx, bv, bi);
-    if (threadIdx.x == 0) thr[plane] = ctr[bi == 0x7fffffff ? 0 : bi];
+    if (threadIdx.x == 0) {
+        thr[plane] = ctr[bi == 0x7fffffff ? 0 : bi];
+        if (thr_code) thr_code[plane] = (double)(2 * (bi == 0x7fffffff ? 0 : bi));
+    }
+}
+
+int amt_i_otsu_from_hist(amt_ctx* ctx, const uint32_t* hist, const double* minmax, int nbins, double* thr,
+                         double* thr_code, int nplanes) {
+    hipLaunchKernelGGL(otsu_f64_kernel, dim3(nplanes), dim3(256), (size_t)5 * nbins * sizeof(double), ctx->stream, hist,
+                       minmax, nbins, thr, thr_code);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
 }
 
 extern "C" int amt_threshold_value(amt_ctx* ctx, const void* in, int in_dtype, int method, int nbins, double* thr_dev,
@@ -469,10 +484,7 @@ extern "C" int amt_threshold_value(amt_ctx* ctx, const void* in, int in_dtype, i
     else
         AMT_TRY(minmax_f64_launch(ctx, (const double*)in, keys, mm, nplanes, n));
     AMT_TRY(hist_f64_launch(ctx, (const double*)in, mm, hist, nbins, nplanes, n));
-    hipLaunchKernelGGL(otsu_f64_kernel, dim3(nplanes), dim3(256), (size_t)5 * nbins * sizeof(double), ctx->stream, hist,
-                       mm, nbins, thr_dev);
-    AMT_LAUNCH_CHECK();
-    return AMT_OK;
+    return amt_i_otsu_from_hist(ctx, hist, mm, nbins, thr_dev, nullptr, nplanes);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -38,8 +38,16 @@ enum { CLS_NONE = 0, CLS_UNIFORM = 1, CLS_S = 2, CLS_M = 3, CLS_L = 4, CLS_X = 5
 // LDS tile classes: max pixels of the bounding box, max d2 (bucket count - 1).  S / M / L are flooded by
 // ws_flood_batch_kernel (6 bytes of LDS per pixel + 8 per bucket), X -- the few boxes between L and the 15-bit
 // index limit -- by the one-pop-at-a-time ws_flood_lds_kernel (4 bytes per pixel).
-constexpr int S_PX = 2048, S_NB = 512;
-constexpr int M_PX = 8192, M_NB = 1024;
+#ifndef AMT_WS_S_PX
+#define AMT_WS_S_PX 2048
+#define AMT_WS_S_NB 512
+#endif
+#ifndef AMT_WS_M_PX
+#define AMT_WS_M_PX 8192
+#define AMT_WS_M_NB 1024
+#endif
+constexpr int S_PX = AMT_WS_S_PX, S_NB = AMT_WS_S_NB;
+constexpr int M_PX = AMT_WS_M_PX, M_NB = AMT_WS_M_NB;
 constexpr int L_PX = 24576, L_NB = 2048;
 constexpr int X_PX = 32512, X_NB = 2048;  // pixel indices must fit the 15-bit link field
 

@@ -125,6 +125,51 @@ def gaussian_nd(a: DeviceArray, sigma: float, mode: str = "nearest", cval: float
     return gaussian(cur, sigma, mode, cval, truncate, scale=cur_scale, out=out)
 
 
+def gaussian_otsu_codes_supported(a: DeviceArray, sigma: float, mode: str = "nearest", truncate: float = 4.0,
+                                  channel: int | None = None) -> bool:
+    """Whether ``gaussian_otsu_codes`` can take this batch (uint16, fused-radius Gaussian, aligned rows)."""
+    if a.dtype != np.uint16 or sigma <= 1e-15:
+        return False
+    _, H, W = _planes(a)
+    r = int(truncate * float(sigma) + 0.5)
+    stride = a.shape[-3] * H * W if channel is not None else 0
+    ptr = a.ptr + (int(channel) * H * W * 2 if channel is not None else 0)
+    return bool(_lib().amt_gaussian_otsu_codes_supported(H, W, r, _hip.MODES[mode], stride)) and ptr % 16 == 0
+
+
+def gaussian_otsu_codes(a: DeviceArray, sigma: float, codes: DeviceArray, thr: DeviceArray, thr_code: DeviceArray,
+                        minmax: DeviceArray, hist: DeviceArray, mode: str = "nearest", truncate: float = 4.0,
+                        channel: int | None = None) -> DeviceArray:
+    """``threshold_otsu(gaussian(a, sigma))`` per plane WITHOUT the float64 image: ``thr`` receives the thresholds,
+    ``codes`` (uint16, one per pixel) and ``thr_code`` continue the chain -- ``gaussian(a) > thr`` is exactly
+    ``codes > thr_code`` (csrc/amt_filters.hip, gauss_lds_kernel EPI 2), so ``threshold_open_close(codes, thr_code)``
+    yields the mask of the separate operators.  ``minmax`` (n, 2) and ``hist`` (n, 256) receive np.histogram's range
+    and counts.  All outputs are caller-owned device arrays (nothing is allocated per call)."""
+    ctx = a.ctx
+    n, H, W = _planes(a)
+    ptr, stride = a.ptr, 0
+    if channel is not None:
+        C = a.shape[-3]
+        n, stride = n // C, C * H * W
+        ptr = a.ptr + int(channel) * H * W * a.dtype.itemsize
+    if a.dtype != np.uint16:
+        raise TypeError("gaussian_otsu_codes takes uint16 images")
+    for name, arr, dt, size in (("codes", codes, np.uint16, n * H * W), ("thr", thr, np.float64, n),
+                                ("thr_code", thr_code, np.float64, n), ("minmax", minmax, np.float64, 2 * n),
+                                ("hist", hist, np.uint32, 256 * n)):
+        if arr.dtype != dt or arr.size != size:
+            raise ValueError(f"{name} must be a {np.dtype(dt).name} DeviceArray of {size} elements")
+        if arr.ctx is not ctx:
+            raise ValueError(f"{name} belongs to another context than the input")
+    w = gaussian_weights(sigma, truncate)
+    r = (len(w) - 1) // 2
+    wa, wp = _host_f64(w)
+    _hip.check(_lib().amt_gaussian_otsu_codes(ctx.handle, ptr, 1.0 / 65535, n, H, W, wp, r, _hip.MODES[mode], stride,
+                                              minmax.ptr, hist.ptr, thr.ptr, thr_code.ptr, codes.ptr),
+               "amt_gaussian_otsu_codes")
+    return codes
+
+
 def difference_of_gaussians(a: DeviceArray, low_sigma: float, high_sigma: float, mode: str = "nearest",
                             cval: float = 0.0, truncate: float = 4.0, out: DeviceArray | None = None) -> DeviceArray:
     """``skimage.filters.difference_of_gaussians`` (SK/filters/_gaussian.py:258-290; R/operations.py:91)."""

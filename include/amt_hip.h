@@ -107,6 +107,17 @@ int amt_deinterleave_u16(amt_ctx* ctx, const uint16_t* yxc, uint16_t* cyx, int n
 int amt_gaussian(amt_ctx* ctx, const void* in, int in_dtype, double scale, double* out, int nplanes, int H, int W,
                  const double* weights, int radius, int mode, double cval, size_t in_plane_stride,
                  double* minmax_dev);
+/* threshold_otsu(gaussian(in)) per plane WITHOUT materialising the float64 image -- the first three calls of the
+ * nuclei recipes (ski.filters.gaussian -> ski.filters.threshold_otsu -> `>`; SURVEY.md A.7/A.8, reached through
+ * R/pipeline.py:25-45).  uint16 input, fused radii (1..12), aligned rows: ask amt_gaussian_otsu_codes_supported first.
+ * Outputs (all caller-owned): minmax_dev[2 n] = range of the smoothed plane, hist_dev[256 n] = np.histogram counts,
+ * thr_dev[n] = the Otsu threshold (bit-identical to amt_gaussian + amt_threshold_value), codes[n H W] = uint16 code
+ * per pixel with   gaussian(in) > thr  <=>  code > thr_code_dev[plane]   exactly, so amt_threshold_gt /
+ * amt_threshold_open_close on (codes, AMT_U16, thr_code_dev) produce the mask of the separate operators. */
+int amt_gaussian_otsu_codes_supported(int H, int W, int radius, int mode, size_t in_plane_stride);
+int amt_gaussian_otsu_codes(amt_ctx* ctx, const uint16_t* in, double scale, int nplanes, int H, int W,
+                            const double* weights, int radius, int mode, size_t in_plane_stride, double* minmax_dev,
+                            uint32_t* hist_dev, double* thr_dev, double* thr_code_dev, uint16_t* codes);
 /* out = G(w_lo) - G(w_hi) of the same converted input (SK/filters/_gaussian.py:284-290). */
 /* One leading axis of an n-D Gaussian (skimage filters EVERY axis of an n-D image, leading axes first,
  * SP/_filters.py:423-427): the array is nplanes x L x inner, the 1-D filter runs along L; out is float64. */

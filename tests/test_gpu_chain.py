@@ -54,6 +54,56 @@ def test_c2_c3_golden_256(ctx, golden):
     _check_props(res.feature_tables()[0], ref)
 
 
+def test_gaussian_otsu_codes_equal_separate_operators(ctx):
+    """The mask chain without the float64 plane (amt_gaussian_otsu_codes): thresholds, histograms, min / max and the
+    thresholded masks must equal those of gaussian -> threshold_otsu -> '>' bit for bit; planes with different
+    statistics in one batch, a constant plane, sigma with radius 4 / 8 / 12, sizes whose last tile is partial."""
+    from arcadia_microscopy_tools_amd import hipops, synth
+    from arcadia_microscopy_tools_amd.segment import FovSegmenter
+
+    rng = np.random.default_rng(17)
+    H, W = 300, 520
+    fov = synth.synth_fov(3, size=520)[:, :H, :]
+    planes = np.stack([fov[1], rng.integers(0, 65536, (H, W)).astype(np.uint16),
+                       np.full((H, W), 1234, np.uint16), (fov[1] // 64 * 64).astype(np.uint16),
+                       rng.integers(0, 3, (H, W)).astype(np.uint16) * 30000])
+    d = ctx.asarray(planes)
+    n = planes.shape[0]
+    for sigma in (1.0, 2.0, 3.0):
+        assert hipops.gaussian_otsu_codes_supported(d, sigma)
+        codes, thr, tc = ctx.empty(planes.shape, np.uint16), ctx.empty((n,), np.float64), ctx.empty((n,), np.float64)
+        mm, hist = ctx.empty((n, 2), np.float64), ctx.empty((n, 256), np.uint32)
+        hipops.gaussian_otsu_codes(d, sigma, codes, thr, tc, mm, hist)
+        g = hipops.gaussian(d, sigma)
+        thr_ref = hipops.threshold_otsu(g).numpy()
+        assert np.array_equal(thr.numpy(), thr_ref), sigma
+        gn = g.numpy()
+        assert np.array_equal(mm.numpy(), np.stack([gn.min(axis=(1, 2)), gn.max(axis=(1, 2))], axis=1))
+        hf, _ = hipops.histogram_f64(g)
+        hn = hist.numpy()
+        for b in range(n):
+            if gn[b].min() < gn[b].max():
+                assert np.array_equal(hn[b], hf.numpy()[b]), (sigma, b)
+        mask = hipops.greater_than(codes, tc).numpy()
+        assert np.array_equal(mask, gn > thr_ref[:, None, None]), sigma
+        # every other threshold of the code space is exact too: code > 2k  <=>  value > centre of bin k
+        lo, hi = mm.numpy()[0]
+        edges = np.linspace(lo, hi, 257)
+        centres = (edges[:-1] + edges[1:]) / 2.0
+        c0 = codes.numpy()[0]
+        for k in (0, 1, 17, 128, 254, 255):
+            assert np.array_equal(c0 > 2 * k, gn[0] > centres[k]), (sigma, k)
+    # through the batch driver: the code path and the separate operators give the same masks and labels
+    fovs = np.stack([synth.synth_fov(i, size=512) for i in (4, 6)])
+    df = ctx.asarray(fovs)
+    a = FovSegmenter(2, 4, 512, 512, ctx=ctx, max_cells=512, low_traffic=True)
+    b = FovSegmenter(2, 4, 512, 512, ctx=ctx, max_cells=512)
+    la, lb = a.run_c3(df).numpy(), b.run_c3(df).numpy()
+    assert a.codes_path and not b.codes_path
+    assert np.array_equal(a.thr.numpy(), b.thr.numpy())
+    assert np.array_equal(a.mask_a.numpy(), b.mask_a.numpy()) and np.array_equal(la, lb)
+
+
 def test_c3_batch_vs_oracle(ctx):
     """Several different FOVs in one batch, odd image size, every FOV checked against the CPU oracle."""
     from arcadia_microscopy_tools_amd import synth
