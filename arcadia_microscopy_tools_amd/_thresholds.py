@@ -4,6 +4,15 @@ The pixel-sized work (histogram, min/max, masked sums) runs on the GPU; what is 
 <= 65,536 (integer images) or 256 (float images) counts, evaluated here with the same numpy
 expressions scikit-image uses, so the thresholds are bit-identical by construction
 (SURVEY.md A.11).  Citations: SK/ = scikit-image 0.18.3 ``filters/thresholding.py``.
+
+Attribution: ``yen``, ``isodata``, ``triangle`` and ``minimum`` below follow scikit-image's expressions closely,
+variable names included -- bit-identical thresholds require the same floating-point expressions in the same order.
+scikit-image is Copyright (C) 2019, the scikit-image team, and distributed under the BSD 3-Clause License
+(https://github.com/scikit-image/scikit-image/blob/main/LICENSE.txt): redistribution in source form must retain
+that copyright notice, the list of conditions and the disclaimer ("THIS SOFTWARE IS PROVIDED BY THE COPYRIGHT HOLDERS
+AND CONTRIBUTORS "AS IS" AND ANY EXPRESS OR IMPLIED WARRANTIES ... ARE DISCLAIMED"); neither the name of skimage nor
+the names of its contributors may be used to endorse or promote products derived from this software without specific
+prior written permission.  See THIRD_PARTY_NOTICES.md at the repository root for the full text.
 """
 from __future__ import annotations
 
