@@ -24,8 +24,8 @@ struct amt_ctx {
     size_t mailbox_off;
     int num_cus;
     // auxiliary streams + events for fork/join of independent latency-bound kernels inside one op
-    hipStream_t aux[2];
-    hipEvent_t ev[3];
+    hipStream_t aux[3];
+    hipEvent_t ev[4];
     bool aux_ready;
 };
 

@@ -78,8 +78,8 @@ extern "C" int amt_ctx_destroy(amt_ctx* ctx) {
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
     if (ctx->aux_ready) {
-        for (int i = 0; i < 2; ++i) (void)hipStreamDestroy(ctx->aux[i]);
-        for (int i = 0; i < 3; ++i) (void)hipEventDestroy(ctx->ev[i]);
+        for (int i = 0; i < 3; ++i) (void)hipStreamDestroy(ctx->aux[i]);
+        for (int i = 0; i < 4; ++i) (void)hipEventDestroy(ctx->ev[i]);
     }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -140,22 +140,22 @@ static bool fork_enabled() {
 
 int amt_fork(amt_ctx* ctx) {
     if (!fork_enabled()) {
-        ctx->aux[0] = ctx->aux[1] = ctx->stream;
+        ctx->aux[0] = ctx->aux[1] = ctx->aux[2] = ctx->stream;
         return AMT_OK;
     }
     if (!ctx->aux_ready) {
-        for (int i = 0; i < 2; ++i) AMT_HIP_CHECK(hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking));
-        for (int i = 0; i < 3; ++i) AMT_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev[i], hipEventDisableTiming));
+        for (int i = 0; i < 3; ++i) AMT_HIP_CHECK(hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking));
+        for (int i = 0; i < 4; ++i) AMT_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev[i], hipEventDisableTiming));
         ctx->aux_ready = true;
     }
     AMT_HIP_CHECK(hipEventRecord(ctx->ev[0], ctx->stream));
-    for (int i = 0; i < 2; ++i) AMT_HIP_CHECK(hipStreamWaitEvent(ctx->aux[i], ctx->ev[0], 0));
+    for (int i = 0; i < 3; ++i) AMT_HIP_CHECK(hipStreamWaitEvent(ctx->aux[i], ctx->ev[0], 0));
     return AMT_OK;
 }
 
 int amt_join(amt_ctx* ctx) {
     if (!fork_enabled()) return AMT_OK;
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 3; ++i) {
         AMT_HIP_CHECK(hipEventRecord(ctx->ev[1 + i], ctx->aux[i]));
         AMT_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev[1 + i], 0));
     }

@@ -34,7 +34,7 @@
 #include "amt_internal.h"
 
 // component classes
-enum { CLS_NONE = 0, CLS_UNIFORM = 1, CLS_S = 2, CLS_M = 3, CLS_L = 4, CLS_X = 5, CLS_G = 6 };
+enum { CLS_NONE = 0, CLS_UNIFORM = 1, CLS_S = 2, CLS_M = 3, CLS_M2 = 4, CLS_L = 5, CLS_X = 6, CLS_G = 7 };
 // LDS tile classes: max pixels of the bounding box, max d2 (bucket count - 1).  S / M / L are flooded by
 // ws_flood_batch_kernel (6 bytes of LDS per pixel + 8 per bucket), X -- the few boxes between L and the 15-bit
 // index limit -- by the one-pop-at-a-time ws_flood_lds_kernel (4 bytes per pixel).
@@ -43,11 +43,17 @@ enum { CLS_NONE = 0, CLS_UNIFORM = 1, CLS_S = 2, CLS_M = 3, CLS_L = 4, CLS_X = 5
 #define AMT_WS_S_NB 512
 #endif
 #ifndef AMT_WS_M_PX
-#define AMT_WS_M_PX 8192
-#define AMT_WS_M_NB 1024
+// 4,096 px (27 KB with the bucket words: five workgroups per CU).  Measured against 8,192 px / 1,024 buckets (two per
+// CU): watershed stage 1.86 -> 1.73 ms per 32 FOVs, 0.95 -> 0.79 ms per 12 FOVs; boxes above 4,096 px join class L
+#define AMT_WS_M_PX 4096
+#define AMT_WS_M_NB 512
 #endif
 constexpr int S_PX = AMT_WS_S_PX, S_NB = AMT_WS_S_NB;
 constexpr int M_PX = AMT_WS_M_PX, M_NB = AMT_WS_M_NB;
+#ifndef AMT_WS_M2_PX
+#define AMT_WS_M2_PX 8192
+#endif
+constexpr int M2_PX = AMT_WS_M2_PX, M2_NB = 1024;  // 54 KB: two workgroups per CU (0 = class unused)
 constexpr int L_PX = 24576, L_NB = 2048;
 constexpr int X_PX = 32512, X_NB = 2048;  // pixel indices must fit the 15-bit link field
 
@@ -251,6 +257,7 @@ __global__ void __launch_bounds__(256) ws_classify_kernel(comp_row* __restrict__
             if (c.labmax >= 0xFFFF) cls = CLS_G;  // labels are kept as 16-bit values in LDS
             else if (area <= S_PX && c.cmax < S_NB) cls = CLS_S;
             else if (area <= M_PX && c.cmax < M_NB) cls = CLS_M;
+            else if (area <= M2_PX && c.cmax < M2_NB) cls = CLS_M2;
             else if (area <= L_PX && c.cmax < L_NB) cls = CLS_L;
             else if (area <= X_PX && c.cmax < X_NB) cls = CLS_X;
             else cls = CLS_G;
@@ -260,7 +267,7 @@ __global__ void __launch_bounds__(256) ws_classify_kernel(comp_row* __restrict__
         // -1 = no marker at all (stays background)
         Fall[(size_t)blockIdx.y * n + c.root] = cls == CLS_UNIFORM ? c.labmin : (cls == CLS_NONE ? -1 : 0);
         if (cls == CLS_G) has_g[blockIdx.y] = 1;
-        if (cls == CLS_S || cls == CLS_M || cls == CLS_L || cls == CLS_X) {
+        if (cls >= CLS_S && cls <= CLS_X) {
             // per-class worklist of this plane (order is irrelevant: components are independent)
             const int k = cls - CLS_S;
             const int pos = atomicAdd(&wl_count[k * nplanes + blockIdx.y], 1);
@@ -1242,8 +1249,8 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     const int trows = amt_i_tile_rows(H);
     const size_t lcap = amt_i_rootlist_cap(W);
     const size_t nlist = (size_t)nplanes * trows;
-    size_t need = 5 * amt_align(np * 4) + amt_align(nlist * lcap * 4) + amt_align(nlist * 4) + 7 * amt_align(nr * 4) + amt_align(nr * sizeof(comp_row)) +
-                  9 * amt_align(nplanes * 4 * 12) + amt_align((size_t)nplanes * 4);
+    size_t need = 5 * amt_align(np * 4) + amt_align(nlist * lcap * 4) + amt_align(nlist * 4) + 8 * amt_align(nr * 4) + amt_align(nr * sizeof(comp_row)) +
+                  9 * amt_align(nplanes * 4 * 16) + amt_align((size_t)nplanes * 4);
     need += use_d2 ? 2 * amt_align((size_t)nplanes * bstride * 4) : amt_align((size_t)nplanes * bstride * sizeof(hp_elem));
     // the sequential emulation's heap (every pixel is pushed at most once): the float64 path reuses its per-component
     // heap space, the bucket path needs it extra -- and only when ties are to be resolved exactly
@@ -1264,10 +1271,10 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     comp_row* rows = arena_take_t<comp_row>(ctx, nr);
     int* btot = arena_take_t<int>(ctx, nplanes);
     int* mtot = arena_take_t<int>(ctx, nplanes);
-    // per plane: work counters of the L / M / S / G floods [0..4), has_g [4], worklist sizes S / M / L / X [5..9), work
-    // counter of the X flood [9], number of components [10]
-    int* counters = arena_take_t<int>(ctx, (size_t)nplanes * 12);
-    int* wl = arena_take_t<int>(ctx, 4 * nr);  // worklists of the four LDS classes
+    // per plane: work counters of the L / M / S / G floods [0..4), has_g [4], worklist sizes S / M / M2 / L / X [5..10),
+    // number of components [10], work counters of the X [11] and M2 [12] floods
+    int* counters = arena_take_t<int>(ctx, (size_t)nplanes * 16);
+    int* wl = arena_take_t<int>(ctx, 5 * nr);  // worklists of the five LDS classes
     int* ties = ties_dev ? ties_dev : arena_take_t<int>(ctx, nplanes);
     int* P = fused_labels ? arena_take_t<int>(ctx, msz) : nullptr;
     int *head = nullptr, *tail = nullptr;
@@ -1283,8 +1290,8 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     }
 
     int* ncomp = counters + 10 * (size_t)nplanes;
-    hipLaunchKernelGGL(ws_zero_counters_kernel, dim3((nplanes * 12 + 63) / 64), dim3(64), 0, ctx->stream, counters,
-                       nplanes * 12);
+    hipLaunchKernelGGL(ws_zero_counters_kernel, dim3((nplanes * 16 + 63) / 64), dim3(64), 0, ctx->stream, counters,
+                       nplanes * 16);
     AMT_LAUNCH_CHECK();
     hipLaunchKernelGGL(ws_set_flags_kernel, dim3((nplanes + 63) / 64), dim3(64), 0, ctx->stream, ties, nplanes, 0);
     AMT_LAUNCH_CHECK();
@@ -1299,7 +1306,7 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     hipLaunchKernelGGL(ws_rows_init_kernel, dim3(64, nplanes), dim3(256), 0, ctx->stream, rows, ncomp, row_stride);
     AMT_LAUNCH_CHECK();
     int* has_g = counters + 4 * nplanes;
-    int* wl_count = counters + 5 * nplanes;  // [4][nplanes]
+    int* wl_count = counters + 5 * nplanes;  // [5][nplanes]
     hipLaunchKernelGGL(ws_stats_kernel, dim3((W + 63) / 64, (H + 31) / 32, nplanes), dim3(256), 0, ctx->stream,
                        use_d2 ? (const int*)relief : (const int*)nullptr, L, T, markers, rows, row_stride, H, W,
                        use_d2 ? 1 : 0);
@@ -1326,6 +1333,7 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     if (use_d2) {
         const size_t ldsS = (size_t)S_PX * 6 + (size_t)S_NB * 6;
         const size_t ldsM = (size_t)M_PX * 6 + (size_t)M_NB * 6;
+        const size_t ldsM2 = (size_t)(M2_PX > 0 ? M2_PX : 64) * 6 + (size_t)M2_NB * 6;
         const size_t ldsL = (size_t)L_PX * 6 + (size_t)L_NB * 6;
         const size_t ldsX = (size_t)X_PX * 4 + (size_t)X_NB * 4;
         // the LDS classes and the HBM path are independent, latency-bound and use few waves each:
@@ -1333,19 +1341,26 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
         hipLaunchKernelGGL(ws_fill_value_kernel, dim3(256, nplanes), dim3(256), 0, ctx->stream, head, btot, bstride, -1);
         AMT_LAUNCH_CHECK();
         AMT_TRY(amt_fork(ctx));
-        hipLaunchKernelGGL((ws_flood_batch_kernel<L_PX, L_NB>), dim3(16, nplanes), dim3(64), ldsL, ctx->stream,
-                           (const int*)relief, L, T, out, rows, wl + 2 * (size_t)nplanes * row_stride,
-                           wl_count + 2 * nplanes, counters + 0 * nplanes, row_stride, H, W, seeds_first, ties, markers);
+        // workgroups per plane and class (a workgroup only takes components of its own plane).  Measured: 2 x / 4 x as
+        // many change nothing at 1, 12 or 32 planes per launch -- the chains per workgroup are not what bounds a class
+        const int gM = 64, gS = 128, gL = 16;
+        hipLaunchKernelGGL((ws_flood_batch_kernel<L_PX, L_NB>), dim3(gL, nplanes), dim3(64), ldsL, ctx->stream,
+                           (const int*)relief, L, T, out, rows, wl + 3 * (size_t)nplanes * row_stride,
+                           wl_count + 3 * nplanes, counters + 0 * nplanes, row_stride, H, W, seeds_first, ties, markers);
         AMT_LAUNCH_CHECK();
         hipLaunchKernelGGL((ws_flood_lds_kernel<X_PX, X_NB, CLS_X>), dim3(8, nplanes), dim3(64), ldsX, ctx->stream,
-                           (const int*)relief, L, T, out, rows, wl + 3 * (size_t)nplanes * row_stride,
-                           wl_count + 3 * nplanes, counters + 9 * nplanes, row_stride, H, W, seeds_first, ties, markers);
+                           (const int*)relief, L, T, out, rows, wl + 4 * (size_t)nplanes * row_stride,
+                           wl_count + 4 * nplanes, counters + 11 * nplanes, row_stride, H, W, seeds_first, ties, markers);
         AMT_LAUNCH_CHECK();
-        hipLaunchKernelGGL((ws_flood_batch_kernel<M_PX, M_NB>), dim3(64, nplanes), dim3(64), ldsM, ctx->aux[0],
+        hipLaunchKernelGGL((ws_flood_batch_kernel<M2_PX, M2_NB>), dim3(32, nplanes), dim3(64), ldsM2, ctx->aux[2],
+                           (const int*)relief, L, T, out, rows, wl + 2 * (size_t)nplanes * row_stride,
+                           wl_count + 2 * nplanes, counters + 12 * nplanes, row_stride, H, W, seeds_first, ties, markers);
+        AMT_LAUNCH_CHECK();
+        hipLaunchKernelGGL((ws_flood_batch_kernel<M_PX, M_NB>), dim3(gM, nplanes), dim3(64), ldsM, ctx->aux[0],
                            (const int*)relief, L, T, out, rows, wl + 1 * (size_t)nplanes * row_stride,
                            wl_count + 1 * nplanes, counters + 1 * nplanes, row_stride, H, W, seeds_first, ties, markers);
         AMT_LAUNCH_CHECK();
-        hipLaunchKernelGGL((ws_flood_batch_kernel<S_PX, S_NB>), dim3(128, nplanes), dim3(64), ldsS, ctx->aux[1],
+        hipLaunchKernelGGL((ws_flood_batch_kernel<S_PX, S_NB>), dim3(gS, nplanes), dim3(64), ldsS, ctx->aux[1],
                            (const int*)relief, L, T, out, rows, wl + 0 * (size_t)nplanes * row_stride,
                            wl_count + 0 * nplanes, counters + 2 * nplanes, row_stride, H, W, seeds_first, ties, markers);
         AMT_LAUNCH_CHECK();
