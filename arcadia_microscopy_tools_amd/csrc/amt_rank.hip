@@ -440,8 +440,8 @@ __global__ void __launch_bounds__(256) mm_u16_kernel(const uint16_t* __restrict_
     }
 }
 
-// ---- the same filter with NO LDS and no barrier: a wave slides down a strip of 62 x 8 columns -------------------
-// Each lane owns 8 consecutive pixels of the row (one 16-byte load; lanes 0 and 63 are halo), the neighbouring groups
+// ---- the same filter with NO LDS and no barrier: a wave slides down a strip of 64 x 8 columns -------------------
+// Each lane owns 8 consecutive pixels of the row (one 16-byte load; see mm_geo for the strip seams), the neighbouring groups
 // come from the adjacent lanes by DPP wave shifts, the run minima H_k are built in registers, and every input row r
 // is folded straight into the 2 RY + 1 output rows it belongs to (out[y] gets H_{h(r - y)}[r]): the accumulators of
 // the pending output rows and the rows loaded ahead live in registers whose indices are compile-time constants
@@ -455,6 +455,70 @@ __device__ __forceinline__ uint4 mm_lane_left(uint4 v) {
 __device__ __forceinline__ uint4 mm_lane_right(uint4 v) {
     return make_uint4((unsigned)amt_lane_right((int)v.x), (unsigned)amt_lane_right((int)v.y),
                       (unsigned)amt_lane_right((int)v.z), (unsigned)amt_lane_right((int)v.w));
+}
+// the same shifts, but the lane without a source (lane 0 / lane 63) keeps `old` (DPP without bound_ctrl)
+__device__ __forceinline__ uint4 mm_lane_left_old(uint4 old, uint4 v) {
+    return make_uint4((unsigned)__builtin_amdgcn_update_dpp((int)old.x, (int)v.x, 0x138, 0xf, 0xf, false),
+                      (unsigned)__builtin_amdgcn_update_dpp((int)old.y, (int)v.y, 0x138, 0xf, 0xf, false),
+                      (unsigned)__builtin_amdgcn_update_dpp((int)old.z, (int)v.z, 0x138, 0xf, 0xf, false),
+                      (unsigned)__builtin_amdgcn_update_dpp((int)old.w, (int)v.w, 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ uint4 mm_lane_right_old(uint4 old, uint4 v) {
+    return make_uint4((unsigned)__builtin_amdgcn_update_dpp((int)old.x, (int)v.x, 0x130, 0xf, 0xf, false),
+                      (unsigned)__builtin_amdgcn_update_dpp((int)old.y, (int)v.y, 0x130, 0xf, 0xf, false),
+                      (unsigned)__builtin_amdgcn_update_dpp((int)old.z, (int)v.z, 0x130, 0xf, 0xf, false),
+                      (unsigned)__builtin_amdgcn_update_dpp((int)old.w, (int)v.w, 0x130, 0xf, 0xf, false));
+}
+__device__ __forceinline__ unsigned mm_swap16(unsigned a) { return __builtin_amdgcn_alignbit(a, a, 16); }
+
+// A wave owns a strip of 64 x 8 = 512 columns, every lane one group of 8 pixels.  The groups left of lane 0 and right of
+// lane 63 belong to the neighbouring strips: those two lanes fetch them with one more (exec-masked) load per row, and
+// the DPP shifts hand them over as the `old` value of the lane that has no source.  At the image edges the missing
+// group is the boundary extension of the edge group itself (reflect: the group reversed; nearest: its edge pixel;
+// constant: cval); in a partial last strip the lane just beyond the edge carries that extension for its left neighbour.
+struct mm_geo {
+    int xg;               // first column of this lane's group
+    bool inside;          // the group lies in the image
+    bool first_g, last_g; // the image's first / last group
+    bool beyond;          // the group just right of the image (partial last strip)
+    bool need_h;          // lane 0 / 63 with a real neighbouring strip
+    bool edge_wave;       // uniform: first or last strip
+    unsigned lane_off, halo_off;  // byte offsets inside a row
+};
+__device__ __forceinline__ mm_geo mm_geometry(int strip, int nstrips, int lane, int W) {
+    mm_geo g;
+    g.xg = strip * 512 + 8 * lane;
+    g.inside = g.xg + 7 < W;
+    g.first_g = g.xg == 0;
+    g.last_g = g.xg + 8 == W;
+    g.beyond = g.xg == W;
+    const bool hl = lane == 0 && strip > 0, hr = lane == 63 && g.xg + 8 < W;
+    g.need_h = hl || hr;
+    g.edge_wave = strip == 0 || strip == nstrips - 1;
+    g.lane_off = (unsigned)(g.inside ? g.xg : 0) * 2u;
+    g.halo_off = (unsigned)(hl ? g.xg - 8 : (hr ? g.xg + 8 : 0)) * 2u;
+    return g;
+}
+// boundary extension on the left (of the first group s) / right (of the last group s)
+__device__ __forceinline__ uint4 mm_extend(uint4 s, bool left, int mode, unsigned cv2) {
+    if (mode == AMT_MODE_REFLECT) return make_uint4(mm_swap16(s.w), mm_swap16(s.z), mm_swap16(s.y), mm_swap16(s.x));
+    if (mode == AMT_MODE_NEAREST) {
+        const unsigned b = left ? ((s.x & 0xFFFFu) | (s.x << 16)) : ((s.w >> 16) | (s.w & 0xFFFF0000u));
+        return make_uint4(b, b, b, b);
+    }
+    return make_uint4(cv2, cv2, cv2, cv2);
+}
+// lf / rt = the groups left / right of every lane's own group; `cur` is rewritten in the lane beyond the right edge
+__device__ __forceinline__ void mm_neighbours(const mm_geo& g, int lane, uint4& cur, uint4 hal, int mode, unsigned cv2,
+                                              uint4& lf, uint4& rt) {
+    if (g.edge_wave) {
+        const uint4 nl = mm_lane_left(cur);
+        if (g.beyond) cur = mm_extend(nl, false, mode, cv2);
+        if (g.first_g) hal = mm_extend(cur, true, mode, cv2);
+        if (g.last_g && lane == 63) hal = mm_extend(cur, false, mode, cv2);
+    }
+    lf = mm_lane_left_old(hal, cur);
+    rt = mm_lane_right_old(hal, cur);
 }
 
 // SHAPE: 0 = half-widths read from the kernel arguments (any centred-run footprint), 1 = disk(RY), 2 = rectangle
@@ -472,7 +536,6 @@ __host__ __device__ constexpr int mm_shape_h(int shape, int ry, int dy) {
 }
 __host__ __device__ constexpr int mm_shape_hmax(int shape, int ry) { return ry; }
 
-__device__ __forceinline__ unsigned mm_swap16(unsigned a) { return __builtin_amdgcn_alignbit(a, a, 16); }
 // two uint16 differences (wrapping, as numpy's uint16 subtraction)
 __device__ __forceinline__ unsigned mm_pk_sub(unsigned a, unsigned b) {
     mm_u16x2 x, y;
@@ -500,15 +563,14 @@ __global__ void __launch_bounds__(256) mmr_u16_kernel(const uint16_t* __restrict
     if (wid >= nstrips * nsegs) return;                   // whole waves only: the DPP shifts need all 64 lanes
     const int strip = wid % nstrips, seg = wid / nstrips;
     const size_t plane = (size_t)blockIdx.y * H * W;
-    const int xg = strip * 496 - 8 + 8 * lane;  // first column of this lane's group
+    const mm_geo g = mm_geometry(strip, nstrips, lane, W);
+    const int xg = g.xg;
     const int y_begin = __builtin_amdgcn_readfirstlane(seg * seg_rows);
     const int y_end = min(H, y_begin + seg_rows);
-    const bool inside = xg >= 0 && xg + 7 < W;
-    const bool halo_l = xg == -8, halo_r = xg == W;  // the groups just outside the image
-    const bool edge_wave = strip == 0 || strip == nstrips - 1;  // uniform
+    const bool inside = g.inside;
     const unsigned ident = ISMAX ? 0u : 0xFFFFFFFFu;
     const unsigned cv2 = (unsigned)cval | ((unsigned)cval << 16);
-    const unsigned lane_off = (unsigned)(inside ? xg : 0) * 2u;  // byte offset inside a row
+    const unsigned lane_off = g.lane_off;  // byte offset inside a row
     const char* const in_plane = reinterpret_cast<const char*>(in + plane);
     const int refl = mode == AMT_MODE_REFLECT;
     // unconditional load from a boundary-mapped, clamped row (scalar arithmetic, no branches); rows outside the image in
@@ -520,12 +582,26 @@ __global__ void __launch_bounds__(256) mmr_u16_kernel(const uint16_t* __restrict
         const char* rowp = in_plane + (size_t)yy * W * 2;
         return *reinterpret_cast<const uint4*>(rowp + lane_off);
     };
-    uint4 inreg[U], acc[PER];
+    // the neighbouring strips' edge groups (lanes 0 / 63 only), requested DH rows ahead
+    constexpr int DH = 4;
+    auto load_halo = [&](int r) -> uint4 {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (g.need_h) {
+            const int lo = refl ? -r - 1 : 0, hi = refl ? 2 * H - 1 - r : H - 1;
+            int yy = r < 0 ? lo : (r >= H ? hi : r);
+            yy = min(max(yy, 0), H - 1);
+            v = *reinterpret_cast<const uint4*>(in_plane + (size_t)yy * W * 2 + g.halo_off);
+        }
+        return v;
+    };
+    uint4 inreg[U], halreg[U], acc[PER];
 #pragma unroll
     for (int u = 0; u < D; ++u) inreg[u] = load_row(y_begin - RY + u);
 #pragma unroll
+    for (int u = 0; u < DH; ++u) halreg[u] = load_halo(y_begin - RY + u);
+#pragma unroll
     for (int u = 0; u < PER; ++u) acc[u] = make_uint4(ident, ident, ident, ident);
-    const bool can_store = lane >= 1 && lane <= 62 && inside;
+    const bool can_store = inside;
     uint16_t* const out_lane = out + plane + (inside ? xg : 0);
     // minuend row of output row yo = r - RY, requested D steps before that row is stored
     const char* const sub_plane = reinterpret_cast<const char*>(SUB ? minuend + plane : in);
@@ -550,30 +626,23 @@ __global__ void __launch_bounds__(256) mmr_u16_kernel(const uint16_t* __restrict
                 subv = subreg[u % (SUB ? U : 1)];
                 subreg[(u + D) % (SUB ? U : 1)] = load_sub(r - RY + D);
             }
-            if (mode == AMT_MODE_CONSTANT && (r < 0 || r >= H)) cur = make_uint4(cv2, cv2, cv2, cv2);
-            if (edge_wave) {  // the group beyond the image edge from its inner neighbour
-                const uint4 nr = mm_lane_right(cur), nl = mm_lane_left(cur);
-                if (halo_l) {
-                    if (mode == AMT_MODE_REFLECT) cur = make_uint4(mm_swap16(nr.w), mm_swap16(nr.z), mm_swap16(nr.y), mm_swap16(nr.x));
-                    else if (mode == AMT_MODE_NEAREST) { const unsigned b = (nr.x & 0xFFFFu) | (nr.x << 16); cur = make_uint4(b, b, b, b); }
-                    else cur = make_uint4(cv2, cv2, cv2, cv2);
-                }
-                if (halo_r) {
-                    if (mode == AMT_MODE_REFLECT) cur = make_uint4(mm_swap16(nl.w), mm_swap16(nl.z), mm_swap16(nl.y), mm_swap16(nl.x));
-                    else if (mode == AMT_MODE_NEAREST) { const unsigned b = (nl.w >> 16) | (nl.w & 0xFFFF0000u); cur = make_uint4(b, b, b, b); }
-                    else cur = make_uint4(cv2, cv2, cv2, cv2);
-                }
+            uint4 hal = halreg[u];
+            halreg[(u + DH) % U] = load_halo(r + DH);
+            if (mode == AMT_MODE_CONSTANT && (r < 0 || r >= H)) {
+                cur = make_uint4(cv2, cv2, cv2, cv2);
+                hal = cur;
             }
             unsigned p[12];
-            p[4] = cur.x, p[5] = cur.y, p[6] = cur.z, p[7] = cur.w;
             if (hmax > 0) {
-                const uint4 lf = mm_lane_left(cur), rt = mm_lane_right(cur);
+                uint4 lf, rt;
+                mm_neighbours(g, lane, cur, hal, mode, cv2, lf, rt);
                 p[0] = lf.x, p[1] = lf.y, p[2] = lf.z, p[3] = lf.w;
                 p[8] = rt.x, p[9] = rt.y, p[10] = rt.z, p[11] = rt.w;
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) p[i] = p[8 + i] = ident;
             }
+            p[4] = cur.x, p[5] = cur.y, p[6] = cur.z, p[7] = cur.w;
             unsigned hk[4] = {p[4], p[5], p[6], p[7]};
             // fold H_k of row r into the output rows y = r - dy whose footprint row dy has half-width k
             auto fold = [&](int k) {
@@ -675,14 +744,13 @@ __global__ void __launch_bounds__(256) medr_u16_kernel(const uint16_t* __restric
     if (wid >= nstrips * nsegs) return;
     const int strip = wid % nstrips, seg = wid / nstrips;
     const size_t plane = (size_t)blockIdx.y * H * W;
-    const int xg = strip * 496 - 8 + 8 * lane;
+    const mm_geo g = mm_geometry(strip, nstrips, lane, W);
+    const int xg = g.xg;
     const int y_begin = __builtin_amdgcn_readfirstlane(seg * seg_rows);
     const int y_end = min(H, y_begin + seg_rows);
-    const bool inside = xg >= 0 && xg + 7 < W;
-    const bool halo_l = xg == -8, halo_r = xg == W;
-    const bool edge_wave = strip == 0 || strip == nstrips - 1;
+    const bool inside = g.inside;
     const unsigned cv2 = (unsigned)cval | ((unsigned)cval << 16);
-    const unsigned lane_off = (unsigned)(inside ? xg : 0) * 2u;
+    const unsigned lane_off = g.lane_off;
     const char* const in_plane = reinterpret_cast<const char*>(in + plane);
     const int refl = mode == AMT_MODE_REFLECT;
     auto load_row = [&](int r) -> uint4 {
@@ -691,11 +759,24 @@ __global__ void __launch_bounds__(256) medr_u16_kernel(const uint16_t* __restric
         yy = min(max(yy, 0), H - 1);
         return *reinterpret_cast<const uint4*>(in_plane + (size_t)yy * W * 2 + lane_off);
     };
-    uint4 inreg[U];
+    constexpr int DH = 4;
+    auto load_halo = [&](int r) -> uint4 {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (g.need_h) {
+            const int lo = refl ? -r - 1 : 0, hi = refl ? 2 * H - 1 - r : H - 1;
+            int yy = r < 0 ? lo : (r >= H ? hi : r);
+            yy = min(max(yy, 0), H - 1);
+            v = *reinterpret_cast<const uint4*>(in_plane + (size_t)yy * W * 2 + g.halo_off);
+        }
+        return v;
+    };
+    uint4 inreg[U], halreg[U];
     unsigned ring[PER][6];
 #pragma unroll
     for (int u = 0; u < D; ++u) inreg[u] = load_row(y_begin - RY + u);
-    const bool can_store = lane >= 1 && lane <= 62 && inside;
+#pragma unroll
+    for (int u = 0; u < DH; ++u) halreg[u] = load_halo(y_begin - RY + u);
+    const bool can_store = inside;
     uint16_t* const out_lane = out + plane + (inside ? xg : 0);
     for (int base = y_begin - RY; base < y_end + RY; base += U) {
 #pragma unroll
@@ -703,24 +784,18 @@ __global__ void __launch_bounds__(256) medr_u16_kernel(const uint16_t* __restric
             const int r = base + u;
             uint4 cur = inreg[u];
             inreg[(u + D) % U] = load_row(r + D);
-            if (mode == AMT_MODE_CONSTANT && (r < 0 || r >= H)) cur = make_uint4(cv2, cv2, cv2, cv2);
-            if (edge_wave) {
-                const uint4 nr = mm_lane_right(cur), nl = mm_lane_left(cur);
-                if (halo_l) {
-                    if (mode == AMT_MODE_REFLECT) cur = make_uint4(mm_swap16(nr.w), mm_swap16(nr.z), mm_swap16(nr.y), mm_swap16(nr.x));
-                    else if (mode == AMT_MODE_NEAREST) { const unsigned b = (nr.x & 0xFFFFu) | (nr.x << 16); cur = make_uint4(b, b, b, b); }
-                    else cur = make_uint4(cv2, cv2, cv2, cv2);
-                }
-                if (halo_r) {
-                    if (mode == AMT_MODE_REFLECT) cur = make_uint4(mm_swap16(nl.w), mm_swap16(nl.z), mm_swap16(nl.y), mm_swap16(nl.x));
-                    else if (mode == AMT_MODE_NEAREST) { const unsigned b = (nl.w >> 16) | (nl.w & 0xFFFF0000u); cur = make_uint4(b, b, b, b); }
-                    else cur = make_uint4(cv2, cv2, cv2, cv2);
-                }
+            uint4 hal = halreg[u];
+            halreg[(u + DH) % U] = load_halo(r + DH);
+            if (mode == AMT_MODE_CONSTANT && (r < 0 || r >= H)) {
+                cur = make_uint4(cv2, cv2, cv2, cv2);
+                hal = cur;
             }
+            uint4 lf, rt;
+            mm_neighbours(g, lane, cur, hal, mode, cv2, lf, rt);
             const int slot = u % PER;
-            ring[slot][0] = (unsigned)amt_lane_left((int)cur.w);
+            ring[slot][0] = lf.w;
             ring[slot][1] = cur.x, ring[slot][2] = cur.y, ring[slot][3] = cur.z, ring[slot][4] = cur.w;
-            ring[slot][5] = (unsigned)amt_lane_right((int)cur.x);
+            ring[slot][5] = rt.x;
             const int yo = r - RY;
             if (yo >= y_begin && yo < y_end) {  // uniform: the warm-up rows of a segment skip the selection
                 unsigned res[4];
@@ -775,7 +850,7 @@ static int medr_try(amt_ctx* ctx, const uint16_t* in, uint16_t* out, int nplanes
     }
     const int key = ry * 1000 + hw[0] * 100 + (ry >= 1 ? hw[1] : 0) * 10 + (ry >= 2 ? hw[2] : 0);
     const int seg_rows = 64;
-    const int nstrips = (W + 495) / 496, nsegs = (H + seg_rows - 1) / seg_rows;
+    const int nstrips = (W + 511) / 512, nsegs = (H + seg_rows - 1) / seg_rows;
     dim3 grid((nstrips * nsegs + 3) / 4, nplanes);
 #define AMT_MEDR(RYV, A, B, C)                                                                                       \
     hipLaunchKernelGGL((medr_u16_kernel<RYV, A, B, C>), grid, dim3(256), 0, ctx->stream, in, out, H, W, mode, cval, \
@@ -926,7 +1001,7 @@ static int rank_filter_impl(amt_ctx* ctx, const void* in, void* out, int dtype, 
                 }
                 const bool sub = minuend != nullptr && op == 1;
                 const int seg_rows = P.ry <= 3 ? 64 : 128;
-                const int nstrips = (W + 495) / 496, nsegs = (H + seg_rows - 1) / seg_rows;
+                const int nstrips = (W + 511) / 512, nsegs = (H + seg_rows - 1) / seg_rows;
                 dim3 gridr((nstrips * nsegs + 3) / 4, nplanes);
                 bool launched = true;
 #define AMT_MMR_GO(RYV, SH)                                                                                            \

@@ -456,11 +456,11 @@ def test_grey_morphology_u16_packed_kernel(ctx, ops):
             assert np.array_equal(ops.opening(d, fp).numpy()[0], skops.opening(img[0], fp))
             assert np.array_equal(ops.closing(d, fp).numpy()[1], skops.closing(img[1], fp))
             assert np.array_equal(ops.white_tophat(d, fp).numpy()[1], skops.white_tophat(img[1], fp))
-    # the register kernel's seams: strips of 496 columns (a width of exactly one / two strips, one group more, a last
-    # strip of a single group), row segments of 64 / 128 rows (heights around the segment length), and the three
+    # the register kernel's seams: strips of 512 columns (a width of exactly one / two strips, one group more, a last
+    # strip of a single group, a last group in lane 62), row segments of 64 / 128 rows (heights around the segment length), and the three
     # boundary modes it takes (grey morphology itself only uses 'reflect')
     from arcadia_microscopy_tools_amd import hipops as _h
-    for shape in ((16, 496), (67, 992), (130, 504), (200, 1000), (129, 2048)):
+    for shape in ((16, 512), (67, 1024), (130, 520), (200, 1000), (40, 1528), (129, 2048)):
         img = rng.integers(0, 65536, shape).astype(np.uint16)
         d = ctx.asarray(img)
         fps["col15"], fps["r3x11"] = np.ones((15, 1), np.uint8), np.ones((3, 11), np.uint8)
@@ -480,7 +480,7 @@ def test_grey_morphology_u16_packed_kernel(ctx, ops):
     oct5 = np.ones((5, 5), np.uint8)
     oct5[0, 0] = oct5[0, 4] = oct5[4, 0] = oct5[4, 4] = 0
     med_fps = {"sq3": fps["sq3"], "cross": fps["cross"], "disk2": fps["disk2"], "sq5": fps["sq5"], "oct5": oct5}
-    for shape in ((16, 496), (67, 992), (130, 504), (129, 2048)):
+    for shape in ((16, 512), (67, 1024), (130, 520), (33, 1016), (129, 2048)):
         img = rng.integers(0, 65536, shape).astype(np.uint16)
         few = rng.integers(0, 4, shape).astype(np.uint16) * 21845  # ties, and both ends of the uint16 range
         for im in (img, few):
