@@ -9,11 +9,15 @@ import sys
 def main():
     path, args = sys.argv[1], sys.argv[2]
     print(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py {args}")
-    print("# one launch = one stage kernel over a batch of 32 FOVs (32 planes of 2048x2048); the three ws_flood_lds "
-          "classes run concurrently")
-    print("kernel,calls,avg_us,total_ms,pct")
     with open(path, newline="") as f:
-        for r in csv.DictReader(f):
+        rows = list(csv.DictReader(f))
+    note = "# one launch = one stage kernel over a batch of 32 planes of 2048x2048"
+    if any("ws_flood" in r["Name"] for r in rows):
+        note += "; the ws_flood_* classes of one chain run concurrently (main + three auxiliary streams)"
+    print(note)
+    print("kernel,calls,avg_us,total_ms,pct")
+    if True:
+        for r in rows:
             name = r["Name"].replace('"', "'")
             print(f'"{name}",{r["Calls"]},{float(r["AverageNs"]) / 1e3:.1f},{float(r["TotalDurationNs"]) / 1e6:.2f},'
                   f'{float(r["Percentage"]):.2f}')
