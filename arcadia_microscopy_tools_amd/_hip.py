@@ -43,6 +43,7 @@ _SIGS = {
     "amt_ctx_create": (c_int, [c_int, POINTER(c_void_p)]),
     "amt_ctx_create_on_stream": (c_int, [c_int, c_void_p, POINTER(c_void_p)]),
     "amt_ctx_destroy": (c_int, [_P]),
+    "amt_ctx_set_fork": (c_int, [_P, c_int]),
     "amt_ctx_stream": (c_int, [_P, POINTER(c_void_p)]),
     "amt_last_error": (c_char_p, []),
     "amt_version": (c_char_p, []),

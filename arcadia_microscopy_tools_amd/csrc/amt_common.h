@@ -27,6 +27,7 @@ struct amt_ctx {
     hipStream_t aux[3];
     hipEvent_t ev[4];
     bool aux_ready;
+    bool fork;  // amt_ctx_set_fork: independent kernels of one op run on the auxiliary streams
 };
 
 // fork: aux streams wait for everything enqueued so far on the main stream; join: main waits for them

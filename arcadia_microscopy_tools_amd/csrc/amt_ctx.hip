@@ -21,6 +21,8 @@ extern "C" int amt_device_count(void) {
     return n;
 }
 
+static bool fork_enabled();
+
 static int ctx_create_common(int device, hipStream_t stream, bool own, amt_ctx** out) {
     AMT_REQUIRE(out != nullptr, "amt_ctx_create: out is null");
     int n = 0;
@@ -51,6 +53,7 @@ static int ctx_create_common(int device, hipStream_t stream, bool own, amt_ctx**
     c->mailbox_cap = 0;
     c->mailbox_off = 0;
     c->aux_ready = false;
+    c->fork = fork_enabled();
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess)
         c->num_cus = prop.multiProcessorCount;
@@ -138,8 +141,18 @@ static bool fork_enabled() {
     return v == 1;
 }
 
+// Per context: a process that already runs several contexts side by side (one per HIP stream) gains nothing from the
+// auxiliary streams -- their events and the extra hardware queues cost more than the overlap inside one op brings
+// (bench.py, 4 contexts: 11.1 k FOV/s without, 10.2 k with) -- while a single context needs them (watershed stage
+// 1.80 ms against 2.32 ms per 32 FOVs).
+extern "C" int amt_ctx_set_fork(amt_ctx* ctx, int enable) {
+    AMT_REQUIRE(ctx != nullptr, "ctx_set_fork: null context");
+    ctx->fork = enable != 0;
+    return AMT_OK;
+}
+
 int amt_fork(amt_ctx* ctx) {
-    if (!fork_enabled()) {
+    if (!ctx->fork) {
         ctx->aux[0] = ctx->aux[1] = ctx->aux[2] = ctx->stream;
         return AMT_OK;
     }
@@ -154,7 +167,7 @@ int amt_fork(amt_ctx* ctx) {
 }
 
 int amt_join(amt_ctx* ctx) {
-    if (!fork_enabled()) return AMT_OK;
+    if (!ctx->fork) return AMT_OK;
     for (int i = 0; i < 3; ++i) {
         AMT_HIP_CHECK(hipEventRecord(ctx->ev[1 + i], ctx->aux[i]));
         AMT_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev[1 + i], 0));

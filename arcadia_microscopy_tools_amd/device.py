@@ -50,6 +50,11 @@ class Context:
         self.handle = h
         self.device = int(device)
 
+    def set_fork(self, enable: bool) -> None:
+        """Let independent kernels inside one call use the context's auxiliary streams (default) or keep everything on
+        its one stream -- the right choice when several contexts already run side by side (amt_ctx_set_fork)."""
+        _hip.check(self._lib.amt_ctx_set_fork(self.handle, 1 if enable else 0), "amt_ctx_set_fork")
+
     # -- lifetime -------------------------------------------------------------------------------
     def close(self):
         if getattr(self, "handle", None):

@@ -57,6 +57,9 @@ int amt_ctx_create(int device, amt_ctx** out);
 /* Share an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); 0 = null stream. */
 int amt_ctx_create_on_stream(int device, void* hip_stream, amt_ctx** out);
 int amt_ctx_destroy(amt_ctx* ctx);
+/* Whether independent kernels inside one call (the watershed's flood classes) run on the context's auxiliary streams
+ * (default 1; AMT_FORK=0 changes the default).  Hosts that drive several contexts concurrently switch it off. */
+int amt_ctx_set_fork(amt_ctx* ctx, int enable);
 /* The context's hipStream_t (e.g. to wrap it in torch.cuda.ExternalStream for an RCCL collective). */
 int amt_ctx_stream(amt_ctx* ctx, void** hip_stream);
 const char* amt_last_error(void);

@@ -22,6 +22,10 @@ if [ "$1" = "1" ]; then
   echo "pmc fetch done"
   timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_w -o w --output-format csv -- python3 $R/bench.py $P > $O/pmc_w.log 2>&1 || exit 1
   echo "pmc write done"
+elif [ "$1" = "3" ]; then
+  cd $R
+  AMT_BENCH_FORCE_DIST=1 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29517 python3 bench.py --no-cpu --no-h2d 2> $O/bench_dist1.err > $O/bench_dist1.json && echo "dist1 done" || exit 1
+  python3 bench.py --unique 64 --tail-reps 24 --no-cpu --no-h2d 2> $O/bench_u64.err > $O/bench_u64.json && echo "u64 done" || exit 1
 else
   cd $R
   python3 bench.py 2> $O/bench.err > $O/bench.json && echo "default bench done" || exit 1
@@ -30,6 +34,6 @@ else
   python3 bench.py --workload filters 2> $O/bench_filters.err > $O/bench_filters.json && echo "filters done" || exit 1
   python3 bench.py --workload c5 --no-cpu 2> $O/bench_c5.err > $O/bench_c5.json && echo "c5 done" || exit 1
   python3 bench.py --plate 48 --no-cpu --no-h2d 2> $O/bench_plate48.err > $O/bench_plate48.json && echo "plate48 done" || exit 1
-  AMT_BENCH_FORCE_DIST=1 python3 bench.py --no-cpu --no-h2d 2> $O/bench_dist1.err > $O/bench_dist1.json && echo "dist1 done" || exit 1
+  AMT_BENCH_FORCE_DIST=1 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29517 python3 bench.py --no-cpu --no-h2d 2> $O/bench_dist1.err > $O/bench_dist1.json && echo "dist1 done" || exit 1
   python3 bench.py --unique 64 --tail-reps 24 --no-cpu --no-h2d 2> $O/bench_u64.err > $O/bench_u64.json && echo "u64 done" || exit 1
 fi
