@@ -343,6 +343,10 @@ def get_context() -> Context:
     ctx = getattr(_tls, "ctx", None)
     if ctx is None or ctx.handle is None or ctx.device != _default_device:
         ctx = Context(_default_device)
+        if threading.current_thread() is not threading.main_thread():
+            # a worker thread's context runs beside its siblings' (Pipeline(parallel=True), R/pipeline.py:145-146): the
+            # threads provide the overlap, every call stays on its context's one stream (amt_ctx_set_fork)
+            ctx.set_fork(False)
         _tls.ctx = ctx
     return ctx
 
