@@ -184,4 +184,4 @@ def segment_image(net, image: np.ndarray, device, compute_dtype, *, cellprob_thr
     c = int(counts.numpy()[0])
     if c < 0:
         raise RuntimeError("the flow field produced more seeds than the post-processing's capacity")
-    return labels.numpy()[0].astype(np.int64)
+    return labels[0].numpy_int64()

@@ -11,6 +11,7 @@ device is a pointer offset (reference: R/microscopy.py:279-282 returns a numpy v
 from __future__ import annotations
 
 import ctypes
+import os
 import threading
 
 import numpy as np
@@ -27,6 +28,27 @@ _DTYPE_CODE = {
     np.dtype(np.float32): _hip.F32,
     np.dtype(np.uint32): _hip.I32,
 }
+
+
+_copy_pool = None
+
+
+def _host_copy(dst: np.ndarray, src: np.ndarray) -> None:
+    """dst[:] = src for flat uint8 arrays; large copies are split over four threads (numpy releases the GIL, and the
+    first touch of a fresh destination -- the kernel zeroing its pages -- is most of the cost of a 33 MB copy)."""
+    global _copy_pool
+    n = dst.shape[0]
+    if n < (8 << 20):
+        dst[:] = src
+        return
+    if _copy_pool is None:
+        from concurrent.futures import ThreadPoolExecutor
+
+        _copy_pool = ThreadPoolExecutor(max_workers=4, thread_name_prefix="amt-copy")
+    step = (n // 4 + 4095) & ~4095
+    futs = [_copy_pool.submit(np.copyto, dst[o:o + step], src[o:o + step]) for o in range(0, n, step)]
+    for f in futs:
+        f.result()
 
 
 def dtype_code(dt) -> int:
@@ -49,6 +71,30 @@ class Context:
                        "amt_ctx_create_on_stream")
         self.handle = h
         self.device = int(device)
+        # Freed device buffers are kept for the next allocation of the same size: hipFree synchronises the device and
+        # costs ~0.15 ms a call, and the reference-level API (one call = a dozen temporaries) would pay it twenty times
+        # per image.  Reuse is safe because every buffer of a context is only ever touched by that context's stream
+        # (arrays handed to another context with DeviceArray.on() are excluded and freed the slow way).
+        self._pool: dict[int, list[int]] = {}
+        self._pool_bytes = 0
+        self._pool_cap = int(os.environ.get("AMT_POOL_BYTES", str(4 << 30)))
+        self._pool_lock = threading.Lock()
+        # Host <-> device copies of pageable numpy arrays go through one page-locked staging buffer per context: the
+        # runtime otherwise registers every fresh host array for DMA, which costs 1.6 ms or 25 ms per 33 MB array
+        # (alternating, measured) against 0.6 ms of PCIe time; a host memcpy through pinned memory is 3 ms and steady
+        self._stage_buf = None
+        self._stage_cap = int(os.environ.get("AMT_STAGE_BYTES", str(256 << 20)))
+
+    def _staging(self, nbytes: int):
+        """A page-locked uint8 array of at least ``nbytes`` (None if the copy is too small to matter or too large)."""
+        if nbytes < (64 << 10) or nbytes > self._stage_cap:
+            return None
+        if self._stage_buf is None or self._stage_buf.array.nbytes < nbytes:
+            if self._stage_buf is not None:
+                self.synchronize()
+                self._stage_buf.close()
+            self._stage_buf = PinnedBuffer((max(nbytes, 64 << 20),), np.uint8)
+        return self._stage_buf.array
 
     def set_fork(self, enable: bool) -> None:
         """Let independent kernels inside one call use the context's auxiliary streams (default) or keep everything on
@@ -58,8 +104,31 @@ class Context:
     # -- lifetime -------------------------------------------------------------------------------
     def close(self):
         if getattr(self, "handle", None):
+            self.trim()
+            if self._stage_buf is not None:
+                self.synchronize()
+                self._stage_buf.close()
+                self._stage_buf = None
             self._lib.amt_ctx_destroy(self.handle)
             self.handle = None
+
+    def trim(self) -> None:
+        """Return every cached buffer to the driver."""
+        with self._pool_lock:
+            ptrs = [p for lst in self._pool.values() for p in lst]
+            self._pool.clear()
+            self._pool_bytes = 0
+        for p in ptrs:
+            self._lib.amt_free(self.handle, p)
+
+    def _release(self, ptr: int, nbytes: int, shared: bool) -> None:
+        if not shared and nbytes:
+            with self._pool_lock:
+                if self._pool_bytes + nbytes <= self._pool_cap:
+                    self._pool.setdefault(nbytes, []).append(ptr)
+                    self._pool_bytes += nbytes
+                    return
+        self._lib.amt_free(self.handle, ptr)
 
     def __del__(self):
         try:
@@ -72,9 +141,19 @@ class Context:
         shape = tuple(int(s) for s in shape)
         dt = np.dtype(dtype)
         nbytes = int(np.prod(shape, dtype=np.int64)) * dt.itemsize
-        p = ctypes.c_void_p()
-        _hip.check(self._lib.amt_malloc(self.handle, nbytes, ctypes.byref(p)), "amt_malloc")
-        return DeviceArray(self, p.value, shape, dt, owner=True)
+        nalloc = max(256, (nbytes + 255) & ~255)
+        with self._pool_lock:
+            lst = self._pool.get(nalloc)
+            ptr = lst.pop() if lst else 0
+            if ptr:
+                self._pool_bytes -= nalloc
+        if not ptr:
+            p = ctypes.c_void_p()
+            _hip.check(self._lib.amt_malloc(self.handle, nalloc, ctypes.byref(p)), "amt_malloc")
+            ptr = p.value
+        a = DeviceArray(self, ptr, shape, dt, owner=True)
+        a._alloc = nalloc
+        return a
 
     def zeros(self, shape, dtype) -> "DeviceArray":
         a = self.empty(shape, dtype)
@@ -88,7 +167,14 @@ class Context:
             a = a.view(np.uint8)
         d = self.empty(a.shape, a.dtype)
         if a.nbytes:
-            _hip.check(self._lib.amt_memcpy_h2d(self.handle, d.ptr, a.ctypes.data, a.nbytes), "amt_memcpy_h2d")
+            stage = self._staging(a.nbytes)
+            if stage is not None:
+                self.synchronize()  # the staging buffer may still feed an earlier copy
+                _host_copy(stage[: a.nbytes], a.reshape(-1).view(np.uint8))
+                src = stage.ctypes.data
+            else:
+                src = a.ctypes.data
+            _hip.check(self._lib.amt_memcpy_h2d(self.handle, d.ptr, src, a.nbytes), "amt_memcpy_h2d")
             self.synchronize()  # the host buffer may be a temporary
         if arr.dtype == np.bool_:
             d.is_bool = True
@@ -184,7 +270,7 @@ class Timer:
 class DeviceArray:
     """A typed view of device memory; frees the allocation when the owning object dies."""
 
-    __slots__ = ("ctx", "ptr", "shape", "dtype", "_owner", "_base", "is_bool")
+    __slots__ = ("ctx", "ptr", "shape", "dtype", "_owner", "_base", "is_bool", "_alloc", "_shared")
 
     def __init__(self, ctx: Context, ptr: int, shape, dtype, owner: bool = False, base=None):
         self.ctx = ctx
@@ -194,6 +280,8 @@ class DeviceArray:
         self._owner = owner
         self._base = base  # keeps the owning array alive for views
         self.is_bool = False
+        self._alloc = 0       # bytes of the allocation (owners made by Context.empty)
+        self._shared = False  # handed to another context: not eligible for the context's buffer cache
 
     # -- geometry -------------------------------------------------------------------------------
     @property
@@ -251,7 +339,9 @@ class DeviceArray:
             return self
         if ctx.device != self.ctx.device:
             raise ValueError(f"cannot bind an array of device {self.ctx.device} to a context of device {ctx.device}")
-        v = DeviceArray(ctx, self.ptr, self.shape, self.dtype, base=self._base if self._base is not None else self)
+        owner = self._base if self._base is not None else self
+        owner._shared = True
+        v = DeviceArray(ctx, self.ptr, self.shape, self.dtype, base=owner)
         v.is_bool = self.is_bool
         return v
 
@@ -270,11 +360,27 @@ class DeviceArray:
         out = np.empty(self.shape, dtype=self.dtype)
         if out.nbytes:
             lib = self.ctx._lib
-            _hip.check(lib.amt_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr, out.nbytes), "amt_memcpy_d2h")
+            stage = self.ctx._staging(out.nbytes)
+            dst = stage.ctypes.data if stage is not None else out.ctypes.data
+            _hip.check(lib.amt_memcpy_d2h(self.ctx.handle, dst, self.ptr, out.nbytes), "amt_memcpy_d2h")
             self.ctx.synchronize()
+            if stage is not None:
+                _host_copy(out.reshape(-1).view(np.uint8), stage[: out.nbytes])
         if self.is_bool and self.dtype == np.uint8:
             return out.view(np.bool_)
         return out
+
+    def numpy_int64(self) -> np.ndarray:
+        """int32 labels as the int64 array the reference's API returns (R/model.py:215, R/masks.py:63-65): widened on
+        the device and copied once, instead of a copy plus a host-side ``astype`` over the plane."""
+        if self.dtype == np.int64:
+            return self.numpy()
+        if self.dtype != np.int32:
+            return self.numpy().astype(np.int64)
+        wide = self.ctx.empty(self.shape, np.int64)
+        if self.size:
+            _hip.check(self.ctx._lib.amt_cast_i32_i64(self.ctx.handle, self.ptr, wide.ptr, self.size), "amt_cast_i32_i64")
+        return wide.numpy()
 
     def copy(self) -> "DeviceArray":
         d = self.ctx.empty(self.shape, self.dtype)
@@ -285,8 +391,9 @@ class DeviceArray:
     def __del__(self):
         try:
             if self._owner and self.ptr and self.ctx.handle:
-                # frees are stream-ordered by hipFree's implicit synchronisation
-                self.ctx._lib.amt_free(self.ctx.handle, self.ptr)
+                # back to the context's cache (same-stream reuse is ordered); shared or uncached buffers go through
+                # hipFree, whose implicit synchronisation orders them against every stream
+                self.ctx._release(self.ptr, self._alloc, self._shared)
                 self.ptr = 0
         except Exception:
             pass

@@ -62,9 +62,10 @@ def _check_label_plane(mask_image) -> None:
         raise TypeError("mask_image must be a numpy array")
     if mask_image.ndim != 2:
         raise ValueError("mask_image must be a 2D array")
-    if (mask_image < 0).any():
+    # one reduction each and no temporaries (the image is 33 MB at 2048^2 int64)
+    if mask_image.dtype.kind not in "bu" and mask_image.size and mask_image.min() < 0:
         raise ValueError("mask_image must have non-negative values")
-    if not mask_image.any():
+    if not mask_image.size or not mask_image.max():
         raise ValueError("mask_image contains no cells (all values are 0)")
 
 
@@ -138,7 +139,7 @@ class SegmentationMask:
     def label_image(self) -> Int64Array:
         """Consecutive int64 labels 1..K, background 0, edge cells removed if requested (R/masks.py:210-218)."""
         lab, _ = self._labels_device
-        return lab.numpy().astype(np.int64)
+        return lab.numpy_int64()
 
     @cached_property
     def num_cells(self) -> int:
@@ -175,7 +176,6 @@ class SegmentationMask:
         assert self.intensity_property_names is not None
         lab, k = self._labels_device
         k = int(k)
-        morph = hipops.regionprops(lab, max(k, 1)).numpy()[0][:k]
         inten = None
         names: list[str] = []
         if self.intensity_image_dict and self.intensity_property_names:
@@ -183,14 +183,26 @@ class SegmentationMask:
             for channel, img in self.intensity_image_dict.items():
                 planes.append(np.asarray(img))
                 names.append(channel.name)
+            ctx = get_context()
             # uint8 / uint16 images are accumulated exactly (integer sums); any other dtype the reference accepts
-            # (R/masks.py:178-190: "any 2-D ndarray") is measured in float64, as regionprops does
-            if all(p.dtype in (np.uint8, np.uint16) for p in planes):
-                stack = np.stack([p.astype(np.uint16, copy=False) for p in planes])
+            # (R/masks.py:178-190: "any 2-D ndarray") is measured in float64, as regionprops does.  The planes go to
+            # the device one by one into their slot of a (C, Y, X) buffer: no host-side stack
+            exact = all(p.dtype in (np.uint8, np.uint16) for p in planes)
+            dt = np.uint16 if exact else np.float64
+            stack = ctx.empty((len(planes),) + tuple(lab.shape[-2:]), dt)
+            for c, p in enumerate(planes):
+                ctx.copy_from_host_async(stack[c], np.ascontiguousarray(p, dtype=dt))
+            ctx.synchronize()  # the converted host planes may be temporaries
+            if exact and lab.size == stack.size // len(planes):
+                # morphology + intensities share the bounding-box pass and the per-label scan
+                m, it = hipops.regionprops_full(lab.reshape((1,) + tuple(lab.shape[-2:])),
+                                                stack.reshape((1,) + stack.shape), max(k, 1))
+                morph, inten = m.numpy()[0][:k], it.numpy()[0][:k]
             else:
-                stack = np.stack([p.astype(np.float64) for p in planes])
-            stack = get_context().asarray(np.ascontiguousarray(stack))
-            inten = hipops.regionprops_intensity(lab, stack, max(k, 1)).numpy()[0][:k]
+                morph = hipops.regionprops(lab, max(k, 1)).numpy()[0][:k]
+                inten = hipops.regionprops_intensity(lab, stack, max(k, 1)).numpy()[0][:k]
+        else:
+            morph = hipops.regionprops(lab, max(k, 1)).numpy()[0][:k]
         return assemble_cell_properties(morph, inten, names, list(self.property_names),
                                         list(self.intensity_property_names))
 
@@ -232,7 +244,7 @@ class SegmentationMask:
         flags[0, 1:] = keep
         lab, _ = self._labels_device
         kept = hipops.keep_labels(lab, get_context().asarray(flags), self.num_cells)
-        new_label_image = kept.numpy().astype(np.int64)
+        new_label_image = kept.numpy_int64()
         if not keep.any():
             raise ValueError(
                 f"No cells remain after filtering '{property_name}' "

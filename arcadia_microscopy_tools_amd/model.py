@@ -181,7 +181,7 @@ class SegmentationModel:
         ws = hipops.watershed_edt(d2, markers, m1, seeds_first=True)
         k = int(nmark.numpy()[0])
         labels, _ = hipops.relabel_sequential(ws, max(k, 1))
-        return labels.numpy().astype(np.int64)
+        return labels.numpy_int64()
 
     # -- public API (R/model.py:171-290) ----------------------------------------------------------------
     def segment(self, intensities: Float64Array, cell_diameter_px: float | None = None,
@@ -199,7 +199,7 @@ class SegmentationModel:
             mask = self._segment_one(intensities, params, cellpose_kwargs)
         except Exception as e:
             raise RuntimeError(f"Cellpose segmentation failed: {e}") from e
-        return mask.astype(np.int64)
+        return mask if mask.dtype == np.int64 else mask.astype(np.int64)
 
     def _segment_one(self, intensities, params: CellposeParams, cellpose_kwargs) -> np.ndarray:
         if self._use_network():
@@ -238,7 +238,7 @@ class SegmentationModel:
         from . import hipops
 
         labels, _ = hipops.relabel_sequential(seg.ws, seg.max_cells)
-        out = labels.numpy().astype(np.int64)
+        out = labels.numpy_int64()
         return [out[i] for i in range(len(arrs))]
 
     def batch_segment(self, intensities_batch: Sequence[Float64Array], cell_diameter_px: float | None = None,

@@ -211,7 +211,7 @@ class SegmentationResult:
 
     def labels_numpy(self) -> np.ndarray:
         """int64 label images (B, H, W), background 0 (dtype contract: R/model.py:215, R/masks.py:63-65)."""
-        return self.seg.labels.numpy().astype(np.int64)
+        return self.seg.labels.numpy_int64()
 
     def feature_tables(self) -> list[dict[str, np.ndarray]]:
         """One dict per FOV with the keys of ``SegmentationMask.cell_properties`` (R/masks.py:247-328,
