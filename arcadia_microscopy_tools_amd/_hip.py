@@ -100,6 +100,7 @@ _SIGS = {
     "amt_subtract": (c_int, [_P, _P, _P, _P, c_int, c_size_t]),
     "amt_label": (c_int, [_P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int]),
     "amt_label_sparse": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int]),
+    "amt_label_sparse_reuse": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "amt_clear_border": (c_int, [_P, _P, _P, c_int, c_int, c_int]),
     "amt_relabel_sequential": (c_int, [_P, _P, _P, _P, c_int, c_size_t, c_int]),
     "amt_clear_border_relabel": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),

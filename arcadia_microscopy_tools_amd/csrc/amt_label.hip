@@ -1043,8 +1043,32 @@ __global__ void sp_clamp_kernel(int* total_clamped, const int* total, int cap, i
     if (i < nplanes) total_clamped[i] = total[i] < cap ? total[i] : cap;
 }
 
+// out[keep_list[k]] = 0 for the pixels the previous call wrote (sparse clear instead of a full-plane memset)
+__global__ void __launch_bounds__(256) sp_unwrite_kernel(const int* __restrict__ list, const int* __restrict__ count,
+                                                         int* __restrict__ out, size_t n, int cap) {
+    const int K = count[blockIdx.y] < cap ? count[blockIdx.y] : cap;
+    const int* lst = list + (size_t)blockIdx.y * cap;
+    int* o = out + (size_t)blockIdx.y * n;
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < K; k += gridDim.x * 256) o[lst[k]] = 0;
+}
+
+static int label_sparse_impl(amt_ctx* ctx, const uint8_t* in, int32_t* out, int32_t* count_dev, int nplanes, int H, int W,
+                             int connectivity, int capacity, int32_t* keep_list, int32_t* keep_count);
+
 extern "C" int amt_label_sparse(amt_ctx* ctx, const uint8_t* in, int32_t* out, int32_t* count_dev, int nplanes, int H,
                                 int W, int connectivity, int capacity) {
+    return label_sparse_impl(ctx, in, out, count_dev, nplanes, H, W, connectivity, capacity, nullptr, nullptr);
+}
+
+extern "C" int amt_label_sparse_reuse(amt_ctx* ctx, const uint8_t* in, int32_t* out, int32_t* count_dev, int nplanes,
+                                      int H, int W, int connectivity, int capacity, int32_t* keep_list,
+                                      int32_t* keep_count) {
+    AMT_REQUIRE(keep_list && keep_count, "label_sparse_reuse: keep_list / keep_count are required");
+    return label_sparse_impl(ctx, in, out, count_dev, nplanes, H, W, connectivity, capacity, keep_list, keep_count);
+}
+
+static int label_sparse_impl(amt_ctx* ctx, const uint8_t* in, int32_t* out, int32_t* count_dev, int nplanes, int H, int W,
+                             int connectivity, int capacity, int32_t* keep_list, int32_t* keep_count) {
     AMT_TRY(amt_set_device(ctx));
     AMT_REQUIRE(in && out && nplanes >= 0 && H > 0 && W > 0, "label_sparse: bad arguments");
     AMT_REQUIRE(connectivity == 1 || connectivity == 2, "label_sparse: connectivity must be 1 or 2");
@@ -1063,7 +1087,18 @@ extern "C" int amt_label_sparse(amt_ctx* ctx, const uint8_t* in, int32_t* out, i
     int* total = arena_take_t<int>(ctx, nplanes);
     int* total_c = arena_take_t<int>(ctx, nplanes);
     int* nroots = arena_take_t<int>(ctx, nplanes);
-    AMT_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)nplanes * n * sizeof(int32_t), ctx->stream));
+    const unsigned gk0 = amt_grid_for((size_t)capacity, 256, 64);
+    if (keep_list) {
+        // `out` is zero except where the previous call on these buffers wrote: undo exactly those writes (the list of
+        // this call replaces the kept one below) -- 0.5 GB of memset per 32 planes of 2048^2 becomes a few thousand stores
+        hipLaunchKernelGGL(sp_unwrite_kernel, dim3(gk0, nplanes), dim3(256), 0, ctx->stream, keep_list, keep_count, out, n,
+                           capacity);
+        AMT_LAUNCH_CHECK();
+        list = keep_list;
+        total_c = keep_count;
+    } else {
+        AMT_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)nplanes * n * sizeof(int32_t), ctx->stream));
+    }
     hipLaunchKernelGGL(sp_count_kernel, dim3(nblk, nplanes), dim3(256), 0, ctx->stream, in, blk, n, nblk);
     AMT_LAUNCH_CHECK();
     AMT_TRY(amt_scan_excl(ctx, blk, nblk, (size_t)nblk, total, nplanes));

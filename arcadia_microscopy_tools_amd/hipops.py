@@ -535,17 +535,34 @@ def label(a: DeviceArray, connectivity: int = 2, out: DeviceArray | None = None,
     return o, c
 
 
-def label_sparse(a: DeviceArray, connectivity: int = 2, capacity: int | None = None, out=None, count=None):
+def label_sparse_capacity(H: int, W: int) -> int:
+    return max(65536, (H * W) // 16)
+
+
+def label_sparse(a: DeviceArray, connectivity: int = 2, capacity: int | None = None, out=None, count=None, keep=None):
     """``label`` for sparse uint8 masks (at most ``capacity`` foreground pixels per plane, default max(65536,
-    plane size / 16)); a plane that overflows reports count -1."""
+    plane size / 16)); a plane that overflows reports count -1.
+
+    ``keep`` = (int32 (n, capacity) list, int32 (n,) counts), both owned by the caller, turns the full-plane clear of
+    ``out`` into a clear of the pixels the previous call wrote (``amt_label_sparse_reuse``): ``out`` must then be the
+    same array every time, zeroed once together with the counts."""
     ctx = a.ctx
     n, H, W = _planes(a)
     if a.dtype != np.uint8:
         raise TypeError("label_sparse expects a uint8 / bool mask")
     if capacity is None:
-        capacity = max(65536, (H * W) // 16)
+        capacity = label_sparse_capacity(H, W)
     o = _out(ctx, out, a.shape, np.int32)
     c = _out(ctx, count, (n,), np.int32)
+    if keep is not None:
+        klist, kcount = keep
+        if out is None:
+            raise ValueError("keep= needs the caller's persistent out= plane")
+        if klist.dtype != np.int32 or klist.size != n * int(capacity) or kcount.dtype != np.int32 or kcount.size != n:
+            raise ValueError("keep must be (int32 (n, capacity), int32 (n,))")
+        _hip.check(_lib().amt_label_sparse_reuse(ctx.handle, a.ptr, o.ptr, c.ptr, n, H, W, int(connectivity),
+                                                 int(capacity), klist.ptr, kcount.ptr), "amt_label_sparse_reuse")
+        return o, c
     _hip.check(_lib().amt_label_sparse(ctx.handle, a.ptr, o.ptr, c.ptr, n, H, W, int(connectivity), int(capacity)),
                "amt_label_sparse")
     return o, c

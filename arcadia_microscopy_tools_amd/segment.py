@@ -74,7 +74,9 @@ class FovSegmenter:
         self.count8 = c.empty((B,), np.int32)
         self.d2 = c.empty(shp, np.int32)
         self.peaks = c.empty(shp, np.uint8)
-        self.markers = c.empty(shp, np.int32)
+        # marker planes are zeroed ONCE: every run clears only the pixels the previous run wrote (label_sparse keep=)
+        self.markers = c.zeros(shp, np.int32)
+        self._marker_keep = (c.empty((B, hipops.label_sparse_capacity(self.H, self.W)), np.int32), c.zeros((B,), np.int32))
         self.nmarkers = c.empty((B,), np.int32)
         self.ws = c.empty(shp, np.int32)
         self.labels = c.empty(shp, np.int32)
@@ -161,7 +163,7 @@ class FovSegmenter:
         self._stage("peaks")
         hipops.peak_mask(self.d2, mask, self.min_distance, out=self.peaks)
         self._stage("markers")
-        hipops.label_sparse(self.peaks, 1, out=self.markers, count=self.nmarkers)  # peaks are a few thousand px
+        hipops.label_sparse(self.peaks, 1, out=self.markers, count=self.nmarkers, keep=self._marker_keep)  # sparse
         if self.fused:
             # watershed + clear_border + relabel_sequential in one call: the watershed image is never written out
             # (self.ws only receives the pixels of flooded components)

@@ -225,6 +225,12 @@ int amt_label(amt_ctx* ctx, const void* in, int in_dtype, int32_t* out, int32_t*
 /* Same result as amt_label for uint8 masks with at most `capacity` foreground pixels per plane (e.g. the EDT
  * peak markers): foreground is compacted in raster order and labelled on the compact list.  If a plane has
  * more foreground pixels than `capacity`, count_dev[plane] = -1 and that plane's labels are invalid. */
+/* The same, for callers that label into the SAME plane batch again and again (a batch driver's marker planes): `out` must
+ * be zero except at the pixels listed in keep_list[plane * capacity ...][0 .. keep_count[plane]) -- the state this
+ * function leaves behind; start from a zeroed `out` and zeroed keep_count.  Only those pixels are cleared (no
+ * full-plane memset), and the lists are replaced by this call's foreground pixels. */
+int amt_label_sparse_reuse(amt_ctx* ctx, const uint8_t* in, int32_t* out, int32_t* count_dev, int nplanes, int H, int W,
+                           int connectivity, int capacity, int32_t* keep_list, int32_t* keep_count);
 int amt_label_sparse(amt_ctx* ctx, const uint8_t* in, int32_t* out, int32_t* count_dev, int nplanes, int H, int W,
                      int connectivity, int capacity);
 /* skimage.segmentation.clear_border(labels) with buffer_size=0: zero every 8-connected component of

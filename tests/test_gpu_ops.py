@@ -230,6 +230,27 @@ def test_grey_morphology_median_tophat(ctx, ops, golden):
     assert np.array_equal(ops.erosion(ctx.asarray(gz), skops.disk(2)).numpy(), skops.erosion(gz, skops.disk(2)))
 
 
+def test_label_sparse_reuse_clears_only_previous_pixels(ctx, ops):
+    """label_sparse(keep=...) -- the marker planes of a batch driver: the output plane is zeroed once and every call
+    undoes only the previous call's writes.  Three different masks in a row (with an overflowing one in between) must
+    give what a fresh label_sparse gives, pixels of earlier masks included (they must be zero again)."""
+    rng = np.random.default_rng(9)
+    shape = (3, 150, 200)
+    cap = 4096
+    out = ctx.zeros(shape, np.int32)
+    keep = (ctx.empty((3, cap), np.int32), ctx.zeros((3,), np.int32))
+    for it, p in enumerate((0.01, 0.05, 0.3, 0.02, 0.0, 0.04)):  # 0.3 overflows the capacity of 4,096 pixels
+        m = rng.random(shape) < p
+        d = ctx.asarray(m)
+        got, cnt = ops.label_sparse(d, 1, capacity=cap, out=out, keep=keep)
+        ref, rcnt = ops.label_sparse(d, 1, capacity=cap)
+        assert np.array_equal(cnt.numpy(), rcnt.numpy()), it
+        if (rcnt.numpy() >= 0).all():
+            assert np.array_equal(got.numpy(), ref.numpy()), it
+        else:
+            assert (cnt.numpy() == -1).all()
+
+
 def test_label_random(ctx, ops):
     from oracle import skops
 
