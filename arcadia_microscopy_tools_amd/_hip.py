@@ -108,6 +108,7 @@ _SIGS = {
     "amt_cast_i32_i64": (c_int, [_P, _P, _P, c_size_t]),
     "amt_edt": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int]),
     "amt_peak_mask": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int]),
+    "amt_peak_mask_reuse": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, c_int, _P]),
     "amt_watershed_edt": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int]),
     "amt_watershed_f64": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int]),
     "amt_watershed_edt_cleared": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),

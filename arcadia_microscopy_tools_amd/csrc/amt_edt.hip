@@ -290,15 +290,55 @@ __global__ void __launch_bounds__(256) peaks_rows_kernel(const int* __restrict__
     }
 }
 
+// peaks[list[k]] = 0 for the listed pixels of every plane
+// (status[plane] < 0: that run's list overflowed and does not hold every peak -- the whole plane is cleared)
+__global__ void __launch_bounds__(256) peaks_unwrite_kernel(const int* __restrict__ list, const int* __restrict__ count,
+                                                            const int* __restrict__ status, uint8_t* __restrict__ peaks,
+                                                            size_t n, int cap) {
+    uint8_t* o = peaks + (size_t)blockIdx.y * n;
+    if (status[blockIdx.y] < 0) {
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) o[i] = 0;
+        return;
+    }
+    const int K = count[blockIdx.y] < cap ? count[blockIdx.y] : cap;
+    const int* lst = list + (size_t)blockIdx.y * cap;
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < K; k += gridDim.x * 256) o[lst[k]] = 0;
+}
+
+static int peak_mask_impl(amt_ctx* ctx, const int32_t* d2, const uint8_t* mask, uint8_t* peaks, int nplanes, int H, int W,
+                          int min_distance, const int32_t* prev_list, const int32_t* prev_count, int capacity,
+                          const int32_t* prev_status);
+
 extern "C" int amt_peak_mask(amt_ctx* ctx, const int32_t* d2, const uint8_t* mask, uint8_t* peaks, int nplanes, int H,
                              int W, int min_distance) {
+    return peak_mask_impl(ctx, d2, mask, peaks, nplanes, H, W, min_distance, nullptr, nullptr, 0, nullptr);
+}
+
+extern "C" int amt_peak_mask_reuse(amt_ctx* ctx, const int32_t* d2, const uint8_t* mask, uint8_t* peaks, int nplanes,
+                                   int H, int W, int min_distance, const int32_t* prev_list, const int32_t* prev_count,
+                                   int capacity, const int32_t* prev_status) {
+    AMT_REQUIRE(prev_list && prev_count && prev_status && capacity >= 1,
+                "peak_mask_reuse: the previous run's peak lists, counts and label counts are required");
+    return peak_mask_impl(ctx, d2, mask, peaks, nplanes, H, W, min_distance, prev_list, prev_count, capacity, prev_status);
+}
+
+static int peak_mask_impl(amt_ctx* ctx, const int32_t* d2, const uint8_t* mask, uint8_t* peaks, int nplanes, int H, int W,
+                          int min_distance, const int32_t* prev_list, const int32_t* prev_count, int capacity,
+                          const int32_t* prev_status) {
     AMT_TRY(amt_set_device(ctx));
     AMT_REQUIRE(d2 && mask && peaks && nplanes >= 0 && H > 0 && W > 0, "peak_mask: bad arguments");
     AMT_REQUIRE(min_distance >= 0 && min_distance <= PK_MAXM, "peak_mask: min_distance %d out of range 0..%d",
                 min_distance, PK_MAXM);
     if (nplanes == 0) return AMT_OK;
     const int m = min_distance;
-    AMT_HIP_CHECK(hipMemsetAsync(peaks, 0, (size_t)nplanes * H * W, ctx->stream));
+    if (prev_list) {
+        // the plane is zero except at the previous run's peaks, which amt_label_sparse_reuse kept as a list
+        hipLaunchKernelGGL(peaks_unwrite_kernel, dim3(amt_grid_for((size_t)capacity, 256, 64), nplanes), dim3(256), 0,
+                           ctx->stream, prev_list, prev_count, prev_status, peaks, (size_t)H * W, capacity);
+        AMT_LAUNCH_CHECK();
+    } else {
+        AMT_HIP_CHECK(hipMemsetAsync(peaks, 0, (size_t)nplanes * H * W, ctx->stream));
+    }
     const int nstrips = (W + PKR_IN - 1) / PKR_IN;
     dim3 grid((nstrips + 3) / 4, (H + PKR_ROWS - 1) / PKR_ROWS, nplanes);
     hipLaunchKernelGGL(peaks_rows_kernel, grid, dim3(256), 0, ctx->stream, d2, mask, peaks, H, W, m);

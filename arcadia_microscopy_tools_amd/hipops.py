@@ -644,11 +644,21 @@ def edt(mask: DeviceArray, want_d2: bool = True, want_edt: bool = True, d2_out=N
     return d2, e
 
 
-def peak_mask(d2: DeviceArray, mask: DeviceArray, min_distance: int = 5, out=None) -> DeviceArray:
-    """Peaks of the EDT per the config-3 marker recipe."""
+def peak_mask(d2: DeviceArray, mask: DeviceArray, min_distance: int = 5, out=None, keep=None, status=None) -> DeviceArray:
+    """Peaks of the EDT per the config-3 marker recipe.  ``keep`` (the lists ``label_sparse(keep=)``
+    maintains) + ``status`` (that call's counts) turn the clear of the persistent ``out`` plane into a clear of the
+    previous run's peaks (``amt_peak_mask_reuse``)."""
     ctx = d2.ctx
     n, H, W = _planes(d2)
     o = _out(ctx, out, d2.shape, np.uint8)
+    if keep is not None:
+        if out is None or status is None:
+            raise ValueError("keep= needs the caller's persistent out= plane and the previous counts (status=)")
+        klist, kcount = keep
+        _hip.check(_lib().amt_peak_mask_reuse(ctx.handle, d2.ptr, mask.ptr, o.ptr, n, H, W, int(min_distance), klist.ptr,
+                                              kcount.ptr, klist.size // n, status.ptr), "amt_peak_mask_reuse")
+        o.is_bool = True
+        return o
     _hip.check(_lib().amt_peak_mask(ctx.handle, d2.ptr, mask.ptr, o.ptr, n, H, W, int(min_distance)), "amt_peak_mask")
     o.is_bool = True
     return o

@@ -73,11 +73,11 @@ class FovSegmenter:
         self.labels8 = None  # config 2 only, allocated on demand
         self.count8 = c.empty((B,), np.int32)
         self.d2 = c.empty(shp, np.int32)
-        self.peaks = c.empty(shp, np.uint8)
+        self.peaks = c.zeros(shp, np.uint8)  # zeroed once; see self._marker_keep
         # marker planes are zeroed ONCE: every run clears only the pixels the previous run wrote (label_sparse keep=)
         self.markers = c.zeros(shp, np.int32)
         self._marker_keep = (c.empty((B, hipops.label_sparse_capacity(self.H, self.W)), np.int32), c.zeros((B,), np.int32))
-        self.nmarkers = c.empty((B,), np.int32)
+        self.nmarkers = c.zeros((B,), np.int32)
         self.ws = c.empty(shp, np.int32)
         self.labels = c.empty(shp, np.int32)
         self.ncells = c.empty((B,), np.int32)
@@ -161,7 +161,7 @@ class FovSegmenter:
         self._stage("edt")
         hipops.edt(mask, want_edt=False, d2_out=self.d2)
         self._stage("peaks")
-        hipops.peak_mask(self.d2, mask, self.min_distance, out=self.peaks)
+        hipops.peak_mask(self.d2, mask, self.min_distance, out=self.peaks, keep=self._marker_keep, status=self.nmarkers)
         self._stage("markers")
         hipops.label_sparse(self.peaks, 1, out=self.markers, count=self.nmarkers, keep=self._marker_keep)  # sparse
         if self.fused:

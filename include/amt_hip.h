@@ -257,6 +257,13 @@ int amt_cast_i32_i64(amt_ctx* ctx, const int32_t* in, int64_t* out, size_t n);
  * float64 square root = scipy.ndimage.distance_transform_edt.  Either output may be NULL. */
 int amt_edt(amt_ctx* ctx, const uint8_t* mask, int32_t* d2_out, double* edt_out, int nplanes, int H, int W);
 /* peaks = (d2 == maximum_filter(d2, (2m+1)^2, constant 0)) & mask & (d2 > 0), border of width m cleared */
+/* The same into a plane batch that is zero except at the pixels listed in prev_list / prev_count (the lists
+ * amt_label_sparse_reuse keeps of the previous run's peaks): only those are cleared, no full-plane memset.
+ * prev_status = that run's label counts (count_dev of amt_label_sparse_reuse): a plane whose count is -1 overflowed
+ * its list and is cleared whole.  Start from zeroed planes, zeroed counts and zeroed status. */
+int amt_peak_mask_reuse(amt_ctx* ctx, const int32_t* d2, const uint8_t* mask, uint8_t* peaks, int nplanes, int H, int W,
+                        int min_distance, const int32_t* prev_list, const int32_t* prev_count, int capacity,
+                        const int32_t* prev_status);
 int amt_peak_mask(amt_ctx* ctx, const int32_t* d2, const uint8_t* mask, uint8_t* peaks, int nplanes, int H, int W,
                   int min_distance);
 /* Priority flood restricted to `mask` (skimage.segmentation.watershed, no compactness, no watershed line;

@@ -104,6 +104,54 @@ def test_gaussian_otsu_codes_equal_separate_operators(ctx):
     assert np.array_equal(a.mask_a.numpy(), b.mask_a.numpy()) and np.array_equal(la, lb)
 
 
+def test_segmenter_reuse_sparse_clears(ctx):
+    """A FovSegmenter keeps its peak / marker planes between runs and clears only what the previous run wrote
+    (label_sparse keep=, peak_mask keep=): different batches through ONE segmenter must equal fresh segmenters, and
+    the low-level pair must survive a run whose peak list overflowed its capacity."""
+    from arcadia_microscopy_tools_amd import hipops, synth
+    from arcadia_microscopy_tools_amd.segment import FovSegmenter
+
+    sets = [np.stack([synth.synth_fov(i, size=384) for i in idx]) for idx in ((11, 12), (13, 14), (11, 14))]
+    seg = FovSegmenter(2, 4, 384, 384, ctx=ctx, max_cells=256)
+    for k, fovs in enumerate(sets):
+        d = ctx.asarray(fovs)
+        got = seg.run_c3(d).numpy()
+        fresh = FovSegmenter(2, 4, 384, 384, ctx=ctx, max_cells=256)
+        ref = fresh.run_c3(d).numpy()
+        assert np.array_equal(got, ref), k
+        assert np.array_equal(seg.peaks.numpy(), fresh.peaks.numpy()) and np.array_equal(seg.markers.numpy(), fresh.markers.numpy())
+        assert np.array_equal(seg.table.numpy()[:, : int(seg.ncells.numpy().max())],
+                              fresh.table.numpy()[:, : int(fresh.ncells.numpy().max())])
+    # low level, with a tiny list capacity so that the middle run overflows
+    rng = np.random.default_rng(2)
+    H, W, cap = 96, 128, 64
+    peaks, markers = ctx.zeros((1, H, W), np.uint8), ctx.zeros((1, H, W), np.int32)
+    keep = (ctx.empty((1, cap), np.int32), ctx.zeros((1,), np.int32))
+    status = ctx.zeros((1,), np.int32)
+    seen = set()
+    for it, density in enumerate((0.002, 0.2, 0.003, 0.0, 0.004)):
+        m = np.zeros((1, H, W), np.uint8)
+        m[0, 4:-4, 4:-4] = 1
+        # a relief whose local maxima are isolated random pixels: every one of them is a peak at min_distance 1
+        d2 = np.zeros((1, H, W), np.int32)
+        pts = rng.random((1, H, W)) < density
+        pts[:, ::2, :] = False
+        pts[:, :, ::2] = False
+        pts &= m.astype(bool)
+        d2[pts] = 50
+        dd2, dm = ctx.asarray(d2), ctx.asarray(m)
+        hipops.peak_mask(dd2, dm, 1, out=peaks, keep=keep, status=status)
+        ref_peaks = hipops.peak_mask(dd2, dm, 1).numpy()
+        assert np.array_equal(peaks.numpy(), ref_peaks), it
+        hipops.label_sparse(peaks, 1, capacity=cap, out=markers, count=status, keep=keep)
+        ref_markers, ref_count = hipops.label_sparse(ctx.asarray(ref_peaks), 1, capacity=cap)
+        assert np.array_equal(status.numpy(), ref_count.numpy()), it
+        seen.add(int(ref_count.numpy()[0]) >= 0)
+        if ref_count.numpy()[0] >= 0:
+            assert np.array_equal(markers.numpy(), ref_markers.numpy()), it
+    assert seen == {True, False}  # the dense run overflowed the 64-entry lists, the others did not
+
+
 def test_c3_batch_vs_oracle(ctx):
     """Several different FOVs in one batch, odd image size, every FOV checked against the CPU oracle."""
     from arcadia_microscopy_tools_amd import synth
