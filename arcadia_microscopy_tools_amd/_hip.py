@@ -81,6 +81,7 @@ _SIGS = {
     "amt_percentile_u16": (c_int, [_P, _P, _P, c_int, _P, c_int, c_size_t]),
     "amt_percentile_f64": (c_int, [_P, _P, _P, c_int, _P, c_int, c_size_t]),
     "amt_masked_sums_f64": (c_int, [_P, _P, _P, _P, c_int, c_size_t]),
+    "amt_pad_edge": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int]),
     "amt_copy_rect": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "amt_threshold_value": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, c_int, c_size_t, _P]),
     "amt_threshold_gt": (c_int, [_P, _P, c_int, _P, _P, c_int, c_size_t]),

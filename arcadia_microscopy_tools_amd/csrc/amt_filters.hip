@@ -1277,6 +1277,35 @@ __global__ void copy_rect_kernel(const uint8_t* __restrict__ src, uint8_t* __res
         d[i] = s[i];
 }
 
+// ---- np.pad(image, ((py, py), (px, px)), mode='edge'): scikit-image pads the image this way before an opening /
+// closing with an even-sized footprint (SK/morphology/grey.py:84-127, pad_for_eccentric_selems) ------------------
+__global__ void pad_edge_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int esz, int H, int W, int py,
+                                int px) {
+    const int Ho = H + 2 * py, Wo = W + 2 * px;
+    const int yo = blockIdx.y;
+    const int ys = min(max(yo - py, 0), H - 1);
+    const uint8_t* s = src + ((size_t)blockIdx.z * H + ys) * W * esz;
+    uint8_t* d = dst + ((size_t)blockIdx.z * Ho + yo) * Wo * esz;
+    for (int xo = blockIdx.x * blockDim.x + threadIdx.x; xo < Wo; xo += gridDim.x * blockDim.x) {
+        const int xs = min(max(xo - px, 0), W - 1);
+        for (int b = 0; b < esz; ++b) d[(size_t)xo * esz + b] = s[(size_t)xs * esz + b];
+    }
+}
+
+extern "C" int amt_pad_edge(amt_ctx* ctx, const void* src, void* dst, int elem_size, int nplanes, int H, int W, int py,
+                            int px) {
+    AMT_TRY(amt_set_device(ctx));
+    AMT_REQUIRE(src && dst && elem_size > 0 && nplanes >= 0 && H > 0 && W > 0 && py >= 0 && px >= 0,
+                "pad_edge: bad arguments");
+    if (nplanes == 0) return AMT_OK;
+    dim3 grid((unsigned)((W + 2 * px + 255) / 256), H + 2 * py, nplanes);
+    if (grid.x > 64) grid.x = 64;
+    hipLaunchKernelGGL(pad_edge_kernel, grid, dim3(256), 0, ctx->stream, (const uint8_t*)src, (uint8_t*)dst, elem_size, H,
+                       W, py, px);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+
 extern "C" int amt_copy_rect(amt_ctx* ctx, const void* src, void* dst, int elem_size, int nplanes, int H, int W,
                              int top, int left, int h, int w) {
     AMT_TRY(amt_set_device(ctx));

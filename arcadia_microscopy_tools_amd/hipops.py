@@ -331,6 +331,16 @@ def crop(a: DeviceArray, top: int, left: int, h: int, w: int, out: DeviceArray |
     return o
 
 
+def pad_edge(a: DeviceArray, py: int, px: int) -> DeviceArray:
+    """``np.pad(a, ((py, py), (px, px)), mode='edge')`` per plane."""
+    ctx = a.ctx
+    n, H, W = _planes(a)
+    o = ctx.empty(a.shape[:-2] + (H + 2 * py, W + 2 * px), a.dtype)
+    _hip.check(_lib().amt_pad_edge(ctx.handle, a.ptr, o.ptr, a.dtype.itemsize, n, H, W, int(py), int(px)), "amt_pad_edge")
+    o.is_bool = a.is_bool
+    return o
+
+
 def threshold_otsu(a: DeviceArray, nbins: int = 256, out: DeviceArray | None = None,
                    minmax: DeviceArray | None = None) -> DeviceArray:
     """``skimage.filters.threshold_otsu`` per plane, value stays on the device (SK/filters/thresholding.py:321-350).
@@ -396,13 +406,25 @@ def cross3() -> np.ndarray:
     return np.array([[0, 1, 0], [1, 1, 1], [0, 1, 0]], dtype=np.uint8)
 
 
-def _fp(footprint):
-    fp = np.ascontiguousarray(cross3() if footprint is None else np.asarray(footprint) != 0, dtype=np.uint8)
+def _fp(footprint, even: str = "scipy"):
+    """The footprint as a C-contiguous uint8 array with ODD sides (what the C ABI takes).  An even side is padded with
+    a zero row / column, which is exact: scipy centres a filter of even size s at s // 2, i.e. where the odd filter
+    of size s + 1 with the zero line APPENDED is centred (``even="scipy"``: ndi.grey_erosion / grey_dilation /
+    median_filter / binary_erosion / binary_dilation all agree with their padded form, dilation's origin shift
+    included); scikit-image's grey erosion / dilation PREPEND it (``even="skimage"``, SK/morphology/grey.py:14-50
+    with shift_x = shift_y = False) and the second halves of its opening / closing append it (``"skimage-shift"``)."""
+    fp = np.asarray(cross3() if footprint is None else np.asarray(footprint) != 0, dtype=np.uint8)
     if fp.ndim != 2:
         raise ValueError("footprint must be 2-D")
-    if fp.shape[0] % 2 == 0 or fp.shape[1] % 2 == 0:
-        raise NotImplementedError("even-sized footprints are not supported on the device path")
-    return fp
+    m, n = fp.shape
+    if m % 2 == 0:
+        z = np.zeros((1, n), np.uint8)
+        fp = np.vstack((z, fp)) if even == "skimage" else np.vstack((fp, z))
+        m += 1
+    if n % 2 == 0:
+        z = np.zeros((m, 1), np.uint8)
+        fp = np.hstack((z, fp)) if even == "skimage" else np.hstack((fp, z))
+    return np.ascontiguousarray(fp)
 
 
 def _binary(which: str, a: DeviceArray, footprint, out, border_value=None):
@@ -465,7 +487,7 @@ def threshold_open_close(a: DeviceArray, thr: DeviceArray, footprint=None, out=N
 def _rank(a: DeviceArray, footprint, op: int, mode: str, cval: float, out):
     ctx = a.ctx
     n, H, W = _planes(a)
-    fp = _fp(footprint)
+    fp = _fp(footprint)  # callers that follow scikit-image's even-size rule pass an odd footprint already
     o = _out(ctx, out, a.shape, a.dtype)
     _hip.check(_lib().amt_rank_filter(ctx.handle, a.ptr, o.ptr, _in_code(a), n, H, W,
                                       fp.ctypes.data_as(ctypes.c_void_p), fp.shape[0], fp.shape[1], op,
@@ -473,26 +495,41 @@ def _rank(a: DeviceArray, footprint, op: int, mode: str, cval: float, out):
     return o
 
 
-def erosion(a, footprint=None, out=None):
-    """``skimage.morphology.erosion`` -> ndi.grey_erosion(footprint), mode 'reflect' (SK/morphology/grey.py:185)."""
-    return _rank(a, footprint, 0, "reflect", 0.0, out)
+def erosion(a, footprint=None, out=None, shift: bool = False):
+    """``skimage.morphology.erosion`` -> ndi.grey_erosion(footprint), mode 'reflect' (SK/morphology/grey.py:185);
+    ``shift`` = scikit-image's shift_x = shift_y (only matters for even-sized footprints)."""
+    return _rank(a, _fp(footprint, "skimage-shift" if shift else "skimage"), 0, "reflect", 0.0, out)
 
 
-def dilation(a, footprint=None, out=None):
+def dilation(a, footprint=None, out=None, shift: bool = False):
     """``skimage.morphology.dilation``: skimage mirrors the footprint and scipy mirrors it back
-    (SK/morphology/grey.py:242-251), i.e. max over in[p + s] for s in the ORIGINAL footprint."""
-    fp = _fp(footprint)
-    return _rank(a, fp[::-1, ::-1], 1, "reflect", 0.0, out)
+    (SK/morphology/grey.py:242-251), i.e. max over in[p + s] for s in the ORIGINAL (odd-padded) footprint."""
+    fp = _fp(footprint, "skimage-shift" if shift else "skimage")
+    return _rank(a, np.ascontiguousarray(fp[::-1, ::-1]), 1, "reflect", 0.0, out)
+
+
+def _eccentric(a, footprint, first, second, out):
+    """scikit-image's opening / closing: the second half runs with shift_x = shift_y = True, and for a footprint with an
+    even side the image is first edge-padded by (side - 1) pixels along that axis and the result cropped back
+    (SK/morphology/grey.py:84-127, :255-353)."""
+    shape = (3, 3) if footprint is None else np.shape(footprint)
+    py = shape[0] - 1 if shape[0] % 2 == 0 else 0
+    px = shape[1] - 1 if shape[1] % 2 == 0 else 0
+    if not (py or px):
+        return second(first(a, footprint), footprint, out=out, shift=True)
+    H, W = a.shape[-2:]
+    res = second(first(pad_edge(a, py, px), footprint), footprint, shift=True)
+    return crop(res, py, px, H, W, out=out)
 
 
 def opening(a, footprint=None, out=None):
-    """``skimage.morphology.opening`` = dilation(erosion(a)) (SK/morphology/grey.py:257-303)."""
-    return dilation(erosion(a, footprint), footprint, out=out)
+    """``skimage.morphology.opening`` = dilation(erosion(a), shift_x=True, shift_y=True) (SK/morphology/grey.py:255-303)."""
+    return _eccentric(a, footprint, erosion, dilation, out)
 
 
 def closing(a, footprint=None, out=None):
-    """``skimage.morphology.closing`` = erosion(dilation(a)) (SK/morphology/grey.py:307-353)."""
-    return erosion(dilation(a, footprint), footprint, out=out)
+    """``skimage.morphology.closing`` = erosion(dilation(a), shift_x=True, shift_y=True) (SK/morphology/grey.py:305-353)."""
+    return _eccentric(a, footprint, dilation, erosion, out)
 
 
 def white_tophat(a, footprint=None, out=None):

@@ -160,6 +160,9 @@ int amt_percentile_f64(amt_ctx* ctx, const double* in, const double* q_host, int
  * (SK/filters/thresholding.py:830, :642-707). */
 int amt_masked_sums_f64(amt_ctx* ctx, const double* in, const double* thr_dev, double* out_dev, int nplanes, size_t n);
 /* dst[plane] (h x w) = src[plane][top:top+h, left:left+w]; crop_to_center (R/operations.py:100-132). */
+/* dst[plane] ((H + 2 py) x (W + 2 px)) = np.pad(src[plane], ((py, py), (px, px)), mode='edge'): what scikit-image does to
+ * the image before an opening / closing with an even-sized footprint (SK/morphology/grey.py:84-127). */
+int amt_pad_edge(amt_ctx* ctx, const void* src, void* dst, int elem_size, int nplanes, int H, int W, int py, int px);
 int amt_copy_rect(amt_ctx* ctx, const void* src, void* dst, int elem_size, int nplanes, int H, int W, int top,
                   int left, int h, int w);
 

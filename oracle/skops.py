@@ -354,26 +354,55 @@ def _mirror_selem(selem):
     return selem[::-1, ::-1]
 
 
-def erosion(image, selem=None):
-    """SK/morphology/grey.py:185 (scipy default mode='reflect'); odd symmetric footprints only."""
-    selem = cross3() if selem is None else selem
-    return ndi.grey_erosion(image, footprint=selem)
+def _shift_selem(selem, shift: bool):
+    """SK/morphology/grey.py:14-50: an even side gets a zero row / column, in front of the footprint (shift False, the
+    default of erosion / dilation) or behind it (shift True: the second half of opening / closing)."""
+    selem = np.asarray(selem)
+    if selem.ndim != 2:
+        return selem
+    m, n = selem.shape
+    if m % 2 == 0:
+        extra = np.zeros((1, n), selem.dtype)
+        selem = np.vstack((selem, extra)) if shift else np.vstack((extra, selem))
+        m += 1
+    if n % 2 == 0:
+        extra = np.zeros((m, 1), selem.dtype)
+        selem = np.hstack((selem, extra)) if shift else np.hstack((extra, selem))
+    return selem
 
 
-def dilation(image, selem=None):
-    """SK/morphology/grey.py:242-251 (footprint mirrored before scipy)."""
+def erosion(image, selem=None, shift: bool = False):
+    """SK/morphology/grey.py:131-187 (scipy default mode='reflect')."""
     selem = cross3() if selem is None else selem
-    return ndi.grey_dilation(image, footprint=_mirror_selem(selem))
+    return ndi.grey_erosion(image, footprint=_shift_selem(selem, shift))
+
+
+def dilation(image, selem=None, shift: bool = False):
+    """SK/morphology/grey.py:190-254 (footprint shifted, then mirrored before scipy)."""
+    selem = cross3() if selem is None else selem
+    return ndi.grey_dilation(image, footprint=_mirror_selem(_shift_selem(selem, shift)))
+
+
+def _eccentric(image, selem, first, second):
+    """SK/morphology/grey.py:84-127 ``pad_for_eccentric_selems``: even footprint sides -> edge-pad the image by
+    (side - 1) along that axis, run the pair, crop back."""
+    selem = cross3() if selem is None else np.asarray(selem)
+    pads = [(n - 1, n - 1) if n % 2 == 0 else (0, 0) for n in selem.shape]
+    if not any(p[0] for p in pads):
+        return second(first(image, selem), selem, shift=True)
+    padded = np.pad(image, pads, mode="edge")
+    res = second(first(padded, selem), selem, shift=True)
+    return res[pads[0][0]: res.shape[0] - pads[0][0], pads[1][0]: res.shape[1] - pads[1][0]]
 
 
 def opening(image, selem=None):
-    """SK/morphology/grey.py:257-303."""
-    return dilation(erosion(image, selem), selem)
+    """SK/morphology/grey.py:255-303: the dilation runs with shift_x = shift_y = True."""
+    return _eccentric(image, selem, erosion, dilation)
 
 
 def closing(image, selem=None):
-    """SK/morphology/grey.py:307-353."""
-    return erosion(dilation(image, selem), selem)
+    """SK/morphology/grey.py:305-353: the erosion runs with shift_x = shift_y = True."""
+    return _eccentric(image, selem, dilation, erosion)
 
 
 def white_tophat(image, selem=None):

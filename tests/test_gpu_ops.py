@@ -230,6 +230,35 @@ def test_grey_morphology_median_tophat(ctx, ops, golden):
     assert np.array_equal(ops.erosion(ctx.asarray(gz), skops.disk(2)).numpy(), skops.erosion(gz, skops.disk(2)))
 
 
+def test_even_and_asymmetric_footprints(ctx, ops, golden):
+    """Even-sized footprints against the real scikit-image (tests/golden/even_footprints.npz): the host pads them to odd
+    ones the way scikit-image / scipy place them; plus asymmetric odd footprints through every grey operator."""
+    from oracle import skops
+
+    g = golden("even_footprints")
+    img, mask = g["img"], g["mask"]
+    d, dm = ctx.asarray(img), ctx.asarray(mask)
+    for name in ("s2", "s4", "r2x3", "r3x4", "c4x1", "L4"):
+        fp = g[f"fp_{name}"]
+        assert np.array_equal(ops.erosion(d, fp).numpy(), g[f"erosion_{name}"]), name
+        assert np.array_equal(ops.dilation(d, fp).numpy(), g[f"dilation_{name}"]), name
+        assert np.array_equal(ops.opening(d, fp).numpy(), g[f"opening_{name}"]), name
+        assert np.array_equal(ops.closing(d, fp).numpy(), g[f"closing_{name}"]), name
+        assert np.array_equal(ops.white_tophat(d, fp).numpy(), g[f"tophat_{name}"]), name
+        assert np.array_equal(ops.median(d, fp).numpy(), g[f"median_{name}"]), name
+        assert np.array_equal(ops.binary_erosion(dm, fp).numpy(), g[f"berosion_{name}"]), name
+        assert np.array_equal(ops.binary_dilation(dm, fp).numpy(), g[f"bdilation_{name}"]), name
+        assert np.array_equal(ops.binary_opening(dm, fp).numpy(), g[f"bopening_{name}"]), name
+        assert np.array_equal(ops.binary_closing(dm, fp).numpy(), g[f"bclosing_{name}"]), name
+    rng = np.random.default_rng(31)
+    big = rng.integers(0, 65536, (70, 520)).astype(np.uint16)  # wide enough for the strip kernels
+    db = ctx.asarray(big)
+    for fp in (np.array([[1, 1, 0], [0, 1, 0], [0, 0, 0]], np.uint8), np.array([[0, 0, 1, 1, 1]], np.uint8),
+               np.array([[1, 0, 0], [1, 1, 0], [1, 1, 1], [0, 0, 1], [0, 0, 1]], np.uint8), np.ones((4, 6), np.uint8)):
+        for fn in ("erosion", "dilation", "opening", "closing", "white_tophat", "median"):
+            assert np.array_equal(getattr(ops, fn)(db, fp).numpy(), getattr(skops, fn)(big, fp)), (fp.shape, fn)
+
+
 def test_label_sparse_reuse_clears_only_previous_pixels(ctx, ops):
     """label_sparse(keep=...) -- the marker planes of a batch driver: the output plane is zeroed once and every call
     undoes only the previous call's writes.  Three different masks in a row (with an overflowing one in between) must

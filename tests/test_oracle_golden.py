@@ -281,3 +281,24 @@ def test_label_int_vs_skimage(golden):
         assert np.array_equal(skops.clear_border(img), g[f"cleared_{i}"]), f"case {i} clear_border"
         if i < 10:
             assert np.array_equal(skops._label_int_per_value(img), g[f"lab2_{i}"])
+
+
+def test_even_footprints_follow_skimage(golden):
+    """Even-sized footprints (tools/make_golden_even.py, real scikit-image 0.18.3): grey erosion / dilation pad in front,
+    the second half of opening / closing behind, the binary operators / median / white_tophat go to scipy as they are."""
+    from oracle import skops
+
+    g = golden("even_footprints")
+    img, mask = g["img"], g["mask"]
+    for name in ("s2", "s4", "r2x3", "r3x4", "c4x1", "L4"):
+        fp = g[f"fp_{name}"]
+        assert np.array_equal(skops.erosion(img, fp), g[f"erosion_{name}"]), name
+        assert np.array_equal(skops.dilation(img, fp), g[f"dilation_{name}"]), name
+        assert np.array_equal(skops.opening(img, fp), g[f"opening_{name}"]), name
+        assert np.array_equal(skops.closing(img, fp), g[f"closing_{name}"]), name
+        assert np.array_equal(skops.white_tophat(img, fp), g[f"tophat_{name}"]), name
+        assert np.array_equal(skops.median(img, fp), g[f"median_{name}"]), name
+        assert np.array_equal(skops.binary_erosion(mask, fp), g[f"berosion_{name}"]), name
+        assert np.array_equal(skops.binary_dilation(mask, fp), g[f"bdilation_{name}"]), name
+        assert np.array_equal(skops.binary_opening(mask, fp), g[f"bopening_{name}"]), name
+        assert np.array_equal(skops.binary_closing(mask, fp), g[f"bclosing_{name}"]), name
