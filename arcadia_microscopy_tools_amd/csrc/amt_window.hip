@@ -79,12 +79,12 @@ __device__ __forceinline__ double local_thr(double m, double s, int method, doub
 // cols: one thread per column slides a (2h+1)-tall running sum down the rows of hs / hq
 __global__ void __launch_bounds__(256) win_cols_u16_kernel(const unsigned* __restrict__ hs, const u64* __restrict__ hq,
                                                            double* __restrict__ thr, int H, int W, int h, int method,
-                                                           double k, double r, int TH) {
+                                                           double k, double r, int TH, int hx) {
     const int x = blockIdx.x * 256 + threadIdx.x;
     if (x >= W) return;
     const int y0 = blockIdx.y * TH;
     const size_t base = (size_t)blockIdx.z * H * W;
-    const double wsz = (double)(2 * h + 1) * (double)(2 * h + 1);
+    const double wsz = (double)(2 * h + 1) * (double)(2 * hx + 1);  // rows of the window x its columns
     u64 s = 0, q = 0;
     for (int dy = -h; dy <= h; ++dy) {
         int yy = amt_map_index(y0 + dy, H, AMT_MODE_MIRROR);
@@ -124,12 +124,12 @@ __global__ void __launch_bounds__(256) win_rows_f64_kernel(const double* __restr
 
 __global__ void __launch_bounds__(256) win_cols_f64_kernel(const double* __restrict__ hs, const double* __restrict__ hq,
                                                            double* __restrict__ thr, int H, int W, int h, int method,
-                                                           double k, double r) {
+                                                           double k, double r, int hx) {
     const int x = blockIdx.x * 256 + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= W) return;
     const size_t base = (size_t)blockIdx.z * H * W;
-    const double wsz = (double)(2 * h + 1) * (double)(2 * h + 1);
+    const double wsz = (double)(2 * h + 1) * (double)(2 * hx + 1);  // rows of the window x its columns
     double s = 0.0, q = 0.0;
     for (int dy = -h; dy <= h; ++dy) {
         int yy = amt_map_index(y + dy, H, AMT_MODE_MIRROR);
@@ -144,28 +144,34 @@ __global__ void __launch_bounds__(256) win_cols_f64_kernel(const double* __restr
 
 extern "C" int amt_window_threshold(amt_ctx* ctx, const void* in, int in_dtype, double* thr_image, int nplanes, int H,
                                     int W, int window_size, int method, double k, double r) {
+    return amt_window_threshold_yx(ctx, in, in_dtype, thr_image, nplanes, H, W, window_size, window_size, method, k, r);
+}
+
+extern "C" int amt_window_threshold_yx(amt_ctx* ctx, const void* in, int in_dtype, double* thr_image, int nplanes, int H,
+                                       int W, int window_y, int window_x, int method, double k, double r) {
     AMT_TRY(amt_set_device(ctx));
     AMT_REQUIRE(in && thr_image && nplanes >= 0 && H > 0 && W > 0, "window_threshold: bad arguments");
     AMT_REQUIRE(in_dtype == AMT_U16 || in_dtype == AMT_F64, "window_threshold: dtype must be AMT_U16 or AMT_F64");
-    AMT_REQUIRE(window_size >= 1 && (window_size & 1), "Window size %d is even.", window_size);
-    AMT_REQUIRE(window_size <= 255, "window_threshold: window_size %d larger than 255", window_size);
+    AMT_REQUIRE(window_y >= 1 && (window_y & 1), "Window size %d is even.", window_y);
+    AMT_REQUIRE(window_x >= 1 && (window_x & 1), "Window size %d is even.", window_x);
+    AMT_REQUIRE(window_y <= 255 && window_x <= 255, "window_threshold: window %d x %d larger than 255", window_y, window_x);
     AMT_REQUIRE(method == 0 || method == 1, "window_threshold: method must be 0 (niblack) or 1 (sauvola)");
-    const int h = window_size / 2;
-    AMT_REQUIRE(h < H && h < W, "window_threshold: window larger than the image");
+    const int h = window_y / 2, hx = window_x / 2;  // h: rows (the column kernels), hx: columns (the row kernels)
+    AMT_REQUIRE(h < H && hx < W, "window_threshold: window larger than the image");
     if (nplanes == 0) return AMT_OK;
     const size_t np = (size_t)nplanes * H * W;
     if (in_dtype == AMT_U16) {
         AMT_TRY(amt_arena_begin(ctx, amt_align(np * 4) + amt_align(np * 8)));
         unsigned* hs = arena_take_t<unsigned>(ctx, np);
         u64* hq = arena_take_t<u64>(ctx, np);
-        size_t smem = (size_t)2 * (W + 2 * h + 1) * sizeof(u64);
+        size_t smem = (size_t)2 * (W + 2 * hx + 1) * sizeof(u64);
         AMT_REQUIRE(smem <= 150 * 1024, "window_threshold: row too long for the LDS prefix (W = %d)", W);
         hipLaunchKernelGGL(win_rows_u16_kernel, dim3(H, nplanes), dim3(256), smem, ctx->stream, (const uint16_t*)in, hs,
-                           hq, H, W, h);
+                           hq, H, W, hx);
         AMT_LAUNCH_CHECK();
         const int TH = 64;
         hipLaunchKernelGGL(win_cols_u16_kernel, dim3((W + 255) / 256, (H + TH - 1) / TH, nplanes), dim3(256), 0,
-                           ctx->stream, hs, hq, thr_image, H, W, h, method, k, r, TH);
+                           ctx->stream, hs, hq, thr_image, H, W, h, method, k, r, TH, hx);
         AMT_LAUNCH_CHECK();
         return AMT_OK;
     }
@@ -173,9 +179,10 @@ extern "C" int amt_window_threshold(amt_ctx* ctx, const void* in, int in_dtype, 
     double* hs = arena_take_t<double>(ctx, np);
     double* hq = arena_take_t<double>(ctx, np);
     dim3 grid((W + 255) / 256, H, nplanes);
-    hipLaunchKernelGGL(win_rows_f64_kernel, grid, dim3(256), 0, ctx->stream, (const double*)in, hs, hq, H, W, h);
+    hipLaunchKernelGGL(win_rows_f64_kernel, grid, dim3(256), 0, ctx->stream, (const double*)in, hs, hq, H, W, hx);
     AMT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(win_cols_f64_kernel, grid, dim3(256), 0, ctx->stream, hs, hq, thr_image, H, W, h, method, k, r);
+    hipLaunchKernelGGL(win_cols_f64_kernel, grid, dim3(256), 0, ctx->stream, hs, hq, thr_image, H, W, h, method, k, r,
+                       hx);
     AMT_LAUNCH_CHECK();
     return AMT_OK;
 }

@@ -365,19 +365,27 @@ def greater_than(a: DeviceArray, thr: DeviceArray, out: DeviceArray | None = Non
     return o
 
 
-def window_threshold(a: DeviceArray, window_size: int = 15, method: str = "niblack", k: float = 0.2, r=None,
+def window_threshold(a: DeviceArray, window_size=15, method: str = "niblack", k: float = 0.2, r=None,
                      out: DeviceArray | None = None) -> DeviceArray:
     """``skimage.filters.threshold_niblack`` / ``threshold_sauvola`` threshold image (float64) per plane
-    (SK/filters/thresholding.py:967-1087).  ``r`` defaults to half the dtype range as in scikit-image."""
+    (SK/filters/thresholding.py:967-1087).  ``window_size`` is an odd integer or one per axis (rows, columns);
+    ``r`` defaults to half the dtype range as in scikit-image."""
     ctx = a.ctx
     n, H, W = _planes(a)
-    if window_size % 2 == 0:
-        raise ValueError(f"Window size {window_size} is even.")
+    if isinstance(window_size, (tuple, list, np.ndarray)):
+        if len(window_size) != 2:
+            raise ValueError("window_size must be an integer or one value per image axis (rows, columns)")
+        wy, wx = (int(v) for v in window_size)
+    else:
+        wy = wx = int(window_size)
+    for v in (wy, wx):
+        if v % 2 == 0:
+            raise ValueError(f"Window size {v} is even.")
     if r is None:
         r = 0.5 * 65535 if a.dtype == np.uint16 else 1.0  # 0.5 * (imax - imin); float range is (-1, 1)
     o = _out(ctx, out, a.shape, np.float64)
-    _hip.check(_lib().amt_window_threshold(ctx.handle, a.ptr, _in_code(a), o.ptr, n, H, W, int(window_size),
-                                           0 if method == "niblack" else 1, float(k), float(r)),
+    _hip.check(_lib().amt_window_threshold_yx(ctx.handle, a.ptr, _in_code(a), o.ptr, n, H, W, wy, wx,
+                                              0 if method == "niblack" else 1, float(k), float(r)),
                "amt_window_threshold")
     return o
 

@@ -269,8 +269,6 @@ def apply_threshold(
             raise TypeError("threshold_local() missing 1 required positional argument: 'block_size'")
         mask = hipops.greater_than_image(d, _local_threshold(d, **kw))
     else:  # niblack / sauvola (SK/filters/thresholding.py:967-1087)
-        if isinstance(kw.get("window_size", 15), (tuple, list, np.ndarray)):
-            raise NotImplementedError("per-axis window sizes are not supported on the device path")
         mask = hipops.greater_than_image(d, hipops.window_threshold(d, method=method_lower, **kw))
     if mask.shape != shape:
         is_bool = mask.is_bool

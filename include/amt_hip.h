@@ -187,6 +187,9 @@ int amt_threshold_gt(amt_ctx* ctx, const void* in, int in_dtype, const double* t
  * (SK/filters/thresholding.py:910-964,1026-1027,1083-1087).  uint16 window sums are exact integers. */
 int amt_window_threshold(amt_ctx* ctx, const void* in, int in_dtype, double* thr_image, int nplanes, int H, int W,
                          int window_size, int method, double k, double r);
+/* The same with a window of window_y rows x window_x columns (scikit-image's per-axis `window_size` tuple). */
+int amt_window_threshold_yx(amt_ctx* ctx, const void* in, int in_dtype, double* thr_image, int nplanes, int H, int W,
+                            int window_y, int window_x, int method, double k, double r);
 /* out = in > thr_image (per-pixel thresholds: local / niblack / sauvola) */
 int amt_threshold_gt_image(amt_ctx* ctx, const void* in, int in_dtype, const double* thr_image, uint8_t* out,
                            size_t n);

@@ -82,6 +82,12 @@ def test_apply_threshold_methods(golden):
                                    skops.threshold_niblack(u, ws, 0.2), rtol=1e-9, atol=1e-9)
         np.testing.assert_allclose(hipops.window_threshold(du, ws, "sauvola", 0.2).numpy(),
                                    skops.threshold_sauvola(u, ws, 0.2), rtol=1e-9, atol=1e-9)
+    for ws in ((5, 21), (31, 3), (1, 9)):  # per-axis windows (rows, columns)
+        np.testing.assert_allclose(hipops.window_threshold(du, ws, "niblack", 0.2).numpy(),
+                                   skops.threshold_niblack(u, ws, 0.2), rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(hipops.window_threshold(get_context().asarray(gz), ws, "sauvola", 0.3).numpy(),
+                                   skops.threshold_sauvola(gz, ws, 0.3), rtol=1e-7, atol=1e-12)
+    assert np.array_equal(apply_threshold(u, "sauvola", window_size=(7, 33)), u > skops.threshold_sauvola(u, (7, 33)))
     assert np.array_equal(apply_threshold(u, "sauvola", window_size=25), u > skops.threshold_sauvola(u, 25))
     assert np.array_equal(apply_threshold(u, "niblack"), u > skops.threshold_niblack(u))
     np.testing.assert_allclose(hipops.window_threshold(get_context().asarray(gz), 15, "sauvola", 0.2).numpy(),
