@@ -100,19 +100,20 @@ def gaussian(a: DeviceArray, sigma: float, mode: str = "nearest", cval: float = 
 
 
 def gaussian_nd(a: DeviceArray, sigma: float, mode: str = "nearest", cval: float = 0.0, truncate: float = 4.0,
-                out: DeviceArray | None = None) -> DeviceArray:
+                out: DeviceArray | None = None, scale: float | None = None) -> DeviceArray:
     """``skimage.filters.gaussian`` of ONE n-D image the way scikit-image / scipy filter it: EVERY axis, leading axes
     first (SP/_filters.py:412-430), the intermediate kept in float64 -- unlike ``gaussian``, whose leading axes are
     independent planes.  2-D arrays go straight to ``gaussian``."""
     if a.ndim <= 2:
-        return gaussian(a, sigma, mode, cval, truncate, out=out)
+        return gaussian(a, sigma, mode, cval, truncate, scale=scale, out=out)
     ctx = a.ctx
     if sigma <= 1e-15:
-        return gaussian(a, sigma, mode, cval, truncate, out=out)
+        return gaussian(a, sigma, mode, cval, truncate, scale=scale, out=out)
     w = gaussian_weights(sigma, truncate)
     r = (len(w) - 1) // 2
     wa, wp = _host_f64(w)
-    scale = 1.0 / 65535 if a.dtype == np.uint16 else 1.0
+    if scale is None:
+        scale = 1.0 / 65535 if a.dtype == np.uint16 else 1.0
     cur, cur_scale = a, scale
     shape = a.shape
     for k in range(a.ndim - 2):  # the leading axes, one 1-D pass each

@@ -206,7 +206,13 @@ def _local_threshold(d: DeviceArray, block_size, method="gaussian", offset=0, mo
         )
     if method == "gaussian":
         sigma = (block_size - 1) / 6.0 if param is None else param
-        t = hipops.gaussian(d, sigma, mode=mode, cval=cval, scale=1.0)
+        # scikit-image filters EVERY axis of an n-D image (ndi.gaussian_filter on the whole stack)
+        t = hipops.gaussian_nd(d, sigma, mode=mode, cval=cval, scale=1.0)
+    elif d.ndim != 2:
+        raise NotImplementedError(
+            f"threshold_local(method='{method}') filters every axis of an n-D image in scikit-image; the device path "
+            "does that for method='gaussian' only -- map a stack over its first axis with Pipeline(parallel=True)"
+        )
     elif method == "mean":
         t = hipops.uniform_filter(d, block_size, mode=mode, cval=cval)
     elif method == "median":
@@ -242,12 +248,13 @@ def apply_threshold(
                                                                  "mean", "li"))
     shape = d.shape
     if d.ndim != 2:
-        if method_lower in ("local", "niblack", "sauvola"):
+        if method_lower in ("niblack", "sauvola"):
             raise NotImplementedError(
                 f"apply_threshold: method '{method_lower}' filters every axis of an n-D image in scikit-image; the device "
-                "path does local thresholds on 2-D images -- map a stack over its first axis with Pipeline(parallel=True)"
+                "path does window statistics on 2-D images -- map a stack over its first axis with Pipeline(parallel=True)"
             )
-        d = _flat(d)  # global methods: ONE threshold from the histogram of the whole stack
+        if method_lower != "local":
+            d = _flat(d)  # global methods: ONE threshold from the histogram of the whole stack
     ctx = d.ctx
     lo, hi = _min_max(d)
     if lo == hi:  # constant image (R/operations.py:201-202)

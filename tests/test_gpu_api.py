@@ -472,8 +472,14 @@ def test_operators_on_stacks_and_other_dtypes():
             ref = np.clip(dog - np.percentile(dog, pct), 0, None)
             got = subtract_background_dog(x, lo, hi, percentile=pct)
             assert got.shape == x.shape and np.array_equal(got, ref), (x.shape, lo, hi, pct)
-    with pytest.raises(NotImplementedError, match="local thresholds on 2-D images"):
+    with pytest.raises(NotImplementedError, match="window statistics on 2-D images"):
         apply_threshold(t3, "sauvola")
+    # threshold_local filters EVERY axis of a stack (its Gaussian is n-D): default method on (T, Y, X) and (Z, C, Y, X)
+    for x in (t3, z4):
+        for kw in (dict(block_size=7), dict(block_size=11, offset=3.5), dict(block_size=5, mode="nearest")):
+            ref = x > skops.threshold_local(x, **kw)
+            got = apply_threshold(x, "local", **kw)
+            assert got.shape == x.shape and got.dtype == bool and np.array_equal(got, ref), (x.shape, kw)
     # other dtypes
     small = t3[0] // 4
     for dt in (np.int32, np.int64, np.uint32):
