@@ -103,13 +103,16 @@ def pmc_traffic_bytes(stage: str):
     return total or None
 
 
-def rocprof_kernel_us(stage: str):
-    """Average duration (us per 32-FOV launch) of the kernels of one stage from the committed rocprofv3 summary
-    (profiles/rNN_kernel_stats.csv), for comparison with the live HIP-event time of the stage."""
-    path = _profile_path("kernel_stats")
+def rocprof_kernel_us(stage: str, launch_fovs: int = 32):
+    """Average duration (us per launch) of the kernels of one stage from the committed rocprofv3 summary, for comparison
+    with the live HIP-event time of the stage: profiles/rNN_kernel_stats_b48.csv is ONE context alone with 48 FOVs per
+    launch and no auxiliary streams (the default run's launch size and settings, what the profiled pass times),
+    profiles/rNN_kernel_stats.csv a single context with 32 FOVs per launch and its auxiliary streams."""
+    path = _profile_path("kernel_stats_b48") if launch_fovs == 48 else None
+    path = path or _profile_path("kernel_stats")
     if path is None or stage not in STAGE_KERNELS:
         return None
-    out = {}
+    out = {"source": os.path.relpath(path, ROOT)}
     with open(path) as f:
         for line in f:
             if not line.startswith('"'):
@@ -255,7 +258,7 @@ def stage_roofline(stage_avg: dict, npx: int, PB: int):
         "algorithmic_bytes_per_launch": dom_bytes, "launch_ms": stage_avg[dom],
         # the stage is one C-ABI call = several kernels (the flood classes run concurrently): their rocprofv3
         # averages from the committed summary, per 32-FOV launch
-        "stage_kernels_rocprof_us": rocprof_kernel_us(dom),
+        "stage_kernels_rocprof_us": rocprof_kernel_us(dom, PB),
         "chain": {"achieved": chain_bytes / (chain_ms * 1e-3) / 1e9,
                   "frac": chain_bytes / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms": chain_ms},
         "stage_ms": stage_avg,

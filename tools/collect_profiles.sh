@@ -12,6 +12,9 @@ C3="--steps 5 --warmup 1 --no-cpu --no-h2d --streams 1 --batch 32"
 if [ "$1" = "1" ]; then
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_c3 -o c3 -- python3 $R/bench.py $C3 > $O/ks_c3.log 2>&1 || exit 1
   echo "c3 stats done"
+  # the default bench configuration itself (4 contexts x 48 FOVs, every call on its context's one stream)
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_default -o c3d -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu --no-h2d > $O/ks_default.log 2>&1 || exit 1
+  echo "default-config stats done"
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_c2 -o c2 -- python3 $R/bench.py --workload c2 $C3 > $O/ks_c2.log 2>&1 || exit 1
   echo "c2 stats done"
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_prep -o prep -- python3 $R/bench.py --workload prep --steps 5 --warmup 1 --no-cpu > $O/ks_prep.log 2>&1 || exit 1
@@ -22,6 +25,13 @@ if [ "$1" = "1" ]; then
   echo "pmc fetch done"
   timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_w -o w --output-format csv -- python3 $R/bench.py $P > $O/pmc_w.log 2>&1 || exit 1
   echo "pmc write done"
+elif [ "$1" = "5" ]; then
+  # one context alone with the timed region's launch size and settings: what bench.py's profiled pass measures
+  AMT_FORK=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_b48 -o b48 -- python3 $R/bench.py --streams 1 --batch 48 --steps 5 --warmup 1 --no-cpu --no-h2d > $O/ks_b48.log 2>&1 || exit 1
+  echo "48-FOV single-context stats done"
+elif [ "$1" = "4" ]; then
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_default -o c3d -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu --no-h2d > $O/ks_default.log 2>&1 || exit 1
+  echo "default-config stats done"
 elif [ "$1" = "3" ]; then
   cd $R
   AMT_BENCH_FORCE_DIST=1 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29517 python3 bench.py --no-cpu --no-h2d 2> $O/bench_dist1.err > $O/bench_dist1.json && echo "dist1 done" || exit 1
