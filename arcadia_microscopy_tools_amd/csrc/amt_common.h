@@ -24,10 +24,11 @@ struct amt_ctx {
     size_t mailbox_off;
     int num_cus;
     // auxiliary streams + events for fork/join of independent latency-bound kernels inside one op
-    hipStream_t aux[3];
+    hipStream_t aux[3];      // the streams an op's independent kernels are launched on (auxiliary ones, or `stream`)
+    hipStream_t aux_own[3];  // the auxiliary streams this context created
     hipEvent_t ev[4];
     bool aux_ready;
-    bool fork;  // amt_ctx_set_fork: independent kernels of one op run on the auxiliary streams
+    int fork;  // amt_ctx_set_fork: how many auxiliary streams the ops of this context use (0..3)
 };
 
 // fork: aux streams wait for everything enqueued so far on the main stream; join: main waits for them

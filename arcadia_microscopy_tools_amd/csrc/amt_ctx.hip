@@ -21,7 +21,7 @@ extern "C" int amt_device_count(void) {
     return n;
 }
 
-static bool fork_enabled();
+static int fork_default();
 
 static int ctx_create_common(int device, hipStream_t stream, bool own, amt_ctx** out) {
     AMT_REQUIRE(out != nullptr, "amt_ctx_create: out is null");
@@ -53,7 +53,7 @@ static int ctx_create_common(int device, hipStream_t stream, bool own, amt_ctx**
     c->mailbox_cap = 0;
     c->mailbox_off = 0;
     c->aux_ready = false;
-    c->fork = fork_enabled();
+    c->fork = fork_default();
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess)
         c->num_cus = prop.multiProcessorCount;
@@ -81,7 +81,7 @@ extern "C" int amt_ctx_destroy(amt_ctx* ctx) {
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
     if (ctx->aux_ready) {
-        for (int i = 0; i < 3; ++i) (void)hipStreamDestroy(ctx->aux[i]);
+        for (int i = 0; i < 3; ++i) (void)hipStreamDestroy(ctx->aux_own[i]);
         for (int i = 0; i < 4; ++i) (void)hipEventDestroy(ctx->ev[i]);
     }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
@@ -130,15 +130,14 @@ int amt_arena_begin(amt_ctx* ctx, size_t total_bytes) {
     return AMT_OK;
 }
 
-// AMT_FORK=0 keeps every kernel of an op on the context's single stream (no auxiliary streams): useful
-// when several contexts already provide the overlap and hardware queues are scarce.
-static bool fork_enabled() {
+// AMT_FORK=0 keeps every kernel of an op on the context's single stream (no auxiliary streams); 1..3 = that many
+static int fork_default() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("AMT_FORK");
-        v = (e && e[0] == '0') ? 0 : 1;
+        v = (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 3;
     }
-    return v == 1;
+    return v;
 }
 
 // Per context: a process that already runs several contexts side by side (one per HIP stream) gains nothing from the
@@ -147,29 +146,32 @@ static bool fork_enabled() {
 // 1.80 ms against 2.32 ms per 32 FOVs).
 extern "C" int amt_ctx_set_fork(amt_ctx* ctx, int enable) {
     AMT_REQUIRE(ctx != nullptr, "ctx_set_fork: null context");
-    ctx->fork = enable != 0;
+    ctx->fork = enable < 0 ? 0 : (enable > 3 ? 3 : enable);  // 1 ("on") .. 3 = that many auxiliary streams
     return AMT_OK;
 }
 
 int amt_fork(amt_ctx* ctx) {
-    if (!ctx->fork) {
+    const int n = ctx->fork;
+    if (n == 0) {
         ctx->aux[0] = ctx->aux[1] = ctx->aux[2] = ctx->stream;
         return AMT_OK;
     }
     if (!ctx->aux_ready) {
-        for (int i = 0; i < 3; ++i) AMT_HIP_CHECK(hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking));
+        for (int i = 0; i < 3; ++i) AMT_HIP_CHECK(hipStreamCreateWithFlags(&ctx->aux_own[i], hipStreamNonBlocking));
         for (int i = 0; i < 4; ++i) AMT_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev[i], hipEventDisableTiming));
         ctx->aux_ready = true;
     }
+    for (int i = 0; i < 3; ++i) ctx->aux[i] = ctx->aux_own[i % n];
     AMT_HIP_CHECK(hipEventRecord(ctx->ev[0], ctx->stream));
-    for (int i = 0; i < 3; ++i) AMT_HIP_CHECK(hipStreamWaitEvent(ctx->aux[i], ctx->ev[0], 0));
+    for (int i = 0; i < n; ++i) AMT_HIP_CHECK(hipStreamWaitEvent(ctx->aux_own[i], ctx->ev[0], 0));
     return AMT_OK;
 }
 
 int amt_join(amt_ctx* ctx) {
-    if (!ctx->fork) return AMT_OK;
-    for (int i = 0; i < 3; ++i) {
-        AMT_HIP_CHECK(hipEventRecord(ctx->ev[1 + i], ctx->aux[i]));
+    const int n = ctx->fork;
+    if (n == 0) return AMT_OK;
+    for (int i = 0; i < n; ++i) {
+        AMT_HIP_CHECK(hipEventRecord(ctx->ev[1 + i], ctx->aux_own[i]));
         AMT_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev[1 + i], 0));
     }
     return AMT_OK;

@@ -96,10 +96,12 @@ class Context:
             self._stage_buf = PinnedBuffer((max(nbytes, 64 << 20),), np.uint8)
         return self._stage_buf.array
 
-    def set_fork(self, enable: bool) -> None:
-        """Let independent kernels inside one call use the context's auxiliary streams (default) or keep everything on
-        its one stream -- the right choice when several contexts already run side by side (amt_ctx_set_fork)."""
-        _hip.check(self._lib.amt_ctx_set_fork(self.handle, 1 if enable else 0), "amt_ctx_set_fork")
+    def set_fork(self, enable) -> None:
+        """Let independent kernels inside one call use the context's auxiliary streams (True = all three, the default;
+        an int = that many) or keep everything on its one stream (False / 0) -- the right choice when several
+        contexts already run side by side (amt_ctx_set_fork)."""
+        n = 3 if enable is True else int(enable)
+        _hip.check(self._lib.amt_ctx_set_fork(self.handle, n), "amt_ctx_set_fork")
 
     # -- lifetime -------------------------------------------------------------------------------
     def close(self):

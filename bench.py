@@ -143,6 +143,8 @@ def parse_args():
     ap.add_argument("--streams", type=int, default=0,
                     help="HIP streams per GPU; the batch is split over them so that the latency-bound flood of one "
                          "part overlaps the bandwidth-bound stages of the others (0 = 6, fewer for small batches)")
+    ap.add_argument("--aux-streams", type=int, default=0,
+                    help="auxiliary streams per context when several contexts run (0..3; a single context uses 3)")
     ap.add_argument("--size", type=int, default=2048)
     ap.add_argument("--max-cells", type=int, default=2048,
                     help="row capacity of the per-FOV feature tables (the synthetic FOVs hold ~1,360 nuclei); a FOV "
@@ -590,7 +592,7 @@ def main():
         # several contexts run side by side: the overlap comes from them, not from auxiliary streams inside a call
         # (measured: 4 contexts x 48 FOVs 11.1 k FOV/s without, 6 x 32 with auxiliary streams 10.2 k)
         for c in ctxs:
-            c.set_fork(False)
+            c.set_fork(args.aux_streams)
     parts = [d_fovs[bounds[i]:bounds[i + 1]] for i in range(nstreams)]
     segs = [FovSegmenter(bounds[i + 1] - bounds[i], 4, S, S, ctx=ctxs[i], max_cells=args.max_cells)
             for i in range(nstreams)]
