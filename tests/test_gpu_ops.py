@@ -389,6 +389,64 @@ def test_watershed(ctx, ops, golden):
         assert np.array_equal(out, watershed(img, mk, mask=mask)), i
 
 
+def test_watershed_every_flood_class(ctx, ops):
+    """Components of every size class of the EDT flood -- bounding boxes of ~1.5 k, 3.5 k, 7 k, 20 k, 30 k pixels (the five
+    LDS classes) and 45 k / 90 k pixels or a distance above the bucket limit (the HBM queue path) -- each with several
+    markers, in one plane and as a batch of two, through ``watershed_edt(seeds_first=True)`` and the fused
+    ``watershed_edt_cleared``; bit-identical to the oracle's heap flood of the seeded relief."""
+    from oracle import skops
+    from oracle.watershed import watershed
+
+    H, W = 640, 1200
+    yy, xx = np.mgrid[0:H, 0:W]
+
+    def blobs(seed):
+        rng = np.random.default_rng(seed)
+        m = np.zeros((H, W), bool)
+        # (centre y, centre x, half height, half width): chains of overlapping ellipses inside the box
+        for cy, cx, hy, hx in ((40, 40, 16, 22), (40, 140, 25, 33), (60, 300, 35, 48), (150, 120, 65, 75),
+                               (150, 420, 80, 92), (330, 150, 100, 110), (420, 600, 140, 160)):
+            for _ in range(6):
+                oy, ox = rng.integers(-hy // 2, hy // 2 + 1), rng.integers(-hx // 2, hx // 2 + 1)
+                ry, rx = rng.integers(hy // 3, hy // 2 + 1), rng.integers(hx // 3, hx // 2 + 1)
+                m |= ((yy - cy - oy) / ry) ** 2 + ((xx - cx - ox) / rx) ** 2 <= 1.0
+        m[200:330, 700:880] = True  # a 130 x 180 rectangle: EDT up to 65 -> d2 > 2,048 buckets
+        for cy, cx in ((50, 960), (50, 990 + seed)):  # two lobes of radius 30: box ~62 x 95 (the 8,192-pixel class)
+            m |= (yy - cy) ** 2 + (xx - cx) ** 2 <= 30 ** 2
+        for cy in (250, 330):  # 2 x 2 disks of radius 44, 80 apart: box ~170 x 170, d2 < 2,048 (the 32,512-pixel class)
+            for cx in (980, 1060):
+                m |= (yy - cy) ** 2 + (xx - cx) ** 2 <= 44 ** 2
+        m[0] = m[-1] = False
+        m[:, 0] = m[:, -1] = False
+        return m
+
+    masks = np.stack([blobs(5), blobs(6)])
+    dm = ctx.asarray(masks)
+    d2, _ = ops.edt(dm)
+    refs = []
+    mks = []
+    for b in range(2):
+        edt = skops.distance_transform_edt(masks[b])
+        markers, _ = skops.peak_markers(edt, masks[b], 5)
+        assert markers.max() >= 12
+        mks.append(markers.astype(np.int32))
+        refs.append(watershed(skops.seeded_flood_image(edt, markers), markers, mask=masks[b]))
+    dmk = ctx.asarray(np.stack(mks))
+    for b in range(2):  # one plane at a time
+        got = ops.watershed_edt(d2[b:b + 1], dmk[b:b + 1], dm[b:b + 1], seeds_first=True).numpy()[0]
+        assert np.array_equal(got, refs[b]), b
+    got = ops.watershed_edt(d2, dmk, dm, seeds_first=True).numpy()
+    assert np.array_equal(got, np.stack(refs))
+    # the fused tail on the same planes
+    nl = ctx.asarray(np.array([m.max() for m in mks], np.int32))
+    scratch = ctx.empty(masks.shape, np.int32)
+    lab, cnt = ops.watershed_edt_cleared(d2, dmk, dm, nl, int(max(m.max() for m in mks)), scratch)
+    for b in range(2):
+        cleared = skops.clear_border(refs[b])
+        ref = skops.relabel_sequential(cleared) if cleared.max() > 0 else cleared
+        assert np.array_equal(lab.numpy()[b], ref) and cnt.numpy()[b] == ref.max(), b
+
+
 def test_watershed_skimage_golden_cases(ctx, ops, golden):
     """All 120 real scikit-image 0.18.3 cases of tests/golden/watershed_cases.npz (tie-heavy integer reliefs and
     -EDT inputs, with / without mask, connectivity 1 and 2) through the C ABI: bit-identical under the default
