@@ -217,18 +217,23 @@ __global__ void __launch_bounds__(256) ws_stats_kernel(const int* __restrict__ d
         }
         // run geometry (needs the ballot of ALL lanes, so it sits outside the divergent branch)
         const unsigned long long hb = __ballot(head || r < 0);  // run boundaries: heads and background
+        // a run with a pixel of its own component right above (below) it cannot be the component's first (last) row:
+        // inside the strip's eight rows that spares four of five y atomics (the strip's first / last row always asks)
+        const unsigned long long ab = __ballot(r >= 0 && k > 0 && rs[k > 0 ? k - 1 : 0] >= 0 && ts[k > 0 ? k - 1 : 0] == ts[k]);
+        const unsigned long long bl = __ballot(r >= 0 && k < 7 && rs[k < 7 ? k + 1 : 7] >= 0 && ts[k < 7 ? k + 1 : 7] == ts[k]);
         if (head) {
             const unsigned long long later = hb & ~((2ull << lane) - 1ull);
             const int end_lane = later ? (__ffsll((long long)later) - 2) : 63;
             const int len = end_lane - lane + 1;
+            const unsigned long long run = (len == 64 ? ~0ull : ((1ull << len) - 1ull)) << lane;
             comp_row* c = prow + (ts[k] - 1);
             // the run that starts at the component root itself: the one pixel that is its own parent (r = L[pixel])
             if ((size_t)r == (size_t)(yb + k) * W + x) c->root = r;
             if (!use_d2) atomicAdd(&c->cmax, len);
             atomicMin(&c->x0, x);
             atomicMax(&c->x1, x + len - 1);
-            atomicMin(&c->y0, yb + k);
-            atomicMax(&c->y1, yb + k);
+            if (!(ab & run)) atomicMin(&c->y0, yb + k);
+            if (!(bl & run)) atomicMax(&c->y1, yb + k);
         }
     }
 }
