@@ -57,7 +57,7 @@ STAGE_BYTES_PER_PX = {
 
 # kernels (name prefixes in the rocprofv3 output) that make up each stage of the chain
 STAGE_KERNELS = {
-    "gaussian": ("gauss_lds_kernel", "gauss_fused_kernel", "conv_v8_kernel", "conv_h8_kernel"),
+    "gaussian": ("gauss_lds_kernel", "gauss_fused_kernel", "conv_v8", "conv_h8"),
     "otsu": ("hist_f64_kernel", "otsu_f64_kernel", "minmax_"),
     "gaussian_otsu": ("gauss_lds_kernel", "otsu_f64_kernel", "minmax_"),
     "threshold_open_close": ("pack_gt_kernel", "toc_fused_kernel", "packed_prim_kernel", "unpack_kernel"),
