@@ -93,6 +93,8 @@ _SIGS = {
     "amt_binary_open": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_int, c_int]),
     "amt_binary_close": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_int, c_int]),
     "amt_threshold_open_close": (c_int, [_P, _P, c_int, _P, _P, c_int, c_int, c_int, _P, c_int, c_int]),
+    "amt_otsu_f64_bins": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_size_t]),
+    "amt_threshold_open_close_bins": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, c_int, c_int]),
     "amt_rank_filter": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_double]),
     "amt_gaussian_otsu_codes_supported": (c_int, [c_int, c_int, c_int, c_int, c_size_t]),
     "amt_gaussian_otsu_codes": (c_int, [_P, _P, c_double, c_int, c_int, c_int, _P, c_int, c_int, c_size_t, _P, _P, _P, _P,

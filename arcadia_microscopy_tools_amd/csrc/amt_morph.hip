@@ -76,6 +76,35 @@ __global__ void __launch_bounds__(256) pack_gt_kernel(const T* __restrict__ in, 
                [t](T v) { return (double)v > t; });
 }
 
+// `vals > thr[plane]` from the byte plane of 256-bin indices (amt_otsu_f64_bins): thr is the centre of bin k, so a sample
+// of a higher bin is above it (>= that bin's lower edge > centre_k), one of a lower bin below it, and only a sample of
+// bin k itself has to be looked at -- 1 byte per pixel instead of 8, plus the float64 values along the objects' rims.
+// A thread owns 16 consecutive pixels (one 16-byte load), four threads make a 64-pixel word.  W % 64 == 0.
+__global__ void __launch_bounds__(256) pack_bins_kernel(const uint8_t* __restrict__ bins, const double* __restrict__ vals,
+                                                        const double* __restrict__ thr,
+                                                        const double* __restrict__ thr_code, u64* __restrict__ packed,
+                                                        size_t n) {
+    const size_t plane = blockIdx.y;
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;  // 16-pixel group of the plane
+    if (q * 16 >= n) return;                                  // whole quads leave together (n % 64 == 0)
+    const double t = thr[plane];
+    const unsigned k = (unsigned)(thr_code[plane] * 0.5);
+    const uint4 b16 = *reinterpret_cast<const uint4*>(bins + plane * n + q * 16);
+    const unsigned wv[4] = {b16.x, b16.y, b16.z, b16.w};
+    const double* v = vals + plane * n + q * 16;
+    unsigned m = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const unsigned b = (wv[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+        bool bit = b > k;
+        if (b == k) bit = v[j] > t;
+        m |= (bit ? 1u : 0u) << j;
+    }
+    const u64 m1 = (u64)(unsigned)__shfl_down((int)m, 1), m2 = (u64)(unsigned)__shfl_down((int)m, 2),
+              m3 = (u64)(unsigned)__shfl_down((int)m, 3);
+    if ((threadIdx.x & 3) == 0) packed[plane * (n / 64) + q / 4] = (u64)m | (m1 << 16) | (m2 << 32) | (m3 << 48);
+}
+
 __device__ __forceinline__ unsigned spread4(unsigned nib) {
     return (nib & 1u) | ((nib & 2u) << 7) | ((nib & 4u) << 14) | ((nib & 8u) << 21);
 }
@@ -411,9 +440,26 @@ __global__ void __launch_bounds__(256) toc_fused_kernel(const u64* __restrict__ 
 
 // `binary_closing(binary_opening(in > thr))` in one packed chain: compare -> 4 word-level primitives ->
 // unpack (the Gaussian -> Otsu -> '>' -> open -> close mask chain of BASELINE configs[1]/[2]).
+static int threshold_open_close_impl(amt_ctx* ctx, const void* in, int in_dtype, const double* thr_dev, uint8_t* out,
+                                     int nplanes, int H, int W, const uint8_t* footprint, int fh, int fw,
+                                     const uint8_t* bins, const double* thr_code_dev);
+
 extern "C" int amt_threshold_open_close(amt_ctx* ctx, const void* in, int in_dtype, const double* thr_dev,
                                         uint8_t* out, int nplanes, int H, int W, const uint8_t* footprint, int fh,
                                         int fw) {
+    return threshold_open_close_impl(ctx, in, in_dtype, thr_dev, out, nplanes, H, W, footprint, fh, fw, nullptr, nullptr);
+}
+
+extern "C" int amt_threshold_open_close_bins(amt_ctx* ctx, const double* in, const uint8_t* bins, const double* thr_dev,
+                                             const double* thr_code_dev, uint8_t* out, int nplanes, int H, int W,
+                                             const uint8_t* footprint, int fh, int fw) {
+    AMT_REQUIRE(bins && thr_code_dev, "threshold_open_close_bins: the bin plane and the threshold's bin are required");
+    return threshold_open_close_impl(ctx, in, AMT_F64, thr_dev, out, nplanes, H, W, footprint, fh, fw, bins, thr_code_dev);
+}
+
+static int threshold_open_close_impl(amt_ctx* ctx, const void* in, int in_dtype, const double* thr_dev, uint8_t* out,
+                                     int nplanes, int H, int W, const uint8_t* footprint, int fh, int fw,
+                                     const uint8_t* bins, const double* thr_code_dev) {
     AMT_TRY(amt_set_device(ctx));
     AMT_REQUIRE(in && thr_dev && out && nplanes >= 0 && H > 0 && W > 0, "threshold_open_close: bad arguments");
     AMT_REQUIRE(in_dtype == AMT_U16 || in_dtype == AMT_F64, "threshold_open_close: dtype must be AMT_U16 or AMT_F64");
@@ -432,7 +478,11 @@ extern "C" int amt_threshold_open_close(amt_ctx* ctx, const void* in, int in_dty
         AMT_TRY(amt_param_upload(ctx, offs, host, sizeof(int2) * noffs));
         const size_t nwords = (size_t)H * WW;
         const unsigned gpack = (unsigned)((nwords + 4 * PACK_WORDS_PER_WAVE - 1) / (4 * PACK_WORDS_PER_WAVE));
-        if (in_dtype == AMT_F64)
+        const size_t npx = (size_t)H * W;
+        if (bins && (W & 63) == 0 && ((reinterpret_cast<uintptr_t>(bins) | npx) & 15) == 0)
+            hipLaunchKernelGGL(pack_bins_kernel, dim3((unsigned)((npx / 16 + 255) / 256), nplanes), dim3(256), 0, ctx->stream,
+                               bins, (const double*)in, thr_dev, thr_code_dev, pa, npx);
+        else if (in_dtype == AMT_F64)
             hipLaunchKernelGGL((pack_gt_kernel<double>), dim3(gpack, nplanes), dim3(256), 0, ctx->stream,
                                (const double*)in, thr_dev, pa, H, W, WW);
         else

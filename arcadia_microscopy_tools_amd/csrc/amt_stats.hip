@@ -169,9 +169,12 @@ __device__ __forceinline__ double linspace_edge(double lo, double hi, double ste
     return i == nbins ? hi : (double)i * step + lo;
 }
 
+// bins (nullable, nbins <= 256): the bin of every sample as a byte plane -- for a threshold that is the centre of bin k
+// (Otsu), `sample > threshold` is decided by the byte alone except inside bin k (amt_threshold_open_close_bins)
 __global__ void __launch_bounds__(256) hist_f64_kernel(const double* __restrict__ in,
                                                        const double* __restrict__ minmax,
-                                                       uint32_t* __restrict__ hist, int nbins, size_t n) {
+                                                       uint32_t* __restrict__ hist, int nbins, size_t n,
+                                                       uint8_t* __restrict__ bins) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* edges = reinterpret_cast<double*>(smem_raw);              // nbins + 1
     uint32_t* lh = reinterpret_cast<uint32_t*>(edges + nbins + 1);    // 4 waves x nbins
@@ -214,6 +217,8 @@ __global__ void __launch_bounds__(256) hist_f64_kernel(const double* __restrict_
                 while (b > 0 && v < edges[b]) --b;
                 while (b < nbins - 1 && v >= edges[b + 1]) ++b;
             }
+            // (a constant plane has no bins: lo == hi makes the scaling infinite -- its bytes are 0 like its threshold's)
+            if (bins && i0 + (size_t)u * 256 < n) bins[(size_t)plane * n + i0 + (size_t)u * 256] = (uint8_t)(ok && lo < hi ? b : 0);
             const unsigned long long act = __ballot(ok);
             if (!act) continue;
             // two rounds of "first lane's bin, counted once for everyone who shares it" (64 same-address LDS atomics
@@ -242,12 +247,12 @@ __global__ void __launch_bounds__(256) hist_f64_kernel(const double* __restrict_
 }
 
 static int hist_f64_launch(amt_ctx* ctx, const double* in, const double* minmax, uint32_t* hist, int nbins,
-                           int nplanes, size_t n) {
+                           int nplanes, size_t n, uint8_t* bins = nullptr) {
     AMT_HIP_CHECK(hipMemsetAsync(hist, 0, (size_t)nplanes * nbins * sizeof(uint32_t), ctx->stream));
     if (n == 0) return AMT_OK;
     size_t smem = (size_t)(nbins + 1) * sizeof(double) + (size_t)4 * nbins * sizeof(uint32_t);
     dim3 grid(amt_grid_for(n, 256 * 16, 512), nplanes);
-    hipLaunchKernelGGL(hist_f64_kernel, grid, dim3(256), smem, ctx->stream, in, minmax, hist, nbins, n);
+    hipLaunchKernelGGL(hist_f64_kernel, grid, dim3(256), smem, ctx->stream, in, minmax, hist, nbins, n, bins);
     AMT_LAUNCH_CHECK();
     return AMT_OK;
 }
@@ -499,6 +504,20 @@ extern "C" int amt_threshold_value(amt_ctx* ctx, const void* in, int in_dtype, i
         AMT_TRY(minmax_f64_launch(ctx, (const double*)in, keys, mm, nplanes, n));
     AMT_TRY(hist_f64_launch(ctx, (const double*)in, mm, hist, nbins, nplanes, n));
     return amt_i_otsu_from_hist(ctx, hist, mm, nbins, thr_dev, nullptr, nplanes);
+}
+
+// Otsu on float64 planes whose [min, max] is known (the Gaussian folds it in), leaving the 256-bin index of every sample
+// behind as a byte plane: thr_dev = the threshold (bit-identical to amt_threshold_value), thr_code_dev = 2 * its bin.
+extern "C" int amt_otsu_f64_bins(amt_ctx* ctx, const double* in, const double* minmax_dev, double* thr_dev,
+                                 double* thr_code_dev, uint8_t* bins, int nplanes, size_t n) {
+    AMT_TRY(amt_set_device(ctx));
+    AMT_REQUIRE(in && minmax_dev && thr_dev && thr_code_dev && bins && nplanes >= 0, "otsu_f64_bins: bad arguments");
+    if (nplanes == 0) return AMT_OK;
+    const int nbins = 256;
+    AMT_TRY(amt_arena_begin(ctx, amt_align((size_t)nplanes * nbins * 4)));
+    uint32_t* hist = arena_take_t<uint32_t>(ctx, (size_t)nplanes * nbins);
+    AMT_TRY(hist_f64_launch(ctx, in, minmax_dev, hist, nbins, nplanes, n, bins));
+    return amt_i_otsu_from_hist(ctx, hist, minmax_dev, nbins, thr_dev, thr_code_dev, nplanes);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -480,12 +480,36 @@ def binary_closing(a, footprint=None, out=None):
     return _binary("close", a, footprint, out)
 
 
-def threshold_open_close(a: DeviceArray, thr: DeviceArray, footprint=None, out=None) -> DeviceArray:
-    """``binary_closing(binary_opening(a > thr[plane], fp), fp)`` as one packed chain (no intermediate masks)."""
+def threshold_otsu_bins(a: DeviceArray, minmax: DeviceArray, thr: DeviceArray, thr_code: DeviceArray,
+                        bins: DeviceArray) -> DeviceArray:
+    """``threshold_otsu`` of float64 planes whose [min, max] is known, leaving every sample's 256-bin index in the uint8
+    plane ``bins`` and the threshold's bin (times two) in ``thr_code``: ``threshold_open_close(a, thr, bins=bins,
+    thr_code=thr_code)`` then compares by the byte plane (amt_otsu_f64_bins)."""
+    ctx = a.ctx
+    n, H, W = _planes(a)
+    if a.dtype != np.float64 or bins.dtype != np.uint8 or bins.size != a.size:
+        raise ValueError("threshold_otsu_bins: float64 image and a uint8 bin plane of the same size")
+    for arr, size in ((minmax, 2 * n), (thr, n), (thr_code, n)):
+        if arr.dtype != np.float64 or arr.size != size:
+            raise ValueError("threshold_otsu_bins: minmax (n, 2), thr (n,), thr_code (n,) must be float64")
+    _hip.check(_lib().amt_otsu_f64_bins(ctx.handle, a.ptr, minmax.ptr, thr.ptr, thr_code.ptr, bins.ptr, n, H * W),
+               "amt_otsu_f64_bins")
+    return thr
+
+
+def threshold_open_close(a: DeviceArray, thr: DeviceArray, footprint=None, out=None, bins=None, thr_code=None) -> DeviceArray:
+    """``binary_closing(binary_opening(a > thr[plane], fp), fp)`` as one packed chain (no intermediate masks).
+    ``bins`` / ``thr_code`` from ``threshold_otsu_bins``: the comparison reads 1 byte per pixel instead of 8."""
     ctx = a.ctx
     n, H, W = _planes(a)
     fp = _fp(footprint)
     o = _out(ctx, out, a.shape, np.uint8)
+    if bins is not None:
+        _hip.check(_lib().amt_threshold_open_close_bins(ctx.handle, a.ptr, bins.ptr, thr.ptr, thr_code.ptr, o.ptr, n, H, W,
+                                                        fp.ctypes.data_as(ctypes.c_void_p), fp.shape[0], fp.shape[1]),
+                   "amt_threshold_open_close_bins")
+        o.is_bool = True
+        return o
     _hip.check(_lib().amt_threshold_open_close(ctx.handle, a.ptr, _in_code(a), thr.ptr, o.ptr, n, H, W,
                                                fp.ctypes.data_as(ctypes.c_void_p), fp.shape[0], fp.shape[1]),
                "amt_threshold_open_close")

@@ -46,7 +46,7 @@ class FovSegmenter:
 
     def __init__(self, batch: int, C: int, H: int, W: int, *, sigma: float = 2.0, radius: int = 2,
                  min_distance: int = 5, max_cells: int = 4096, dapi_index: int = 1, ctx: Context | None = None,
-                 props: bool = True, profile: bool = False, fused: bool = True, low_traffic: bool = False):
+                 props: bool = True, profile: bool = False, fused: bool = True, low_traffic: bool = False, bin_plane: bool = True):
         self.ctx = ctx or get_context()
         self.B, self.C, self.H, self.W = int(batch), int(C), int(H), int(W)
         self.sigma, self.radius, self.min_distance = float(sigma), int(radius), int(min_distance)
@@ -59,6 +59,9 @@ class FovSegmenter:
         # thresholds).  Off by default: the Gaussian is fp64-issue bound, so computing it twice costs more time than
         # the two reads of the float64 plane it saves (rocprofv3, 32 FOVs: 1.13 ms against 0.93 ms)
         self.low_traffic = bool(low_traffic)
+        # bin_plane: the Otsu histogram pass leaves every sample's bin as a byte plane and '>' reads that plane
+        # (amt_otsu_f64_bins / amt_threshold_open_close_bins); False = compare the float64 plane (same masks)
+        self.bin_plane = bool(bin_plane)
         self.footprint = hipops.disk(self.radius)
         c, B = self.ctx, self.B
         shp = (B, self.H, self.W)
@@ -66,6 +69,7 @@ class FovSegmenter:
         self.codes_path = None  # decided on the first batch (needs the batch's alignment)
         self._gauss = None
         self.codes = self.thr_code = self.ghist = None
+        self._bins = self._thr_code = None
         self.thr = c.empty((B,), np.float64)
         self.gmm = c.empty((B, 2), np.float64)  # [min, max] of the smoothed image, folded in by the Gaussian
         self.mask_a = c.empty(shp, np.uint8)
@@ -128,11 +132,23 @@ class FovSegmenter:
             return self.mask_a
         self._stage("gaussian")
         hipops.gaussian(fovs, self.sigma, channel=self.dapi_index, out=self.gauss, minmax_out=self.gmm)
+        if not self.bin_plane:
+            self._stage("otsu")
+            hipops.threshold_otsu(self.gauss, out=self.thr, minmax=self.gmm)
+            self._stage("threshold_open_close")
+            hipops.threshold_open_close(self.gauss, self.thr, self.footprint, out=self.mask_a)
+            return self.mask_a
+        if self._bins is None:
+            # the histogram pass leaves every sample's bin as a byte plane, and the threshold comparison reads that
+            # plane instead of the float64 one (8 -> 1 byte per pixel, identical masks)
+            self._bins = self.ctx.empty((self.B, self.H, self.W), np.uint8)
+            self._thr_code = self.ctx.empty((self.B,), np.float64)
         self._stage("otsu")
-        hipops.threshold_otsu(self.gauss, out=self.thr, minmax=self.gmm)
+        hipops.threshold_otsu_bins(self.gauss, self.gmm, self.thr, self._thr_code, self._bins)
         # '>' + opening + closing as one bit-packed chain (identical to the three separate operators)
         self._stage("threshold_open_close")
-        hipops.threshold_open_close(self.gauss, self.thr, self.footprint, out=self.mask_a)
+        hipops.threshold_open_close(self.gauss, self.thr, self.footprint, out=self.mask_a, bins=self._bins,
+                                    thr_code=self._thr_code)
         return self.mask_a
 
     @property

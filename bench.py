@@ -594,7 +594,8 @@ def main():
         for c in ctxs:
             c.set_fork(args.aux_streams)
     parts = [d_fovs[bounds[i]:bounds[i + 1]] for i in range(nstreams)]
-    segs = [FovSegmenter(bounds[i + 1] - bounds[i], 4, S, S, ctx=ctxs[i], max_cells=args.max_cells)
+    segs = [FovSegmenter(bounds[i + 1] - bounds[i], 4, S, S, ctx=ctxs[i], max_cells=args.max_cells,
+                         bin_plane=os.environ.get("AMT_BENCH_NO_BINS") != "1")
             for i in range(nstreams)]
     packed = None
     gather = distributed and args.workload == "c3" and not args.no_gather and os.environ.get("AMT_BENCH_NO_GATHER") != "1"
@@ -682,7 +683,8 @@ def main():
     # ---- per-stage device times (HIP events on the kernels' own stream), outside the timed region ----
     # one launch of the timed region covers the FOVs of ONE stream: profile that launch size
     PB = bounds[1] - bounds[0]
-    prof = FovSegmenter(PB, 4, S, S, ctx=ctx, profile=True, max_cells=args.max_cells)
+    prof = FovSegmenter(PB, 4, S, S, ctx=ctx, profile=True, max_cells=args.max_cells,
+                        bin_plane=os.environ.get("AMT_BENCH_NO_BINS") != "1")
     d_prof = d_fovs[:PB]
     stage_ms: dict[str, list[float]] = {}
     reps = 3

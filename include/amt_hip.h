@@ -210,6 +210,13 @@ int amt_binary_close(amt_ctx* ctx, const uint8_t* in, uint8_t* out, int nplanes,
  * configs[1]/[2]: R/operations.py:216 followed by SK/morphology/binary.py:82-147). */
 int amt_threshold_open_close(amt_ctx* ctx, const void* in, int in_dtype, const double* thr_dev, uint8_t* out,
                              int nplanes, int H, int W, const uint8_t* footprint, int fh, int fw);
+/* The same chain for a float64 image whose Otsu threshold came from amt_otsu_f64_bins: the comparison reads the byte
+ * plane of bin indices (1 B/px) and the float64 value only inside the threshold's own bin -- identical masks. */
+int amt_otsu_f64_bins(amt_ctx* ctx, const double* in, const double* minmax_dev, double* thr_dev, double* thr_code_dev,
+                      uint8_t* bins, int nplanes, size_t n);
+int amt_threshold_open_close_bins(amt_ctx* ctx, const double* in, const uint8_t* bins, const double* thr_dev,
+                                  const double* thr_code_dev, uint8_t* out, int nplanes, int H, int W,
+                                  const uint8_t* footprint, int fh, int fw);
 /* grey erosion / dilation / median over a footprint (uint16 or float64 images), scipy boundary `mode`.
  * op: 0 = erosion (min), 1 = dilation (max, footprint already mirrored by the caller), 2 = median */
 int amt_rank_filter(amt_ctx* ctx, const void* in, void* out, int dtype, int nplanes, int H, int W,

@@ -104,6 +104,45 @@ def test_gaussian_otsu_codes_equal_separate_operators(ctx):
     assert np.array_equal(a.mask_a.numpy(), b.mask_a.numpy()) and np.array_equal(la, lb)
 
 
+def test_otsu_bins_mask_equals_plain_comparison(ctx):
+    """threshold_otsu_bins + threshold_open_close(bins=...) -- the comparison by the byte plane of histogram bins -- against
+    threshold_otsu + threshold_open_close on the float64 plane: same thresholds, same masks, on widths that take the
+    16-pixel kernel (multiples of 64) and widths that fall back, smooth / noisy / constant / two-valued planes."""
+    from arcadia_microscopy_tools_amd import hipops, synth
+
+    rng = np.random.default_rng(23)
+    for H, W in ((130, 512), (70, 520), (96, 64)):
+        fov = synth.synth_fov(5, size=max(H, W))[:, :H, :W]
+        planes = np.stack([fov[1], rng.integers(0, 65536, (H, W)).astype(np.uint16), np.full((H, W), 999, np.uint16),
+                           rng.integers(0, 2, (H, W)).astype(np.uint16) * 40000])
+        d = ctx.asarray(planes)
+        n = planes.shape[0]
+        mm = ctx.empty((n, 2), np.float64)
+        g = hipops.gaussian(d, 2.0, minmax_out=mm)
+        thr, tc = ctx.empty((n,), np.float64), ctx.empty((n,), np.float64)
+        bins = ctx.empty(planes.shape, np.uint8)
+        hipops.threshold_otsu_bins(g, mm, thr, tc, bins)
+        ref_thr = hipops.threshold_otsu(g, minmax=mm)
+        assert np.array_equal(thr.numpy(), ref_thr.numpy()), (H, W)
+        gn = g.numpy()
+        lo, hi = mm.numpy()[0]
+        edges = np.linspace(lo, hi, 257)
+        ref_bins = np.clip(np.searchsorted(edges, gn[0], side="right") - 1, 0, 255)
+        assert np.array_equal(bins.numpy()[0], ref_bins.astype(np.uint8)), (H, W)
+        fp = hipops.disk(2)
+        got = hipops.threshold_open_close(g, thr, fp, bins=bins, thr_code=tc).numpy()
+        ref = hipops.threshold_open_close(g, ref_thr, fp).numpy()
+        assert np.array_equal(got, ref), (H, W)
+        # every threshold that is a bin centre works through the bin plane: shift the threshold's bin by hand
+        centres = (edges[:-1] + edges[1:]) / 2.0
+        for k in (0, 3, 100, 254, 255):
+            t1 = ctx.asarray(np.array([centres[k]] * n))
+            c1 = ctx.asarray(np.array([2.0 * k] * n))
+            a = hipops.threshold_open_close(g[0:1], t1[0:1], fp, bins=bins[0:1], thr_code=c1[0:1]).numpy()
+            b = hipops.threshold_open_close(g[0:1], t1[0:1], fp).numpy()
+            assert np.array_equal(a, b), (H, W, k)
+
+
 def test_segmenter_reuse_sparse_clears(ctx):
     """A FovSegmenter keeps its peak / marker planes between runs and clears only what the previous run wrote
     (label_sparse keep=, peak_mask keep=): different batches through ONE segmenter must equal fresh segmenters, and
