@@ -58,3 +58,27 @@ def well_id(fov_index: int) -> str:
     """384-well plate id (rows A..P, columns 1..24) for a FOV index 0..383 (R/microplate.py:24-45 style)."""
     row, col = divmod(int(fov_index) % 384, 24)
     return f"{chr(ord('A') + row)}{col + 1:02d}"
+
+
+def synthetic_flows(shape, n_cells: int, seed: int = 0, noise: float = 0.0):
+    """A flow field of the kind the network is trained to produce: for every synthetic cell (a disk) the unit vectors
+    that point to its centre times a smooth profile, plus the logit-like cell probability.  -> (dP, cellprob, truth)."""
+    rng = np.random.default_rng(seed)
+    H, W = shape
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    dP = np.zeros((2, H, W), np.float32)
+    prob = np.full((H, W), -6.0, np.float32)
+    truth = np.zeros((H, W), np.int32)
+    for k in range(n_cells):
+        r = float(rng.integers(7, 14))
+        cy, cx = float(rng.uniform(r + 2, H - r - 2)), float(rng.uniform(r + 2, W - r - 2))
+        d = np.hypot(yy - cy, xx - cx)
+        inside = (d < r) & (truth == 0)
+        truth[inside] = k + 1
+        norm = np.maximum(d, 1e-3)
+        dP[0][inside] = (-(yy - cy) / norm)[inside] * 5.0 * np.minimum(d / 2.0, 1.0)[inside]
+        dP[1][inside] = (-(xx - cx) / norm)[inside] * 5.0 * np.minimum(d / 2.0, 1.0)[inside]
+        prob[inside] = 6.0
+    if noise:
+        dP += rng.normal(0, noise, dP.shape).astype(np.float32)
+    return dP, prob, truth

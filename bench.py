@@ -392,7 +392,7 @@ def run_c5(args, json_fd):
     (cellpose_hip.make_standin; the real weights are fetched from the network and are unobtainable offline) on
     --tiles tiles of 2 x 1024 x 1024 in bf16, then the HIP post-processing of as many flow fields.  A random network's
     output is not a flow field, so the post-processing runs on SYNTHETIC flow fields of the same shape
-    (oracle.cellpose_dynamics.synthetic_flows: disks with centre-pointing flows, ~1,200 per tile) that stay resident
+    (synth.synthetic_flows: disks with centre-pointing flows, ~1,200 per tile) that stay resident
     on the device; both halves are inside the timed region.  The roofline object is the forward pass against the
     dense bf16 MFMA peak (FLOPs from torch.utils.flop_counter, time from HIP events on torch's stream)."""
     import torch
@@ -400,7 +400,7 @@ def run_c5(args, json_fd):
     from arcadia_microscopy_tools_amd import cellpose_hip as ch
     from arcadia_microscopy_tools_amd import hipops
     from arcadia_microscopy_tools_amd.device import Context, set_default_device
-    from oracle import cellpose_dynamics as cd
+    from arcadia_microscopy_tools_amd import synth
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -425,7 +425,7 @@ def run_c5(args, json_fd):
     flops = ch.forward_flops(net, x)
     t0 = time.perf_counter()
     nuniq = max(1, min(args.unique, T, 2))
-    syn = [cd.synthetic_flows((S, S), 1200, seed=100 * rank + i) for i in range(nuniq)]
+    syn = [synth.synthetic_flows((S, S), 1200, seed=100 * rank + i) for i in range(nuniq)]
     dP = ctx.asarray(np.stack([syn[i % nuniq][0] for i in range(T)]))
     pr = ctx.asarray(np.stack([syn[i % nuniq][1] for i in range(T)]))
     gen_s = time.perf_counter() - t0

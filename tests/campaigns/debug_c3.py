@@ -1,6 +1,6 @@
 """Stage-by-stage comparison of the device config-3 chain with the oracle for given synthetic FOVs."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from arcadia_microscopy_tools_amd import synth
 from arcadia_microscopy_tools_amd.device import get_context

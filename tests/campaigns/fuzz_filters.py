@@ -1,9 +1,9 @@
 """Randomised differential test of the round-2 filter kernels against scipy (run on the GPU box):
 strip kernels (grey min / max with random centred-run footprints, the fused top-hat subtraction, medians), the
 LDS-DMA wide Gaussian, over random shapes (every strip / segment seam position), boundary modes and constants.
-usage: python tools/fuzz_filters.py [cases] [seed]"""
+usage: python tests/campaigns/fuzz_filters.py [cases] [seed]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from scipy import ndimage as ndi
 from arcadia_microscopy_tools_amd import hipops

@@ -1,9 +1,9 @@
 """Randomised differential test of labelling (4 / 8-connected, masks and integer images), clear_border, relabel_sequential
 and the region-property tables (morphology + intensities) against the oracle, on random images whose components range
 from single pixels to blobs spanning many 64 x 64 tiles, thin diagonal structures, rings with holes, labels that touch
-the frame.   usage: python tools/fuzz_labels_props.py [cases] [seed]"""
+the frame.   usage: python tests/campaigns/fuzz_labels_props.py [cases] [seed]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from scipy import ndimage as ndi
 from arcadia_microscopy_tools_amd import _hip, hipops

@@ -1,8 +1,8 @@
 """Randomised differential test of the EDT watershed (every flood class: blobs from a few hundred to > 100,000 pixels of
 bounding box, thin and thick) against the oracle's heap flood of the seeded relief; the planes of a case go through
-ONE batch call and through the fused clear_border + relabel tail.   usage: python tools/fuzz_watershed.py [cases] [seed]"""
+ONE batch call and through the fused clear_border + relabel tail.   usage: python tests/campaigns/fuzz_watershed.py [cases] [seed]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from arcadia_microscopy_tools_amd import hipops
 from arcadia_microscopy_tools_amd.device import get_context

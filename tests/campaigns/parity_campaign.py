@@ -1,6 +1,6 @@
 """One-off parity campaign at BASELINE size: config 3 on 12 synthetic 4 x 2048 x 2048 fields of view (indices 2..13)
 through the HIP path and through the CPU oracle (12 threads); labels must be bit-identical, features within 1e-5.
-Run on the GPU box: python tools/parity_campaign.py  (CAMPAIGN_FIRST / CAMPAIGN_LAST select the FOV indices; last runs: 72 / 72 identical)."""
+Run on the GPU box: python tests/campaigns/parity_campaign.py  (CAMPAIGN_FIRST / CAMPAIGN_LAST select the FOV indices; last runs: 72 / 72 identical)."""
 import sys, time
 sys.path.insert(0, '.')
 import numpy as np

@@ -1,6 +1,6 @@
 """One-off robustness sweep: config 3 end to end at odd image sizes (every non-aligned fallback path: widths that are
 not multiples of 8 / 64, partial tiles, strips and row blocks) through the HIP path and the CPU oracle; labels must be
-bit-identical, features within 1e-5.  Run on the GPU box: python tools/size_sweep.py [seed]"""
+bit-identical, features within 1e-5.  Run on the GPU box: python tests/campaigns/size_sweep.py [seed]"""
 import sys
 
 sys.path.insert(0, '.')

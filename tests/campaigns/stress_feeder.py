@@ -3,7 +3,7 @@ while the previous one is segmented, every stage compared with the oracle's inte
 Found in round 2: operators run on the stream of their INPUT's context, so the feeder's buffers (owned by the copy
 context) must be re-bound with DeviceArray.on(); FovSegmenter now does that itself."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from arcadia_microscopy_tools_amd import synth
 from arcadia_microscopy_tools_amd.device import Context

@@ -11,13 +11,14 @@ pytestmark = pytest.mark.gpu
 def test_cellpose_masks_vs_oracle():
     from arcadia_microscopy_tools_amd import hipops
     from arcadia_microscopy_tools_amd.device import get_context
+    from arcadia_microscopy_tools_amd import synth
     from oracle import cellpose_dynamics as cd
 
     ctx = get_context()
     cases = [((96, 120), 8, 0, 0.0, 60), ((160, 200), 18, 3, 0.0, 200), ((130, 97), 10, 5, 0.3, 100),
              ((64, 64), 0, 1, 0.0, 20)]
     for shape, ncells, seed, noise, niter in cases:
-        dP, prob, truth = cd.synthetic_flows(shape, ncells, seed=seed, noise=noise)
+        dP, prob, truth = synth.synthetic_flows(shape, ncells, seed=seed, noise=noise)
         ref = cd.compute_masks(dP, prob, niter=niter)
         lab, cnt = hipops.cellpose_masks(ctx.asarray(dP[None]), ctx.asarray(prob[None]), niter=niter)
         got = lab.numpy()[0]
@@ -29,15 +30,15 @@ def test_cellpose_masks_vs_oracle():
                 if vals.size:
                     assert np.bincount(vals).argmax() > 0
     # thresholds and size filters
-    dP, prob, _ = cd.synthetic_flows((120, 150), 12, seed=9)
+    dP, prob, _ = synth.synthetic_flows((120, 150), 12, seed=9)
     for thr, min_size, frac in ((0.0, 15, 0.4), (7.0, 15, 0.4), (0.0, 400, 0.4), (0.0, 15, 0.01)):
         ref = cd.compute_masks(dP, prob, cellprob_threshold=thr, niter=80, min_size=min_size, max_size_fraction=frac)
         lab, cnt = hipops.cellpose_masks(ctx.asarray(dP[None]), ctx.asarray(prob[None]), cellprob_threshold=thr, niter=80,
                                          min_size=min_size, max_size_fraction=frac)
         assert np.array_equal(lab.numpy()[0], ref) and int(cnt.numpy()[0]) == int(ref.max())
     # a batch of planes in one call, and the seed-capacity flag
-    dP2 = np.stack([cd.synthetic_flows((80, 96), 6, seed=s)[0] for s in (1, 2)])
-    pr2 = np.stack([cd.synthetic_flows((80, 96), 6, seed=s)[1] for s in (1, 2)])
+    dP2 = np.stack([synth.synthetic_flows((80, 96), 6, seed=s)[0] for s in (1, 2)])
+    pr2 = np.stack([synth.synthetic_flows((80, 96), 6, seed=s)[1] for s in (1, 2)])
     lab, cnt = hipops.cellpose_masks(ctx.asarray(dP2), ctx.asarray(pr2), niter=60)
     for b in range(2):
         assert np.array_equal(lab.numpy()[b], cd.compute_masks(dP2[b], pr2[b], niter=60))
@@ -53,10 +54,11 @@ def test_segmentation_model_network_backend():
 
     from arcadia_microscopy_tools_amd.exceptions import SegmentationWarning
     from arcadia_microscopy_tools_amd.model import SegmentationModel
+    from arcadia_microscopy_tools_amd import synth
     from oracle import cellpose_dynamics as cd
 
     H, W = 112, 144
-    dP, prob, _ = cd.synthetic_flows((H, W), 9, seed=4)
+    dP, prob, _ = synth.synthetic_flows((H, W), 9, seed=4)
     flows = torch.from_numpy(np.concatenate([dP, prob[None]])[None])
 
     class Fixed(torch.nn.Module):
