@@ -59,6 +59,7 @@ _SIGS = {
     "amt_event_create": (c_int, [_P, POINTER(c_void_p)]),
     "amt_event_record": (c_int, [_P, _P]),
     "amt_event_wait": (c_int, [_P, _P]),
+    "amt_event_sync": (c_int, [_P, _P]),
     "amt_event_destroy": (c_int, [_P, _P]),
     "amt_host_alloc": (c_int, [c_size_t, POINTER(c_void_p)]),
     "amt_host_free": (c_int, [_P]),

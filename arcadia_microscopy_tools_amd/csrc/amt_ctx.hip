@@ -294,6 +294,13 @@ extern "C" int amt_event_wait(amt_ctx* ctx, void* event) {
     AMT_HIP_CHECK(hipStreamWaitEvent(ctx->stream, (hipEvent_t)event, 0));
     return AMT_OK;
 }
+extern "C" int amt_event_sync(amt_ctx* ctx, void* event) {
+    // the HOST waits for the event's last record: a chunked download hands finished chunks to host threads
+    AMT_TRY(amt_set_device(ctx));
+    AMT_REQUIRE(event != nullptr, "amt_event_sync: event is null");
+    AMT_HIP_CHECK(hipEventSynchronize((hipEvent_t)event));
+    return AMT_OK;
+}
 extern "C" int amt_event_destroy(amt_ctx* ctx, void* event) {
     AMT_TRY(amt_set_device(ctx));
     if (event) AMT_HIP_CHECK(hipEventDestroy((hipEvent_t)event));

@@ -31,24 +31,106 @@ _DTYPE_CODE = {
 
 
 _copy_pool = None
+_PIPE_MIN = 4 << 20   # device bytes from which a staged transfer is cut into chunks
+_PIPE_CHUNKS = 8      # chunks per transfer: the DMA of one overlaps the host-side copy / conversion of the others
+
+
+def _pool4():
+    global _copy_pool
+    if _copy_pool is None:
+        from concurrent.futures import ThreadPoolExecutor
+
+        _copy_pool = ThreadPoolExecutor(max_workers=4, thread_name_prefix="amt-copy")
+    return _copy_pool
 
 
 def _host_copy(dst: np.ndarray, src: np.ndarray) -> None:
     """dst[:] = src for flat uint8 arrays; large copies are split over four threads (numpy releases the GIL, and the
     first touch of a fresh destination -- the kernel zeroing its pages -- is most of the cost of a 33 MB copy)."""
-    global _copy_pool
     n = dst.shape[0]
     if n < (8 << 20):
         dst[:] = src
         return
-    if _copy_pool is None:
-        from concurrent.futures import ThreadPoolExecutor
-
-        _copy_pool = ThreadPoolExecutor(max_workers=4, thread_name_prefix="amt-copy")
     step = (n // 4 + 4095) & ~4095
-    futs = [_copy_pool.submit(np.copyto, dst[o:o + step], src[o:o + step]) for o in range(0, n, step)]
+    futs = [_pool4().submit(np.copyto, dst[o:o + step], src[o:o + step]) for o in range(0, n, step)]
     for f in futs:
         f.result()
+
+
+def _stage_chunk(dst: np.ndarray, src: np.ndarray, stats: bool):
+    """One chunk of a staged upload: convert / copy into the page-locked buffer and, on request, the chunk's extrema
+    (the chunk is still in cache: the constructor checks of a label image cost no second pass over it)."""
+    np.copyto(dst, src, casting="unsafe")
+    return (src.min(), src.max()) if stats else None
+
+
+def _chunks(n: int):
+    step = ((-(-n // _PIPE_CHUNKS)) + 4095) & ~4095
+    return [(o, min(step, n - o)) for o in range(0, n, step)]
+
+
+class _PinnedBlock:
+    """Page-locked host memory behind a returned numpy array (its ``base``): when the last view dies the block goes
+    back to the pool, already faulted in and registered for DMA."""
+
+    __slots__ = ("ptr", "nbytes", "pool", "__array_interface__", "__weakref__")
+
+    def __init__(self, ptr: int, nbytes: int, pool: "_ResultPool"):
+        self.ptr, self.nbytes, self.pool = ptr, nbytes, pool
+        self.__array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 3}
+
+    def __del__(self):
+        try:
+            self.pool._put(self.ptr, self.nbytes)
+        except Exception:
+            pass
+
+
+class _ResultPool:
+    """Large results (label images, filtered planes: 17-34 MB at 2048^2) are copied by the DMA engine straight into
+    page-locked blocks that become the returned arrays: a fresh pageable array costs 8,192 page faults (2-3 ms,
+    more than the 0.6 ms the bus takes) before the copy out of a staging buffer can even land.  At most
+    AMT_RESULT_PINNED_BYTES (default 1 GiB; 0 = off) are handed out at any time -- beyond that, and for anything
+    below 4 MB, results are ordinary arrays -- and up to 256 MiB of returned blocks are kept for the next call."""
+
+    def __init__(self):
+        self.lock = threading.Lock()
+        self.free: dict[int, list[int]] = {}
+        self.kept = 0
+        self.out = 0
+        self.cap_out = int(os.environ.get("AMT_RESULT_PINNED_BYTES", str(1 << 30)))
+        self.cap_keep = 256 << 20
+
+    def get(self, nbytes: int):
+        size = (nbytes + (1 << 20) - 1) & ~((1 << 20) - 1)
+        with self.lock:
+            lst = self.free.get(size)
+            if lst:
+                ptr = lst.pop()
+                self.kept -= size
+                self.out += size
+                return _PinnedBlock(ptr, size, self)
+            if self.out + size > self.cap_out:
+                return None
+            self.out += size
+        p = ctypes.c_void_p()
+        if _hip.load_library().amt_host_alloc(size, ctypes.byref(p)) != 0 or not p.value:
+            with self.lock:
+                self.out -= size
+            return None
+        return _PinnedBlock(p.value, size, self)
+
+    def _put(self, ptr: int, size: int):
+        with self.lock:
+            self.out -= size
+            if self.kept + size <= self.cap_keep:
+                self.free.setdefault(size, []).append(ptr)
+                self.kept += size
+                return
+        _hip.load_library().amt_host_free(ctypes.c_void_p(ptr))
+
+
+_result_pool = _ResultPool()
 
 
 def dtype_code(dt) -> int:
@@ -84,6 +166,7 @@ class Context:
         # (alternating, measured) against 0.6 ms of PCIe time; a host memcpy through pinned memory is 3 ms and steady
         self._stage_buf = None
         self._stage_cap = int(os.environ.get("AMT_STAGE_BYTES", str(256 << 20)))
+        self._chunk_events: list[ctypes.c_void_p] = []
 
     def _staging(self, nbytes: int):
         """A page-locked uint8 array of at least ``nbytes`` (None if the copy is too small to matter or too large)."""
@@ -95,6 +178,13 @@ class Context:
                 self._stage_buf.close()
             self._stage_buf = PinnedBuffer((max(nbytes, 64 << 20),), np.uint8)
         return self._stage_buf.array
+
+    def _events_for_chunks(self, n: int):
+        while len(self._chunk_events) < n:
+            h = ctypes.c_void_p()
+            _hip.check(self._lib.amt_event_create(self.handle, ctypes.byref(h)), "amt_event_create")
+            self._chunk_events.append(h)
+        return self._chunk_events[:n]
 
     def set_fork(self, enable) -> None:
         """Let independent kernels inside one call use the context's auxiliary streams (True = all three, the default;
@@ -111,6 +201,9 @@ class Context:
                 self.synchronize()
                 self._stage_buf.close()
                 self._stage_buf = None
+            for ev in self._chunk_events:
+                self._lib.amt_event_destroy(self.handle, ev)
+            self._chunk_events = []
             self._lib.amt_ctx_destroy(self.handle)
             self.handle = None
 
@@ -162,25 +255,58 @@ class Context:
         _hip.check(self._lib.amt_memset(self.handle, a.ptr, 0, a.nbytes), "amt_memset")
         return a
 
-    def asarray(self, arr: np.ndarray) -> "DeviceArray":
-        """Host -> device copy (bool becomes uint8 0/1)."""
+    def asarray(self, arr: np.ndarray, dtype=None, stats: bool = False, out: "DeviceArray | None" = None):
+        """Host -> device copy (bool becomes uint8 0/1).  ``dtype``: the element type on the device, converted while
+        the data moves into the page-locked staging buffer (int64 label images travel as int32).  ``stats=True``
+        returns ``(array, (min, max))`` of the HOST values, computed chunk by chunk in the same pass.  Transfers of
+        4 MB and more are cut into chunks: four host threads fill the staging buffer while the DMA engine drains
+        the chunks already there.  ``out``: an existing device array (or a slot of one) to fill instead of a new one."""
         a = np.ascontiguousarray(arr)
         if a.dtype == np.bool_:
             a = a.view(np.uint8)
-        d = self.empty(a.shape, a.dtype)
-        if a.nbytes:
-            stage = self._staging(a.nbytes)
-            if stage is not None:
-                self.synchronize()  # the staging buffer may still feed an earlier copy
-                _host_copy(stage[: a.nbytes], a.reshape(-1).view(np.uint8))
-                src = stage.ctypes.data
+        if out is not None:
+            dt = out.dtype
+            if out.size != a.size:
+                raise ValueError("asarray(out=...): the destination has a different number of elements")
+            d = out
+        else:
+            dt = np.dtype(dtype) if dtype is not None else a.dtype
+            d = self.empty(a.shape, dt)
+        mm = None
+        if a.size:
+            flat = a.reshape(-1)
+            isz = dt.itemsize
+            nbytes = flat.shape[0] * isz
+            stage = self._staging(nbytes)
+            if stage is None or nbytes < _PIPE_MIN:
+                if stats:
+                    mm = (flat.min(), flat.max())
+                src_arr = flat if flat.dtype == dt else flat.astype(dt)
+                if stage is not None:
+                    self.synchronize()  # the staging buffer may still feed an earlier copy
+                    stage[:nbytes] = src_arr.view(np.uint8)
+                    src = stage.ctypes.data
+                else:
+                    src = src_arr.ctypes.data
+                _hip.check(self._lib.amt_memcpy_h2d(self.handle, d.ptr, src, nbytes), "amt_memcpy_h2d")
+                self.synchronize()  # the host buffer may be a temporary
             else:
-                src = a.ctypes.data
-            _hip.check(self._lib.amt_memcpy_h2d(self.handle, d.ptr, src, a.nbytes), "amt_memcpy_h2d")
-            self.synchronize()  # the host buffer may be a temporary
-        if arr.dtype == np.bool_:
+                self.synchronize()
+                st = stage[:nbytes].view(dt)
+                parts = _chunks(flat.shape[0])
+                pool = _pool4()
+                futs = [pool.submit(_stage_chunk, st[o:o + m], flat[o:o + m], stats) for o, m in parts]
+                base = stage.ctypes.data
+                for (o, m), f in zip(parts, futs):
+                    r = f.result()
+                    if r is not None:
+                        mm = r if mm is None else (min(mm[0], r[0]), max(mm[1], r[1]))
+                    _hip.check(self._lib.amt_memcpy_h2d(self.handle, d.ptr + o * isz, base + o * isz, m * isz),
+                               "amt_memcpy_h2d")
+                self.synchronize()
+        if a.dtype == np.uint8 and getattr(arr, "dtype", None) == np.bool_ and out is None:
             d.is_bool = True
-        return d
+        return (d, mm) if stats else d
 
     def synchronize(self):
         _hip.check(self._lib.amt_sync(self.handle), "amt_sync")
@@ -357,32 +483,66 @@ class DeviceArray:
         return v
 
     # -- transfers ------------------------------------------------------------------------------
-    def numpy(self) -> np.ndarray:
-        """Device -> host copy (synchronises the stream). uint8 masks flagged as bool come back as bool."""
-        out = np.empty(self.shape, dtype=self.dtype)
-        if out.nbytes:
-            lib = self.ctx._lib
-            stage = self.ctx._staging(out.nbytes)
-            dst = stage.ctypes.data if stage is not None else out.ctypes.data
-            _hip.check(lib.amt_memcpy_d2h(self.ctx.handle, dst, self.ptr, out.nbytes), "amt_memcpy_d2h")
-            self.ctx.synchronize()
-            if stage is not None:
-                _host_copy(out.reshape(-1).view(np.uint8), stage[: out.nbytes])
-        if self.is_bool and self.dtype == np.uint8:
+    def numpy(self, dtype=None) -> np.ndarray:
+        """Device -> host copy (synchronises the stream). uint8 masks flagged as bool come back as bool.  ``dtype``:
+        the element type of the returned array.  Results of 4 MB and more land directly in a page-locked block that
+        backs the returned array (_ResultPool; int32 -> int64 is widened on the device first).  When the pool's
+        budget is spent the copy arrives in chunks in the staging buffer and four host threads move / convert the
+        finished chunks into an ordinary array while the DMA engine delivers the next ones."""
+        odt = np.dtype(dtype) if dtype is not None else self.dtype
+        ctx = self.ctx
+        lib = ctx._lib
+        nbytes = self.nbytes
+        if self.size * odt.itemsize >= _PIPE_MIN and (odt == self.dtype or (self.dtype == np.int32 and odt == np.int64)):
+            block = _result_pool.get(self.size * odt.itemsize)
+            if block is not None:
+                src = self
+                if odt != self.dtype:  # widened on the device: the DMA engine writes the final array
+                    src = ctx.empty(self.shape, odt)
+                    _hip.check(lib.amt_cast_i32_i64(ctx.handle, self.ptr, src.ptr, self.size), "amt_cast_i32_i64")
+                _hip.check(lib.amt_memcpy_d2h(ctx.handle, block.ptr, src.ptr, src.nbytes), "amt_memcpy_d2h")
+                ctx.synchronize()
+                out = np.asarray(block)[: src.nbytes].view(odt).reshape(self.shape)
+                if self.is_bool and self.dtype == np.uint8 and dtype is None:
+                    return out.view(np.bool_)
+                return out
+        out = np.empty(self.shape, dtype=odt)
+        if out.size:
+            isz = self.dtype.itemsize
+            stage = ctx._staging(nbytes)
+            if stage is None or nbytes < _PIPE_MIN:
+                raw = out if odt == self.dtype else np.empty(self.shape, dtype=self.dtype)
+                dst = stage.ctypes.data if stage is not None else raw.ctypes.data
+                _hip.check(lib.amt_memcpy_d2h(ctx.handle, dst, self.ptr, nbytes), "amt_memcpy_d2h")
+                ctx.synchronize()
+                if stage is not None:
+                    raw.reshape(-1).view(np.uint8)[:] = stage[:nbytes]
+                if raw is not out:
+                    np.copyto(out, raw, casting="unsafe")
+            else:
+                st = stage[:nbytes].view(self.dtype)
+                flat = out.reshape(-1)
+                parts = _chunks(flat.shape[0])
+                evs = ctx._events_for_chunks(len(parts))
+                base = stage.ctypes.data
+                for (o, m), ev in zip(parts, evs):
+                    _hip.check(lib.amt_memcpy_d2h(ctx.handle, base + o * isz, self.ptr + o * isz, m * isz),
+                               "amt_memcpy_d2h")
+                    _hip.check(lib.amt_event_record(ctx.handle, ev), "amt_event_record")
+                pool = _pool4()
+                futs = []
+                for (o, m), ev in zip(parts, evs):
+                    _hip.check(lib.amt_event_sync(ctx.handle, ev), "amt_event_sync")
+                    futs.append(pool.submit(np.copyto, flat[o:o + m], st[o:o + m], "unsafe"))
+                for f in futs:
+                    f.result()
+        if self.is_bool and self.dtype == np.uint8 and dtype is None:
             return out.view(np.bool_)
         return out
 
     def numpy_int64(self) -> np.ndarray:
-        """int32 labels as the int64 array the reference's API returns (R/model.py:215, R/masks.py:63-65): widened on
-        the device and copied once, instead of a copy plus a host-side ``astype`` over the plane."""
-        if self.dtype == np.int64:
-            return self.numpy()
-        if self.dtype != np.int32:
-            return self.numpy().astype(np.int64)
-        wide = self.ctx.empty(self.shape, np.int64)
-        if self.size:
-            _hip.check(self.ctx._lib.amt_cast_i32_i64(self.ctx.handle, self.ptr, wide.ptr, self.size), "amt_cast_i32_i64")
-        return wide.numpy()
+        """int32 labels as the int64 array the reference's API returns (R/model.py:215, R/masks.py:63-65)."""
+        return self.numpy(dtype=np.int64)
 
     def copy(self) -> "DeviceArray":
         d = self.ctx.empty(self.shape, self.dtype)

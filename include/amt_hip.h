@@ -81,6 +81,7 @@ int amt_stream_wait(amt_ctx* ctx, amt_ctx* other);
 int amt_event_create(amt_ctx* ctx, void** event);
 int amt_event_record(amt_ctx* ctx, void* event);
 int amt_event_wait(amt_ctx* ctx, void* event);
+int amt_event_sync(amt_ctx* ctx, void* event); /* host waits for the last record */
 int amt_event_destroy(amt_ctx* ctx, void* event);
 /* pinned host staging buffers for the FOV feeder */
 int amt_host_alloc(size_t bytes, void** hptr);

@@ -507,3 +507,61 @@ def test_operators_on_stacks_and_other_dtypes():
     for k in ("intensity_mean", "intensity_max", "intensity_min", "intensity_std"):
         np.testing.assert_allclose(props[f"{k}_dapi"], ref[f"{k}_dapi"], rtol=1e-12, err_msg=k)
         np.testing.assert_allclose(props[f"{k}_fitc"], ref[f"{k}_fitc"], rtol=1e-12, err_msg=k)
+
+
+def test_host_transfers_every_path():
+    """Uploads (small / chunked, converted on the way, into a slot, with extrema) and downloads (small / page-locked
+    result block / chunked fallback, widened) return exactly the host values; result blocks are recycled only after
+    the arrays that live in them are gone."""
+    import gc
+
+    from arcadia_microscopy_tools_amd import device as dv
+    from arcadia_microscopy_tools_amd.device import get_context
+
+    ctx = get_context()
+    rng = np.random.default_rng(17)
+    for shape in ((5, 7), (1000, 1003), (2048, 2048)):
+        lab = rng.integers(0, 5000, shape).astype(np.int64)
+        d, (mn, mx) = ctx.asarray(lab, dtype=np.int32, stats=True)
+        assert d.dtype == np.int32 and (mn, mx) == (lab.min(), lab.max())
+        back = d.numpy()
+        assert back.dtype == np.int32 and np.array_equal(back, lab)
+        wide = d.numpy_int64()
+        assert wide.dtype == np.int64 and np.array_equal(wide, lab)
+        wide[0, 0] = -1  # writable, and private to this result
+        assert d.numpy_int64()[0, 0] == lab[0, 0]
+        u16 = rng.integers(0, 65536, shape).astype(np.uint16)
+        stack = ctx.empty((3,) + shape, np.float64)
+        for c in range(3):
+            ctx.asarray(u16 + c if c < 2 else (u16 / 3.0).astype(np.float32), out=stack[c])
+        got = stack.numpy()
+        assert np.array_equal(got[0], u16.astype(np.float64)) and np.array_equal(got[1], (u16 + 1).astype(np.float64))
+        assert np.array_equal(got[2], (u16 / 3.0).astype(np.float32).astype(np.float64))
+        m = ctx.asarray(u16 > 30000)
+        assert m.numpy().dtype == np.bool_ and np.array_equal(m.numpy(), u16 > 30000)
+    # results stay intact while later calls reuse the pool; a block comes back only when its array is dropped
+    big = ctx.asarray(rng.random((2048, 2048)))
+    keep = [big.numpy() for _ in range(3)]
+    ptrs = {k.ctypes.data for k in keep}
+    assert len(ptrs) == 3 and all(np.array_equal(k, keep[0]) for k in keep)
+    first = keep[0].copy()
+    del keep[1:]
+    gc.collect()
+    again = big.numpy()
+    assert again.ctypes.data in ptrs and again.ctypes.data != keep[0].ctypes.data and np.array_equal(keep[0], first)
+    # budget spent -> ordinary arrays through the chunked staging path, same values
+    cap = dv._result_pool.cap_out
+    dv._result_pool.cap_out = 0
+    try:
+        with dv._result_pool.lock:
+            drained = [(s, p) for s, lst in dv._result_pool.free.items() for p in lst]
+            dv._result_pool.free.clear()
+            dv._result_pool.kept = 0
+        for _, p in drained:
+            ctx._lib.amt_host_free(p)
+        plain = big.numpy()
+        assert plain.flags.owndata and np.array_equal(plain, first)
+        lab = rng.integers(0, 70000, (2048, 2048)).astype(np.int64)
+        assert np.array_equal(ctx.asarray(lab, dtype=np.int32).numpy_int64(), lab)
+    finally:
+        dv._result_pool.cap_out = cap

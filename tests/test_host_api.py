@@ -308,3 +308,52 @@ def test_plate_well_keyed_export():
     assert list(df.columns[:3]) == ["well_id", "fov_index", "label"] and len(df) == 10
     assert df["well_id"].tolist() == ["A01"] * 3 + ["B01"] * 6 + ["P24"]
     assert df["sample"].tolist()[:4] == ["ctrl", "ctrl", "ctrl", ""] and df["dose"].iloc[0] == 1.0
+
+
+# ---- host side of the transfers: result blocks and chunking ----------------------------------------------------
+def test_result_block_lives_as_long_as_its_last_view():
+    import ctypes
+    import gc
+
+    from arcadia_microscopy_tools_amd import device as dv
+
+    returned = []
+
+    class Pool:
+        def _put(self, ptr, nbytes):
+            returned.append((ptr, nbytes))
+
+    buf = ctypes.create_string_buffer(1 << 16)
+    block = dv._PinnedBlock(ctypes.addressof(buf), 1 << 16, Pool())
+    a = np.asarray(block)[: 64 * 64 * 8].view(np.int64).reshape(64, 64)
+    assert a.flags.writeable and not a.flags.owndata
+    row = a[3]
+    del block, a
+    gc.collect()
+    assert returned == []  # a view is still alive
+    row[:] = 7
+    assert bytes(buf[3 * 64 * 8: 3 * 64 * 8 + 8]) == (7).to_bytes(8, "little")
+    del row
+    gc.collect()
+    assert returned == [(ctypes.addressof(buf), 1 << 16)]
+
+
+def test_transfer_chunks_cover_the_array_once():
+    from arcadia_microscopy_tools_amd import device as dv
+
+    for n in (1, 4095, 4096, 1 << 20, (1 << 22) + 17, 2048 * 2048):
+        parts = dv._chunks(n)
+        assert len(parts) <= dv._PIPE_CHUNKS and parts[0][0] == 0
+        assert all(o % 4096 == 0 for o, _ in parts)
+        assert sum(m for _, m in parts) == n and all(parts[i][0] + parts[i][1] == parts[i + 1][0]
+                                                     for i in range(len(parts) - 1))
+
+
+def test_label_plane_extrema_threaded_equals_numpy():
+    from arcadia_microscopy_tools_amd.masks import _extrema
+
+    rng = np.random.default_rng(5)
+    for shape in ((7, 9), (1030, 1100), (2048, 2048)):
+        a = rng.integers(-3, 1000, shape)
+        assert _extrema(a) == (a.min(), a.max())
+        assert _extrema(a[:, ::2]) == (a[:, ::2].min(), a[:, ::2].max())
