@@ -357,3 +357,78 @@ def test_label_plane_extrema_threaded_equals_numpy():
         a = rng.integers(-3, 1000, shape)
         assert _extrema(a) == (a.min(), a.max())
         assert _extrema(a[:, ::2]) == (a[:, ::2].min(), a[:, ::2].max())
+
+
+# ---- Well / MicroplateLayout (RT/test_microplate.py) and the plate table keyed by them ----------------------------
+def test_well_and_layout_follow_the_reference(tmp_path):
+    from arcadia_microscopy_tools_amd.microplate import MicroplateLayout, Well
+
+    w = Well(id="A01", sample="sample1")
+    assert (w.id, w.sample, w.row, w.column, str(w)) == ("A01", "sample1", "A", 1, "A01")
+    assert Well(id="a1").id == "A01" and Well("p24").id == "P24" and Well("H048").column == 48
+    assert repr(Well("b2", "x")) == "Well(id='B02', sample='x')"
+    assert repr(Well("b2", "x", {"c": 1})) == "Well(id='B02', sample='x', properties={'c': 1})"
+    for bad, msg in (("A", "Well ID must be at least 2 characters"), ("", "Well ID must be at least 2 characters"),
+                     ("1A", "Row must be A-Z, got '1'"), ("Ax", "Could not parse column number from 'Ax'"),
+                     ("A49", "Column must be 1-48, got 49"), ("A0", "Column must be 1-48, got 0")):
+        with pytest.raises(ValueError, match=re.escape(msg)):
+            Well(id=bad)
+    with pytest.raises(Exception):
+        w.sample = "other"  # frozen
+    well = Well.from_dict({"well_id": "B02", "sample": "test_sample", "concentration": 10})
+    assert (well.id, well.sample, well.properties) == ("B02", "test_sample", {"concentration": 10})
+    with pytest.raises(ValueError, match="Dictionary must contain 'well_id' key"):
+        Well.from_dict({"sample": "s"})
+    with pytest.raises(ValueError, match="well_id must be a string, got int"):
+        Well.from_dict({"well_id": 7})
+
+    layout = MicroplateLayout([Well(id="A01", sample="s1"), Well(id="B02", sample="s2", properties={"dose": 0.5})])
+    assert len(layout) == 2 and "A01" in layout and "b2" in layout and "C03" not in layout and "??" not in layout
+    assert layout["A1"].sample == "s1" and layout["B02"].properties == {"dose": 0.5}
+    assert (layout.rows, layout.columns, layout.well_ids) == (["A", "B"], [1, 2], ["A01", "B02"])
+    assert [x.id for x in layout] == ["A01", "B02"] and layout.layout["A01"] is layout["A01"]
+    with pytest.raises(KeyError, match="not found in plate layout"):
+        layout["C03"]
+    with pytest.raises(KeyError, match="Invalid well ID 'A99'"):
+        layout["A99"]
+    with pytest.raises(ValueError, match="Duplicate well ID: 'A01'"):
+        MicroplateLayout([Well(id="A01", sample="s1"), Well(id="a1", sample="s2")])
+    df = layout.to_dataframe()
+    assert len(df) == 2 and list(df.columns) == ["well_id", "row", "column", "sample", "dose"]
+    assert df["well_id"].tolist() == ["A01", "B02"] and df["column"].tolist() == [1, 2]
+    grid = layout.display().splitlines()
+    assert grid[0].split() == ["column", "1", "2"] and grid[2].split() == ["A", "s1", "-"] and \
+        grid[3].split() == ["B", "-", "s2"]
+    assert MicroplateLayout([]).display() == "Empty plate layout" and MicroplateLayout([]).to_dataframe().empty
+
+    csv = tmp_path / "plate.csv"
+    csv.write_text("well_id,sample,dose\na1,dmso,0.0\nA02,drug,1.5\n")
+    from_csv = MicroplateLayout.from_csv(csv)
+    assert from_csv.well_ids == ["A01", "A02"] and from_csv["A2"].sample == "drug" and \
+        from_csv["A02"].properties == {"dose": 1.5}
+    (tmp_path / "nokey.csv").write_text("well,sample\nA1,x\n")
+    with pytest.raises(ValueError, match="missing required 'well_id' column"):
+        MicroplateLayout.from_csv(tmp_path / "nokey.csv")
+    (tmp_path / "empty.csv").write_text("well_id,sample\n")
+    with pytest.raises(ValueError, match="is empty"):
+        MicroplateLayout.from_csv(tmp_path / "empty.csv")
+
+
+def test_plate_table_keyed_by_microplate_layout():
+    from arcadia_microscopy_tools_amd import plate
+    from arcadia_microscopy_tools_amd.microplate import MicroplateLayout, Well
+
+    names = ["DAPI", "FITC"]
+    cols = plate.table_columns(names)
+    rows = np.zeros((5, len(cols)))
+    rows[:, cols.index("fov_index")] = [0, 0, 1, 25, 383]
+    rows[:, cols.index("label")] = [1, 2, 1, 1, 1]
+    rows[:, cols.index("area")] = [10, 20, 30, 40, 50]
+    layout = MicroplateLayout([Well("A1", "dmso", {"dose": 0.0}), Well("A2", "drug", {"dose": 1.5}), Well("P24", "edge")])
+    df = plate.plate_dataframe(rows, names, layout=layout)
+    assert df["well_id"].tolist() == ["A01", "A01", "A02", "B02", "P24"]
+    assert df["sample"].tolist() == ["dmso", "dmso", "drug", "", "edge"]
+    assert df["dose"].tolist()[:3] == [0.0, 0.0, 1.5] and df["dose"].isna().tolist()[3:] == [True, True]
+    assert df["area"].tolist() == [10, 20, 30, 40, 50] and df["label"].dtype == np.int64
+    merged = df.merge(layout.to_dataframe()[["well_id", "row", "column"]], on="well_id", how="left")
+    assert merged["row"].tolist() == ["A", "A", "A", np.nan, "P"] or merged["row"].isna().tolist() == [False, False, False, True, False]
