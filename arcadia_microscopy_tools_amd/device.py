@@ -94,7 +94,9 @@ class _ResultPool:
     below 4 MB, results are ordinary arrays -- and up to 256 MiB of returned blocks are kept for the next call."""
 
     def __init__(self):
-        self.lock = threading.Lock()
+        # re-entrant: a block's __del__ (-> _put) can run from the garbage collector at any allocation, including
+        # one made while this thread holds the lock in get()
+        self.lock = threading.RLock()
         self.free: dict[int, list[int]] = {}
         self.kept = 0
         self.out = 0
@@ -160,7 +162,7 @@ class Context:
         self._pool: dict[int, list[int]] = {}
         self._pool_bytes = 0
         self._pool_cap = int(os.environ.get("AMT_POOL_BYTES", str(4 << 30)))
-        self._pool_lock = threading.Lock()
+        self._pool_lock = threading.RLock()  # re-entrant: DeviceArray.__del__ -> _release may run under empty()
         # Host <-> device copies of pageable numpy arrays go through one page-locked staging buffer per context: the
         # runtime otherwise registers every fresh host array for DMA, which costs 1.6 ms or 25 ms per 33 MB array
         # (alternating, measured) against 0.6 ms of PCIe time; a host memcpy through pinned memory is 3 ms and steady
