@@ -168,7 +168,9 @@ __global__ void __launch_bounds__(256) edt_cols_kernel(const unsigned short* __r
                     best = c < best ? c : best;
                 }
             }
-            if (best > 0x7fffffffu) best = 0x7fffffffu;  // no zero pixel anywhere: saturate
+            // no zero pixel in the whole plane (a column sees none only then): scipy's feature transform then
+            // measures from index (-1, 0) -- distance_transform_edt(np.ones((2, 2))) == [[1, sqrt 2], [2, sqrt 5]]
+            if (best > 0x7fffffffu) best = (unsigned)(y + 1) * (unsigned)(y + 1) + (unsigned)x * (unsigned)x;
         }
         const size_t i = plane + (size_t)y * W + x;
         if (d2_out) d2_out[i] = (int)best;

@@ -157,7 +157,7 @@ extern "C" int amt_window_threshold_yx(amt_ctx* ctx, const void* in, int in_dtyp
     AMT_REQUIRE(window_y <= 255 && window_x <= 255, "window_threshold: window %d x %d larger than 255", window_y, window_x);
     AMT_REQUIRE(method == 0 || method == 1, "window_threshold: method must be 0 (niblack) or 1 (sauvola)");
     const int h = window_y / 2, hx = window_x / 2;  // h: rows (the column kernels), hx: columns (the row kernels)
-    AMT_REQUIRE(h < H && hx < W, "window_threshold: window larger than the image");
+    // windows reaching past the far edge reflect again: amt_map_index is periodic, as numpy's 'reflect' padding is
     if (nplanes == 0) return AMT_OK;
     const size_t np = (size_t)nplanes * H * W;
     if (in_dtype == AMT_U16) {

@@ -334,6 +334,37 @@ def test_edt_peaks(ctx, ops, golden):
         assert np.array_equal(e.numpy(), skops.distance_transform_edt(mm)), shape
 
 
+def test_edt_without_background_and_windows_beyond_the_image(ctx, ops):
+    """Two corners found by tests/campaigns/fuzz_tiny.py: a plane without a single zero pixel (scipy's feature transform
+    then measures from index (-1, 0)), and Niblack / Sauvola windows larger than the image (numpy's 'reflect' padding
+    bounces as often as it takes)."""
+    from arcadia_microscopy_tools_amd.operations import apply_threshold
+    from oracle import skops
+
+    for shape in ((1, 1), (1, 2), (2, 2), (7, 5), (40, 70), (130, 64)):
+        m = np.ones(shape, bool)
+        d2, e = ops.edt(ctx.asarray(m))
+        ref = skops.distance_transform_edt(m)
+        assert np.array_equal(e.numpy(), ref), shape
+        yy, xx = np.mgrid[0:shape[0], 0:shape[1]]
+        assert np.array_equal(d2.numpy(), (yy + 1) ** 2 + xx ** 2), shape
+    # a stack in which only ONE plane has no background
+    m = np.ones((2, 9, 11), bool)
+    m[1, 4, 5] = False
+    e = ops.edt(ctx.asarray(m))[1].numpy()
+    assert np.array_equal(e[0], skops.distance_transform_edt(m[0])) and np.array_equal(e[1], skops.distance_transform_edt(m[1]))
+    rng = np.random.default_rng(3)
+    for shape, w in (((3, 4), 9), ((1, 6), 5), ((5, 1), 3), ((2, 2), 15), ((10, 30), 25), ((30, 7), 15)):
+        img = rng.integers(0, 65536, shape).astype(np.uint16)
+        for method in ("niblack", "sauvola"):
+            got = apply_threshold(img, method=method, window_size=w)
+            assert np.array_equal(got, img > getattr(skops, "threshold_" + method)(img, window_size=w)), (shape, w, method)
+        f = img.astype(np.float64) / 65535.0
+        # float64 images: window sums in a different order than scikit-image's integral images -> rounding only
+        np.testing.assert_allclose(ops.window_threshold(ctx.asarray(f), w, "niblack", 0.2).numpy(),
+                                   skops.threshold_niblack(f, w, 0.2), rtol=1e-7, atol=1e-12)
+
+
 def test_peak_mask_random(ctx, ops):
     """peak_mask against scipy's maximum_filter formulation (oracle/skops.py:peak_markers) on integer
     reliefs with plateaus and ties, every strip / row-block boundary, m = 0, 1, 5, 16, masks unrelated to the
