@@ -94,15 +94,18 @@ def minimum(counts, bin_centers, max_iter: int = 10000):
     """SK thresholding.py:763-799; raises RuntimeError like scikit-image when no two maxima exist."""
 
     def local_maxima(h):
-        idx, direction = [], 1
-        for i in range(h.shape[0] - 1):
-            if direction > 0:
-                if h[i + 1] < h[i]:
-                    direction = -1
-                    idx.append(i)
-            elif h[i + 1] > h[i]:
-                direction = 1
-        return idx
+        # scikit-image walks the histogram with a direction flag (+1 rising, -1 falling; flat steps keep it) and
+        # records i whenever a rise turns into a fall.  After every non-flat step the flag equals the step's sign,
+        # so the recorded positions are the falling steps whose previous non-flat step rose (or that come first):
+        # one vector pass instead of a Python loop over 65,536 bins, up to 10,000 times.
+        step = np.diff(h)
+        nz = np.flatnonzero(step)
+        if nz.size == 0:
+            return []
+        falling = step[nz] < 0
+        prev_rising = np.ones(nz.size, bool)
+        prev_rising[1:] = ~falling[:-1]
+        return nz[falling & prev_rising].tolist()
 
     smooth = counts.astype(np.float64, copy=False)
     maxima: list[int] = []

@@ -172,27 +172,31 @@ def gaussian_otsu_codes(a: DeviceArray, sigma: float, codes: DeviceArray, thr: D
 
 
 def difference_of_gaussians(a: DeviceArray, low_sigma: float, high_sigma: float, mode: str = "nearest",
-                            cval: float = 0.0, truncate: float = 4.0, out: DeviceArray | None = None) -> DeviceArray:
-    """``skimage.filters.difference_of_gaussians`` (SK/filters/_gaussian.py:258-290; R/operations.py:91)."""
+                            cval: float = 0.0, truncate: float = 4.0, out: DeviceArray | None = None,
+                            scale: float | None = None) -> DeviceArray:
+    """``skimage.filters.difference_of_gaussians`` (SK/filters/_gaussian.py:258-290; R/operations.py:91).  ``scale``:
+    the factor of ``img_as_float`` (default: 1/65535 for uint16 planes, 1 for float64)."""
     ctx = a.ctx
     n, H, W = _planes(a)
     o = _out(ctx, out, a.shape, np.float64)
     wl, wh = gaussian_weights(low_sigma, truncate), gaussian_weights(high_sigma, truncate)
     wla, wlp = _host_f64(wl)
     wha, whp = _host_f64(wh)
-    scale = 1.0 / 65535 if a.dtype == np.uint16 else 1.0
+    if scale is None:
+        scale = 1.0 / 65535 if a.dtype == np.uint16 else 1.0
     _hip.check(_lib().amt_dog(ctx.handle, a.ptr, _in_code(a), scale, o.ptr, n, H, W, wlp, (len(wl) - 1) // 2, whp,
                               (len(wh) - 1) // 2, _hip.MODES[mode], float(cval)), "amt_dog")
     return o
 
 
 def difference_of_gaussians_nd(a: DeviceArray, low_sigma: float, high_sigma: float, mode: str = "nearest",
-                               cval: float = 0.0, truncate: float = 4.0, out: DeviceArray | None = None) -> DeviceArray:
+                               cval: float = 0.0, truncate: float = 4.0, out: DeviceArray | None = None,
+                               scale: float | None = None) -> DeviceArray:
     """``skimage.filters.difference_of_gaussians`` of ONE n-D image: both Gaussians filter EVERY axis
     (SK/filters/_gaussian.py:284-290), unlike ``difference_of_gaussians``, whose leading axes are independent planes."""
     ctx = a.ctx
-    lo = gaussian_nd(a, low_sigma, mode, cval, truncate)
-    hi = gaussian_nd(a, high_sigma, mode, cval, truncate)
+    lo = gaussian_nd(a, low_sigma, mode, cval, truncate, scale=scale)
+    hi = gaussian_nd(a, high_sigma, mode, cval, truncate, scale=scale)
     o = _out(ctx, out, a.shape, np.float64)
     _hip.check(_lib().amt_subtract(ctx.handle, lo.ptr, hi.ptr, o.ptr, _hip.F64, a.size), "amt_subtract")
     return o

@@ -15,6 +15,8 @@ Still refused for n-D input: the local thresholds (``local`` / ``niblack`` / ``s
 dtypes: uint8 / uint16 / float64 are computed as the reference computes them (bit-exact).  Other integer
 types are converted on upload: to uint16 when the values fit (exact), otherwise to float64 (exact below 2^53; the
 histogram thresholds then bin like a float image and are refused instead, since scikit-image bins integers by value).
+Where scikit-image's result depends on the dtype itself -- ``img_as_float`` inside the Gaussians of the DoG, Sauvola's
+default ``r`` -- the CALLER's dtype decides (``_img_as_float_plan``, ``_sauvola_r``), not the type the data travels as.
 float32 / float16 are computed in float64: numpy / scikit-image keep float32 arithmetic for them, so results agree
 to float32 rounding (~1e-7 relative), inside the 1e-5 bar for float outputs but not bit for bit.
 """
@@ -61,6 +63,41 @@ def _to_device(intensities, what: str, integer_histogram: bool = False):
     elif a.dtype not in (np.uint16, np.float64):
         raise TypeError(f"{what}: dtype {a.dtype} is not supported on the MI355X path")
     return get_context().asarray(np.ascontiguousarray(a)), True
+
+
+def _img_as_float_plan(intensities):
+    """How ``skimage.util.img_as_float`` (SK/util/dtype.py:280-330, called by ``filters.gaussian``) treats the dtype of a
+    host array -> (array to upload, scale for the device Gaussian or None for its default).  uint16 and uint8 travel as
+    uint16 and are multiplied by 1/65535 resp. 1/255 on the device, bool by 1; wider unsigned integers are multiplied by
+    1/imax and signed integers mapped by (x + 0.5) * 2 / (imax - imin) on the host, in float64, exactly as scikit-image
+    does, and travel as float64."""
+    if isinstance(intensities, DeviceArray):
+        return intensities, None
+    a = np.asarray(intensities)
+    if a.dtype == np.bool_:
+        return a, 1.0
+    if a.dtype == np.uint8:
+        return a, 1.0 / 255
+    if a.dtype.kind == "u" and a.dtype != np.uint16:
+        return np.multiply(a, 1.0 / int(np.iinfo(a.dtype).max), dtype=np.float64), None
+    if a.dtype.kind == "i":
+        info = np.iinfo(a.dtype)
+        f = np.add(a, 0.5, dtype=np.float64)
+        f *= 2 / (int(info.max) - int(info.min))
+        return f, None
+    return a, None
+
+
+def _sauvola_r(dtype) -> float:
+    """threshold_sauvola's default ``r``: half the dtype's range, ``dtype_limits(image, clip_negative=False)``
+    (SK/filters/thresholding.py:1079-1081; floats count as (-1, 1), bool as (False, True))."""
+    dt = np.dtype(dtype)
+    if dt == np.bool_:
+        return 0.5
+    if dt.kind in "ui":
+        info = np.iinfo(dt)
+        return 0.5 * (int(info.max) - int(info.min))
+    return 1.0
 
 
 def _flat(d: DeviceArray) -> DeviceArray:
@@ -115,9 +152,10 @@ def subtract_background_dog(
         raise ValueError(f"Percentile must be between 0 and 100, got {percentile}")
     if low_sigma >= high_sigma:
         raise ValueError(f"low_sigma ({low_sigma}) must be smaller than high_sigma ({high_sigma})")
+    intensities, scale = _img_as_float_plan(intensities)
     d, was_numpy = _to_device(intensities, "subtract_background_dog")
-    dog = (hipops.difference_of_gaussians(d, low_sigma, high_sigma) if d.ndim == 2 else
-           hipops.difference_of_gaussians_nd(d, low_sigma, high_sigma))
+    dog = (hipops.difference_of_gaussians(d, low_sigma, high_sigma, scale=scale) if d.ndim == 2 else
+           hipops.difference_of_gaussians_nd(d, low_sigma, high_sigma, scale=scale))
     f = _flat(dog)
     level = hipops.percentile(f, percentile)
     hipops.sub_clip0(f, level, out=f)
@@ -243,6 +281,7 @@ def apply_threshold(
             f"Unsupported thresholding method: '{method}'. "
             f"Supported methods: {', '.join(_SUPPORTED_METHODS)}"
         )
+    src_dtype = intensities.dtype if isinstance(intensities, DeviceArray) else np.asarray(intensities).dtype
     d, was_numpy = _to_device(intensities, "apply_threshold",
                               integer_histogram=method_lower in ("otsu", "yen", "isodata", "triangle", "minimum",
                                                                  "mean", "li"))
@@ -276,6 +315,8 @@ def apply_threshold(
             raise TypeError("threshold_local() missing 1 required positional argument: 'block_size'")
         mask = hipops.greater_than_image(d, _local_threshold(d, **kw))
     else:  # niblack / sauvola (SK/filters/thresholding.py:967-1087)
+        if method_lower == "sauvola" and kw.get("r") is None:
+            kw["r"] = _sauvola_r(src_dtype)  # half the range of the CALLER's dtype, not of the uint16 it travels as
         mask = hipops.greater_than_image(d, hipops.window_threshold(d, method=method_lower, **kw))
     if mask.shape != shape:
         is_bool = mask.is_bool

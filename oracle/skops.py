@@ -26,6 +26,13 @@ def img_as_float(image: np.ndarray) -> np.ndarray:
         return image.astype(np.float64)
     if image.dtype in (np.float32, np.float64):
         return image.astype(np.float64)
+    if image.dtype.kind == "u":  # SK/util/dtype.py:_convert, unsigned -> float: multiply by 1 / imax
+        return np.multiply(image, 1.0 / int(np.iinfo(image.dtype).max), dtype=np.float64)
+    if image.dtype.kind == "i":  # signed -> float: (x + 0.5) * 2 / (imax - imin)
+        info = np.iinfo(image.dtype)
+        out = np.add(image, 0.5, dtype=np.float64)
+        out *= 2 / (int(info.max) - int(info.min))
+        return out
     raise TypeError(f"oracle img_as_float: unsupported dtype {image.dtype}")
 
 
@@ -281,11 +288,12 @@ def threshold_niblack(image, window_size=15, k=0.2):
 def threshold_sauvola(image, window_size=15, k=0.2, r=None):
     """SK/filters/thresholding.py:1083-1087."""
     if r is None:
-        if image.dtype == np.uint16:
-            imin, imax = 0, 65535
-        elif image.dtype == np.uint8:
-            imin, imax = 0, 255
-        elif image.dtype in (np.float32, np.float64):
+        # dtype_limits(image, clip_negative=False): integer range, (False, True) for bool, (-1, 1) for floats
+        if image.dtype == bool:
+            imin, imax = 0, 1
+        elif image.dtype.kind in "ui":
+            imin, imax = int(np.iinfo(image.dtype).min), int(np.iinfo(image.dtype).max)
+        elif image.dtype.kind == "f":
             imin, imax = -1, 1
         else:
             raise TypeError("oracle sauvola: dtype")

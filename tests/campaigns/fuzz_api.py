@@ -1,0 +1,209 @@
+"""The reference-level API under random dtypes (uint8 / uint16 / float64), ranks (2-D, (T,Y,X), (Z,C,Y,X)), memory
+layouts (channel-last views, strided crops, negative strides), parameters and Pipeline modes, against numpy + the CPU
+oracle; and SegmentationMask on random label images (gaps in the numbering, bool masks, cells on the frame, both
+outline extractors, filter).  Usage: fuzz_api.py [cases] [seed]."""
+import os, sys, warnings
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+from scipy import ndimage as ndi
+from arcadia_microscopy_tools_amd.channels import DAPI, FITC
+from arcadia_microscopy_tools_amd.masks import SegmentationMask
+from arcadia_microscopy_tools_amd.operations import (apply_threshold, crop_to_center, rescale_by_percentile,
+                                                    subtract_background_dog)
+from arcadia_microscopy_tools_amd.pipeline import ImageOperation, Pipeline
+from oracle import contours as oc
+from oracle import regionprops as orp
+from oracle import skops
+
+ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+bad = 0
+counts = {}
+
+
+def check(name, ok, info):
+    global bad
+    counts[name] = counts.get(name, 0) + 1
+    if not ok:
+        bad += 1
+        print("MISMATCH", name, info, flush=True)
+
+
+def random_image():
+    nd = int(rng.choice([2, 2, 2, 3, 4]))
+    shape = tuple(int(rng.integers(1, 5)) for _ in range(nd - 2)) + (int(rng.integers(2, 90)), int(rng.integers(2, 100)))
+    kind = int(rng.integers(0, 4))
+    base = rng.random(shape)
+    if kind >= 2:
+        base = ndi.gaussian_filter(base, [0] * (nd - 2) + [2, 2])
+        base = (base - base.min()) / max(base.max() - base.min(), 1e-12)
+    dt = (np.uint8, np.uint16, np.uint16, np.float64, np.int16, np.int32, np.uint32, np.int64)[int(rng.integers(0, 8))]
+    if dt == np.float64:
+        x = base * float(rng.choice([1.0, 4095.0, 1e-3])) - float(rng.choice([0.0, 0.0, 0.25]))
+    else:
+        x = (base * (min(np.iinfo(dt).max, 65535) * rng.uniform(0.05, 1.0))).astype(dt)
+    layout = int(rng.integers(0, 5))
+    if layout == 1:    # a view with the leading axis last in memory (channel-last files)
+        x = np.ascontiguousarray(np.moveaxis(x, 0, -1)) if x.ndim > 2 else x
+        x = np.moveaxis(x, -1, 0) if x.ndim > 2 else x
+    elif layout == 2:  # strided crop
+        big = np.zeros(tuple(2 * s for s in x.shape), x.dtype)
+        big[tuple(slice(0, 2 * s, 2) for s in x.shape)] = x
+        x = big[tuple(slice(0, 2 * s, 2) for s in x.shape)]
+    elif layout == 3:  # negative strides
+        x = x[..., ::-1, ::-1][..., ::-1, ::-1] if rng.random() < 0.5 else np.ascontiguousarray(x[..., ::-1])[..., ::-1]
+    return x
+
+
+def ref_rescale(x, q, o):
+    if x.size == 0:
+        return np.zeros_like(x, dtype=float)
+    if x.min() == x.max():
+        return np.full_like(x, o[0], dtype=float)
+    p = np.percentile(x, q)
+    return skops.rescale_intensity(x, (p[0], p[1]), o)
+
+
+def ref_dog(x, lo, hi, pct):
+    f = skops.img_as_float(x)
+    dog = ndi.gaussian_filter(f, lo, mode="nearest", truncate=4.0) - ndi.gaussian_filter(f, hi, mode="nearest", truncate=4.0)
+    return np.clip(dog - np.percentile(dog, pct), 0, None)
+
+
+def ref_threshold(x, method, **kw):
+    if x.size == 0 or x.min() == x.max():
+        return np.zeros(x.shape, bool)
+    return x > getattr(skops, "threshold_" + method)(x, **kw)
+
+
+for case in range(ncases):
+    x = random_image()
+    keep = x.copy()
+    info = (x.shape, str(x.dtype), x.strides)
+    q = tuple(sorted(rng.uniform(0, 100, 2)))
+    if q[1] - q[0] > 1e-2:
+        o = ((0.0, 1.0), (0.0, 65535.0), (-1.0, 1.0))[int(rng.integers(0, 3))]
+        want = ref_rescale(x, q, o)
+        p = np.percentile(x, q) if x.size and x.min() != x.max() else (0, 1)
+        if p[0] != p[1]:
+            got = rescale_by_percentile(x, q, o)
+            check("rescale", got.dtype == np.float64 and np.array_equal(got, want), info + (q, o))
+    lo = float(rng.choice([0.6, 1.0, 1.5]))
+    hi = lo + float(rng.choice([0.5, 2.0, 7.5, 15.4]))
+    pct = float(rng.choice([0, 0, 5, 50]))
+    got = subtract_background_dog(x, lo, hi, percentile=pct)
+    want = ref_dog(x, lo, hi, pct)
+    if x.dtype == np.float64 and x.ndim == 2:
+        check("dog", np.array_equal(got, want), info + (lo, hi, pct))
+    else:
+        check("dog", got.shape == want.shape and np.array_equal(got, want), info + (lo, hi, pct))
+    th, tw = int(rng.integers(1, x.shape[-2] + 3)), int(rng.integers(1, x.shape[-1] + 3))
+    ch, cw = min(th, x.shape[-2]), min(tw, x.shape[-1])
+    y0, x0 = (x.shape[-2] - ch) // 2, (x.shape[-1] - cw) // 2
+    check("crop", np.array_equal(crop_to_center(x, (th, tw)), x[..., y0:y0 + ch, x0:x0 + cw]), info + (th, tw))
+    for method in ("otsu", "yen", "isodata", "triangle", "mean", "li", "minimum"):
+        if method == "minimum":
+            if x.dtype.kind in "ui" and int(x.max()) - int(x.min()) > 4096:
+                continue
+            try:
+                want = ref_threshold(x, method)
+            except RuntimeError as e:
+                try:
+                    apply_threshold(x, method)
+                    check("threshold minimum raises", False, info)
+                except RuntimeError as e2:
+                    check("threshold minimum raises", str(e) == str(e2), (info, str(e), str(e2)))
+                continue
+        else:
+            want = ref_threshold(x, method)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            got = apply_threshold(x, method)
+        ok = got.dtype == bool and np.array_equal(got, want)
+        if not ok and x.dtype == np.float64 and method in ("li", "mean"):
+            ok = (got != want).mean() < 1e-3  # float64 sums in another order: the threshold may move by an ulp
+        check("threshold " + method, ok, info)
+    if x.ndim == 2:
+        w = int(rng.choice([3, 7, 15]))
+        k = float(rng.choice([0.2, -0.1, 0.5]))
+        for method in ("niblack", "sauvola"):
+            got, want = apply_threshold(x, method, window_size=w, k=k), ref_threshold(x, method, window_size=w, k=k)
+            ok = np.array_equal(got, want) if x.dtype != np.float64 else (got != want).mean() < 2e-3
+            check("threshold " + method, ok, info + (w, k))
+    kw = dict(block_size=int(rng.choice([3, 7, 13])), offset=float(rng.choice([0, 0, 2.5])))
+    got, want = apply_threshold(x, "local", **kw), ref_threshold(x, "local", **kw)
+    check("threshold local", np.array_equal(got, want), info + (kw,))
+    check("input untouched", np.array_equal(x, keep), info)
+    # Pipeline: sequential vs parallel over axis 0, dtype preservation
+    if x.ndim >= 3 and x.dtype != np.float64:
+        ops = [ImageOperation(subtract_background_dog, low_sigma=1.0, high_sigma=3.0),
+               ImageOperation(rescale_by_percentile, percentile_range=(1, 99), out_range=(0, 1000))]
+        par = Pipeline(ops, parallel=True, preserve_dtype=bool(rng.integers(0, 2)))
+        got = par(x)
+        planes = [ref_rescale(ref_dog(pl, 1.0, 3.0, 0), (1, 99), (0, 1000)) for pl in x]
+        want = np.array(planes)
+        if par.preserve_dtype:
+            want = want.astype(x.dtype)
+        check("pipeline parallel", got.dtype == want.dtype and np.array_equal(got, want), info)
+
+# ---- SegmentationMask on random label images ----------------------------------------------------------------------
+for case in range(max(20, ncases // 4)):
+    H, W = int(rng.integers(8, 120)), int(rng.integers(8, 140))
+    lab = np.zeros((H, W), np.int64)
+    yy, xx = np.mgrid[0:H, 0:W]
+    ncell = int(rng.integers(1, 12))
+    ids = rng.choice(np.arange(1, 60), ncell, replace=False)  # gaps in the numbering
+    for i in ids:
+        cy, cx = rng.integers(0, H), rng.integers(0, W)
+        ry, rx = rng.integers(2, max(3, H // 4)), rng.integers(2, max(3, W // 4))
+        sel = ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1
+        lab[sel & (lab == 0)] = i
+    if not lab.any():
+        continue
+    as_bool = rng.random() < 0.3
+    mask_in = lab > 0 if as_bool else lab
+    rem = bool(rng.integers(0, 2))
+    chans = {DAPI: rng.integers(0, 65536, (H, W)).astype(np.uint16), FITC: rng.integers(0, 4096, (H, W)).astype(np.uint16)}
+    # reference semantics (R/masks.py:38-65): clear_border, then label (bool) or relabel_sequential (int)
+    work = skops.label(mask_in, connectivity=2) if as_bool else lab.copy()
+    if rem:
+        work = skops.clear_border(work)
+    if as_bool:
+        # label() ran BEFORE clear_border in this restatement: renumber to what label(clear_border(mask)) gives
+        work = skops.label(work > 0, connectivity=2) if rem else work
+    want_lab = skops.relabel_sequential(work).astype(np.int64) if not as_bool else work.astype(np.int64)
+    info = ((H, W), as_bool, rem, ncell)
+    try:
+        sm = SegmentationMask(mask_in, chans, remove_edge_cells=rem, outline_extractor=("skimage", "cellpose")[case % 2])
+        got_lab = sm.label_image
+    except ValueError as e:
+        check("mask all removed", want_lab.max() == 0 and "No cells remain" in str(e), info + (str(e),))
+        continue
+    check("mask labels", got_lab.dtype == np.int64 and np.array_equal(got_lab, want_lab), info)
+    if not np.array_equal(got_lab, want_lab):
+        continue
+    check("num_cells", sm.num_cells == int(want_lab.max()), info)
+    ref = orp.cell_properties(want_lab, {"DAPI": chans[DAPI], "FITC": chans[FITC]})
+    got = sm.cell_properties
+    okp = set(got) == set(ref) and all(np.allclose(got[c], ref[c], rtol=1e-5, atol=1e-8, equal_nan=True)
+                                       for c in ref if c != "orientation")
+    check("cell_properties", okp, info)
+    outl = sm.cell_outlines
+    ref_out = (oc.extract_outlines_skimage if case % 2 == 0 else oc.extract_outlines_cellpose)(want_lab)
+    check("outlines", len(outl) == len(ref_out) and all(a.shape == b.shape and np.array_equal(a, b)
+                                                        for a, b in zip(outl, ref_out)), info + (case % 2,))
+    if sm.num_cells >= 2:
+        area = got["area"]
+        cut = float(np.median(area))
+        keep_ids = got["label"][area >= cut]
+        try:
+            sub = sm.filter("area", min_value=cut)
+            want_sub = skops.relabel_sequential(np.where(np.isin(want_lab, keep_ids), want_lab, 0))
+            check("filter", np.array_equal(sub.label_image, want_sub), info)
+        except Exception as e:  # noqa: BLE001
+            check("filter", False, info + (repr(e),))
+    if case % 10 == 9:
+        print(f"masks {case + 1}, bad {bad}", flush=True)
+print({k: v for k, v in sorted(counts.items())})
+print("BAD", bad)
+sys.exit(1 if bad else 0)

@@ -565,3 +565,31 @@ def test_host_transfers_every_path():
         assert np.array_equal(ctx.asarray(lab, dtype=np.int32).numpy_int64(), lab)
     finally:
         dv._result_pool.cap_out = cap
+
+
+def test_integer_dtypes_keep_their_own_float_conversion():
+    """Found by tests/campaigns/fuzz_api.py: images travel to the device as uint16 or float64, but ``img_as_float``
+    (inside the Gaussians of ``subtract_background_dog``) and Sauvola's default ``r`` depend on the CALLER's dtype
+    (SK/util/dtype.py:_convert; SK/filters/thresholding.py:1079-1081)."""
+    from scipy import ndimage as ndi
+
+    from oracle import skops
+
+    rng = np.random.default_rng(21)
+    base = ndi.gaussian_filter(rng.random((3, 40, 52)), (0, 2, 2))
+    base = (base - base.min()) / (base.max() - base.min())
+    for dt, top in ((np.uint8, 255), (np.uint16, 65535), (np.uint32, 60000), (np.int16, 30000), (np.int32, 50000),
+                    (np.int64, 1000), (np.bool_, 1)):
+        x = (base * top).astype(dt) if dt != np.bool_ else base > 0.5
+        for img in (x[0], x):  # one plane, and a stack (every axis filtered)
+            f = skops.img_as_float(img)
+            dog = ndi.gaussian_filter(f, 1.0, mode="nearest") - ndi.gaussian_filter(f, 4.0, mode="nearest")
+            want = np.clip(dog - np.percentile(dog, 5), 0, None)
+            got = subtract_background_dog(img, 1.0, 4.0, percentile=5)
+            assert np.array_equal(got, want), (np.dtype(dt), img.shape)
+        if dt != np.bool_:
+            for w in (7, 15):
+                assert np.array_equal(apply_threshold(x[0], "sauvola", window_size=w),
+                                      x[0] > skops.threshold_sauvola(x[0], window_size=w)), (np.dtype(dt), w)
+            assert np.array_equal(apply_threshold(x[0], "sauvola", window_size=7, r=100.0),
+                                  x[0] > skops.threshold_sauvola(x[0], window_size=7, r=100.0)), np.dtype(dt)

@@ -432,3 +432,44 @@ def test_plate_table_keyed_by_microplate_layout():
     assert df["area"].tolist() == [10, 20, 30, 40, 50] and df["label"].dtype == np.int64
     merged = df.merge(layout.to_dataframe()[["well_id", "row", "column"]], on="well_id", how="left")
     assert merged["row"].tolist() == ["A", "A", "A", np.nan, "P"] or merged["row"].isna().tolist() == [False, False, False, True, False]
+
+
+def test_minimum_threshold_vector_search_equals_the_loop():
+    """``_thresholds.minimum`` finds the histogram's local maxima in one vector pass; scikit-image (and the oracle)
+    walk it with a direction flag.  Same indices on random histograms with plateaus, same threshold on an image."""
+    from scipy import ndimage as ndi
+
+    from arcadia_microscopy_tools_amd import _thresholds
+    from oracle import skops
+
+    rng = np.random.default_rng(0)
+    img = (ndi.gaussian_filter(rng.random((96, 96)), 3) * 2000).astype(np.uint16)
+    img[:48] += 3000
+    counts, centers = skops._counts_centers(img, 256)
+    assert _thresholds.minimum(counts, centers) == skops.threshold_minimum(img)
+    flat = np.full((16, 16), 7, np.uint16)
+    flat[0, 0] = 9
+    c2, b2 = skops._counts_centers(flat, 256)
+    with pytest.raises(RuntimeError, match="Unable to find two maxima"):
+        _thresholds.minimum(c2, b2)
+    with pytest.raises(RuntimeError, match="Unable to find two maxima"):
+        skops.threshold_minimum(flat)
+
+
+def test_img_as_float_plan_follows_skimage_per_dtype():
+    from arcadia_microscopy_tools_amd import operations as op
+    from oracle import skops
+
+    vals = np.array([[0, 1, 2], [3, 100, 127]])
+    for dt in (np.uint8, np.uint16, np.uint32, np.uint64, np.int8, np.int16, np.int32, np.int64, np.bool_, np.float64):
+        a = vals.astype(dt)
+        b, scale = op._img_as_float_plan(a)
+        if scale is not None:
+            got = b.astype(np.float64) * scale
+        elif b.dtype == np.uint16:
+            got = b.astype(np.float64) * (1.0 / 65535)
+        else:
+            got = b
+        assert got.dtype == np.float64 and np.array_equal(got, skops.img_as_float(a)), np.dtype(dt)
+    assert [op._sauvola_r(d) for d in (np.uint8, np.uint16, np.int16, np.bool_, np.float32, np.float64)] == \
+        [127.5, 32767.5, 32767.5, 0.5, 1.0, 1.0]
