@@ -5,7 +5,8 @@ large metadata parser).  The hot path only needs the pixels and the channel list
 chunk map itself (layout: SURVEY.md A.10), decodes the "lite variant" attribute blocks far enough to get
 width / height / component count / frame count and the optical-configuration names, and de-interleaves the
 (Y, X, C) frames into (C, Y, X) on the GPU (``hipops.deinterleave``) or, for plumbing without a GPU, with a
-numpy transpose.  Compressed frames, montages and multi-loop experiments are out of scope (row "next 1").
+numpy transpose.  The loop axes (time / z / position) are named from the experiment tree.  Compressed frames are out
+of scope (row "next 1").
 """
 from __future__ import annotations
 
@@ -153,6 +154,38 @@ def read_channel_names(data: bytes, cmap, n_components: int) -> list[str]:
         return []
 
 
+_LOOP_AXIS = {1: "T", 8: "T", 2: "P", 4: "Z"}  # SLxExperiment.eType: time, non-equidistant time, XY position, z stack
+
+
+def read_experiment_loops(data: bytes, cmap) -> list[tuple[str, int]]:
+    """[(axis letter, count)] of the acquisition loops, outermost first, from the ``SLxExperiment`` tree of the
+    ``ImageMetadataLV!`` chunk (what ``nd2.ND2File.sizes`` is built from, R/nikon.py:197-210 reads 'T' / 'Z' / 'P'
+    from it).  Loops of one step and loop kinds without a frame axis (spectral, eType 6) are skipped; [] when the
+    chunk is absent or cannot be read."""
+    key = b"ImageMetadataLV!"
+    if key not in cmap:
+        return []
+    try:
+        meta, _ = parse_lite_variant(chunk_payload(data, cmap[key]))
+    except Exception:
+        return []
+    loops: list[tuple[str, int]] = []
+    level = meta.get("SLxExperiment", meta)
+    while isinstance(level, dict):
+        pars = level.get("uLoopPars")
+        if isinstance(pars, dict) and len(pars) == 1 and isinstance(next(iter(pars.values())), dict):
+            pars = next(iter(pars.values()))  # some writers wrap the parameters in an unnamed level
+        count = int(pars.get("uiCount", 1)) if isinstance(pars, dict) else 1
+        axis = _LOOP_AXIS.get(int(level.get("eType", 0) or 0))
+        if axis is not None and count > 1:
+            loops.append((axis, count))
+        nxt = level.get("ppNextLevelEx") if int(level.get("uiNextLevelCount", 0) or 0) > 0 else None
+        if isinstance(nxt, dict) and "eType" not in nxt:
+            nxt = next((v for v in nxt.values() if isinstance(v, dict)), None)  # first (only) child level
+        level = nxt
+    return loops
+
+
 def read_frames_interleaved(path: Path):
     """-> (frames (N, Y, X, C) uint16 little-endian, attributes, channel names)."""
     data = Path(path).read_bytes()
@@ -177,6 +210,7 @@ def read_frames_interleaved(path: Path):
             raise NotImplementedError("compressed ND2 frames are not supported")
         rows = np.ndarray((H, W, C), dtype="<u2", buffer=payload, offset=8, strides=(stride, C * 2, 2))
         frames[i] = rows
+    at["loops"] = read_experiment_loops(data, cmap)
     return frames, at, read_channel_names(data, cmap, C)
 
 
@@ -184,8 +218,9 @@ def load_nd2(nd2_path: Path, channels: list[Channel] | None = None, use_device: 
     """-> (intensities uint16, InstrumentMetadata) like R/nikon.py:25-43.
 
     Shapes follow ``nd2.ND2File.asarray()`` for the supported cases: (Y, X), (C, Y, X), (N, Y, X) or
-    (N, C, Y, X) with size-1 axes dropped.  The loop axis of multi-frame files is named 'T' (the chunk map
-    alone does not say whether it is a time or a z loop).
+    (N, C, Y, X) with size-1 axes dropped.  The loop axes of multi-frame files are named after the experiment's
+    loops ('T' time, 'Z' z stack, 'P' positions, outermost first: ``read_experiment_loops``) when their counts
+    multiply to the number of frames; otherwise the frames form one 'T' axis.
     """
     from .microscopy import InstrumentMetadata
 
@@ -207,7 +242,11 @@ def load_nd2(nd2_path: Path, channels: list[Channel] | None = None, use_device: 
         cyx = np.ascontiguousarray(frames.transpose(0, 3, 1, 2))
     sizes: dict[str, int] = {}
     if N > 1:
-        sizes["T"] = N
+        loops = at.get("loops") or []
+        if loops and int(np.prod([c for _, c in loops])) == N and len({a for a, _ in loops}) == len(loops):
+            sizes.update(loops)
+        else:
+            sizes["T"] = N
     if C > 1:
         sizes["C"] = C
     sizes["Y"], sizes["X"] = H, W
@@ -217,6 +256,12 @@ def load_nd2(nd2_path: Path, channels: list[Channel] | None = None, use_device: 
         for i in range(C):
             ch = resolve_optical_config(names[i]) if i < len(names) else None
             channels.append(ch or Channel(names[i] if i < len(names) else f"CH{i}", "#FFFFFF"))
-    flags = DimensionFlags.TIMELAPSE if N > 1 else DimensionFlags(0)
+    flags = DimensionFlags(0)  # as R/nikon.py:197-210 derives them from the sizes
+    if sizes.get("T", 1) > 1:
+        flags |= DimensionFlags.TIMELAPSE
+    if sizes.get("Z", 1) > 1:
+        flags |= DimensionFlags.Z_STACK
+    if sizes.get("P", 1) > 1:
+        flags |= DimensionFlags.MONTAGE
     meta = InstrumentMetadata(sizes, [ChannelMetadata(ch, flags) for ch in channels])
     return out, meta

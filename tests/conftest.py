@@ -27,9 +27,11 @@ def golden():
     return load
 
 
-def write_synthetic_nd2(path, frames_yxc, row_pad_bytes: int = 0):
+def write_synthetic_nd2(path, frames_yxc, row_pad_bytes: int = 0, loops=None):
     """Write an uncompressed ND2 container (chunk map + lite-variant attributes) holding
-    ``frames_yxc`` = (N, Y, X, C) uint16 frames; ``row_pad_bytes`` pads every pixel row (uiWidthBytes > X*C*2).
+    ``frames_yxc`` = (N, Y, X, C) uint16 frames; ``row_pad_bytes`` pads every pixel row (uiWidthBytes > X*C*2);
+    ``loops`` = [(eType, count), ...] outermost first writes an ``ImageMetadataLV!`` chunk with that experiment tree
+    (eType 1 time, 2 positions, 4 z stack, 6 spectral, 8 non-equidistant time).
     The reference's fixture files do not travel to the GPU box; their pixels are pinned in tests/golden."""
     import struct
 
@@ -55,6 +57,23 @@ def write_synthetic_nd2(path, frames_yxc, row_pad_bytes: int = 0):
         return struct.pack("<IIQ", 0x0ABECEDA, len(nm), len(payload)) + nm + payload
 
     chunks = [(b"ImageAttributesLV!", attrs)]
+    if loops:
+        def level(lname, items):
+            nm = (lname + "\x00").encode("utf-16-le")
+            hd = bytes([11, len(nm) // 2]) + nm
+            body = b"".join(items)
+            return hd + struct.pack("<IQ", len(items), len(hd) + 12 + len(body)) + body + b"\x00" * (8 * len(items))
+
+        def experiment(rest):
+            (etype, count), deeper = rest[0], rest[1:]
+            items = [lv(3, "eType", struct.pack("<I", etype)),
+                     level("uLoopPars", [lv(3, "uiCount", struct.pack("<I", count)), lv(6, "dStart", struct.pack("<d", 0.0))]),
+                     lv(3, "uiNextLevelCount", struct.pack("<I", 1 if deeper else 0))]
+            if deeper:
+                items.append(level("ppNextLevelEx", [level("", experiment(deeper))]))
+            return items
+
+        chunks.append((b"ImageMetadataLV!", level("SLxExperiment", experiment(list(loops)))))
     for i in range(N):
         rows = b"".join(frames_yxc[i, y].tobytes() + b"\xAB" * row_pad_bytes for y in range(H))
         chunks.append((b"ImageDataSeq|%d!" % i, b"\x00" * 8 + rows))

@@ -473,3 +473,52 @@ def test_img_as_float_plan_follows_skimage_per_dtype():
         assert got.dtype == np.float64 and np.array_equal(got, skops.img_as_float(a)), np.dtype(dt)
     assert [op._sauvola_r(d) for d in (np.uint8, np.uint16, np.int16, np.bool_, np.float32, np.float64)] == \
         [127.5, 32767.5, 32767.5, 0.5, 1.0, 1.0]
+
+
+def test_nd2_loop_axes_come_from_the_experiment_tree(tmp_path):
+    """(T, Z, C, Y, X) naming of multi-frame ND2 files: 'T' / 'Z' / 'P' from SLxExperiment.eType, outermost loop
+    first, as ``nd2.ND2File.sizes`` reports them (R/nikon.py:197-210 derives the dimension flags from those)."""
+    from conftest import write_synthetic_nd2
+
+    from arcadia_microscopy_tools_amd import nd2lite
+    from arcadia_microscopy_tools_amd.metadata_structures import DimensionFlags
+
+    rng = np.random.default_rng(4)
+    frames = rng.integers(0, 65536, (6, 10, 12, 2)).astype(np.uint16)
+    chans = [DAPI, FITC]
+    want = frames.transpose(0, 3, 1, 2)
+    for loops, sizes, flags in (
+            ([(1, 2), (4, 3)], {"T": 2, "Z": 3, "C": 2, "Y": 10, "X": 12}, DimensionFlags.TIMELAPSE | DimensionFlags.Z_STACK),
+            ([(4, 6)], {"Z": 6, "C": 2, "Y": 10, "X": 12}, DimensionFlags.Z_STACK),
+            ([(4, 6), (6, 2)], {"Z": 6, "C": 2, "Y": 10, "X": 12}, DimensionFlags.Z_STACK),   # spectral level: no axis
+            ([(2, 3), (8, 2)], {"P": 3, "T": 2, "C": 2, "Y": 10, "X": 12}, DimensionFlags.MONTAGE | DimensionFlags.TIMELAPSE),
+            ([(1, 1), (4, 6)], {"Z": 6, "C": 2, "Y": 10, "X": 12}, DimensionFlags.Z_STACK),   # one-step loop dropped
+            ([(1, 4)], {"T": 6, "C": 2, "Y": 10, "X": 12}, DimensionFlags.TIMELAPSE),         # counts do not match
+            (None, {"T": 6, "C": 2, "Y": 10, "X": 12}, DimensionFlags.TIMELAPSE)):            # no experiment chunk
+        f = write_synthetic_nd2(tmp_path / "loops.nd2", frames, loops=loops)
+        arr, meta = nd2lite.load_nd2(f, channels=chans, use_device=False)
+        assert meta.sizes == sizes and arr.shape == tuple(sizes.values()), (loops, meta.sizes)
+        assert all(cm.dimensions == flags for cm in meta.channel_metadata_list), loops
+        assert np.array_equal(arr.reshape(want.shape), want), loops
+
+
+def test_nd2lite_on_the_reference_fixtures_when_present():
+    """Plumbing check against the files the reference's own tests read (RT/data, known-metadata.yml sizes); skipped on
+    machines without /root/reference (the pixels of config 1 are pinned in tests/golden/nd2_multichannel.npz)."""
+    import pathlib
+
+    from arcadia_microscopy_tools_amd import nd2lite
+    from arcadia_microscopy_tools_amd.metadata_structures import DimensionFlags
+
+    data = pathlib.Path("/root/reference/src/arcadia_microscopy_tools/tests/data")
+    if not (data / "example-zstack.nd2").exists():
+        pytest.skip("reference fixtures are not on this machine")
+    want = {"example-multichannel.nd2": ({"C": 4, "Y": 256, "X": 256}, DimensionFlags(0)),
+            "example-pbmc.nd2": ({"C": 4, "Y": 256, "X": 256}, DimensionFlags(0)),
+            "example-cerevisiae.nd2": ({"C": 2, "Y": 256, "X": 256}, DimensionFlags(0)),
+            "example-timelapse.nd2": ({"T": 53, "Y": 64, "X": 64}, DimensionFlags.TIMELAPSE),
+            "example-zstack.nd2": ({"Z": 11, "Y": 128, "X": 128}, DimensionFlags.Z_STACK)}
+    for name, (sizes, flags) in want.items():
+        arr, meta = nd2lite.load_nd2(data / name, use_device=False)
+        assert meta.sizes == sizes and arr.shape == tuple(sizes.values()) and arr.dtype == np.uint16, name
+        assert meta.channel_metadata_list[0].dimensions == flags, name
