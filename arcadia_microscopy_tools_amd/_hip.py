@@ -88,6 +88,8 @@ _SIGS = {
     "amt_threshold_gt": (c_int, [_P, _P, c_int, _P, _P, c_int, c_size_t]),
     "amt_window_threshold": (c_int, [_P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_double, c_double]),
     "amt_window_threshold_yx": (c_int, [_P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_double, c_double]),
+    "amt_window_threshold_nd": (c_int, [_P, _P, c_int, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_double,
+                                        c_double]),
     "amt_threshold_gt_image": (c_int, [_P, _P, c_int, _P, _P, c_size_t]),
     "amt_binary_erode": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_int, c_int, c_int]),
     "amt_binary_dilate": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_int, c_int, c_int]),

@@ -371,27 +371,39 @@ def greater_than(a: DeviceArray, thr: DeviceArray, out: DeviceArray | None = Non
 
 
 def window_threshold(a: DeviceArray, window_size=15, method: str = "niblack", k: float = 0.2, r=None,
-                     out: DeviceArray | None = None) -> DeviceArray:
-    """``skimage.filters.threshold_niblack`` / ``threshold_sauvola`` threshold image (float64) per plane
-    (SK/filters/thresholding.py:967-1087).  ``window_size`` is an odd integer or one per axis (rows, columns);
-    ``r`` defaults to half the dtype range as in scikit-image."""
+                     out: DeviceArray | None = None, nd: bool = False) -> DeviceArray:
+    """``skimage.filters.threshold_niblack`` / ``threshold_sauvola`` threshold image (float64)
+    (SK/filters/thresholding.py:967-1087).  Default: per plane, ``window_size`` an odd integer or (rows, columns).
+    ``nd=True``: ``a`` is ONE n-D image and the window spans every axis, as scikit-image treats a stack -- an odd
+    integer (the same on every axis) or one value per axis.  ``r`` defaults to half the dtype range as in scikit-image."""
     ctx = a.ctx
     n, H, W = _planes(a)
+    nlead = a.ndim - 2 if nd else 0
     if isinstance(window_size, (tuple, list, np.ndarray)):
-        if len(window_size) != 2:
-            raise ValueError("window_size must be an integer or one value per image axis (rows, columns)")
-        wy, wx = (int(v) for v in window_size)
+        if len(window_size) != 2 + nlead:
+            raise ValueError("window_size must be an integer or one value per image axis"
+                             + ("" if nd else " (rows, columns)"))
+        ws = [int(v) for v in window_size]
     else:
-        wy = wx = int(window_size)
-    for v in (wy, wx):
+        ws = [int(window_size)] * (2 + nlead)
+    for v in ws:
         if v % 2 == 0:
             raise ValueError(f"Window size {v} is even.")
+    wy, wx = ws[-2], ws[-1]
     if r is None:
         r = 0.5 * 65535 if a.dtype == np.uint16 else 1.0  # 0.5 * (imax - imin); float range is (-1, 1)
     o = _out(ctx, out, a.shape, np.float64)
-    _hip.check(_lib().amt_window_threshold_yx(ctx.handle, a.ptr, _in_code(a), o.ptr, n, H, W, wy, wx,
-                                              0 if method == "niblack" else 1, float(k), float(r)),
-               "amt_window_threshold")
+    meth = 0 if method == "niblack" else 1
+    if nlead and any(v != 1 for v in ws[:nlead]):
+        import ctypes
+
+        shp = (ctypes.c_int * nlead)(*[int(v) for v in a.shape[:nlead]])
+        win = (ctypes.c_int * nlead)(*ws[:nlead])
+        _hip.check(_lib().amt_window_threshold_nd(ctx.handle, a.ptr, _in_code(a), o.ptr, nlead, shp, win, H, W, wy, wx,
+                                                  meth, float(k), float(r)), "amt_window_threshold")
+    else:  # windows of one sample along the leading axes: every plane on its own
+        _hip.check(_lib().amt_window_threshold_yx(ctx.handle, a.ptr, _in_code(a), o.ptr, n, H, W, wy, wx, meth, float(k),
+                                                  float(r)), "amt_window_threshold")
     return o
 
 

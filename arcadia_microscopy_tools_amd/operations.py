@@ -10,7 +10,8 @@ n-D inputs follow the reference, which hands whatever array it is given to numpy
 global thresholds are taken over the WHOLE stack, a difference of Gaussians filters EVERY axis (leading axes first, as
 scipy does), ``crop_to_center`` crops the last two axes.  To treat a (T, Y, X) / (Z, Y, X) stack plane by plane use
 ``Pipeline(parallel=True)``, which maps the operations over axis 0 as the reference does (R/pipeline.py:139-149).
-Still refused for n-D input: the local thresholds (``local`` / ``niblack`` / ``sauvola``).
+The local thresholds follow suit: Niblack / Sauvola windows span every axis of a stack (``window_size`` an odd integer
+or one per axis), ``threshold_local`` filters every axis with its Gaussian; its ``mean`` / ``median`` methods are 2-D only.
 
 dtypes: uint8 / uint16 / float64 are computed as the reference computes them (bit-exact).  Other integer
 types are converted on upload: to uint16 when the values fit (exact), otherwise to float64 (exact below 2^53; the
@@ -286,14 +287,8 @@ def apply_threshold(
                               integer_histogram=method_lower in ("otsu", "yen", "isodata", "triangle", "minimum",
                                                                  "mean", "li"))
     shape = d.shape
-    if d.ndim != 2:
-        if method_lower in ("niblack", "sauvola"):
-            raise NotImplementedError(
-                f"apply_threshold: method '{method_lower}' filters every axis of an n-D image in scikit-image; the device "
-                "path does window statistics on 2-D images -- map a stack over its first axis with Pipeline(parallel=True)"
-            )
-        if method_lower != "local":
-            d = _flat(d)  # global methods: ONE threshold from the histogram of the whole stack
+    if d.ndim != 2 and method_lower not in ("local", "niblack", "sauvola"):
+        d = _flat(d)  # global methods: ONE threshold from the histogram of the whole stack
     ctx = d.ctx
     lo, hi = _min_max(d)
     if lo == hi:  # constant image (R/operations.py:201-202)
@@ -317,7 +312,8 @@ def apply_threshold(
     else:  # niblack / sauvola (SK/filters/thresholding.py:967-1087)
         if method_lower == "sauvola" and kw.get("r") is None:
             kw["r"] = _sauvola_r(src_dtype)  # half the range of the CALLER's dtype, not of the uint16 it travels as
-        mask = hipops.greater_than_image(d, hipops.window_threshold(d, method=method_lower, **kw))
+        # the window spans EVERY axis of a stack, as in scikit-image (window_size: one odd integer or one per axis)
+        mask = hipops.greater_than_image(d, hipops.window_threshold(d, method=method_lower, nd=d.ndim > 2, **kw))
     if mask.shape != shape:
         is_bool = mask.is_bool
         mask = mask.reshape(shape)

@@ -191,6 +191,11 @@ int amt_window_threshold(amt_ctx* ctx, const void* in, int in_dtype, double* thr
 /* The same with a window of window_y rows x window_x columns (scikit-image's per-axis `window_size` tuple). */
 int amt_window_threshold_yx(amt_ctx* ctx, const void* in, int in_dtype, double* thr_image, int nplanes, int H, int W,
                             int window_y, int window_x, int method, double k, double r);
+/* The same for ONE n-D image whose window spans every axis, as scikit-image's _mean_std does for stacks
+ * (SK/filters/thresholding.py:910-964): nlead axes of lead_shape[] in front of (H, W), one odd window per axis. */
+int amt_window_threshold_nd(amt_ctx* ctx, const void* in, int in_dtype, double* thr_image, int nlead,
+                            const int* lead_shape, const int* lead_window, int H, int W, int window_y, int window_x,
+                            int method, double k, double r);
 /* out = in > thr_image (per-pixel thresholds: local / niblack / sauvola) */
 int amt_threshold_gt_image(amt_ctx* ctx, const void* in, int in_dtype, const double* thr_image, uint8_t* out,
                            size_t n);

@@ -123,8 +123,10 @@ for case in range(ncases):
         if not ok and x.dtype == np.float64 and method in ("li", "mean"):
             ok = (got != want).mean() < 1e-3  # float64 sums in another order: the threshold may move by an ulp
         check("threshold " + method, ok, info)
-    if x.ndim == 2:
+    if True:  # n-D: the window spans every axis
         w = int(rng.choice([3, 7, 15]))
+        if x.ndim > 2 and rng.random() < 0.5:
+            w = tuple(int(rng.choice([1, 3, 5])) for _ in range(x.ndim - 2)) + (int(rng.choice([3, 9])), int(rng.choice([5, 7])))
         k = float(rng.choice([0.2, -0.1, 0.5]))
         for method in ("niblack", "sauvola"):
             got, want = apply_threshold(x, method, window_size=w, k=k), ref_threshold(x, method, window_size=w, k=k)

@@ -472,8 +472,26 @@ def test_operators_on_stacks_and_other_dtypes():
             ref = np.clip(dog - np.percentile(dog, pct), 0, None)
             got = subtract_background_dog(x, lo, hi, percentile=pct)
             assert got.shape == x.shape and np.array_equal(got, ref), (x.shape, lo, hi, pct)
-    with pytest.raises(NotImplementedError, match="window statistics on 2-D images"):
-        apply_threshold(t3, "sauvola")
+    # Niblack / Sauvola windows span EVERY axis of a stack (scikit-image's _mean_std builds n-D integral images)
+    from arcadia_microscopy_tools_amd import hipops
+    from arcadia_microscopy_tools_amd.device import get_context
+
+    for x in (t3, z4):
+        for ws in (5, (1,) * (x.ndim - 2) + (7, 9), (3,) * (x.ndim - 2) + (5, 11), (3,) + (1,) * (x.ndim - 3) + (15, 3)):
+            for method in ("niblack", "sauvola"):
+                want_t = getattr(skops, "threshold_" + method)(x, window_size=ws)
+                got_t = hipops.window_threshold(get_context().asarray(x), ws, method, 0.2,
+                                                r=32767.5 if method == "sauvola" else None, nd=True).numpy()
+                np.testing.assert_allclose(got_t, want_t, rtol=1e-9, atol=1e-9, err_msg=f"{x.shape} {ws} {method}")
+                got = apply_threshold(x, method, window_size=ws)
+                assert got.shape == x.shape and np.array_equal(got, x > want_t), (x.shape, ws, method)
+    xf = t3.astype(np.float64) / 65535.0
+    np.testing.assert_allclose(hipops.window_threshold(get_context().asarray(xf), (3, 7, 5), "sauvola", 0.3, nd=True).numpy(),
+                               skops.threshold_sauvola(xf, (3, 7, 5), 0.3), rtol=1e-7, atol=1e-12)
+    with pytest.raises(ValueError, match="is even"):
+        apply_threshold(t3, "niblack", window_size=(2, 5, 5))
+    with pytest.raises(ValueError, match="one value per image axis"):
+        apply_threshold(t3, "niblack", window_size=(5, 5))
     # threshold_local filters EVERY axis of a stack (its Gaussian is n-D): default method on (T, Y, X) and (Z, C, Y, X)
     for x in (t3, z4):
         for kw in (dict(block_size=7), dict(block_size=11, offset=3.5), dict(block_size=5, mode="nearest")):
