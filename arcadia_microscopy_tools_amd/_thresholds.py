@@ -33,6 +33,21 @@ def counts_centers_f64(hist: np.ndarray, vmin: float, vmax: float):
     return hist.astype(np.int64), (edges[:-1] + edges[1:]) / 2.0
 
 
+def otsu(counts, bin_centers):
+    """SK thresholding.py:321-350 on a histogram: the bin centre that maximises the between-class variance.  (uint16
+    images take ``amt_i_otsu_from_hist`` on the device; this is for integer images that travel shifted.)"""
+    counts = counts.astype(float)
+    if len(bin_centers) == 1:
+        return bin_centers[0]
+    w_lo = np.cumsum(counts)
+    w_hi = np.cumsum(counts[::-1])[::-1]
+    weighted = counts * bin_centers
+    m_lo = np.cumsum(weighted) / w_lo
+    m_hi = (np.cumsum(weighted[::-1]) / w_hi[::-1])[::-1]
+    between = w_lo[:-1] * w_hi[1:] * (m_lo[:-1] - m_hi[1:]) ** 2
+    return bin_centers[np.argmax(between)]
+
+
 def yen(counts, bin_centers):
     """SK thresholding.py:394-411."""
     counts = counts.astype(float)

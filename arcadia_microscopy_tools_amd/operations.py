@@ -14,8 +14,9 @@ The local thresholds follow suit: Niblack / Sauvola windows span every axis of a
 or one per axis), ``threshold_local`` filters every axis with its Gaussian; its ``mean`` / ``median`` methods are 2-D only.
 
 dtypes: uint8 / uint16 / float64 are computed as the reference computes them (bit-exact).  Other integer
-types are converted on upload: to uint16 when the values fit (exact), otherwise to float64 (exact below 2^53; the
-histogram thresholds then bin like a float image and are refused instead, since scikit-image bins integers by value).
+types are converted on upload: to uint16 when the values fit (exact), otherwise to float64 (exact below 2^53).  The
+histogram thresholds bin integers one bin per value as scikit-image does: an integer image beyond the uint16 range
+travels as ``x - min`` when its RANGE fits 65,536 values, and is refused when it does not.
 Where scikit-image's result depends on the dtype itself -- ``img_as_float`` inside the Gaussians of the DoG, Sauvola's
 default ``r`` -- the CALLER's dtype decides (``_img_as_float_plan``, ``_sauvola_r``), not the type the data travels as.
 float32 / float16 are computed in float64: numpy / scikit-image keep float32 arithmetic for them, so results agree
@@ -35,9 +36,12 @@ from .typing import BoolArray, Float64Array, ScalarArray
 _SUPPORTED_METHODS = ("otsu", "li", "yen", "isodata", "mean", "minimum", "triangle", "local", "niblack", "sauvola")
 
 
-def _to_device(intensities, what: str, integer_histogram: bool = False):
+def _to_device(intensities, what: str, integer_histogram: bool = False, shifted: list | None = None):
     """-> (DeviceArray, was_numpy).  See the module docstring for the dtype rules.  ``integer_histogram``: the caller
-    bins integer images by value (scikit-image's histogram), so integers beyond uint16 cannot be taken."""
+    bins integer images by value (scikit-image's histogram), so integers beyond uint16 cannot be taken -- unless the
+    caller passes ``shifted`` (a one-element list) and the image's RANGE fits 65,536 values: it then travels as
+    ``x - min`` in uint16 and ``shifted[0]`` receives ``min`` (scikit-image bins such images from image_min to
+    image_max, one bin per integer: SK/exposure/exposure.py:38-74)."""
     if isinstance(intensities, DeviceArray):
         d = intensities
         if d.dtype not in (np.uint16, np.float64):
@@ -52,6 +56,9 @@ def _to_device(intensities, what: str, integer_histogram: bool = False):
         lo, hi = (int(a.min()), int(a.max())) if a.size else (0, 0)
         if lo >= 0 and hi <= 65535:
             a = a.astype(np.uint16)  # exact: same values, same integer histogram
+        elif integer_histogram and shifted is not None and hi - lo <= 65535:
+            shifted[0] = lo
+            a = (a - a.dtype.type(lo)).astype(np.uint16)  # lo is a value of the image: no overflow in its own dtype
         elif integer_histogram:
             raise NotImplementedError(
                 f"{what}: integer image with values in [{lo}, {hi}]: scikit-image bins integers one bin per value, "
@@ -283,9 +290,11 @@ def apply_threshold(
             f"Supported methods: {', '.join(_SUPPORTED_METHODS)}"
         )
     src_dtype = intensities.dtype if isinstance(intensities, DeviceArray) else np.asarray(intensities).dtype
-    d, was_numpy = _to_device(intensities, "apply_threshold",
-                              integer_histogram=method_lower in ("otsu", "yen", "isodata", "triangle", "minimum",
-                                                                 "mean", "li"))
+    shifted = [0]
+    hist_method = method_lower in ("otsu", "yen", "isodata", "triangle", "minimum", "mean", "li")
+    d, was_numpy = _to_device(intensities, "apply_threshold", integer_histogram=hist_method,
+                              shifted=shifted if hist_method else None)
+    offset = int(shifted[0])
     shape = d.shape
     if d.ndim != 2 and method_lower not in ("local", "niblack", "sauvola"):
         d = _flat(d)  # global methods: ONE threshold from the histogram of the whole stack
@@ -295,7 +304,24 @@ def apply_threshold(
         z = np.zeros(shape, dtype=bool)
         return z if was_numpy else ctx.asarray(z)
     kw = dict(kwargs)
-    if method_lower == "otsu":
+    if offset:
+        # integer image beyond uint16 whose range fits: histogram of x - min on the device, the reference's threshold
+        # from (counts, arange(min, max + 1)) on the host, and x > t  <=>  x - min > floor(t) - min for integers
+        hist = hipops.histogram_u16(d).numpy()[0]
+        counts, centers = _thresholds.counts_centers_u16(hist)
+        centers = centers + offset
+        if method_lower == "otsu":
+            kw.pop("nbins", None)
+            t = _thresholds.otsu(counts, centers)
+        elif method_lower == "mean":
+            t = _thresholds.mean_from_hist(counts, centers)
+        elif method_lower == "li":
+            t = _thresholds.li_from_hist(counts, centers, **kw)
+        else:
+            kw.pop("nbins", None)
+            t = getattr(_thresholds, method_lower)(counts, centers, **kw)
+        mask = hipops.greater_than(d, ctx.asarray(np.array([float(int(np.floor(t)) - offset)])))
+    elif method_lower == "otsu":
         thr = hipops.threshold_otsu(d, nbins=int(kw.pop("nbins", 256)))
         mask = hipops.greater_than(d, thr)
     elif method_lower in ("yen", "isodata", "triangle", "minimum"):

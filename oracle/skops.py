@@ -75,12 +75,11 @@ def histogram(image: np.ndarray, nbins: int = 256):
     if np.issubdtype(image.dtype, np.integer):
         image_min = int(image.min())
         image_max = int(image.max())
-        # _offset_array: non-negative images are used as is
-        if image_min < 0:
-            raise NotImplementedError("negative integer images are off the hot path")
-        hist = np.bincount(image, minlength=image_max - image_min + 1)
+        # one bin per integer from image_min to image_max.  scikit-image counts non-negative images from 0 and drops
+        # the bins below image_min, and shifts images with negative values by image_min first (_offset_array):
+        # either way the counts are those of image - image_min
+        hist = np.bincount((image.astype(np.int64) - image_min).ravel(), minlength=image_max - image_min + 1)
         bin_centers = np.arange(image_min, image_max + 1)
-        hist = hist[max(image_min, 0):]
         return hist, bin_centers
     hist, bin_edges = np.histogram(image, bins=nbins, range=None)
     bin_centers = (bin_edges[:-1] + bin_edges[1:]) / 2.0

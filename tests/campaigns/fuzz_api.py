@@ -42,6 +42,10 @@ def random_image():
         x = base * float(rng.choice([1.0, 4095.0, 1e-3])) - float(rng.choice([0.0, 0.0, 0.25]))
     else:
         x = (base * (min(np.iinfo(dt).max, 65535) * rng.uniform(0.05, 1.0))).astype(dt)
+        if np.dtype(dt).itemsize >= 4 and rng.random() < 0.4:  # beyond uint16, range still within 65,536 values
+            x = x + dt(rng.choice([70000, 1 << 20, 2_000_000_000]))
+        elif np.dtype(dt).kind == "i" and rng.random() < 0.3:
+            x = x - dt(rng.choice([5, 300, 20000]))
     layout = int(rng.integers(0, 5))
     if layout == 1:    # a view with the leading axis last in memory (channel-last files)
         x = np.ascontiguousarray(np.moveaxis(x, 0, -1)) if x.ndim > 2 else x
@@ -130,7 +134,10 @@ for case in range(ncases):
         k = float(rng.choice([0.2, -0.1, 0.5]))
         for method in ("niblack", "sauvola"):
             got, want = apply_threshold(x, method, window_size=w, k=k), ref_threshold(x, method, window_size=w, k=k)
-            ok = np.array_equal(got, want) if x.dtype != np.float64 else (got != want).mean() < 2e-3
+            exact = x.dtype != np.float64 and int(x.min()) >= 0 and int(x.max()) <= 65535  # else float64 window sums
+            ok = np.array_equal(got, want) if exact else (got != want).mean() < 2e-3
+            if not exact and x.dtype != np.float64 and int(x.max()) > (1 << 24):
+                continue  # E[x^2] - E[x]^2 at 2e9 +- 3e4 cancels to noise in float64, in scikit-image as here
             check("threshold " + method, ok, info + (w, k))
     kw = dict(block_size=int(rng.choice([3, 7, 13])), offset=float(rng.choice([0, 0, 2.5])))
     got, want = apply_threshold(x, "local", **kw), ref_threshold(x, "local", **kw)

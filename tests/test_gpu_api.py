@@ -507,7 +507,15 @@ def test_operators_on_stacks_and_other_dtypes():
     p = np.percentile(wide, (1, 99))
     assert np.array_equal(rescale_by_percentile(wide, (1, 99)), skops.rescale_intensity(wide, (p[0], p[1]), (0, 1)))
     with pytest.raises(NotImplementedError, match="one bin per value"):
-        apply_threshold(wide, "otsu")
+        apply_threshold(wide, "otsu")  # range of 40 million values: refused
+    # integer images beyond uint16 whose RANGE fits 65,536 values: binned from min to max like scikit-image
+    for shift, dt in ((100000, np.int32), (3_000_000_000, np.int64), (-20000, np.int32), (70000, np.uint32)):
+        y = (t3[0].astype(np.int64) + shift).astype(dt)
+        for method in ("otsu", "yen", "isodata", "triangle", "mean", "li"):
+            want = y > getattr(skops, "threshold_" + method)(y)
+            assert np.array_equal(apply_threshold(y, method), want), (shift, method)
+        ys = (t3.astype(np.int64) + shift).astype(dt)  # a stack: ONE threshold from the histogram of all planes
+        assert np.array_equal(apply_threshold(ys, "otsu"), ys > skops.threshold_otsu(ys)), shift
     f32 = (t3[1] / 65535.0).astype(np.float32)
     p32 = np.percentile(f32, (1, 99))
     ref32 = skops.rescale_intensity(f32.astype(np.float64), (float(p32[0]), float(p32[1])), (0, 1))
