@@ -188,12 +188,19 @@ __global__ void __launch_bounds__(256) hist_f64_kernel(const double* __restrict_
     const double norm = (double)nbins / (hi - lo);
     const double* src = in + (size_t)plane * n;
     const int lane = threadIdx.x & 63;
-    // four independent loads per thread and step; a smoothed image is mostly background, so whole waves often
-    // fall into ONE bin: those add their population count once instead of 64 same-address LDS atomics
-    for (size_t i0 = (size_t)blockIdx.x * 1024 + threadIdx.x; i0 < n; i0 += (size_t)gridDim.x * 1024) {
+    // four CONSECUTIVE samples per thread and step (two 16-byte loads, ONE packed 4-byte store of their bins); a
+    // smoothed image is mostly background, so whole waves often fall into ONE bin: those add their population
+    // count once instead of 64 same-address LDS atomics
+    const bool vec = (n & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 31) == 0;
+    for (size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i0 < n; i0 += (size_t)gridDim.x * 1024) {
         double v4[4];
+        if (vec) {
+            const double2 a = *reinterpret_cast<const double2*>(src + i0), c = *reinterpret_cast<const double2*>(src + i0 + 2);
+            v4[0] = a.x, v4[1] = a.y, v4[2] = c.x, v4[3] = c.y;
+        } else {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v4[u] = (i0 + (size_t)u * 256 < n) ? src[i0 + (size_t)u * 256] : __builtin_nan("");
+            for (int u = 0; u < 4; ++u) v4[u] = (i0 + u < n) ? src[i0 + u] : __builtin_nan("");
+        }
         // first guess of every bin and BOTH of its edges (eight LDS reads in flight, no dependent chain); the guess
         // is exact unless the value sits within rounding distance of an edge -- only then the walk below runs
         int b4[4];
@@ -205,9 +212,10 @@ __global__ void __launch_bounds__(256) hist_f64_kernel(const double* __restrict_
             int b = ok ? (int)((v - lo) * norm) : 0;
             b = b < 0 ? 0 : (b > nbins - 1 ? nbins - 1 : b);
             b4[u] = b;
-            elo4[u] = edges[b];
-            ehi4[u] = edges[b + 1];
+            elo4[u] = (double)b * step + lo;  // == edges[b] (b < nbins), without the LDS round trip
+            ehi4[u] = b + 1 == nbins ? hi : (double)(b + 1) * step + lo;
         }
+        unsigned packed = 0;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const double v = v4[u];
@@ -218,7 +226,7 @@ __global__ void __launch_bounds__(256) hist_f64_kernel(const double* __restrict_
                 while (b < nbins - 1 && v >= edges[b + 1]) ++b;
             }
             // (a constant plane has no bins: lo == hi makes the scaling infinite -- its bytes are 0 like its threshold's)
-            if (bins && i0 + (size_t)u * 256 < n) bins[(size_t)plane * n + i0 + (size_t)u * 256] = (uint8_t)(ok && lo < hi ? b : 0);
+            packed |= (unsigned)(ok && lo < hi ? b : 0) << (8 * u);
             const unsigned long long act = __ballot(ok);
             if (!act) continue;
             // two rounds of "first lane's bin, counted once for everyone who shares it" (64 same-address LDS atomics
@@ -235,6 +243,16 @@ __global__ void __launch_bounds__(256) hist_f64_kernel(const double* __restrict_
                 if (lane == l1) atomicAdd(&mine[b1], (unsigned)__popcll(s1));
                 rest &= ~s1;
                 if ((rest >> lane) & 1ull) atomicAdd(&mine[b], 1u);
+            }
+        }
+        if (bins) {
+            uint8_t* dst = bins + (size_t)plane * n + i0;
+            if (vec) {
+                *reinterpret_cast<unsigned*>(dst) = packed;
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (i0 + u < n) dst[u] = (uint8_t)(packed >> (8 * u));
             }
         }
     }
