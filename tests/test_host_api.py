@@ -522,3 +522,33 @@ def test_nd2lite_on_the_reference_fixtures_when_present():
         arr, meta = nd2lite.load_nd2(data / name, use_device=False)
         assert meta.sizes == sizes and arr.shape == tuple(sizes.values()) and arr.dtype == np.uint16, name
         assert meta.channel_metadata_list[0].dimensions == flags, name
+
+
+def test_compat_install_aliases_the_reference_import_names():
+    """Scripts written against the reference run unchanged after compat.install(): the reference's import names
+    resolve to this package's modules (same objects), and uninstall() removes them again."""
+    import importlib
+    import sys
+
+    from arcadia_microscopy_tools_amd import compat
+
+    assert "arcadia_microscopy_tools" not in sys.modules
+    compat.install()
+    try:
+        import arcadia_microscopy_tools as ref  # noqa: F401
+        from arcadia_microscopy_tools import ImageOperation as RefOp, Pipeline as RefPipeline
+        from arcadia_microscopy_tools.channels import DAPI as RefDapi
+        from arcadia_microscopy_tools.masks import SegmentationMask as RefMask
+        from arcadia_microscopy_tools.microplate import MicroplateLayout as RefLayout
+        from arcadia_microscopy_tools.operations import rescale_by_percentile as ref_rescale
+
+        from arcadia_microscopy_tools_amd.microplate import MicroplateLayout
+
+        assert ref is amt and RefOp is ImageOperation and RefPipeline is Pipeline and RefDapi is DAPI
+        assert RefMask is SegmentationMask and RefLayout is MicroplateLayout and ref_rescale is rescale_by_percentile
+        assert importlib.import_module("arcadia_microscopy_tools.model").SegmentationModel is SegmentationModel
+        with pytest.raises(ImportError):
+            importlib.import_module("arcadia_microscopy_tools.nikon")
+    finally:
+        compat.uninstall()
+    assert "arcadia_microscopy_tools" not in sys.modules and "arcadia_microscopy_tools.masks" not in sys.modules
