@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes
 import os
 import threading
-from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_size_t, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # AMT_HIP_LIB: another build of the same library (instrumented / experimental variants made by tools/), never a fallback
