@@ -3,13 +3,16 @@
 The reference wraps Cellpose-SAM, whose weights are fetched from the network by name (R/model.py:160-169)
 and therefore cannot be loaded offline.  This class keeps the reference's constructor fields, parameter
 resolution / validation (same messages), return dtype (int64 labels, background 0) and per-image failure
-semantics of ``batch_segment`` (warning + ``None``), and adds a ``backend`` switch:
+semantics of ``batch_segment`` (warning + ``None``), and adds a ``backend`` switch.  The DEFAULT is the reference's own
+behaviour (``backend="cellpose"``): ``SegmentationModel()`` never silently runs a different algorithm -- without the
+cellpose package it fails loudly (``RuntimeError: Failed to load Cellpose model``), and the module keeps the name
+``CellposeModel`` at module level, where the reference has it (its tests patch it there).
 
-  backend="classical" (default): the nuclei chain of BASELINE.json config 3 on the GPU -- Gaussian -> Otsu ->
+  backend="classical": the nuclei chain of BASELINE.json config 3 on the GPU -- Gaussian -> Otsu ->
       opening/closing -> EDT -> peak markers -> watershed -> sequential labels (``segment.FovSegmenter``).
       ``cell_diameter_px`` sets the marker spacing (min_distance = round(diameter / 6), 5 px for the default
       30 px); the Cellpose-specific thresholds are validated for API parity but do not apply.
-  backend="cellpose": delegates to ``cellpose.models.CellposeModel`` exactly like the reference when that
+  backend="cellpose" (default): delegates to ``cellpose.models.CellposeModel`` exactly like the reference when that
       package and its weights are available (PyTorch-ROCm device selection is unchanged: ``torch.cuda`` is
       the ROCm device).  Without the package, a flow network given as ``network=`` (any ``torch.nn.Module`` mapping
       (N, C, H, W) images to (N, 3, H, W) = dY, dX, cellprob -- e.g. a locally stored checkpoint) runs in bf16
@@ -35,6 +38,18 @@ from .typing import Float64Array, Int64Array
 
 logger = logging.getLogger(__name__)
 
+try:  # the reference imports this name at module level (R/model.py:9); kept so that it can be patched / replaced
+    from cellpose.models import CellposeModel
+except Exception as _cellpose_error:  # not installed (or its own imports fail): constructing it says so
+    _CELLPOSE_IMPORT_ERROR = _cellpose_error
+
+    class CellposeModel:  # type: ignore[no-redef]
+        """Placeholder for ``cellpose.models.CellposeModel`` on machines without the cellpose package."""
+
+        def __init__(self, *args, **kwargs):
+            raise ImportError(f"the cellpose package is not available ({_CELLPOSE_IMPORT_ERROR}); use "
+                              "backend='classical', or backend='cellpose-hip' with network=")
+
 
 class CellposeParams(TypedDict):
     """Resolved parameters in ``CellposeModel.eval`` naming (R/model.py:18-25)."""
@@ -56,7 +71,7 @@ class SegmentationModel:
     default_num_iterations: int | None = None
     default_batch_size: int = 8
     device: Any = field(default=None)
-    backend: str = "classical"
+    backend: str = "cellpose"
     sigma: float = 2.0
     opening_radius: int = 2
     network: Any = field(default=None, repr=False)
@@ -119,9 +134,7 @@ class SegmentationModel:
         if self._model is None:
             logger.info(f"Loading Cellpose-SAM model on {self.device}")
             try:
-                from cellpose.models import CellposeModel
-
-                self._model = CellposeModel(device=self.device)
+                self._model = CellposeModel(device=self.device)  # the module-level name, as in the reference
             except Exception as e:
                 raise RuntimeError(f"Failed to load Cellpose model: {e}") from e
         return self._model
@@ -132,9 +145,7 @@ class SegmentationModel:
         if self.backend == "cellpose-hip":
             return True
         if self.backend == "cellpose" and self.network is not None:
-            import importlib.util
-
-            return importlib.util.find_spec("cellpose") is None
+            return "_CELLPOSE_IMPORT_ERROR" in globals()  # the package is absent: the network + HIP route
         return False
 
     def _flow_network(self):

@@ -239,7 +239,7 @@ def test_segmentation_model_classical():
     from oracle import chains, skops
 
     fov = synth.synth_fov(4, size=320)
-    model = SegmentationModel()
+    model = SegmentationModel(backend="classical")
     mask = model.segment(fov[1])
     assert mask.dtype == np.int64 and mask.shape == (320, 320)
     _, inter = chains.c3_labels(fov[1])

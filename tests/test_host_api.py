@@ -226,7 +226,9 @@ def test_segmentation_mask_validation():
 
 # ---- SegmentationModel parameter handling (RT/test_model.py:40-80,453-490) ----------------------------------
 def test_segmentation_model_parameters():
-    model = SegmentationModel()
+    default = SegmentationModel()  # the reference's behaviour: Cellpose, device picked, nothing loaded yet
+    assert default.backend == "cellpose" and default.device is not None and default._model is None
+    model = SegmentationModel(backend="classical")
     assert (model.default_cell_diameter_px, model.default_flow_threshold, model.default_cellprob_threshold,
             model.default_num_iterations, model.default_batch_size) == (30, 0.4, 0, None, 8)
     p = model._resolve_and_validate_parameters(None, None, None, None, None)
