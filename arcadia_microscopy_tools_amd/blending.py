@@ -93,6 +93,42 @@ def _build_lut(color: str, zero_transparent: bool) -> np.ndarray:
     return lut
 
 
+class _LutColormap:
+    """What the reference gets from ``LinearSegmentedColormap.from_list`` (R/blending.py:204-221), reduced to what it
+    uses: a callable that maps floats in [0, 1] to RGBA rows of the 256-entry table (``Colormap.__call__``: the
+    index is ``int(x * 256)``, 1.0 lands in the last entry)."""
+
+    def __init__(self, name: str, table: np.ndarray):
+        self.name, self.N, self._table = name, table.shape[0], table
+
+    def __call__(self, x):
+        scaled = np.array(x, dtype=np.float64, copy=True) * self.N
+        scaled[scaled == self.N] = self.N - 1
+        return self._table[np.clip(scaled, 0, self.N - 1).astype(int)]
+
+
+@lru_cache(maxsize=64)
+def _build_colormap(color: str, zero_transparent: bool) -> _LutColormap:
+    """The reference's cached two-stop colour map (R/blending.py:204-221) as a host-side callable; the device kernel
+    reads the same table (``_build_lut``)."""
+    return _LutColormap(f"_chan_{color}", _build_lut(color, zero_transparent))
+
+
+def _blend_alpha(background, foreground, alpha):
+    """Porter-Duff 'over' on host arrays (R/blending.py:186-192); ``amt_overlay`` evaluates the same expression."""
+    return np.clip(alpha * foreground + (1 - alpha) * background, 0.0, 1.0)
+
+
+def _blend_additive(background, foreground, alpha):
+    """Additive compositing on host arrays (R/blending.py:195-201)."""
+    return np.clip(background + alpha * foreground, 0.0, 1.0)
+
+
+def _gray_to_rgb(image):
+    """(H, W) -> (H, W, 3) on the host (R/blending.py:224-226)."""
+    return np.repeat(np.asarray(image)[:, :, np.newaxis], 3, axis=2)
+
+
 def overlay_channels(background, channel_intensities: dict, *, opacity: float = 1.0, zero_transparent: bool = True,
                      blend_mode: BlendMode = BlendMode.ALPHA):
     """Overlay with uniform settings for all channels (R/blending.py:74-113)."""

@@ -56,6 +56,46 @@ def _process_mask_device(mask_image, remove_edge_cells: bool, mx=None):
     return lab, int(cnt.numpy()[0])
 
 
+def _process_mask(mask_image, remove_edge_cells: bool):
+    """The reference's module-level helper (R/masks.py:38-65): host array in, int64 label image out."""
+    return _process_mask_device(np.asarray(mask_image), remove_edge_cells)[0].numpy_int64()
+
+
+def _sequential_labels_on_device(label_image):
+    """Arbitrary positive labels -> (int32 device plane numbered 1..k in ascending order of the labels, k)."""
+    from . import hipops
+    from .device import get_context
+
+    a = np.asarray(label_image)
+    if a.ndim != 2:
+        raise ValueError("label_image must be a 2D array")
+    mx = int(a.max()) if a.size else 0
+    if mx <= 0:
+        return None, 0
+    if mx >= 2**31 - 1:
+        raise ValueError("label values above 2**31 - 2 are not supported on the device path")
+    lab, cnt = hipops.relabel_sequential(get_context().asarray(a, dtype=np.int32), mx)
+    return lab, int(cnt.numpy()[0])
+
+
+def _extract_outlines_skimage(label_image):
+    """The reference's module-level helper (R/masks.py:82-115): one (n, 2) float64 (y, x) outline per label present
+    in ``label_image``, in ascending label order -- marching squares on the device (``hipops.cell_outlines``)."""
+    from . import hipops
+
+    lab, k = _sequential_labels_on_device(label_image)
+    return hipops.cell_outlines(lab, k) if k else []
+
+
+def _extract_outlines_cellpose(label_image):
+    """The reference's module-level helper (R/masks.py:68-79): ``cellpose.utils.outlines_list`` per label, (y, x)
+    order -- border following on the device (``hipops.cell_outlines_borders``; parity unpinned)."""
+    from . import hipops
+
+    lab, k = _sequential_labels_on_device(label_image)
+    return hipops.cell_outlines_borders(lab, k) if k else []
+
+
 def _extrema(a: np.ndarray):
     """(min, max) of a 2-D array; planes of a megapixel and more are reduced in four row bands on the host-copy
     threads (numpy releases the GIL): 0.4 ms instead of 1.4 for a 2048^2 int64 label image."""

@@ -619,3 +619,28 @@ def test_integer_dtypes_keep_their_own_float_conversion():
                                       x[0] > skops.threshold_sauvola(x[0], window_size=w)), (np.dtype(dt), w)
             assert np.array_equal(apply_threshold(x[0], "sauvola", window_size=7, r=100.0),
                                   x[0] > skops.threshold_sauvola(x[0], window_size=7, r=100.0)), np.dtype(dt)
+
+
+def test_module_level_mask_helpers_of_the_reference(golden):
+    """R/masks.py keeps ``_process_mask`` / ``_extract_outlines_skimage`` / ``_extract_outlines_cellpose`` at module
+    level and its own tests call them (RT/test_masks.py:86-149): same names here, arbitrary positive labels in,
+    one outline per PRESENT label in ascending order."""
+    from arcadia_microscopy_tools_amd import masks
+    from oracle import contours as oc
+    from oracle import skops
+
+    g = golden("disks_80")
+    lab = g["labels"].astype(np.int64)
+    sparse = np.where(lab > 0, lab * 7 + 3, 0)  # labels 10, 17, 24, ...: gaps, same order
+    want = oc.extract_outlines_skimage(lab)
+    for image in (lab, sparse):
+        got = masks._extract_outlines_skimage(image)
+        assert len(got) == len(want) and all(a.dtype == np.float64 and np.array_equal(a, b) for a, b in zip(got, want))
+        got_c = masks._extract_outlines_cellpose(image)
+        want_c = oc.extract_outlines_cellpose(lab)
+        assert len(got_c) == len(want_c) and all(np.array_equal(a, b) for a, b in zip(got_c, want_c))
+    assert masks._extract_outlines_skimage(np.zeros((9, 9), np.int64)) == []
+    out = masks._process_mask(sparse, remove_edge_cells=False)
+    assert out.dtype == np.int64 and np.array_equal(out, skops.relabel_sequential(sparse))
+    assert np.array_equal(masks._process_mask(lab > 0, remove_edge_cells=True),
+                          skops.label(skops.clear_border(skops.label(lab > 0)) > 0))

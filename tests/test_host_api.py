@@ -554,3 +554,26 @@ def test_compat_install_aliases_the_reference_import_names():
     finally:
         compat.uninstall()
     assert "arcadia_microscopy_tools" not in sys.modules and "arcadia_microscopy_tools.masks" not in sys.modules
+
+
+def test_blending_host_helpers_of_the_reference():
+    """RT/test_blending.py exercises ``_blend_alpha`` / ``_blend_additive`` / ``_build_colormap`` / ``_gray_to_rgb``
+    directly; same names and contracts here (host numpy, no GPU)."""
+    from arcadia_microscopy_tools_amd.blending import _blend_additive, _blend_alpha, _build_colormap, _gray_to_rgb
+    from oracle import blending as ob
+
+    bg, fg = np.full((4, 5, 3), 0.25), np.full((4, 5, 3), 0.75)
+    assert np.array_equal(_blend_alpha(bg, fg, np.zeros((4, 5, 1))), bg)
+    assert np.array_equal(_blend_alpha(bg, fg, np.ones((4, 5, 1))), fg)
+    assert np.allclose(_blend_alpha(bg, fg, np.full((4, 5, 1), 0.5)), 0.5)
+    assert np.array_equal(_blend_additive(bg, fg, np.zeros((4, 5, 1))), bg)
+    assert _blend_additive(fg, fg, np.ones((4, 5, 1))).max() == 1.0  # clipped
+    assert np.array_equal(_blend_additive(bg, fg, np.ones((4, 5, 1))), _blend_additive(fg, bg, np.ones((4, 5, 1))))
+    t, o = _build_colormap("#FF0000", True), _build_colormap("#FF0000", False)
+    assert t is _build_colormap("#FF0000", True) and t is not o  # cached per (colour, transparency)
+    assert t(np.array([0.0]))[0, 3] == 0.0 and o(np.array([0.0]))[0, 3] == 1.0
+    assert np.array_equal(t(np.array([1.0]))[0], [1.0, 0.0, 0.0, 1.0])
+    x = np.random.default_rng(0).random((6, 7))
+    assert np.array_equal(t(x), ob.apply_lut(ob.build_lut("#FF0000", True), x))
+    g = _gray_to_rgb(x)
+    assert g.shape == (6, 7, 3) and all(np.array_equal(g[..., c], x) for c in range(3))
