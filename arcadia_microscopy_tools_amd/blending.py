@@ -124,6 +124,11 @@ def _blend_additive(background, foreground, alpha):
     return np.clip(background + alpha * foreground, 0.0, 1.0)
 
 
+def _composite(background, foreground, alpha, mode):
+    """Dispatch on the blend mode (R/blending.py:174-183)."""
+    return (_blend_additive if mode is BlendMode.ADDITIVE else _blend_alpha)(background, foreground, alpha)
+
+
 def _gray_to_rgb(image):
     """(H, W) -> (H, W, 3) on the host (R/blending.py:224-226)."""
     return np.repeat(np.asarray(image)[:, :, np.newaxis], 3, axis=2)

@@ -14,12 +14,24 @@ from .channels import Channel
 class DimensionFlags(Flag):
     """Which dimensions an acquisition has (R/metadata_structures.py:34-67)."""
 
-    MULTICHANNEL = auto()
-    TIMELAPSE = auto()
+    SPATIAL_2D = 0
+    MULTICHANNEL = auto()  # member order (= bit values) as in R/metadata_structures.py:37-43
     Z_STACK = auto()
+    TIMELAPSE = auto()
     SPECTRAL = auto()
     RGB = auto()
     MONTAGE = auto()
+
+    def _has(self, flag: "DimensionFlags") -> bool:
+        return bool(self & flag)
+
+    # the reference's convenience tests (R/metadata_structures.py:45-67)
+    is_multichannel = property(lambda self: self._has(DimensionFlags.MULTICHANNEL))
+    is_zstack = property(lambda self: self._has(DimensionFlags.Z_STACK))
+    is_timelapse = property(lambda self: self._has(DimensionFlags.TIMELAPSE))
+    is_spectral = property(lambda self: self._has(DimensionFlags.SPECTRAL))
+    is_rgb = property(lambda self: self._has(DimensionFlags.RGB))
+    is_montage = property(lambda self: self._has(DimensionFlags.MONTAGE))
 
 
 @dataclass

@@ -125,6 +125,17 @@ class MicroscopyImage:
         intensities, instrument = load_nd2(Path(nd2_path), channels)
         return cls(intensities, Metadata(instrument, sample_metadata))
 
+    @classmethod
+    def from_lif_path(cls, lif_path: Path, image_name: str, channels: list[Channel] | None = None,
+                      sample_metadata: dict[str, Any] | None = None) -> "MicroscopyImage":
+        """The reference reads Leica LIF files through the ``liffile`` package (R/microscopy.py:178-203,
+        R/leica.py); file loaders other than uncompressed ND2 are outside this package: load the
+        pixels with the reference's loader and hand them to ``from_array``."""
+        raise NotImplementedError(
+            "Leica LIF loading is not part of the MI355X hot path: read the image with the reference's "
+            "arcadia_microscopy_tools.leica.load_lif_image and pass the array to MicroscopyImage.from_array"
+        )
+
     # -- properties -------------------------------------------------------------------------------
     @property
     def shape(self) -> tuple[int, ...]:
