@@ -16,7 +16,8 @@ from pathlib import Path
 import numpy as np
 
 from .channels import BRIGHTFIELD, CHANNELS, FITC, Channel
-from .metadata_structures import ChannelMetadata, DimensionFlags
+from .metadata_structures import (AcquisitionSettings, ChannelMetadata, DimensionFlags, MicroscopeConfig,
+                                  NominalDimensions)
 
 _MAGIC = 0x0ABECEDA
 _MAP_SIG = b"ND2 CHUNK MAP SIGNATURE 0000001!"
@@ -154,7 +155,51 @@ def read_channel_names(data: bytes, cmap, n_components: int) -> list[str]:
         return []
 
 
+def read_channel_settings(data: bytes, cmap, n_components: int) -> list[dict]:
+    """Per component: pixel size, objective, exposure, zoom and binning as the acquisition software stored them
+    (``SLxPictureMetadata`` of ``ImageMetadataSeqLV|0!``: ``dCalibration`` and one ``sSampleSetting`` per plane) --
+    the values R/nikon.py:220-300 takes from the ``nd2`` package's channel records.  Missing pieces stay None."""
+    key = b"ImageMetadataSeqLV|0!"
+    out = [dict(xy_step_um=None, magnification=None, numerical_aperture=None, exposure_time_s=None, zoom=None,
+                binning=None) for _ in range(n_components)]
+    if key not in cmap:
+        return out
+    try:
+        pic = parse_lite_variant(chunk_payload(data, cmap[key]))[0]["SLxPictureMetadata"]
+    except Exception:
+        return out
+    cal = pic.get("dCalibration")
+    planes = pic.get("sPicturePlanes", {}) if isinstance(pic.get("sPicturePlanes"), dict) else {}
+    settings = planes.get("sSampleSetting", {}) if isinstance(planes.get("sSampleSetting"), dict) else {}
+    order = sorted(settings, key=lambda s: int("".join(c for c in s if c.isdigit()) or 0))
+    for i, rec in enumerate(out):
+        if isinstance(cal, float) and cal > 0:
+            rec["xy_step_um"] = cal
+        st = settings.get(order[i]) if i < len(order) else None
+        if not isinstance(st, dict):
+            continue
+        obj = st.get("pObjectiveSetting") if isinstance(st.get("pObjectiveSetting"), dict) else {}
+        if isinstance(obj.get("dObjectiveMag"), float) and obj["dObjectiveMag"] > 0:
+            rec["magnification"] = obj["dObjectiveMag"]
+        if isinstance(obj.get("dObjectiveNA"), float) and obj["dObjectiveNA"] > 0:
+            rec["numerical_aperture"] = obj["dObjectiveNA"]
+        if isinstance(st.get("dExposureTime"), float) and st["dExposureTime"] >= 0:
+            rec["exposure_time_s"] = st["dExposureTime"] / 1000.0  # stored in milliseconds
+        dev = st.get("pDeviceSetting") if isinstance(st.get("pDeviceSetting"), dict) else {}
+        if isinstance(dev.get("m_dZoomPosition"), float):
+            rec["zoom"] = dev["m_dZoomPosition"]
+        cam = st.get("pCameraSetting") if isinstance(st.get("pCameraSetting"), dict) else {}
+        fmt = cam.get("FormatQuality") or cam.get("FormatFast") or {}
+        desc = fmt.get("fmtDesc", {}) if isinstance(fmt, dict) else {}
+        if isinstance(desc.get("dBinningX"), float) and isinstance(desc.get("dBinningY"), float):
+            rec["binning"] = f"{desc['dBinningX']:g}x{desc['dBinningY']:g}"
+    return out
+
+
 _LOOP_AXIS = {1: "T", 8: "T", 2: "P", 4: "Z"}  # SLxExperiment.eType: time, non-equidistant time, XY position, z stack
+
+
+_LOOP_STEPS: dict[str, float] = {}  # filled by the last read_experiment_loops call: {"Z": z step in um, "T": period in ms}
 
 
 def read_experiment_loops(data: bytes, cmap) -> list[tuple[str, int]]:
@@ -170,6 +215,7 @@ def read_experiment_loops(data: bytes, cmap) -> list[tuple[str, int]]:
     except Exception:
         return []
     loops: list[tuple[str, int]] = []
+    _LOOP_STEPS.clear()
     level = meta.get("SLxExperiment", meta)
     while isinstance(level, dict):
         pars = level.get("uLoopPars")
@@ -179,6 +225,10 @@ def read_experiment_loops(data: bytes, cmap) -> list[tuple[str, int]]:
         axis = _LOOP_AXIS.get(int(level.get("eType", 0) or 0))
         if axis is not None and count > 1:
             loops.append((axis, count))
+            if isinstance(pars, dict):
+                step = pars.get("dZStep") if axis == "Z" else pars.get("dAvgPeriodDiff") or pars.get("dPeriod")
+                if isinstance(step, float) and step > 0:
+                    _LOOP_STEPS[axis] = step
         nxt = level.get("ppNextLevelEx") if int(level.get("uiNextLevelCount", 0) or 0) > 0 else None
         if isinstance(nxt, dict) and "eType" not in nxt:
             nxt = next((v for v in nxt.values() if isinstance(v, dict)), None)  # first (only) child level
@@ -211,6 +261,8 @@ def read_frames_interleaved(path: Path):
         rows = np.ndarray((H, W, C), dtype="<u2", buffer=payload, offset=8, strides=(stride, C * 2, 2))
         frames[i] = rows
     at["loops"] = read_experiment_loops(data, cmap)
+    at["loop_steps"] = dict(_LOOP_STEPS)
+    at["channel_settings"] = read_channel_settings(data, cmap, C)
     return frames, at, read_channel_names(data, cmap, C)
 
 
@@ -263,5 +315,22 @@ def load_nd2(nd2_path: Path, channels: list[Channel] | None = None, use_device: 
         flags |= DimensionFlags.Z_STACK
     if sizes.get("P", 1) > 1:
         flags |= DimensionFlags.MONTAGE
-    meta = InstrumentMetadata(sizes, [ChannelMetadata(ch, flags) for ch in channels])
+    steps = at.get("loop_steps", {})
+    records = []
+    for i, ch in enumerate(channels):
+        st = at["channel_settings"][i] if i < len(at.get("channel_settings", [])) else {}
+        resolution = acquisition = optics = None
+        if st.get("xy_step_um") is not None:
+            # z_size_px / z_step_um default to one plane of 1 um, as the nd2 package reports 2-D acquisitions
+            resolution = NominalDimensions(
+                x_size_px=W, y_size_px=H, xy_step_um=st["xy_step_um"], z_size_px=sizes.get("Z", 1),
+                z_step_um=steps.get("Z", 1.0), t_size_px=sizes.get("T") if sizes.get("T", 1) > 1 else None,
+                t_step_ms=steps.get("T") if sizes.get("T", 1) > 1 else None)
+        if any(st.get(k) is not None for k in ("exposure_time_s", "zoom", "binning")):
+            acquisition = AcquisitionSettings(exposure_time_s=st.get("exposure_time_s"), zoom=st.get("zoom"),
+                                              binning=st.get("binning"))
+        if st.get("magnification") is not None and st.get("numerical_aperture") is not None:
+            optics = MicroscopeConfig(magnification=st["magnification"], numerical_aperture=st["numerical_aperture"])
+        records.append(ChannelMetadata(ch, dimensions=flags, resolution=resolution, acquisition=acquisition, optics=optics))
+    meta = InstrumentMetadata(sizes, records)
     return out, meta
