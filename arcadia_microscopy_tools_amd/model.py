@@ -272,9 +272,9 @@ class SegmentationModel:
         iterator = enumerate(intensities_batch)
         if show_progress:
             try:
-                from tqdm import tqdm
+                from .utils import get_tqdm  # notebook-aware, as R/model.py:270-273
 
-                iterator = tqdm(iterator, total=len(intensities_batch), desc="Segmenting")
+                iterator = get_tqdm()(iterator, total=len(intensities_batch), desc="Segmenting")
             except Exception:
                 pass
         for i, intensities in iterator:
