@@ -2,7 +2,7 @@
 ``import arcadia_microscopy_tools`` (and its hot-path submodules) resolve to this package, so scripts written against the
 reference -- ``from arcadia_microscopy_tools.operations import rescale_by_percentile`` and so on -- run on the MI355X
 without an edit.  Only the modules this package implements are aliased (the hot path of SURVEY.md section 8 and its
-neighbours); ``leica`` / ``nikon`` stay the reference's own concern and raise ImportError here.
+neighbours); ``leica`` (LIF files) stays the reference's own concern and raises ImportError here.
 
 ``install()`` refuses to shadow a real installation of the reference unless ``force=True``; ``uninstall()`` removes
 the aliases again.
@@ -16,7 +16,7 @@ import sys
 REFERENCE_NAME = "arcadia_microscopy_tools"
 # reference submodule -> module of this package with the same public names
 SUBMODULES = ("blending", "channels", "exceptions", "masks", "metadata_structures", "microplate", "microscopy", "model",
-              "operations", "pipeline", "typing", "utils")
+              "nikon", "operations", "pipeline", "typing", "utils")
 _installed: list[str] = []
 
 

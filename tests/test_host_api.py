@@ -564,8 +564,10 @@ def test_compat_install_aliases_the_reference_import_names():
         assert ref is amt and RefOp is ImageOperation and RefPipeline is Pipeline and RefDapi is DAPI
         assert RefMask is SegmentationMask and RefLayout is MicroplateLayout and ref_rescale is rescale_by_percentile
         assert importlib.import_module("arcadia_microscopy_tools.model").SegmentationModel is SegmentationModel
+        assert callable(importlib.import_module("arcadia_microscopy_tools.nikon").load_nd2)
+        assert callable(importlib.import_module("arcadia_microscopy_tools.utils").get_tqdm)
         with pytest.raises(ImportError):
-            importlib.import_module("arcadia_microscopy_tools.nikon")
+            importlib.import_module("arcadia_microscopy_tools.leica")
     finally:
         compat.uninstall()
     assert "arcadia_microscopy_tools" not in sys.modules and "arcadia_microscopy_tools.masks" not in sys.modules
