@@ -644,3 +644,50 @@ def test_module_level_mask_helpers_of_the_reference(golden):
     assert out.dtype == np.int64 and np.array_equal(out, skops.relabel_sequential(sparse))
     assert np.array_equal(masks._process_mask(lab > 0, remove_edge_cells=True),
                           skops.label(skops.clear_border(skops.label(lab > 0)) > 0))
+
+
+def test_the_reference_tests_that_need_the_device():
+    """The 17 tests of the reference's own suite that cannot run without a GPU (14 of RT/test_blending.py:193-300, 3 of
+    RT/test_pipeline.py:264-328; the other 109 pass unchanged in the build container, tools/reference_tests_plugin.py):
+    the same situations and expectations, restated."""
+    import warnings
+
+    from arcadia_microscopy_tools_amd import BlendMode, Channel, Layer, create_overlay, overlay_channels
+
+    blue, green = Channel("Blue", "#0000FF"), Channel("Green", "#00FF00")
+    bg, ones = np.full((4, 4), 0.5), np.ones((4, 4))
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")  # an in-range background raises no warning of any kind
+        empty = create_overlay(bg, [])
+    assert empty.shape == (4, 4, 3) and np.allclose(empty, 0.5)
+    with pytest.warns(UserWarning, match=r"outside \[0, 1\]"):
+        clipped = create_overlay(np.array([[0.0, 2.0], [-0.5, 0.5]]), [])
+    assert clipped.min() >= 0.0 and clipped.max() <= 1.0
+    assert create_overlay(bg, [Layer(blue, ones)]).shape == (4, 4, 3)
+    two = create_overlay(bg, [Layer(blue, ones), Layer(green, ones, opacity=0.5)])
+    assert two.min() >= 0.0 and two.max() <= 1.0
+    assert np.allclose(create_overlay(bg, [Layer(blue, ones, opacity=0.0)]), 0.5, atol=1e-10)
+    alpha = create_overlay(bg, [Layer(blue, ones, blend_mode=BlendMode.ALPHA)])
+    assert alpha.shape == (4, 4, 3) and 0.0 <= alpha.min() and alpha.max() <= 1.0
+    a, b = Layer(blue, ones * 0.5, blend_mode=BlendMode.ADDITIVE), Layer(green, ones * 0.25, blend_mode=BlendMode.ADDITIVE)
+    assert np.allclose(create_overlay(bg, [a, b]), create_overlay(bg, [b, a]))  # additive layers commute
+    assert overlay_channels(bg, {blue: ones}).shape == (4, 4, 3)
+    assert np.allclose(overlay_channels(bg, {}), 0.5)
+    both = overlay_channels(bg, {blue: ones, green: ones})
+    assert both.shape == (4, 4, 3) and 0.0 <= both.min() and both.max() <= 1.0
+    assert overlay_channels(bg, {blue: ones}, zero_transparent=False).shape == (4, 4, 3)
+    assert np.array_equal(overlay_channels(bg, {blue: ones}, blend_mode=BlendMode.ALPHA), overlay_channels(bg, {blue: ones}))
+
+    rng = np.random.default_rng(0)
+    stack = rng.integers(0, 65535, (3, 128, 128)).astype(np.uint16)
+    norm = Pipeline([ImageOperation(rescale_by_percentile, percentile_range=(2, 98), out_range=(0, 1))],
+                    preserve_dtype=False, parallel=True)(stack)
+    assert norm.dtype in (np.float32, np.float64) and norm.min() >= 0 and norm.max() <= 1
+    kept = Pipeline([ImageOperation(rescale_by_percentile, percentile_range=(2, 98), out_range=(0, 65535))],
+                    preserve_dtype=True, parallel=True)(stack)
+    assert kept.dtype == np.uint16 and kept.shape == stack.shape
+    dim = rng.integers(100, 200, (2, 64, 64)).astype(np.uint16)
+    flow = Pipeline([ImageOperation(subtract_background_dog, low_sigma=1, high_sigma=10),
+                     ImageOperation(rescale_by_percentile, percentile_range=(1, 99), out_range=(0, 1))],
+                    preserve_dtype=False, parallel=True)(dim)
+    assert flow.dtype in (np.float32, np.float64) and flow.shape == dim.shape
