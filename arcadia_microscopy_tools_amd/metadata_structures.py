@@ -9,7 +9,7 @@ SURVEY.md 2a #10).
 """
 from __future__ import annotations
 
-from dataclasses import dataclass, field, fields
+from dataclasses import dataclass, field, fields, make_dataclass
 from datetime import datetime
 from enum import Flag, auto
 from typing import Any
@@ -56,57 +56,50 @@ class DimensionValidatorMixin:
                 raise ValueError(f"{info.name} is required for {needed.name}")
 
 
-@dataclass
-class NominalDimensions(DimensionValidatorMixin):
-    """Nominal sampling of every axis (R/metadata_structures.py:70-95)."""
-
-    x_size_px: int
-    y_size_px: int
-    xy_step_um: float
-    z_size_px: int | None = dimension_field(DimensionFlags.Z_STACK)
-    z_step_um: float | None = dimension_field(DimensionFlags.Z_STACK)
-    t_size_px: int | None = dimension_field(DimensionFlags.TIMELAPSE)
-    t_step_ms: float | None = dimension_field(DimensionFlags.TIMELAPSE)
-    w_size_px: int | None = dimension_field(DimensionFlags.SPECTRAL)
-    w_step_nm: float | None = dimension_field(DimensionFlags.SPECTRAL)
-
-
-@dataclass
-class MeasuredDimensions(DimensionValidatorMixin):
-    """Axis values as recorded during the acquisition (R/metadata_structures.py:98-116); the minimal ND2 reader leaves
-    them unset."""
-
-    x_values_um: Any = dimension_field(DimensionFlags.MONTAGE)
-    y_values_um: Any = dimension_field(DimensionFlags.MONTAGE)
-    z_values_um: Any = dimension_field(DimensionFlags.Z_STACK)
-    t_values_ms: Any = dimension_field(DimensionFlags.TIMELAPSE)
-    w_values_nm: Any = dimension_field(DimensionFlags.SPECTRAL)
+def _record(name: str, doc: str, spec, mixin: bool = True):
+    """A dataclass from a compact table: (field, type[, dimension that requires it]) rows; fields without a default
+    come first and are mandatory, the others default to None (tagged with their dimension where given)."""
+    rows = []
+    for row in spec:
+        fname, ftype = row[0], row[1]
+        if len(row) == 2:
+            rows.append((fname, ftype))
+        elif row[2] is None:
+            rows.append((fname, ftype, field(default=None)))
+        else:
+            rows.append((fname, ftype, dimension_field(row[2])))
+    cls = make_dataclass(name, rows, bases=(DimensionValidatorMixin,) if mixin else ())
+    cls.__doc__, cls.__module__ = doc, __name__
+    return cls
 
 
-@dataclass
-class AcquisitionSettings(DimensionValidatorMixin):
-    """Camera / scanner settings of one channel (R/metadata_structures.py:119-140)."""
+_Z, _T, _W, _M = DimensionFlags.Z_STACK, DimensionFlags.TIMELAPSE, DimensionFlags.SPECTRAL, DimensionFlags.MONTAGE
 
-    exposure_time_s: float | None = None
-    zoom: float | None = None
-    binning: str | None = None
-    pixel_dwell_time_us: float | None = None
-    line_scan_speed_hz: float | None = None
-    line_averaging: int | None = None
-    line_accumulation: int | None = None
-    frame_averaging: int | None = None
-    frame_accumulation: int | None = None
+NominalDimensions = _record(
+    "NominalDimensions", "Nominal sampling of every axis (R/metadata_structures.py:70-95).",
+    (("x_size_px", int), ("y_size_px", int), ("xy_step_um", float),
+     ("z_size_px", "int | None", _Z), ("z_step_um", "float | None", _Z),
+     ("t_size_px", "int | None", _T), ("t_step_ms", "float | None", _T),
+     ("w_size_px", "int | None", _W), ("w_step_nm", "float | None", _W)))
 
+MeasuredDimensions = _record(
+    "MeasuredDimensions", "Axis values as recorded during the acquisition (R/metadata_structures.py:98-116); the minimal "
+    "ND2 reader leaves them unset.",
+    (("x_values_um", Any, _M), ("y_values_um", Any, _M), ("z_values_um", Any, _Z), ("t_values_ms", Any, _T),
+     ("w_values_nm", Any, _W)))
 
-@dataclass
-class MicroscopeConfig:
-    """Objective and light source (R/metadata_structures.py:143-158)."""
+AcquisitionSettings = _record(
+    "AcquisitionSettings", "Camera / scanner settings of one channel (R/metadata_structures.py:119-140).",
+    tuple((n, t, None) for n, t in (
+        ("exposure_time_s", "float | None"), ("zoom", "float | None"), ("binning", "str | None"),
+        ("pixel_dwell_time_us", "float | None"), ("line_scan_speed_hz", "float | None"),
+        ("line_averaging", "int | None"), ("line_accumulation", "int | None"), ("frame_averaging", "int | None"),
+        ("frame_accumulation", "int | None"))))
 
-    magnification: int
-    numerical_aperture: float
-    objective: str | None = None
-    light_source: str | None = None
-    power_mw: float | None = None
+MicroscopeConfig = _record(
+    "MicroscopeConfig", "Objective and light source (R/metadata_structures.py:143-158).",
+    (("magnification", int), ("numerical_aperture", float), ("objective", "str | None", None),
+     ("light_source", "str | None", None), ("power_mw", "float | None", None)), mixin=False)
 
 
 @dataclass
