@@ -32,6 +32,7 @@
 // list threaded through one link per pixel.
 // amt_watershed_f64: arbitrary float64 relief; per-component binary heap keyed (value, age, raster).
 #include "amt_internal.h"
+#include <hip/hip_ext.h>
 
 // component classes
 enum { CLS_NONE = 0, CLS_UNIFORM = 1, CLS_S = 2, CLS_M = 3, CLS_M2 = 4, CLS_L = 5, CLS_X = 6, CLS_G = 7 };
@@ -1203,6 +1204,27 @@ __global__ void __launch_bounds__(256) ws_final_kernel(const int* __restrict__ L
     }
 }
 
+// AMT_WS_ANYORDER=0 keeps the flood classes of a context without auxiliary streams strictly in order (A/B switch)
+static bool ws_anyorder() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("AMT_WS_ANYORDER");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
+}
+
+// AMT_WS_LDS_PAD=bytes: extra dynamic LDS per flood workgroup (occupancy experiments only)
+static size_t ws_lds_pad() {
+    static long v = -1;
+    if (v < 0) {
+        const char* e = getenv("AMT_WS_LDS_PAD");
+        v = e ? atol(e) : 0;
+        if (v < 0) v = 0;
+    }
+    return (size_t)v;
+}
+
 static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const int32_t* markers,
                             const uint8_t* mask, int32_t* out, int nplanes, int H, int W, int seeds_first,
                             int connectivity, int tie_policy, int32_t* ties_dev, int32_t* fused_labels = nullptr,
@@ -1349,30 +1371,44 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
         // workgroups per plane and class (a workgroup only takes components of its own plane).  Measured: 2 x / 4 x as
         // many change nothing at 1, 12 or 32 planes per launch -- the chains per workgroup are not what bounds a class
         const int gM = 64, gS = 128, gL = 16;
-        hipLaunchKernelGGL((ws_flood_batch_kernel<L_PX, L_NB>), dim3(gL, nplanes), dim3(64), ldsL, ctx->stream,
-                           (const int*)relief, L, T, out, rows, wl + 3 * (size_t)nplanes * row_stride,
-                           wl_count + 3 * nplanes, counters + 0 * nplanes, row_stride, H, W, seeds_first, ties, markers);
-        AMT_LAUNCH_CHECK();
-        hipLaunchKernelGGL((ws_flood_lds_kernel<X_PX, X_NB, CLS_X>), dim3(8, nplanes), dim3(64), ldsX, ctx->stream,
-                           (const int*)relief, L, T, out, rows, wl + 4 * (size_t)nplanes * row_stride,
-                           wl_count + 4 * nplanes, counters + 11 * nplanes, row_stride, H, W, seeds_first, ties, markers);
-        AMT_LAUNCH_CHECK();
-        hipLaunchKernelGGL((ws_flood_batch_kernel<M2_PX, M2_NB>), dim3(32, nplanes), dim3(64), ldsM2, ctx->aux[2],
-                           (const int*)relief, L, T, out, rows, wl + 2 * (size_t)nplanes * row_stride,
-                           wl_count + 2 * nplanes, counters + 12 * nplanes, row_stride, H, W, seeds_first, ties, markers);
-        AMT_LAUNCH_CHECK();
-        hipLaunchKernelGGL((ws_flood_batch_kernel<M_PX, M_NB>), dim3(gM, nplanes), dim3(64), ldsM, ctx->aux[0],
-                           (const int*)relief, L, T, out, rows, wl + 1 * (size_t)nplanes * row_stride,
-                           wl_count + 1 * nplanes, counters + 1 * nplanes, row_stride, H, W, seeds_first, ties, markers);
-        AMT_LAUNCH_CHECK();
-        hipLaunchKernelGGL((ws_flood_batch_kernel<S_PX, S_NB>), dim3(gS, nplanes), dim3(64), ldsS, ctx->aux[1],
-                           (const int*)relief, L, T, out, rows, wl + 0 * (size_t)nplanes * row_stride,
-                           wl_count + 0 * nplanes, counters + 2 * nplanes, row_stride, H, W, seeds_first, ties, markers);
-        AMT_LAUNCH_CHECK();
-        hipLaunchKernelGGL(ws_flood_edt_kernel, dim3(4, nplanes), dim3(64), 0, ctx->aux[1], (const int*)relief, mask, out,
-                           next, head, tail, mlist, rows, moff, boff, ncomp, counters + 3 * nplanes, row_stride, H, W, n,
-                           bstride, seeds_first, ties);
-        AMT_LAUNCH_CHECK();
+        // Without auxiliary streams the classes still overlap: the first flood is an ordinary (barrier) launch, the
+        // others carry hipExtAnyOrderLaunch -- their packets have no barrier bit, so the command processor dispatches
+        // them while the earlier floods are still running; the next ordinary launch waits for all of them.
+        const bool any = ctx->fork == 0 && ws_anyorder();
+        int nflood = 0;
+        auto flood = [&](const void* fn, int gx, size_t lds, hipStream_t st, int cls_slot, int counter_slot) -> int {
+            const int* a_d2 = (const int*)relief;
+            const int* a_L = L;
+            const int* a_T = T;
+            int* a_out = out;
+            const comp_row* a_rows = rows;
+            const int* a_wl = wl + (size_t)cls_slot * nplanes * row_stride;
+            const int* a_wlc = wl_count + cls_slot * nplanes;
+            int* a_cnt = counters + counter_slot * nplanes;
+            size_t a_rs = row_stride;
+            int a_H = H, a_W = W, a_sf = seeds_first;
+            int* a_ties = ties;
+            const int* a_mk = markers;
+            void* args[] = {&a_d2, &a_L, &a_T, &a_out, &a_rows, &a_wl, &a_wlc, &a_cnt, &a_rs, &a_H, &a_W, &a_sf, &a_ties, &a_mk};
+            AMT_HIP_CHECK(hipExtLaunchKernel(fn, dim3(gx, nplanes), dim3(64), args, lds + ws_lds_pad(), st, nullptr, nullptr,
+                                             (any && nflood > 0) ? (int)hipExtAnyOrderLaunch : 0));
+            ++nflood;
+            return AMT_OK;
+        };
+        AMT_TRY(flood((const void*)ws_flood_batch_kernel<L_PX, L_NB>, gL, ldsL, ctx->stream, 3, 0));
+        AMT_TRY(flood((const void*)ws_flood_lds_kernel<X_PX, X_NB, CLS_X>, 8, ldsX, ctx->stream, 4, 11));
+        AMT_TRY(flood((const void*)ws_flood_batch_kernel<M2_PX, M2_NB>, 32, ldsM2, ctx->aux[2], 2, 12));
+        AMT_TRY(flood((const void*)ws_flood_batch_kernel<M_PX, M_NB>, gM, ldsM, ctx->aux[0], 1, 1));
+        AMT_TRY(flood((const void*)ws_flood_batch_kernel<S_PX, S_NB>, gS, ldsS, ctx->aux[1], 0, 2));
+        {
+            const int* a_d2 = (const int*)relief;
+            void* args[] = {&a_d2, (void*)&mask, &out, &next, &head, &tail, &mlist, (void*)&rows, &moff, &boff, &ncomp, nullptr,
+                            (void*)&row_stride, &H, &W, (void*)&n, (void*)&bstride, &seeds_first, &ties};
+            int* a_cnt = counters + 3 * nplanes;
+            args[11] = &a_cnt;
+            AMT_HIP_CHECK(hipExtLaunchKernel((const void*)ws_flood_edt_kernel, dim3(4, nplanes), dim3(64), args, 0, ctx->aux[1],
+                                             nullptr, nullptr, any ? (int)hipExtAnyOrderLaunch : 0));
+        }
         AMT_TRY(amt_join(ctx));
     } else {
         hipLaunchKernelGGL(ws_flood_heap_kernel, dim3(64, nplanes), dim3(64), 0, ctx->stream, (const double*)relief,

@@ -199,14 +199,12 @@ def read_channel_settings(data: bytes, cmap, n_components: int) -> list[dict]:
 _LOOP_AXIS = {1: "T", 8: "T", 2: "P", 4: "Z"}  # SLxExperiment.eType: time, non-equidistant time, XY position, z stack
 
 
-_LOOP_STEPS: dict[str, float] = {}  # filled by the last read_experiment_loops call: {"Z": z step in um, "T": period in ms}
-
-
-def read_experiment_loops(data: bytes, cmap) -> list[tuple[str, int]]:
+def read_experiment_loops(data: bytes, cmap, steps: dict | None = None) -> list[tuple[str, int]]:
     """[(axis letter, count)] of the acquisition loops, outermost first, from the ``SLxExperiment`` tree of the
     ``ImageMetadataLV!`` chunk (what ``nd2.ND2File.sizes`` is built from, R/nikon.py:197-210 reads 'T' / 'Z' / 'P'
     from it).  Loops of one step and loop kinds without a frame axis (spectral, eType 6) are skipped; [] when the
-    chunk is absent or cannot be read."""
+    chunk is absent or cannot be read.  ``steps`` (optional dict) receives {"Z": z step in um, "T": period in ms} for
+    the loops that state a positive step."""
     key = b"ImageMetadataLV!"
     if key not in cmap:
         return []
@@ -215,7 +213,6 @@ def read_experiment_loops(data: bytes, cmap) -> list[tuple[str, int]]:
     except Exception:
         return []
     loops: list[tuple[str, int]] = []
-    _LOOP_STEPS.clear()
     level = meta.get("SLxExperiment", meta)
     while isinstance(level, dict):
         pars = level.get("uLoopPars")
@@ -227,8 +224,8 @@ def read_experiment_loops(data: bytes, cmap) -> list[tuple[str, int]]:
             loops.append((axis, count))
             if isinstance(pars, dict):
                 step = pars.get("dZStep") if axis == "Z" else pars.get("dAvgPeriodDiff") or pars.get("dPeriod")
-                if isinstance(step, float) and step > 0:
-                    _LOOP_STEPS[axis] = step
+                if steps is not None and isinstance(step, float) and step > 0:
+                    steps[axis] = step
         nxt = level.get("ppNextLevelEx") if int(level.get("uiNextLevelCount", 0) or 0) > 0 else None
         if isinstance(nxt, dict) and "eType" not in nxt:
             nxt = next((v for v in nxt.values() if isinstance(v, dict)), None)  # first (only) child level
@@ -260,8 +257,8 @@ def read_frames_interleaved(path: Path):
             raise NotImplementedError("compressed ND2 frames are not supported")
         rows = np.ndarray((H, W, C), dtype="<u2", buffer=payload, offset=8, strides=(stride, C * 2, 2))
         frames[i] = rows
-    at["loops"] = read_experiment_loops(data, cmap)
-    at["loop_steps"] = dict(_LOOP_STEPS)
+    at["loop_steps"] = {}
+    at["loops"] = read_experiment_loops(data, cmap, at["loop_steps"])
     at["channel_settings"] = read_channel_settings(data, cmap, C)
     return frames, at, read_channel_names(data, cmap, C)
 
@@ -320,12 +317,15 @@ def load_nd2(nd2_path: Path, channels: list[Channel] | None = None, use_device: 
     for i, ch in enumerate(channels):
         st = at["channel_settings"][i] if i < len(at.get("channel_settings", [])) else {}
         resolution = acquisition = optics = None
-        if st.get("xy_step_um") is not None:
+        timelapse = sizes.get("T", 1) > 1
+        # a time loop without a stated period (non-equidistant loops, "no delay" acquisitions, frame counts that had
+        # to be taken as T): the optional calibration record is left out rather than failing the whole read
+        if st.get("xy_step_um") is not None and (not timelapse or steps.get("T") is not None):
             # z_size_px / z_step_um default to one plane of 1 um, as the nd2 package reports 2-D acquisitions
             resolution = NominalDimensions(
                 x_size_px=W, y_size_px=H, xy_step_um=st["xy_step_um"], z_size_px=sizes.get("Z", 1),
-                z_step_um=steps.get("Z", 1.0), t_size_px=sizes.get("T") if sizes.get("T", 1) > 1 else None,
-                t_step_ms=steps.get("T") if sizes.get("T", 1) > 1 else None)
+                z_step_um=steps.get("Z", 1.0), t_size_px=sizes.get("T") if timelapse else None,
+                t_step_ms=steps.get("T") if timelapse else None)
         if any(st.get(k) is not None for k in ("exposure_time_s", "zoom", "binning")):
             acquisition = AcquisitionSettings(exposure_time_s=st.get("exposure_time_s"), zoom=st.get("zoom"),
                                               binning=st.get("binning"))

@@ -58,7 +58,9 @@ def _to_device(intensities, what: str, integer_histogram: bool = False, shifted:
             a = a.astype(np.uint16)  # exact: same values, same integer histogram
         elif integer_histogram and shifted is not None and hi - lo <= 65535:
             shifted[0] = lo
-            a = (a - a.dtype.type(lo)).astype(np.uint16)  # lo is a value of the image: no overflow in its own dtype
+            # subtract in a type that holds the whole range: int8 [-128, 127] - (-128) overflows int8 itself
+            wide = a if a.dtype == np.uint64 else a.astype(np.int64)
+            a = (wide - wide.dtype.type(lo)).astype(np.uint16)
         elif integer_histogram:
             raise NotImplementedError(
                 f"{what}: integer image with values in [{lo}, {hi}]: scikit-image bins integers one bin per value, "

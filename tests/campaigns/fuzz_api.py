@@ -37,15 +37,16 @@ def random_image():
     if kind >= 2:
         base = ndi.gaussian_filter(base, [0] * (nd - 2) + [2, 2])
         base = (base - base.min()) / max(base.max() - base.min(), 1e-12)
-    dt = (np.uint8, np.uint16, np.uint16, np.float64, np.int16, np.int32, np.uint32, np.int64)[int(rng.integers(0, 8))]
+    dt = (np.uint8, np.uint16, np.uint16, np.float64, np.int16, np.int32, np.uint32, np.int64, np.int8)[int(rng.integers(0, 9))]
     if dt == np.float64:
         x = base * float(rng.choice([1.0, 4095.0, 1e-3])) - float(rng.choice([0.0, 0.0, 0.25]))
     else:
         x = (base * (min(np.iinfo(dt).max, 65535) * rng.uniform(0.05, 1.0))).astype(dt)
         if np.dtype(dt).itemsize >= 4 and rng.random() < 0.4:  # beyond uint16, range still within 65,536 values
             x = x + dt(rng.choice([70000, 1 << 20, 2_000_000_000]))
-        elif np.dtype(dt).kind == "i" and rng.random() < 0.3:
-            x = x - dt(rng.choice([5, 300, 20000]))
+        elif np.dtype(dt).kind == "i" and rng.random() < (0.6 if dt == np.int8 else 0.3):
+            # negative values (int8: down to -128, so that the image spans more than 127 values of its own dtype)
+            x = (x.astype(np.int64) - min(int(rng.choice([5, 300, 20000])), int(np.iinfo(dt).max) + 1)).astype(dt)
     layout = int(rng.integers(0, 5))
     if layout == 1:    # a view with the leading axis last in memory (channel-last files)
         x = np.ascontiguousarray(np.moveaxis(x, 0, -1)) if x.ndim > 2 else x

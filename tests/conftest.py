@@ -27,11 +27,12 @@ def golden():
     return load
 
 
-def write_synthetic_nd2(path, frames_yxc, row_pad_bytes: int = 0, loops=None):
+def write_synthetic_nd2(path, frames_yxc, row_pad_bytes: int = 0, loops=None, calibration=None, period_ms=None):
     """Write an uncompressed ND2 container (chunk map + lite-variant attributes) holding
     ``frames_yxc`` = (N, Y, X, C) uint16 frames; ``row_pad_bytes`` pads every pixel row (uiWidthBytes > X*C*2);
     ``loops`` = [(eType, count), ...] outermost first writes an ``ImageMetadataLV!`` chunk with that experiment tree
-    (eType 1 time, 2 positions, 4 z stack, 6 spectral, 8 non-equidistant time).
+    (eType 1 time, 2 positions, 4 z stack, 6 spectral, 8 non-equidistant time); ``period_ms`` gives its time loops a
+    ``dPeriod``; ``calibration`` (um per pixel) writes an ``ImageMetadataSeqLV|0!`` chunk with ``dCalibration``.
     The reference's fixture files do not travel to the GPU box; their pixels are pinned in tests/golden."""
     import struct
 
@@ -57,17 +58,24 @@ def write_synthetic_nd2(path, frames_yxc, row_pad_bytes: int = 0, loops=None):
         return struct.pack("<IIQ", 0x0ABECEDA, len(nm), len(payload)) + nm + payload
 
     chunks = [(b"ImageAttributesLV!", attrs)]
-    if loops:
-        def level(lname, items):
-            nm = (lname + "\x00").encode("utf-16-le")
-            hd = bytes([11, len(nm) // 2]) + nm
-            body = b"".join(items)
-            return hd + struct.pack("<IQ", len(items), len(hd) + 12 + len(body)) + body + b"\x00" * (8 * len(items))
 
+    def level(lname, items):
+        nm = (lname + "\x00").encode("utf-16-le")
+        hd = bytes([11, len(nm) // 2]) + nm
+        body = b"".join(items)
+        return hd + struct.pack("<IQ", len(items), len(hd) + 12 + len(body)) + body + b"\x00" * (8 * len(items))
+
+    if calibration is not None:
+        chunks.append((b"ImageMetadataSeqLV|0!",
+                       level("SLxPictureMetadata", [lv(6, "dCalibration", struct.pack("<d", float(calibration)))])))
+    if loops:
         def experiment(rest):
             (etype, count), deeper = rest[0], rest[1:]
+            pars = [lv(3, "uiCount", struct.pack("<I", count)), lv(6, "dStart", struct.pack("<d", 0.0))]
+            if period_ms is not None and etype in (1, 8):
+                pars.append(lv(6, "dPeriod", struct.pack("<d", float(period_ms))))
             items = [lv(3, "eType", struct.pack("<I", etype)),
-                     level("uLoopPars", [lv(3, "uiCount", struct.pack("<I", count)), lv(6, "dStart", struct.pack("<d", 0.0))]),
+                     level("uLoopPars", pars),
                      lv(3, "uiNextLevelCount", struct.pack("<I", 1 if deeper else 0))]
             if deeper:
                 items.append(level("ppNextLevelEx", [level("", experiment(deeper))]))

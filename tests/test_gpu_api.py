@@ -516,6 +516,12 @@ def test_operators_on_stacks_and_other_dtypes():
             assert np.array_equal(apply_threshold(y, method), want), (shift, method)
         ys = (t3.astype(np.int64) + shift).astype(dt)  # a stack: ONE threshold from the histogram of all planes
         assert np.array_equal(apply_threshold(ys, "otsu"), ys > skops.threshold_otsu(ys)), shift
+    # int8 with negative values spanning more than 127: the shift to uint16 must not wrap in int8 itself
+    y8 = ((t3[0].astype(np.int64) - int(t3[0].min())) * 255 // int(t3[0].max() - t3[0].min()) - 128).astype(np.int8)
+    assert int(y8.max()) - int(y8.min()) > 127
+    for method in ("otsu", "yen", "isodata", "triangle", "mean", "li"):
+        want = y8 > getattr(skops, "threshold_" + method)(y8)
+        assert np.array_equal(apply_threshold(y8, method), want), ("int8", method)
     f32 = (t3[1] / 65535.0).astype(np.float32)
     p32 = np.percentile(f32, (1, 99))
     ref32 = skops.rescale_intensity(f32.astype(np.float64), (float(p32[0]), float(p32[1])), (0, 1))

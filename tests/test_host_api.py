@@ -504,6 +504,29 @@ def test_nd2_loop_axes_come_from_the_experiment_tree(tmp_path):
         assert np.array_equal(arr.reshape(want.shape), want), loops
 
 
+def test_nd2_timelapse_without_a_period_still_loads(tmp_path):
+    """A calibrated time-lapse whose loop states no period ('no delay' acquisitions, non-equidistant loops, frame
+    counts taken as T): the optional resolution record is left out, the read does not fail; with a period it is
+    filled.  Two files read one after the other do not inherit each other's steps."""
+    from conftest import write_synthetic_nd2
+
+    from arcadia_microscopy_tools_amd import nd2lite
+
+    frames = np.arange(4 * 6 * 8 * 2, dtype=np.uint16).reshape(4, 6, 8, 2)
+    with_period = write_synthetic_nd2(tmp_path / "tp.nd2", frames, loops=[(1, 4)], calibration=0.65, period_ms=250.0)
+    arr, meta = nd2lite.load_nd2(with_period, channels=[DAPI, FITC], use_device=False)
+    res = meta.channel_metadata_list[0].resolution
+    assert arr.shape == (4, 2, 6, 8) and res.xy_step_um == 0.65 and res.t_size_px == 4 and res.t_step_ms == 250.0
+    for loops in ([(1, 4)], [(8, 4)], None):
+        f = write_synthetic_nd2(tmp_path / "t0.nd2", frames, loops=loops, calibration=0.65)
+        arr, meta = nd2lite.load_nd2(f, channels=[DAPI, FITC], use_device=False)
+        assert meta.sizes == {"T": 4, "C": 2, "Y": 6, "X": 8}
+        assert all(cm.resolution is None for cm in meta.channel_metadata_list), loops
+    single = write_synthetic_nd2(tmp_path / "s.nd2", frames[:1], calibration=0.65)
+    _, meta = nd2lite.load_nd2(single, channels=[DAPI, FITC], use_device=False)
+    assert meta.channel_metadata_list[0].resolution.xy_step_um == 0.65
+
+
 def test_nd2lite_on_the_reference_fixtures_when_present():
     """Plumbing check against the files the reference's own tests read (RT/data, known-metadata.yml sizes); skipped on
     machines without /root/reference (the pixels of config 1 are pinned in tests/golden/nd2_multichannel.npz)."""
