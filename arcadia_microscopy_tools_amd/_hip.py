@@ -134,6 +134,10 @@ _SIGS = {
     "amt_borders_find": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P]),
     "amt_borders_emit": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),
     "amt_cellpose_masks": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, c_int, c_int, c_float, c_int]),
+    "amt_cellpose_masks_ex": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, c_int, c_int, c_float, c_int,
+                                      c_float, c_int]),
+    "amt_cellpose_flow_error": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int]),
+    "amt_fill_holes_remove_small": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int]),
     "amt_overlay": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_int]),
 }
 

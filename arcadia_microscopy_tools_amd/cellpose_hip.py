@@ -134,11 +134,14 @@ def tensor_as_device_array(t, ctx: Context) -> DeviceArray:
 
 
 def flows_to_masks(flows, cellprob_threshold: float = 0.0, niter: int | None = None, min_size: int = 15,
-                   ctx: Context | None = None, max_seeds: int = 16384):
+                   ctx: Context | None = None, max_seeds: int = 16384, flow_threshold: float = 0.0,
+                   fill_holes: bool = False, max_size_fraction: float = 0.4):
     """``(N, 3, H, W)`` float32 network output (dY, dX, cellprob) -- a CUDA tensor or a numpy array -- -> (int32
-    labels (N, H, W) DeviceArray, counts (N,) DeviceArray).  ``niter`` defaults to Cellpose's 200."""
+    labels (N, H, W) DeviceArray, counts (N,) DeviceArray).  ``niter`` defaults to Cellpose's 200; ``flow_threshold``
+    > 0 runs the flow-error filter, ``fill_holes`` the hole filling (``hipops.cellpose_masks``)."""
     ctx = ctx or get_context()
-    niter = 200 if niter is None else int(niter)
+    niter = 200 if niter is None or niter == 0 else int(niter)
+    keep = None
     if isinstance(flows, np.ndarray):
         f = np.ascontiguousarray(flows, dtype=np.float32)
         d = ctx.asarray(f)
@@ -148,6 +151,7 @@ def flows_to_masks(flows, cellprob_threshold: float = 0.0, niter: int | None = N
         t = flows.detach().to(torch.float32).contiguous()
         torch.cuda.current_stream(t.device).synchronize()  # the network ran on torch's stream, the kernels run on ctx's
         d = tensor_as_device_array(t, ctx)
+        keep = t  # a temporary made here must outlive the kernels that read it (they run on ctx's stream)
         N, _, H, W = t.shape
     if d.shape[1] != 3:
         raise ValueError(f"expected (N, 3, H, W) flows, got {d.shape}")
@@ -157,15 +161,80 @@ def flows_to_masks(flows, cellprob_threshold: float = 0.0, niter: int | None = N
     counts = ctx.empty((N,), np.int32)
     for i in range(N):
         img = d[i]
-        hipops.cellpose_masks(img[0:2], img[2], cellprob_threshold, niter, min_size, out=labels[i:i + 1].reshape(H, W),
-                              count=counts[i:i + 1], max_seeds=max_seeds)
+        hipops.cellpose_masks(img[0:2], img[2], cellprob_threshold, niter, min_size, max_size_fraction,
+                              out=labels[i:i + 1].reshape(H, W), count=counts[i:i + 1], max_seeds=max_seeds,
+                              flow_threshold=flow_threshold or 0.0, fill_holes=fill_holes)
+    if keep is not None:
+        ctx.synchronize()  # torch's allocator may hand the block to the next torch op once `keep` dies
     return labels, counts
 
 
+def tile_starts(L: int, bsize: int, tile_overlap: float = 0.1):
+    """Tile origins along one axis as ``cellpose.transforms.make_tiles`` places them: tiles of min(bsize, L) pixels,
+    ceil((1 + 2 * overlap) * L / bsize) of them, evenly spaced from 0 to L - tile."""
+    tile_overlap = min(0.5, max(0.05, tile_overlap))
+    b = min(bsize, L)
+    n = 1 if L <= bsize else int(np.ceil((1.0 + 2 * tile_overlap) * L / bsize))
+    return np.linspace(0, L - b, n).astype(int), b
+
+
+def taper_mask(ly: int, lx: int, sig: float = 7.5) -> np.ndarray:
+    """``cellpose.transforms._taper_mask``: sigmoid roll-off towards the tile edges (float64, host: a 256 x 256 table)."""
+    bsize = max(224, max(ly, lx))
+    xm = np.arange(bsize)
+    xm = np.abs(xm - xm.mean())
+    m = 1 / (1 + np.exp((xm - (bsize / 2 - 20)) / sig))
+    m = m * m[:, np.newaxis]
+    return m[bsize // 2 - ly // 2: bsize // 2 + ly // 2 + ly % 2, bsize // 2 - lx // 2: bsize // 2 + lx // 2 + lx % 2]
+
+
+def tiled_forward(net, x, batch_size: int = 8, bsize: int = 256, tile_overlap: float = 0.1):
+    """``cellpose``'s ``run_net``: the (C, H, W) image tensor ``x`` is cut into overlapping ``bsize`` tiles, the network
+    runs on ``batch_size`` tiles at a time, and the outputs are blended with the taper mask (``average_tiles``).
+    Returns (3, H, W) float32.  ``bsize`` <= 0 runs the whole image in one pass."""
+    torch = _torch()
+    C, H, W = x.shape
+    if bsize <= 0:
+        with torch.no_grad():
+            return net(x[None])[0].to(torch.float32)
+    ys, by = tile_starts(H, bsize, tile_overlap)
+    xs, bx = tile_starts(W, bsize, tile_overlap)
+    origins = [(int(y), int(xx)) for y in ys for xx in xs]
+    mask = torch.from_numpy(taper_mask(by, bx).astype(np.float32)).to(x.device)
+    out = torch.zeros((3, H, W), dtype=torch.float32, device=x.device)
+    navg = torch.zeros((H, W), dtype=torch.float32, device=x.device)
+    bs = max(1, int(batch_size))
+    for k0 in range(0, len(origins), bs):
+        chunk = origins[k0:k0 + bs]
+        tiles = torch.stack([x[:, y:y + by, xx:xx + bx] for y, xx in chunk])
+        if x.dim() == 3 and tiles.shape[1] > 1:
+            tiles = tiles.contiguous(memory_format=torch.channels_last)
+        with torch.no_grad():
+            y_t = net(tiles).to(torch.float32)
+        for (y, xx), o in zip(chunk, y_t):
+            out[:, y:y + by, xx:xx + bx] += o * mask
+            navg[y:y + by, xx:xx + bx] += mask
+    return out / navg
+
+
+_EVAL_KWARGS = ("min_size", "max_size_fraction", "bsize", "tile_overlap", "fill_holes", "max_seeds")
+
+
 def segment_image(net, image: np.ndarray, device, compute_dtype, *, cellprob_threshold=0.0, niter=None, batch_size=8,
-                  ctx: Context | None = None) -> np.ndarray:
-    """One ``([C], H, W)`` image -> int64 labels through ``net`` + the HIP post-processing.  The image is padded to a
-    multiple of 16 (four 2x poolings) by edge replication and the result cropped back."""
+                  flow_threshold=0.4, diameter=30.0, ctx: Context | None = None, min_size: int = 15,
+                  max_size_fraction: float = 0.4, bsize: int = 256, tile_overlap: float = 0.1, fill_holes: bool = True,
+                  max_seeds: int = 16384) -> np.ndarray:
+    """One ``([C], H, W)`` image -> int64 labels through ``net`` + the HIP post-processing, with the parameters
+    ``CellposeModel.eval`` takes from the reference (R/model.py:206-215) doing what they do there:
+
+    * ``diameter``: the image is resized by 30 / diameter (bilinear) before the network and the flows are resized back
+      to the image's size before the masks are computed (30 = no resizing);
+    * ``batch_size``: tiles per forward pass of the tiled network run (``bsize`` pixels per tile, ``tile_overlap``);
+    * ``flow_threshold``: the flow-error filter (0 / None switches it off), ``cellprob_threshold``, ``niter`` (None / 0 =
+      200), ``min_size`` (with the hole filling of ``fill_holes_and_remove_small_masks``), ``max_size_fraction``.
+
+    Tiles smaller than 16 pixels per side cannot pass the four poolings of a U-Net; the (resized) image is padded to a
+    multiple of 16 by edge replication and the flows cropped back."""
     torch = _torch()
     a = np.asarray(image, dtype=np.float32)
     if a.ndim == 2:
@@ -173,14 +242,23 @@ def segment_image(net, image: np.ndarray, device, compute_dtype, *, cellprob_thr
     if a.ndim != 3:
         raise ValueError(f"expected an image of shape ([channel], height, width), got {np.shape(image)}")
     C, H, W = a.shape
-    ph, pw = (-H) % 16, (-W) % 16
+    x = torch.from_numpy(np.ascontiguousarray(a)).to(device=device)
+    rescale = 30.0 / float(diameter)
+    Hr, Wr = (H, W) if rescale == 1.0 else (max(1, int(H * rescale)), max(1, int(W * rescale)))
+    F = torch.nn.functional
+    if (Hr, Wr) != (H, W):
+        x = F.interpolate(x[None], size=(Hr, Wr), mode="bilinear", align_corners=False, antialias=False)[0]
+    ph, pw = (-Hr) % 16, (-Wr) % 16
     if ph or pw:
-        a = np.pad(a, ((0, 0), (0, ph), (0, pw)), mode="edge")
-    x = torch.from_numpy(a[None]).to(device=device, dtype=compute_dtype).contiguous(memory_format=torch.channels_last)
-    with torch.no_grad():
-        y = net(x)
-    y = y[:, :, :H, :W].to(torch.float32).contiguous()
-    labels, counts = flows_to_masks(y, cellprob_threshold, niter, ctx=ctx)
+        x = F.pad(x[None], (0, pw, 0, ph), mode="replicate")[0]
+    y = tiled_forward(net, x.to(compute_dtype), batch_size=batch_size, bsize=bsize, tile_overlap=tile_overlap)
+    y = y[:, :Hr, :Wr]
+    if (Hr, Wr) != (H, W):
+        y = F.interpolate(y[None], size=(H, W), mode="bilinear", align_corners=False, antialias=False)[0]
+    y = y[None].contiguous()
+    labels, counts = flows_to_masks(y, cellprob_threshold, niter, min_size=min_size, ctx=ctx, max_seeds=max_seeds,
+                                    flow_threshold=flow_threshold or 0.0, fill_holes=fill_holes,
+                                    max_size_fraction=max_size_fraction)
     c = int(counts.numpy()[0])
     if c < 0:
         raise RuntimeError("the flow field produced more seeds than the post-processing's capacity")

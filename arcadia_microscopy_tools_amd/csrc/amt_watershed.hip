@@ -1390,7 +1390,7 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
             int* a_ties = ties;
             const int* a_mk = markers;
             void* args[] = {&a_d2, &a_L, &a_T, &a_out, &a_rows, &a_wl, &a_wlc, &a_cnt, &a_rs, &a_H, &a_W, &a_sf, &a_ties, &a_mk};
-            AMT_HIP_CHECK(hipExtLaunchKernel(fn, dim3(gx, nplanes), dim3(64), args, lds + ws_lds_pad(), st, nullptr, nullptr,
+            AMT_HIP_CHECK(hipExtLaunchKernel(fn, dim3(gx, nplanes), dim3(64), args, lds + (cls_slot <= 1 ? ws_lds_pad() : 0), st, nullptr, nullptr,
                                              (any && nflood > 0) ? (int)hipExtAnyOrderLaunch : 0));
             ++nflood;
             return AMT_OK;

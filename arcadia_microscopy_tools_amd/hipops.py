@@ -905,22 +905,64 @@ def regionprops_intensity(labels: DeviceArray, intensity: DeviceArray, max_label
 
 
 def cellpose_masks(dP: DeviceArray, cellprob: DeviceArray, cellprob_threshold: float = 0.0, niter: int = 200,
-                   min_size: int = 15, max_size_fraction: float = 0.4, max_seeds: int = 16384, out=None, count=None):
-    """Cellpose's flow -> mask post-processing on the device (include/amt_hip.h ``amt_cellpose_masks``; parity
+                   min_size: int = 15, max_size_fraction: float = 0.4, max_seeds: int = 16384, out=None, count=None,
+                   flow_threshold: float = 0.0, fill_holes: bool = False):
+    """Cellpose's flow -> mask post-processing on the device (include/amt_hip.h ``amt_cellpose_masks_ex``; parity
     unpinned): ``dP`` (..., 2, Y, X) float32 flows (dY, dX), ``cellprob`` (..., Y, X) float32 -> (int32 labels, counts).
-    A plane that produces more than ``max_seeds`` seeds reports count -1."""
+    ``flow_threshold`` > 0 adds the flow-error filter (``remove_bad_flow_masks``), ``fill_holes`` the hole filling of
+    ``fill_holes_and_remove_small_masks``; with neither, the rounds-1/2 entry point.  A plane that produces more than
+    ``max_seeds`` seeds reports count -1."""
     ctx = dP.ctx
     if dP.dtype != np.float32 or cellprob.dtype != np.float32:
         raise TypeError("cellpose_masks expects float32 flows and cell probabilities")
     n, H, W = _planes(cellprob)
     if dP.ndim < 3 or dP.shape[-3] != 2 or dP.shape[-2:] != cellprob.shape[-2:] or dP.size != 2 * cellprob.size:
         raise ValueError(f"dP must be (..., 2, Y, X) matching cellprob (..., Y, X); got {dP.shape} and {cellprob.shape}")
+    if flow_threshold is None:
+        flow_threshold = 0.0
+    if flow_threshold < 0:
+        raise ValueError(f"flow_threshold must be non-negative, got {flow_threshold}")
     o = _out(ctx, out, cellprob.shape, np.int32)
     c = _out(ctx, count, (n,), np.int32)
-    _hip.check(_lib().amt_cellpose_masks(ctx.handle, dP.ptr, cellprob.ptr, o.ptr, c.ptr, n, H, W,
-                                         float(cellprob_threshold), int(niter), int(min_size), float(max_size_fraction),
-                                         int(max_seeds)), "amt_cellpose_masks")
+    _hip.check(_lib().amt_cellpose_masks_ex(ctx.handle, dP.ptr, cellprob.ptr, o.ptr, c.ptr, n, H, W,
+                                            float(cellprob_threshold), int(niter), int(min_size),
+                                            float(max_size_fraction), int(max_seeds), float(flow_threshold),
+                                            1 if fill_holes else 0), "amt_cellpose_masks_ex")
     return o, c
+
+
+def cellpose_flow_error(labels: DeviceArray, dP: DeviceArray, max_label: int, nlabels: DeviceArray | None = None):
+    """``cellpose.metrics.flow_error`` on the device: (..., Y, X) int32 labels carrying 1..K and (..., 2, Y, X) float32
+    network flows -> (nplanes, max_label) float64 errors (absent labels 0).  Parity unpinned."""
+    ctx = labels.ctx
+    if labels.dtype != np.int32 or dP.dtype != np.float32:
+        raise TypeError("cellpose_flow_error expects int32 labels and float32 flows")
+    n, H, W = _planes(labels)
+    if dP.ndim < 3 or dP.shape[-3] != 2 or dP.shape[-2:] != labels.shape[-2:] or dP.size != 2 * labels.size:
+        raise ValueError(f"dP must be (..., 2, Y, X) matching labels (..., Y, X); got {dP.shape} and {labels.shape}")
+    if nlabels is None:
+        nlabels = ctx.asarray(np.full((n,), int(max_label), np.int32))
+    err = ctx.empty((n, int(max_label)), np.float64)
+    _hip.check(_lib().amt_cellpose_flow_error(ctx.handle, labels.ptr, dP.ptr, nlabels.ptr, err.ptr, n, H, W,
+                                              int(max_label)), "amt_cellpose_flow_error")
+    return err
+
+
+def fill_holes_remove_small(labels: DeviceArray, max_label: int, min_size: int = 15, fill_holes: bool = True,
+                            nlabels: DeviceArray | None = None):
+    """``cellpose.utils.fill_holes_and_remove_small_masks`` on (..., Y, X) int32 labels carrying 1..max_label ->
+    (new int32 labels, counts).  Parity unpinned (oracle/cellpose_dynamics.py)."""
+    ctx = labels.ctx
+    if labels.dtype != np.int32:
+        raise TypeError("fill_holes_remove_small expects int32 labels")
+    n, H, W = _planes(labels)
+    out = labels.copy()
+    if nlabels is None:
+        nlabels = ctx.asarray(np.full((n,), int(max_label), np.int32))
+    c = ctx.empty((n,), np.int32)
+    _hip.check(_lib().amt_fill_holes_remove_small(ctx.handle, out.ptr, nlabels.ptr, c.ptr, n, H, W, int(max_label),
+                                                  int(min_size), 1 if fill_holes else 0), "amt_fill_holes_remove_small")
+    return out, c
 
 
 def label_bboxes(labels: DeviceArray, max_label: int) -> np.ndarray:

@@ -11,14 +11,17 @@ cellpose package it fails loudly (``RuntimeError: Failed to load Cellpose model`
   backend="classical": the nuclei chain of BASELINE.json config 3 on the GPU -- Gaussian -> Otsu ->
       opening/closing -> EDT -> peak markers -> watershed -> sequential labels (``segment.FovSegmenter``).
       ``cell_diameter_px`` sets the marker spacing (min_distance = round(diameter / 6), 5 px for the default
-      30 px); the Cellpose-specific thresholds are validated for API parity but do not apply.
+      30 px).  The Cellpose-specific parameters have no meaning for this algorithm: passing a NON-DEFAULT
+      ``flow_threshold`` / ``cellprob_threshold`` / ``num_iterations`` or any ``**cellpose_kwargs`` raises
+      (nothing is accepted and ignored); ``batch_size`` is the number of images per launch of ``batch_segment``.
   backend="cellpose" (default): delegates to ``cellpose.models.CellposeModel`` exactly like the reference when that
       package and its weights are available (PyTorch-ROCm device selection is unchanged: ``torch.cuda`` is
       the ROCm device).  Without the package, a flow network given as ``network=`` (any ``torch.nn.Module`` mapping
       (N, C, H, W) images to (N, 3, H, W) = dY, dX, cellprob -- e.g. a locally stored checkpoint) runs in bf16
       through PyTorch-ROCm and its output goes through the HIP flow -> mask post-processing
-      (``cellpose_hip.flows_to_masks``; restated from the published algorithm, parity unpinned); with neither,
-      ``RuntimeError`` as before.
+      (``cellpose_hip.segment_image``: diameter rescaling, tiled forward in batches of ``batch_size``, flow following,
+      flow-error filter at ``flow_threshold``, size filters and hole filling; restated from the published algorithm,
+      parity unpinned); with neither, ``RuntimeError`` as before.
   backend="cellpose-hip": always the ``network=`` + HIP post-processing route (``network="standin"`` builds the
       random-weight architectural stand-in of ``cellpose_hip.make_standin`` -- for throughput measurements only,
       its masks mean nothing).
@@ -156,13 +159,23 @@ class SegmentationModel:
             self._net = cellpose_hip.prepare_network(net, self.device, self.compute_dtype)
         return self._net
 
-    def _segment_network(self, intensities: np.ndarray, params: CellposeParams) -> Int64Array:
+    def _segment_network(self, intensities: np.ndarray, params: CellposeParams, cellpose_kwargs=None) -> Int64Array:
+        """Every parameter of R/model.py:171-215 reaches the route and acts there (``cellpose_hip.segment_image``):
+        ``diameter`` resizes around the network, ``batch_size`` is the tile batch, ``flow_threshold`` the flow-error
+        filter.  Extra ``**cellpose_kwargs`` are the post-processing / tiling options of ``CellposeModel.eval`` this
+        route implements; any other name is refused (never ignored)."""
         from . import cellpose_hip
 
+        kw = dict(cellpose_kwargs or {})
+        unknown = sorted(set(kw) - set(cellpose_hip._EVAL_KWARGS))
+        if unknown:
+            raise TypeError(f"the network + HIP route does not implement CellposeModel.eval option(s) {unknown}; "
+                            f"supported: {list(cellpose_hip._EVAL_KWARGS)}")
         net, dt = self._flow_network()
         return cellpose_hip.segment_image(net, intensities, self.device, dt,
                                           cellprob_threshold=params["cellprob_threshold"], niter=params["niter"],
-                                          batch_size=params["batch_size"])
+                                          batch_size=params["batch_size"], flow_threshold=params["flow_threshold"],
+                                          diameter=params["diameter"], **kw)
 
     # -- classical backend ------------------------------------------------------------------------------
     def _segment_classical(self, intensities: np.ndarray, params: CellposeParams) -> Int64Array:
@@ -214,11 +227,23 @@ class SegmentationModel:
 
     def _segment_one(self, intensities, params: CellposeParams, cellpose_kwargs) -> np.ndarray:
         if self._use_network():
-            return self._segment_network(intensities, params)
+            return self._segment_network(intensities, params, cellpose_kwargs)
         if self.backend == "cellpose":
             mask, *_ = self.cellpose_model.eval(x=intensities, **params, **cellpose_kwargs)
             return mask
+        self._refuse_unused_classical(params, cellpose_kwargs)
         return self._segment_classical(intensities, params)
+
+    def _refuse_unused_classical(self, params: CellposeParams, cellpose_kwargs) -> None:
+        """backend='classical' has no flow field: a caller who tunes a Cellpose-only parameter is told so."""
+        if cellpose_kwargs:
+            raise TypeError(f"backend='classical' takes no CellposeModel.eval options, got {sorted(cellpose_kwargs)}")
+        for name, default in (("flow_threshold", self.default_flow_threshold),
+                              ("cellprob_threshold", self.default_cellprob_threshold),
+                              ("niter", self.default_num_iterations)):
+            if params[name] != default:
+                raise ValueError(f"backend='classical' does not use {name} (got {params[name]}, the model's default is "
+                                 f"{default}); only cell_diameter_px and batch_size apply to the watershed chain")
 
     def _batch_classical(self, images, params: CellposeParams):
         """All images of one shape through ``FovSegmenter`` in ONE batch of launches (the per-image loop costs a
@@ -263,6 +288,7 @@ class SegmentationModel:
         )
         masks: list[Int64Array | None] = []
         if self.backend == "classical" and len(intensities_batch) > 1:
+            self._refuse_unused_classical(params, cellpose_kwargs)
             try:
                 done = self._batch_classical(intensities_batch, params)
             except Exception:

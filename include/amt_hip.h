@@ -404,13 +404,35 @@ int amt_borders_emit(amt_ctx* ctx, const int32_t* labels, int H, int W, int nlab
  * dynamics: follow the flow for niter Euler steps with bilinear sampling, histogram the end points, seeds = 5 x 5
  * maxima with more than 10 pixels, five rounds of 3 x 3 growth over bins with more than 2 pixels, labels by end point,
  * masks above max_size_fraction of the image or below min_size dropped, renumbered in raster order); the flow-error
- * filter and hole filling are not part of this entry point.  PARITY UNPINNED: cellpose is not available offline and the
+ * filter and hole filling: amt_cellpose_masks_ex.  PARITY UNPINNED: cellpose is not available offline and the
  * reference holds no vector for it (oracle: oracle/cellpose_dynamics.py).
  *   dP = nplanes x 2 x H x W float32 (dY, dX), cellprob = nplanes x H x W float32, labels_out = nplanes x H x W int32,
  *   count_dev[plane] = number of masks, or -1 if the plane produced more than max_seeds seeds. */
 int amt_cellpose_masks(amt_ctx* ctx, const float* dP, const float* cellprob, int32_t* labels_out, int32_t* count_dev,
                        int nplanes, int H, int W, float cellprob_threshold, int niter, int min_size,
                        float max_size_fraction, int max_seeds);
+/* The same with the rest of cellpose's compute_masks, as CellposeModel.eval runs it with the parameters the reference
+ * hands over (R/model.py:206-215: flow_threshold, default 0.4):
+ *   flow_threshold > 0: remove_bad_flow_masks -- the flows are re-derived from the masks (float64 heat diffusion from
+ *       each mask's centre, 2 * max(height + width + 2) steps) and a mask whose mean squared difference to dP / 5
+ *       exceeds the threshold is dropped;
+ *   then fill_holes_and_remove_small_masks: masks below min_size dropped, (fill_holes != 0) the others hole-filled
+ *       inside their bounding box, renumbered 1..K in ascending order.
+ * flow_threshold == 0 and fill_holes == 0 is amt_cellpose_masks.  PARITY UNPINNED like the above. */
+int amt_cellpose_masks_ex(amt_ctx* ctx, const float* dP, const float* cellprob, int32_t* labels_out, int32_t* count_dev,
+                          int nplanes, int H, int W, float cellprob_threshold, int niter, int min_size,
+                          float max_size_fraction, int max_seeds, float flow_threshold, int fill_holes);
+/* cellpose.utils.fill_holes_and_remove_small_masks on its own (the last step of amt_cellpose_masks_ex): labels_io =
+ * nplanes x H x W int32 carrying labels 1..nlabels_dev[plane] (<= max_label; gaps allowed, larger values are treated as
+ * background), in place: labels in ascending order, those with fewer than min_size pixels dropped, (fill_holes != 0)
+ * the others hole-filled inside their bounding box -- written over whatever lies in the hole, in sequence, as the
+ * package's loop does --, renumbered 1..K; count_dev[plane] = K. */
+int amt_fill_holes_remove_small(amt_ctx* ctx, int32_t* labels_io, const int32_t* nlabels_dev, int32_t* count_dev,
+                                int nplanes, int H, int W, int max_label, int min_size, int fill_holes);
+/* metrics.flow_error of cellpose on its own: labels = nplanes x H x W int32 carrying 1..nlabels_dev[plane] (<= max_label),
+ * dP as above; err_out = nplanes x max_label float64 (absent labels 0). */
+int amt_cellpose_flow_error(amt_ctx* ctx, const int32_t* labels, const float* dP, const int32_t* nlabels_dev,
+                            double* err_out, int nplanes, int H, int W, int max_label);
 
 /* ---- channel overlay: R/blending.py:116-226 (create_overlay / overlay_channels) ------------------------
  * out_rgb = H x W x 3 float64 (interleaved).  background and every layer are H x W float64 planes on the device
