@@ -321,6 +321,15 @@ class Context:
             raise ValueError("copy_from_host_async needs a C-contiguous source of the destination's size")
         _hip.check(self._lib.amt_memcpy_h2d(self.handle, dst.ptr, src.ctypes.data, src.nbytes), "amt_memcpy_h2d")
 
+    def copy_to_host_async(self, dst: np.ndarray, src: "DeviceArray", nbytes: int | None = None):
+        """Enqueue a device -> host copy of the first ``nbytes`` of ``src`` on this context's stream WITHOUT waiting
+        for it (``dst``: page-locked, C-contiguous, large enough; read it after an event recorded behind the copy)."""
+        nbytes = src.nbytes if nbytes is None else int(nbytes)
+        if not dst.flags["C_CONTIGUOUS"] or nbytes > dst.nbytes or nbytes > src.nbytes:
+            raise ValueError("copy_to_host_async needs a C-contiguous destination of at least nbytes")
+        if nbytes:
+            _hip.check(self._lib.amt_memcpy_d2h(self.handle, dst.ctypes.data, src.ptr, nbytes), "amt_memcpy_d2h")
+
     @property
     def stream_ptr(self) -> int:
         """The context's hipStream_t as an integer (0 = the null stream)."""
@@ -362,6 +371,10 @@ class Event:
 
     def wait(self, ctx: Context):
         _hip.check(ctx._lib.amt_event_wait(ctx.handle, self.h), "amt_event_wait")
+
+    def synchronize(self):
+        """The HOST waits for the last record of this event."""
+        _hip.check(self.ctx._lib.amt_event_sync(self.ctx.handle, self.h), "amt_event_sync")
 
     def __del__(self):
         try:

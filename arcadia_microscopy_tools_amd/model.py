@@ -246,8 +246,12 @@ class SegmentationModel:
                                  f"{default}); only cell_diameter_px and batch_size apply to the watershed chain")
 
     def _batch_classical(self, images, params: CellposeParams):
-        """All images of one shape through ``FovSegmenter`` in ONE batch of launches (the per-image loop costs a
-        host round trip per image); None if the batch does not qualify (mixed shapes / dtypes, 3-D inputs)."""
+        """Images of one shape through ``FovSegmenter``, ``batch_size`` images per batch of launches (the per-image loop
+        costs a host round trip per image); None if the batch does not qualify (mixed shapes / dtypes, 3-D inputs).
+        The segmenter of a (batch, shape) is kept per thread: its buffers are reused by the next call."""
+        import threading
+
+        from . import hipops
         from .device import get_context
         from .segment import FovSegmenter
 
@@ -258,24 +262,36 @@ class SegmentationModel:
                 a = a[0]
             if a.ndim != 2 or a.dtype not in (np.uint8, np.uint16):
                 return None
-            arrs.append(a.astype(np.uint16, copy=False))
+            arrs.append(a)
         if not arrs or any(a.shape != arrs[0].shape for a in arrs):
             return None
         H, W = arrs[0].shape
         ctx = get_context()
         min_distance = max(1, int(round(params["diameter"] / 6.0)))
-        seg = FovSegmenter(len(arrs), 1, H, W, sigma=self.sigma, radius=self.opening_radius, min_distance=min_distance,
-                           max_cells=max(4096, (H * W) // 64), dapi_index=0, ctx=ctx, props=False, fused=False)
-        seg.run_c3(ctx.asarray(np.stack(arrs)[:, None]))
-        nm = seg.nmarkers.numpy()
-        if (nm < 0).any() or (nm > seg.max_cells).any():
-            return None
-        # segment() keeps edge cells (clear_border belongs to SegmentationMask): relabel the watershed image itself
-        from . import hipops
-
-        labels, _ = hipops.relabel_sequential(seg.ws, seg.max_cells)
-        out = labels.numpy_int64()
-        return [out[i] for i in range(len(arrs))]
+        chunk = max(1, min(int(params["batch_size"]), len(arrs)))
+        cache = self.__dict__.setdefault("_seg_cache", threading.local())
+        out: list = []
+        for i0 in range(0, len(arrs), chunk):
+            part = arrs[i0:i0 + chunk]
+            key = (len(part), H, W, min_distance, self.sigma, self.opening_radius, id(ctx))
+            seg = getattr(cache, "seg", None)
+            if seg is None or getattr(cache, "key", None) != key:
+                seg = FovSegmenter(len(part), 1, H, W, sigma=self.sigma, radius=self.opening_radius,
+                                   min_distance=min_distance, max_cells=max(4096, (H * W) // 64), dapi_index=0, ctx=ctx,
+                                   props=False, fused=False)
+                cache.seg, cache.key = seg, key
+                cache.inp = ctx.empty((len(part), 1, H, W), np.uint16)
+            for j, a in enumerate(part):  # each plane converted on its way through the page-locked staging buffer
+                ctx.asarray(a, dtype=np.uint16, out=cache.inp[j, 0])
+            seg.run_c3(cache.inp)
+            nm = seg.nmarkers.numpy()
+            if (nm < 0).any() or (nm > seg.max_cells).any():
+                return None
+            # segment() keeps edge cells (clear_border belongs to SegmentationMask): relabel the watershed image itself
+            labels, _ = hipops.relabel_sequential(seg.ws, seg.max_cells)
+            for j in range(len(part)):
+                out.append(labels[j].numpy_int64())
+        return out
 
     def batch_segment(self, intensities_batch: Sequence[Float64Array], cell_diameter_px: float | None = None,
                       flow_threshold: float | None = None, cellprob_threshold: float | None = None,

@@ -46,7 +46,8 @@ class FovSegmenter:
 
     def __init__(self, batch: int, C: int, H: int, W: int, *, sigma: float = 2.0, radius: int = 2,
                  min_distance: int = 5, max_cells: int = 4096, dapi_index: int = 1, ctx: Context | None = None,
-                 props: bool = True, profile: bool = False, fused: bool = True, low_traffic: bool = False, bin_plane: bool = True):
+                 props: bool = True, profile: bool = False, fused: bool = True, low_traffic: bool = False, bin_plane: bool = True,
+                 relief: str = "seeded", ties: str = "exact"):
         self.ctx = ctx or get_context()
         self.B, self.C, self.H, self.W = int(batch), int(C), int(H), int(W)
         self.sigma, self.radius, self.min_distance = float(sigma), int(radius), int(min_distance)
@@ -54,6 +55,15 @@ class FovSegmenter:
         # fused = watershed + clear_border + relabel in one C-ABI call (self.ws is then only flood scratch: use
         # fused=False to inspect the watershed image itself)
         self.fused = bool(fused)
+        # relief: "seeded" = the config-3 recipe (marker pixels spread first: oracle/skops.py:seeded_flood_image; cannot
+        # tie); "plain" = SURVEY.md A.8 as written, watershed(-edt, markers, mask), whose equal-valued markers are
+        # resolved by ``ties`` ('exact' = scikit-image's single heap, emulated for the planes that tie)
+        if relief not in ("seeded", "plain"):
+            raise ValueError(f"relief must be 'seeded' or 'plain', got {relief!r}")
+        self.relief, self.ties = relief, ties
+        if relief == "plain":
+            self.fused = False
+        self.tied = None  # per-plane tie flags of the last plain-relief run
         # low_traffic = Gaussian -> Otsu -> '>' through amt_gaussian_otsu_codes: the float64 smoothed planes are never
         # made (8 instead of 26 bytes of HBM traffic per pixel, 25 MB less memory per field of view; same masks, same
         # thresholds).  Off by default: the Gaussian is fp64-issue bound, so computing it twice costs more time than
@@ -188,7 +198,13 @@ class FovSegmenter:
                                          out=self.labels, count=self.ncells)
         else:
             self._stage("watershed")
-            hipops.watershed_edt(self.d2, self.markers, mask, seeds_first=True, out=self.ws)
+            if self.relief == "plain":
+                if self.tied is None:
+                    self.tied = self.ctx.zeros((self.B,), np.int32)
+                hipops.watershed_edt(self.d2, self.markers, mask, seeds_first=False, out=self.ws, ties=self.ties,
+                                     ties_out=self.tied)
+            else:
+                hipops.watershed_edt(self.d2, self.markers, mask, seeds_first=True, out=self.ws)
             # every watershed label is one 4-connected region grown from one marker component, so
             # clear_border + relabel_sequential (R/masks.py:56,65) collapse into one flag-and-renumber pass; the
             # markers lie inside the mask, so exactly the labels 1..nmarkers occur in the result

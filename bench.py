@@ -20,6 +20,16 @@ collective on the data path, and each step (= one plate) ends with the plate's f
 Rank 0 prints ONE JSON line (contract in the task statement).  ``--workload prep`` / ``filters`` time the
 reference's canonical preprocessing (R/operations.py:57-97,10-54) and the north_star's filter set per stage, with
 a roofline per stage; their ``value`` is planes/s and they are supplementary lines, not the headline metric.
+
+The default N = 1 run also times, AFTER the headline and inside the same command (so that the driver's clock covers
+them), the supplementary lines ``sublines``: c2, prep, filters, plate48 (the per-GPU share of configs[3]), unique64
+(64 distinct FOVs), api (the reference-level batch_segment + cell_properties calls on host arrays) and a8_exact (the
+same chain with SURVEY A.8's plain -EDT relief and exact tie handling).  ``--no-sublines`` skips them.
+
+Watershed recipe of the headline: the reference defines no marker recipe.  The timed chain floods the
+SEEDED relief (marker pixels are spread first, in raster order: oracle/skops.py:seeded_flood_image, ``seeds_first``),
+an ordinary watershed(image, markers, mask) call that cannot tie; SURVEY A.8's plain watershed(-edt, markers, mask)
+ties on nearly every plane and is reported separately under ``sublines.a8_exact``.
 """
 from __future__ import annotations
 
@@ -72,7 +82,7 @@ STAGE_KERNELS = {
 }
 # committed rocprofv3 summaries the `traffic` / `stage_kernels_rocprof_us` fields are read from (NOT measured in
 # this run: PMC collection needs separate rocprofv3 passes); the newest tag present wins
-PROFILE_TAGS = ("r02", "r01")
+PROFILE_TAGS = ("r03", "r02", "r01")
 
 
 def _profile_path(kind: str):
@@ -103,6 +113,19 @@ def pmc_traffic_bytes(stage: str):
     return total or None
 
 
+def pmc_total_bytes():
+    """HBM bytes of ONE 32-FOV chain execution from the committed PMC summary (its TOTAL row: fetch x2 + write), or None."""
+    path = _profile_path("hbm_pmc")
+    if path is None:
+        return None
+    with open(path) as f:
+        for line in f:
+            if line.startswith("TOTAL"):
+                parts = line.rstrip("\n").split(",")
+                return (float(parts[3]) + float(parts[4])) * 1e6
+    return None
+
+
 def rocprof_kernel_us(stage: str, launch_fovs: int = 32):
     """Average duration (us per launch) of the kernels of one stage from the committed rocprofv3 summary, for comparison
     with the live HIP-event time of the stage: profiles/rNN_kernel_stats_b48.csv is ONE context alone with 48 FOVs per
@@ -122,6 +145,27 @@ def rocprof_kernel_us(stage: str, launch_fovs: int = 32):
             if any(short.startswith(pfx) for pfx in STAGE_KERNELS[stage]):
                 out[short] = float(rest.split(",")[1])
     return out or None
+
+
+_FOV_CACHE: dict = {}
+
+
+def synth_fovs(indices, size):
+    """Distinct synthetic FOVs (SURVEY.md 8(d) generator), generated on all host cores and cached for the sublines."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from arcadia_microscopy_tools_amd import synth
+
+    todo = [i for i in indices if (i, size) not in _FOV_CACHE]
+    if todo:
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            cores = os.cpu_count() or 1
+        with ThreadPoolExecutor(max_workers=max(1, min(cores, 16))) as ex:
+            for i, f in zip(todo, ex.map(lambda k: synth.synth_fov(k, size=size), todo)):
+                _FOV_CACHE[(i, size)] = f
+    return [_FOV_CACHE[(i, size)] for i in indices]
 
 
 def log(msg):
@@ -152,13 +196,19 @@ def parse_args():
     ap.add_argument("--unique", type=int, default=8,
                     help="distinct synthetic FOVs generated per GPU (host-side generation costs ~0.5 s each); the "
                          "batch cycles through them")
-    ap.add_argument("--workload", choices=["c3", "c2", "prep", "filters", "c5"], default="c3")
+    ap.add_argument("--workload", choices=["c3", "c2", "prep", "filters", "c5", "api", "a8"], default="c3")
     ap.add_argument("--tiles", type=int, default=8, help="c5: 2 x 1024 x 1024 tiles per step (the network's batch)")
     ap.add_argument("--cpu-fovs", type=int, default=12, help="FOVs timed through the single-thread CPU oracle")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N > 1 without the per-plate feature-table exchange")
     ap.add_argument("--no-h2d", action="store_true",
                     help="skip the extra host-fed run (FOVs streamed from pinned host memory over PCIe, N = 1 only)")
+    ap.add_argument("--no-sublines", action="store_true",
+                    help="N = 1 default run: skip the supplementary lines (c2, prep, filters, plate48, unique64, api, "
+                         "a8_exact) that are otherwise timed after the headline")
+    ap.add_argument("--no-deliver", action="store_true",
+                    help="N = 1: keep the feature tables on the device (by default every step packs its table and "
+                         "copies it to page-locked host memory inside the timed region, one step lagged)")
     ap.add_argument("--tail-reps", type=int, default=0,
                     help="c3: time the watershed stage of a 32-FOV launch this many times over rotating windows of "
                          "the distinct FOVs and report p50 / p99 (flood time is set by the largest component)")
@@ -284,7 +334,7 @@ def stage_roofline(stage_avg: dict, npx: int, PB: int):
 # ------------------------------------------------------------------------------------------------------
 # reference-level operator chains on B resident planes (supplementary workloads)
 # ------------------------------------------------------------------------------------------------------
-def run_ops(args, json_fd):
+def run_ops(args):
     from arcadia_microscopy_tools_amd import hipops, synth
     from arcadia_microscopy_tools_amd.device import Context, set_default_device
 
@@ -378,7 +428,7 @@ def run_ops(args, json_fd):
         fovs = np.stack(uniq)
         out["cpu_baseline"] = cpu_baseline(fovs, args.workload, min(args.cpu_fovs, 4))
         out["gpu_over_cpu_1thread"] = out["value"] / out["cpu_baseline"]["value"]
-    os.write(json_fd, (json.dumps(out) + "\n").encode())
+    return out
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -515,6 +565,132 @@ def run_c5(args, json_fd):
 
 
 # ------------------------------------------------------------------------------------------------------
+# the reference-level calls on HOST arrays: batch_segment -> SegmentationMask(...).cell_properties
+# ------------------------------------------------------------------------------------------------------
+def run_api(args):
+    """What a drop-in user runs (R/model.py:217-290 + R/masks.py:247-328): host numpy FOVs through
+    ``SegmentationModel(backend="classical").batch_segment`` (int64 label images back on the host), then one
+    ``SegmentationMask(labels, {channel: plane x 4}).cell_properties`` per FOV (labels and the four intensity planes go
+    back to the device, the feature table comes home).  Worker threads, one context (= HIP stream + page-locked
+    staging) each, as the reference's own parallel mode (R/pipeline.py:139-149).  One step = ``--batch`` FOVs (48 when
+    left at the default)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from arcadia_microscopy_tools_amd.channels import BRIGHTFIELD, DAPI, FITC, TRITC
+    from arcadia_microscopy_tools_amd.device import set_default_device
+    from arcadia_microscopy_tools_amd.masks import SegmentationMask
+    from arcadia_microscopy_tools_amd.model import SegmentationModel
+
+    set_default_device(0)
+    S = args.size
+    B = args.batch if args.batch != 192 else 48
+    workers = int(os.environ.get("AMT_API_WORKERS", "8"))
+    per_call = int(os.environ.get("AMT_API_CHUNK", "6"))
+    t0 = time.perf_counter()
+    nuniq = max(1, min(args.unique, B))
+    uniq = synth_fovs(list(range(nuniq)), S)
+    gen_s = time.perf_counter() - t0
+    fovs = [uniq[i % nuniq] for i in range(B)]
+    chans = (BRIGHTFIELD, DAPI, FITC, TRITC)
+    model = SegmentationModel(backend="classical")
+
+    def work(chunk):
+        masks = model.batch_segment([f[1] for f in chunk], batch_size=len(chunk), show_progress=False)
+        out = []
+        for f, m in zip(chunk, masks):
+            sm = SegmentationMask(m, {c: f[i] for i, c in enumerate(chans)})
+            out.append((m, sm.cell_properties))
+        return out
+
+    chunks = [fovs[i:i + per_call] for i in range(0, B, per_call)]
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        for _ in range(max(1, args.warmup)):
+            res = [r for part in ex.map(work, chunks) for r in part]
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            res = [r for part in ex.map(work, chunks) for r in part]
+        elapsed = time.perf_counter() - t0
+    # the batch results equal the per-image calls (segment(), then the same SegmentationMask)
+    equal = True
+    for k in (0, min(B - 1, per_call + 1)):
+        m1 = model.segment(fovs[k][1])
+        p1 = SegmentationMask(m1, {c: fovs[k][i] for i, c in enumerate(chans)}).cell_properties
+        equal = equal and np.array_equal(m1, res[k][0]) and all(np.array_equal(p1[c], res[k][1][c], equal_nan=True) for c in p1)
+    if not equal:
+        raise RuntimeError("batch_segment + cell_properties differ from the per-image calls")
+    # bytes that must cross the bus per FOV on this API: DAPI plane up, int64 labels down, labels (narrowed to int32 on
+    # their way into the staging buffer) + four uint16 planes up
+    h2d = S * S * (2 + 4 + 4 * 2)
+    d2h = S * S * 8
+    bus = 53e9  # measured host-link rate of this box class (tools/xfer_probe.py; PCIe Gen5 x16: 63 GB/s nominal)
+    return {
+        "metric": "fields-of-view/sec through the reference-level API on host arrays (batch_segment + cell_properties)",
+        "value": B * args.steps / elapsed, "unit": "FOV/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "host numpy FOVs -> SegmentationModel(backend='classical').batch_segment -> int64 labels on "
+                               "the host -> SegmentationMask(labels, 4 channels).cell_properties -> feature dict on the host "
+                               "(R/model.py:217-290, R/masks.py:247-328)",
+                   "fovs_per_step": B, "worker_threads": workers, "images_per_batch_segment_call": per_call,
+                   "fov_shape": [4, S, S], "cells_per_fov_mean": float(np.mean([len(r[1]["label"]) for r in res]))},
+        "pcie_bound": {"h2d_bytes_per_fov": h2d, "d2h_bytes_per_fov": d2h, "assumed_GBps_per_direction": bus / 1e9,
+                       "fov_per_s": bus / max(h2d, d2h),
+                       "note": "labels travel host <-> device twice because the API hands int64 numpy label images from "
+                               "batch_segment to SegmentationMask; the resident-FOV headline needs 33.5 MB per FOV one way"},
+        "results_equal_per_image_calls": True, "host_gen_s": gen_s,
+    }
+
+
+# ------------------------------------------------------------------------------------------------------
+# SURVEY A.8 as written: watershed(-edt, markers, mask) with exact tie handling
+# ------------------------------------------------------------------------------------------------------
+def run_a8(args):
+    """The config-3 chain with the PLAIN -EDT relief and ties='exact': planes in which two markers of
+    one component carry the same value (on an EDT relief: nearly all) are re-flooded by the sequential emulation of
+    scikit-image's single heap (bit-identical; one lane per plane).  A short run: ``--batch`` FOVs (8 when left at the
+    default) per step."""
+    from arcadia_microscopy_tools_amd.device import Context, set_default_device
+    from arcadia_microscopy_tools_amd.segment import FovSegmenter
+
+    set_default_device(0)
+    ctx = Context(0)
+    S = args.size
+    B = args.batch if args.batch != 192 else 8
+    nuniq = max(1, min(args.unique, B))
+    uniq = synth_fovs(list(range(nuniq)), S)
+    d = ctx.asarray(np.stack([uniq[i % nuniq] for i in range(B)]))
+    seg = FovSegmenter(B, 4, S, S, ctx=ctx, max_cells=args.max_cells, relief="plain", ties="exact")
+    for _ in range(max(1, args.warmup)):
+        seg.run_c3(d)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        seg.run_c3(d)
+    ctx.synchronize()
+    elapsed = time.perf_counter() - t0
+    tied = seg.tied.numpy()
+    prof = FovSegmenter(B, 4, S, S, ctx=ctx, max_cells=args.max_cells, relief="plain", ties="exact", profile=True)
+    prof.run_c3(d)
+    ctx.synchronize()
+    stage_ms = prof.times.ms()
+    return {
+        "metric": "fields-of-view/sec (4x2048^2 uint16), config 3 with SURVEY A.8's plain -EDT relief, ties exact",
+        "value": B * args.steps / elapsed, "unit": "FOV/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "config 3 with watershed(-edt, markers, mask) as SURVEY A.8 writes it (seeds_first=False, "
+                               "ties='exact'): tied planes take the sequential single-heap emulation",
+                   "fovs_per_step": B, "fov_shape": [4, S, S]},
+        "tied_plane_fraction": float((tied != 0).mean()),
+        "roofline": {"kernel": "watershed", "stage_ms": stage_ms,
+                     "launch_ms": stage_ms.get("watershed"), "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                     "achieved": STAGE_BYTES_PER_PX["watershed"] * B * S * S / (stage_ms["watershed"] * 1e-3) / 1e9,
+                     "frac": STAGE_BYTES_PER_PX["watershed"] * B * S * S / (stage_ms["watershed"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        "note": "the CPU (scikit-image's own watershed) floods one such plane in 0.3-0.5 s (BASELINE.md section 2)",
+    }
+
+
+# ------------------------------------------------------------------------------------------------------
 def main():
     args = parse_args()
     launch_ranks_if_needed(args)
@@ -523,14 +699,74 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
-    if args.workload in ("prep", "filters"):
-        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-            print("bench.py: --workload prep/filters are single-GPU lines", file=sys.stderr)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.workload in ("prep", "filters", "api", "a8"):
+        if world > 1:
+            print(f"bench.py: --workload {args.workload} is a single-GPU line", file=sys.stderr)
             sys.exit(2)
-        return run_ops(args, json_fd)
+        out = {"prep": run_ops, "filters": run_ops, "api": run_api, "a8": run_a8}[args.workload](args)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        return
     if args.workload == "c5":
         return run_c5(args, json_fd)
+    out = run_chain(args)
+    default_run = (world == 1 and args.workload == "c3" and args.plate == 0 and not args.no_sublines
+                   and os.environ.get("AMT_BENCH_FORCE_DIST") != "1")
+    if out is not None and default_run:
+        out["sublines"] = run_sublines(args)
+    if out is not None:
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
 
+
+def _sub_args(args, **kw):
+    d = dict(vars(args))
+    d.update(kw)
+    return argparse.Namespace(**d)
+
+
+def _brief(line: dict) -> dict:
+    """What a supplementary line keeps of a full bench line."""
+    keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "cpu_baseline",
+            "pcie_bound", "results_equal_per_image_calls", "note", "tied_plane_fraction", "delivered_to_host")
+    out = {k: line[k] for k in keep if k in line}
+    r = out.get("roofline")
+    if isinstance(r, dict):
+        out["roofline"] = {k: r[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "launch_ms", "chain", "stage_ms",
+                                             "stage_frac", "stages", "filter_morphology_chain", "watershed_tail",
+                                             "end_to_end") if k in r}
+    return out
+
+
+def run_sublines(args) -> dict:
+    """The supplementary lines of the default N = 1 run, a few steps each, timed inside this same command."""
+    import gc
+
+    subs = {}
+
+    def attempt(name, fn):
+        t0 = time.perf_counter()
+        try:
+            subs[name] = _brief(fn())
+            subs[name]["wall_s"] = time.perf_counter() - t0
+            log(f"subline {name}: {subs[name]['value']:.1f} {subs[name]['unit']} ({subs[name]['wall_s']:.1f} s)")
+        except Exception as e:  # a supplementary line must not take the headline down with it
+            subs[name] = {"error": f"{type(e).__name__}: {e}"}
+            log(f"subline {name} FAILED: {subs[name]['error']}")
+        gc.collect()
+
+    quick = dict(no_cpu=True, no_h2d=True, no_sublines=True, tail_reps=0)
+    attempt("c2", lambda: run_chain(_sub_args(args, workload="c2", steps=10, warmup=2, **quick)))
+    attempt("plate48", lambda: run_chain(_sub_args(args, plate=48, steps=20, warmup=3, **quick)))
+    attempt("unique64", lambda: run_chain(_sub_args(args, unique=64, steps=5, warmup=1, **dict(quick, tail_reps=24))))
+    attempt("prep", lambda: run_ops(_sub_args(args, workload="prep", steps=10, warmup=2, no_cpu=True)))
+    attempt("filters", lambda: run_ops(_sub_args(args, workload="filters", steps=10, warmup=2, no_cpu=True)))
+    attempt("api", lambda: run_api(_sub_args(args, steps=3, warmup=1)))
+    attempt("a8_exact", lambda: run_a8(_sub_args(args, steps=1, warmup=1)))
+    return subs
+
+
+def run_chain(args):
+    """One line of the config-2 / config-3 chain on resident FOVs (the headline, plate48, unique64, c2)."""
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -577,7 +813,7 @@ def main():
         raise SystemExit(f"rank {rank} has no field of view to process (plate {args.plate} over {world} ranks)")
     t0 = time.perf_counter()
     nuniq = max(1, min(args.unique, B))
-    uniq = [synth.synth_fov(fov0 + i, size=S) for i in range(nuniq)]
+    uniq = synth_fovs([fov0 + i for i in range(nuniq)], S)
     fovs = np.stack([uniq[i % nuniq] for i in range(B)])
     gen_s = time.perf_counter() - t0
     log(f"rank {rank}: generated {nuniq} distinct synthetic FOVs (batch {B}) in {gen_s:.1f}s; "
@@ -605,9 +841,20 @@ def main():
         # this rank's staging ring + packed row blocks of the per-plate feature tables
         packed = PlateTables(segs, torch.device("cuda", device), cap_fovs=max_B, keep=2)
 
+    # N = 1: there is no exchange, but the plate's feature table still has to reach the host -- every step packs
+    # its table and copies the rows that exist to page-locked host memory (plate.HostTables, one step lagged)
+    deliver = (not distributed) and args.workload == "c3" and not args.no_deliver
+    host_tables = None
+    if deliver:
+        from arcadia_microscopy_tools_amd.plate import HostTables
+
+        host_tables = HostTables(segs, slots=3)
+
     def step(i=0):
         if gather:
             packed.point(i)
+        if deliver:
+            host_tables.point(i)
         for sg, part in zip(segs, parts):
             if args.workload == "c3":
                 sg.run_c3(part)
@@ -617,6 +864,8 @@ def main():
             # this plate's exchange: row counts now, the ONE all-gather of its rows when the next step has been
             # enqueued (it overlaps that step's compute)
             packed.gather_step(i, fov_index0=fov0)
+        if deliver:
+            host_tables.deliver_step(i, fov_index0=fov0)
 
     def sync():
         if distributed:
@@ -624,6 +873,8 @@ def main():
         else:
             for c in ctxs:
                 c.synchronize()
+            if deliver:
+                host_tables.gctx.synchronize()
 
     def barrier():
         if distributed:
@@ -633,6 +884,8 @@ def main():
         step(i)
     if gather:
         packed.all_gather()
+    if deliver:
+        host_tables.flush()
     sync()
     log("warmup done")
     n_warm_blocks = packed.exchange.n_finished if gather else 0
@@ -643,6 +896,8 @@ def main():
         step(args.warmup + i)
     if gather:
         packed.all_gather()  # the last plate's rows: every exchange is inside the timed region
+    if deliver:
+        host_tables.flush()  # the last step's rows: every copy is inside the timed region
     sync()
     barrier()
     sync()
@@ -679,6 +934,23 @@ def main():
             "backend": "rccl" if backend == "nccl" else backend,
         }
         log(f"plate tables exchanged: {rows_last.shape} rows in the last plate, counts {counts_last}")
+
+    delivered = None
+    if deliver:  # outside the timed region: what arrived on the host is what the segmenters computed
+        last = args.warmup + args.steps - 1
+        rows = host_tables.rows_of(last)
+        ncells_all = np.concatenate([sg.ncells.numpy() for sg in segs])
+        if rows.shape[0] != int(ncells_all.sum()) or len(np.unique(rows[:, 0])) != B:
+            raise RuntimeError(f"delivered table is inconsistent: {rows.shape[0]} rows for {int(ncells_all.sum())} cells")
+        t_dev = np.concatenate([sg.table.numpy()[b, : ncells_all[off + b]] for off, sg in
+                                zip(np.cumsum([0] + [g.B for g in segs[:-1]]), segs) for b in range(sg.B)])
+        if not np.array_equal(rows[:, 2: 2 + t_dev.shape[1]], t_dev, equal_nan=True):
+            raise RuntimeError("the delivered feature table differs from the device tables")
+        delivered = {"what": "packed per-cell rows (fov index, label, 14 morphology + 4 x 4 intensity columns) copied to "
+                             "page-locked host memory inside the timed region, one step lagged; label images stay in HBM",
+                     "rows_per_step": int(rows.shape[0]), "row_bytes": host_tables.ncols * 8,
+                     "bytes_per_step": int(rows.shape[0]) * host_tables.ncols * 8}
+        log(f"feature tables delivered to the host: {rows.shape[0]} rows per step")
 
     # ---- per-stage device times (HIP events on the kernels' own stream), outside the timed region ----
     # one launch of the timed region covers the FOVs of ONE stream: profile that launch size
@@ -761,6 +1033,7 @@ def main():
         log(f"host-fed: {pcie['value']:.0f} FOV/s, H2D {pcie['h2d_GBps']:.1f} GB/s")
         feeder.close()
 
+    out = None
     if rank == 0:
         npx = PB * S * S  # pixels per launch (one stream's share of the batch)
         roofline = stage_roofline(stage_avg, npx, PB)
@@ -783,7 +1056,10 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": ("configs[2]: synthetic 4-channel 2048x2048 uint16 FOVs, DAPI Gaussian+Otsu+open/close+EDT+"
-                             "watershed nuclei + morphology and 4-channel intensity regionprops"
+                             "peak markers+watershed nuclei (SEEDED relief, seeds_first: marker pixels spread first in "
+                             "raster order, cannot tie; SURVEY A.8's plain -EDT relief with exact ties is reported "
+                             "under sublines.a8_exact) + clear_border/relabel + morphology and 4-channel intensity "
+                             "regionprops"
                              if args.workload == "c3" else
                              "configs[1]: synthetic 2048x2048 uint16 DAPI plane, Gaussian(2)+Otsu+open/close+CCL"),
                 "mode": (f"configs[3]: one step = one {args.plate}-FOV plate sharded over {world} GPU(s)"
@@ -797,16 +1073,35 @@ def main():
             "roofline": roofline,
             "host_gen_s": gen_s,
         }
+        if args.workload == "c3":
+            # the whole job against the chain's roofline (448.8 MB algorithmic per FOV -> 17.8 k FOV/s at
+            # 8 TB/s), and against the bytes the kernels really move (committed PMC passes, per FOV)
+            alg_mb = 107 * S * S / 1e6  # C2's 40 B/px + 67 B/px for EDT ... intensity props
+            roof_fovs = HBM_PEAK_GBS * 1e3 / alg_mb
+            pmc = pmc_total_bytes()
+            e2e = {"roofline_fovs_per_s_per_gpu": roof_fovs, "algorithmic_MB_per_fov": alg_mb,
+                   "frac": out["value"] / world / roof_fovs,
+                   "frac_of_measured_peak": out["value"] / world / (6290.0 * 1e3 / alg_mb)}
+            if pmc is not None and S == 2048:
+                e2e["pmc_MB_per_fov"] = pmc / 32.0 / 1e6
+                e2e["pmc_GBps"] = out["value"] / world * pmc / 32.0 / 1e9
+                e2e["frac_pmc"] = e2e["pmc_GBps"] / HBM_PEAK_GBS
+                e2e["pmc_source"] = os.path.relpath(_profile_path("hbm_pmc"), ROOT) + " (TOTAL row, per 32-FOV chain)"
+            roofline["end_to_end"] = e2e
+        if delivered is not None:
+            out["delivered_to_host"] = delivered
         if pcie is not None:
             out["pcie_inclusive"] = pcie
         if not args.no_cpu and world == 1:  # the CPU baseline is a rank-0, N = 1 measurement
             out["cpu_baseline"] = cpu_baseline(np.stack(uniq), args.workload, args.cpu_fovs)
             out["gpu_over_cpu_1thread"] = out["value"] / out["cpu_baseline"]["value"]
             out["gpu_over_cpu_all_cores"] = out["value"] / out["cpu_baseline"]["all_cores"]["value"]
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if host_tables is not None:
+        host_tables.close()
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+    return out if rank == 0 else None
 
 
 if __name__ == "__main__":

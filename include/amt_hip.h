@@ -15,7 +15,14 @@
  *   - return value: 0 on success, a negative AMT_E* code otherwise; amt_last_error() returns a
  *     thread-local message for the last failure on the calling thread;
  *   - a context is not thread-safe; use one context per host thread (they are cheap), which
- *     makes the library re-entrant for Pipeline(parallel=True) (R/pipeline.py:145-146).
+ *     makes the library re-entrant for Pipeline(parallel=True) (R/pipeline.py:145-146);
+ *   - STREAMS: every amt_* call runs on the stream of the context it is GIVEN -- never on the stream that
+ *     produced its operands.  Memory written through context A may be read through context B only after B's
+ *     stream has been ordered behind A's: amt_stream_wait(B, A) (everything A was given so far), or
+ *     amt_event_record(A, ev) + amt_event_wait(B, ev) (exactly up to the record), or amt_sync(A).  Nothing in the
+ *     library checks this (pointers carry no owner); a binding that keeps arrays with their context should refuse
+ *     mixed-context calls, as the Python binding does for `out=` (tests/test_gpu_api.py::test_stream_rule_at_the_boundary).
+ *     Host memory handed to amt_memcpy_h2d / amt_memcpy_d2h must stay valid until the stream has passed the copy.
  */
 #ifndef AMT_HIP_H
 #define AMT_HIP_H

@@ -249,6 +249,55 @@ def test_segmentation_model_classical():
     assert out[1] is None and np.array_equal(out[0], mask) and np.array_equal(out[2], mask)
     # larger diameter -> larger marker spacing -> no more cells than before
     assert model.segment(fov[1], cell_diameter_px=60).max() <= mask.max()
+    # the batched fast path (same-shape uint16 / uint8 images, batch_size images per launch) equals segment() per image
+    fov2 = synth.synth_fov(5, size=320)
+    imgs = [fov[1], fov2[1], fov[2]]
+    want = [model.segment(im) for im in imgs]
+    for bs in (8, 2, 1):
+        got = model.batch_segment(imgs, batch_size=bs, show_progress=False)
+        assert all(g is not None and g.dtype == np.int64 and np.array_equal(g, w) for g, w in zip(got, want)), bs
+    imgs8 = [(im >> 6).astype(np.uint8) for im in imgs[:2]]
+    got8 = model.batch_segment(imgs8, show_progress=False)
+    assert all(np.array_equal(g, model.segment(im)) for g, im in zip(got8, imgs8))
+
+
+def test_stream_rule_at_the_boundary():
+    """include/amt_hip.h, "Streams": an amt_* call runs on the stream of the context it is given, so an array produced
+    on another context must be bound (``DeviceArray.on``) and ordered (``Context.wait_for`` / ``Event``) first.  The
+    Python layer refuses the silent variants: an ``out=`` of another context, and a segmenter fed through the wrong
+    context still computes on ITS stream (the round-1 race)."""
+    from arcadia_microscopy_tools_amd import hipops, synth
+    from arcadia_microscopy_tools_amd.device import Context, get_context
+    from arcadia_microscopy_tools_amd.segment import FovSegmenter
+
+    a, b = get_context(), Context(get_context().device)
+    plane = synth.synth_fov(2, size=256)[1]
+    da = a.asarray(plane)
+    with pytest.raises(ValueError, match="another context"):
+        hipops.gaussian(da, 2.0, out=b.empty((256, 256), np.float64))
+    # the supported hand-over: produce on a, order b behind it, bind, consume on b
+    ga = hipops.gaussian(da, 2.0)
+    b.wait_for(a)
+    gb = ga.on(b)
+    assert gb.ctx is b and gb.ptr == ga.ptr
+    thr_b = hipops.threshold_otsu(gb)
+    assert thr_b.ctx is b and thr_b.numpy()[0] == hipops.threshold_otsu(ga).numpy()[0]
+    ev = a.event()
+    ev.record(a)
+    ev.wait(b)  # the event form of the same ordering
+    # a batch uploaded by one context and segmented by another: the segmenter binds it to its own context
+    fovs = a.asarray(np.stack([synth.synth_fov(i, size=256) for i in (7, 8)]))
+    a.synchronize()
+    seg = FovSegmenter(2, 4, 256, 256, ctx=b)
+    seg.run_c3(fovs)
+    assert seg.labels.ctx is b
+    ref = FovSegmenter(2, 4, 256, 256, ctx=a)
+    ref.run_c3(fovs)
+    assert np.array_equal(seg.labels.numpy(), ref.labels.numpy())
+    with pytest.raises(ValueError, match="device"):
+        class Fake:  # a context of another device cannot adopt the memory
+            device = a.device + 1
+        da.on(Fake())
 
 
 def test_microscopy_image_to_device(golden):
