@@ -143,12 +143,23 @@ def mean_from_hist(counts, values):
     return float(np.sum(counts * values)) / float(np.sum(counts))
 
 
-def li_from_hist(counts, values, tolerance=None, initial_guess=None):
+def li_from_hist(counts, values, tolerance=None, initial_guess=None, wrap_dtype=None):
     """SK thresholding.py:642-707 for integer images, evaluated on the exact histogram: every mean the
-    iteration needs is an exact integer sum divided by a count, as in numpy's own float64 reduction."""
+    iteration needs is an exact integer sum divided by a count, as in numpy's own float64 reduction.
+
+    ``wrap_dtype``: the caller's integer dtype.  scikit-image subtracts the minimum IN that dtype (``image -=
+    image_min``), so a signed image whose range exceeds the dtype's maximum (int8 from -128 to 127, ...) wraps around
+    there and the iteration runs on the wrapped values -- reproduced here value for value (the result is then as
+    meaningless as scikit-image's own, possibly nan, but it is the reference's)."""
     values = values.astype(np.int64)
+    counts = np.asarray(counts)
     image_min = int(values[0])
     v = values - image_min
+    if wrap_dtype is not None and np.dtype(wrap_dtype).kind == "i" and int(v[-1]) > int(np.iinfo(wrap_dtype).max):
+        half = int(np.iinfo(wrap_dtype).max) + 1
+        v = (v + half) % (2 * half) - half  # two's-complement wrap of x - min in the image's own dtype
+        order = np.argsort(v, kind="stable")
+        v, counts = v[order], counts[order]
     present = v[counts > 0]
     if present.size == 1:
         return values[0]
@@ -159,12 +170,13 @@ def li_from_hist(counts, values, tolerance=None, initial_guess=None):
     t_curr = -2 * tolerance
     csum = np.cumsum(counts * v)
     ccnt = np.cumsum(counts)
-    while abs(t_next - t_curr) > tolerance:
-        t_curr = t_next
-        k = int(np.searchsorted(v, t_curr, side="right")) - 1  # last value <= t_curr
-        s_le = csum[k] if k >= 0 else 0
-        c_le = ccnt[k] if k >= 0 else 0
-        mean_back = np.float64(s_le) / np.float64(c_le)
-        mean_fore = np.float64(total_sum - s_le) / np.float64(total_cnt - c_le)
-        t_next = (mean_back - mean_fore) / (np.log(mean_back) - np.log(mean_fore))
+    with np.errstate(invalid="ignore", divide="ignore"):  # wrapped (negative) values: nan, as in scikit-image
+        while abs(t_next - t_curr) > tolerance:
+            t_curr = t_next
+            k = int(np.searchsorted(v, t_curr, side="right")) - 1  # last value <= t_curr
+            s_le = csum[k] if k >= 0 else 0
+            c_le = ccnt[k] if k >= 0 else 0
+            mean_back = np.float64(s_le) / np.float64(c_le)
+            mean_fore = np.float64(total_sum - s_le) / np.float64(total_cnt - c_le)
+            t_next = (mean_back - mean_fore) / (np.log(mean_back) - np.log(mean_fore))
     return t_next + image_min

@@ -8,9 +8,12 @@
 #include "amt_common.h"
 
 // ------------------------------------------------------------------------------------------------
-// uint16 histogram: 65536 uint32 bins per plane.  Each 1024-thread workgroup privatises the window
-// [0, 32768) in 128 KiB of LDS (microscopy cameras rarely fill the top bit) and sends the rest to
-// global atomics; the LDS window is flushed with one global atomic per non-empty bin.
+// uint16 histogram: 65536 uint32 bins per plane.  A 1024-thread workgroup privatises a WINDOW of 32768 bins in
+// 128 KiB of LDS and takes a chunk of at least 262,144 pixels, so that the flush (one global atomic per non-empty
+// bin) is a fraction of the counting.  Window [0, 32768) comes first; only if the chunk held a value with the top bit
+// set (microscopy cameras rarely fill it) does the workgroup read its chunk a second time for [32768, 65536) --
+// round 2 sent those values to global atomics one by one, which made a full-range plane (82 us) ten times slower
+// than a 12-bit one.
 // ------------------------------------------------------------------------------------------------
 constexpr int HIST_LDS_BINS = 32768;
 
@@ -22,36 +25,123 @@ __global__ void __launch_bounds__(1024) hist_u16_kernel(const uint16_t* __restri
     const int part = blockIdx.x - plane * blocks_per_plane;
     const uint16_t* src = in + (size_t)plane * n;
     uint32_t* gh = hist + (size_t)plane * 65536;
-    for (int i = threadIdx.x; i < HIST_LDS_BINS; i += 1024) lh[i] = 0;
-    __syncthreads();
     // 8 pixels (16 bytes) per thread per step when aligned
     const size_t nvec = ((reinterpret_cast<uintptr_t>(src) & 15) == 0) ? n / 8 : 0;
     const uint4* v4 = reinterpret_cast<const uint4*>(src);
-    for (size_t i = (size_t)part * 1024 + threadIdx.x; i < nvec; i += (size_t)blocks_per_plane * 1024) {
-        uint4 q = v4[i];
-        uint32_t wds[4] = {q.x, q.y, q.z, q.w};
+    // this workgroup's contiguous share of the vector part (the scalar tail is strided: a few pixels)
+    const size_t per = (nvec + blocks_per_plane - 1) / blocks_per_plane;
+    const size_t v0 = (size_t)part * per, v1 = v0 + per < nvec ? v0 + per : nvec;
+    for (unsigned win = 0; win < 2; ++win) {
+        for (int i = threadIdx.x; i < HIST_LDS_BINS; i += 1024) lh[i] = 0;
+        __syncthreads();
+        unsigned other = 0;  // values of the other window seen
+        for (size_t i = v0 + threadIdx.x; i < v1; i += 1024) {
+            const uint4 q = v4[i];
+            const uint32_t wds[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            uint32_t a = wds[k] & 0xffffu, b = wds[k] >> 16;
-            if (a < HIST_LDS_BINS) atomicAdd(&lh[a], 1u); else atomicAdd(&gh[a], 1u);
-            if (b < HIST_LDS_BINS) atomicAdd(&lh[b], 1u); else atomicAdd(&gh[b], 1u);
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t a = wds[k] & 0xffffu, b = wds[k] >> 16;
+                if ((a >> 15) == win) atomicAdd(&lh[a & 0x7fffu], 1u); else other = 1;
+                if ((b >> 15) == win) atomicAdd(&lh[b & 0x7fffu], 1u); else other = 1;
+            }
         }
-    }
-    for (size_t i = nvec * 8 + (size_t)part * 1024 + threadIdx.x; i < n; i += (size_t)blocks_per_plane * 1024) {
-        uint32_t a = src[i];
-        if (a < HIST_LDS_BINS) atomicAdd(&lh[a], 1u); else atomicAdd(&gh[a], 1u);
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < HIST_LDS_BINS; i += 1024) {
-        uint32_t c = lh[i];
-        if (c) atomicAdd(&gh[i], c);
+        for (size_t i = nvec * 8 + (size_t)part * 1024 + threadIdx.x; i < n; i += (size_t)blocks_per_plane * 1024) {
+            const uint32_t a = src[i];
+            if ((a >> 15) == win) atomicAdd(&lh[a & 0x7fffu], 1u); else other = 1;
+        }
+        const int more = __syncthreads_or((int)other);  // also orders the counting before the flush
+        for (int i = threadIdx.x; i < HIST_LDS_BINS; i += 1024) {
+            const uint32_t c = lh[i];
+            if (c) atomicAdd(&gh[win * HIST_LDS_BINS + i], c);
+        }
+        if (win == 0 && !more) break;  // uniform: nothing for the upper window in this chunk
+        __syncthreads();
     }
 }
 
-static int hist_u16_launch(amt_ctx* ctx, const uint16_t* in, uint32_t* hist, int nplanes, size_t n) {
+// Few planes: no atomics leave the workgroup at all.  Every workgroup counts a part of HIST_PART_PX pixels into ALL
+// 65536 bins as 16-bit counters (two per LDS word; a counter cannot overflow within a part of fewer than 65536
+// pixels), stores its 128 KiB as plain coalesced stores, and a second kernel adds the parts up.  A single full-range
+// 2048^2 plane: 82 us (round 2) -> 54 us (two windows) -> see DESIGN.md for this path.
+constexpr int HIST_PART_PX = 32760;   // multiple of 8 (16-byte loads), below 65536; 129 parts for a 2048^2 plane
+constexpr int HIST_MAX_PARTS = 1024;  // 128 MiB of partial histograms at most
+
+__global__ void __launch_bounds__(1024) hist_u16_part_kernel(const uint16_t* __restrict__ in, uint32_t* __restrict__ partial,
+                                                             size_t n, int parts) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    uint32_t* lh = reinterpret_cast<uint32_t*>(smem_raw);  // 32768 words = 65536 16-bit counters
+    const int plane = blockIdx.x / parts;
+    const int part = blockIdx.x - plane * parts;
+    const uint16_t* src = in + (size_t)plane * n;
+    uint4* l4 = reinterpret_cast<uint4*>(lh);
+    for (int i = threadIdx.x; i < 8192; i += 1024) l4[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    const size_t p0 = (size_t)part * HIST_PART_PX;
+    const size_t p1 = p0 + HIST_PART_PX < n ? p0 + HIST_PART_PX : n;
+    const bool aligned = (reinterpret_cast<uintptr_t>(src + p0) & 15) == 0;
+    const size_t nvec = aligned ? (p1 - p0) / 8 : 0;
+    const uint4* v4 = reinterpret_cast<const uint4*>(src + p0);
+    for (size_t i = threadIdx.x; i < nvec; i += 1024) {
+        const uint4 q = v4[i];
+        const uint32_t wds[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t a = wds[k] & 0xffffu, b = wds[k] >> 16;
+            atomicAdd(&lh[a >> 1], 1u << ((a & 1u) * 16));
+            atomicAdd(&lh[b >> 1], 1u << ((b & 1u) * 16));
+        }
+    }
+    for (size_t i = p0 + nvec * 8 + threadIdx.x; i < p1; i += 1024) {
+        const uint32_t a = src[i];
+        atomicAdd(&lh[a >> 1], 1u << ((a & 1u) * 16));
+    }
+    __syncthreads();
+    uint4* out = reinterpret_cast<uint4*>(partial + (size_t)blockIdx.x * 32768);
+    for (int i = threadIdx.x; i < 8192; i += 1024) out[i] = l4[i];
+}
+
+// hist[plane][2 w], [2 w + 1] = sum over the plane's parts of the two 16-bit halves of word w
+__global__ void __launch_bounds__(256) hist_u16_reduce_kernel(const uint32_t* __restrict__ partial, uint32_t* __restrict__ hist,
+                                                              int parts) {
+    const int plane = blockIdx.y;
+    const int w = blockIdx.x * 256 + threadIdx.x;  // 0 .. 32767
+    const uint32_t* p = partial + (size_t)plane * parts * 32768 + w;
+    uint32_t lo = 0, hi = 0;
+    for (int k = 0; k < parts; ++k) {
+        const uint32_t v = p[(size_t)k * 32768];
+        lo += v & 0xffffu;
+        hi += v >> 16;
+    }
+    reinterpret_cast<uint2*>(hist + (size_t)plane * 65536)[w] = make_uint2(lo, hi);
+}
+
+// bytes of scratch hist_u16_launch wants for this call (0: it takes the two-window kernel)
+static size_t hist_u16_scratch_bytes(int nplanes, size_t n) {
+    if (n == 0 || nplanes <= 0) return 0;
+    const size_t parts = (n + HIST_PART_PX - 1) / HIST_PART_PX;
+    if (parts * (size_t)nplanes > (size_t)HIST_MAX_PARTS) return 0;
+    return amt_align(parts * (size_t)nplanes * 32768 * sizeof(uint32_t));
+}
+
+static int hist_u16_launch(amt_ctx* ctx, const uint16_t* in, uint32_t* hist, int nplanes, size_t n,
+                           uint32_t* scratch = nullptr) {
+    if (n == 0) {
+        AMT_HIP_CHECK(hipMemsetAsync(hist, 0, (size_t)nplanes * 65536 * sizeof(uint32_t), ctx->stream));
+        return AMT_OK;
+    }
+    if (scratch && hist_u16_scratch_bytes(nplanes, n) > 0) {
+        const int parts = (int)((n + HIST_PART_PX - 1) / HIST_PART_PX);
+        hipLaunchKernelGGL(hist_u16_part_kernel, dim3(nplanes * parts), dim3(1024), 32768 * sizeof(uint32_t), ctx->stream, in,
+                           scratch, n, parts);
+        AMT_LAUNCH_CHECK();
+        hipLaunchKernelGGL(hist_u16_reduce_kernel, dim3(128, nplanes), dim3(256), 0, ctx->stream, scratch, hist, parts);
+        AMT_LAUNCH_CHECK();
+        return AMT_OK;
+    }
     AMT_HIP_CHECK(hipMemsetAsync(hist, 0, (size_t)nplanes * 65536 * sizeof(uint32_t), ctx->stream));
-    if (n == 0) return AMT_OK;
-    int bpp = (int)((n + 65535) / 65536);
+    // >= 262,144 pixels per workgroup (4 flushed bins per counted pixel at worst), and no more workgroups than keep
+    // every CU busy twice over
+    int bpp = (int)((n + 262143) / 262144);
     int cap = (2 * ctx->num_cus + nplanes - 1) / nplanes;
     if (cap < 1) cap = 1;
     if (bpp > cap) bpp = cap;
@@ -66,7 +156,13 @@ extern "C" int amt_hist_u16(amt_ctx* ctx, const uint16_t* in, uint32_t* hist, in
     AMT_TRY(amt_set_device(ctx));
     AMT_REQUIRE(in && hist && nplanes >= 0, "hist_u16: bad arguments");
     if (nplanes == 0) return AMT_OK;
-    return hist_u16_launch(ctx, in, hist, nplanes, n);
+    const size_t sb = hist_u16_scratch_bytes(nplanes, n);
+    uint32_t* scratch = nullptr;
+    if (sb) {
+        AMT_TRY(amt_arena_begin(ctx, sb));
+        scratch = reinterpret_cast<uint32_t*>(amt_arena_take(ctx, sb));
+    }
+    return hist_u16_launch(ctx, in, hist, nplanes, n, scratch);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -504,9 +600,11 @@ extern "C" int amt_threshold_value(amt_ctx* ctx, const void* in, int in_dtype, i
     if (nplanes == 0) return AMT_OK;
     if (status_dev) AMT_HIP_CHECK(hipMemsetAsync(status_dev, 0, (size_t)nplanes * sizeof(int32_t), ctx->stream));
     if (in_dtype == AMT_U16) {
-        AMT_TRY(amt_arena_begin(ctx, amt_align((size_t)nplanes * 65536 * sizeof(uint32_t))));
+        const size_t sb = hist_u16_scratch_bytes(nplanes, n);
+        AMT_TRY(amt_arena_begin(ctx, amt_align((size_t)nplanes * 65536 * sizeof(uint32_t)) + sb));
         uint32_t* hist = arena_take_t<uint32_t>(ctx, (size_t)nplanes * 65536);
-        AMT_TRY(hist_u16_launch(ctx, (const uint16_t*)in, hist, nplanes, n));
+        uint32_t* scratch = sb ? reinterpret_cast<uint32_t*>(amt_arena_take(ctx, sb)) : nullptr;
+        AMT_TRY(hist_u16_launch(ctx, (const uint16_t*)in, hist, nplanes, n, scratch));
         hipLaunchKernelGGL(otsu_u16_kernel, dim3(nplanes), dim3(1024), 0, ctx->stream, hist, thr_dev);
         AMT_LAUNCH_CHECK();
         return AMT_OK;
@@ -700,11 +798,13 @@ extern "C" int amt_percentile_u16(amt_ctx* ctx, const uint16_t* in, const double
     if (nplanes == 0) return AMT_OK;
     rank_req reqs[64];
     make_rank_reqs(q_host, nq, n, reqs);
-    AMT_TRY(amt_arena_begin(ctx, amt_align((size_t)nplanes * 65536 * 4) + amt_align(sizeof(reqs))));
+    const size_t sb = hist_u16_scratch_bytes(nplanes, n);
+    AMT_TRY(amt_arena_begin(ctx, amt_align((size_t)nplanes * 65536 * 4) + amt_align(sizeof(reqs)) + sb));
     uint32_t* hist = arena_take_t<uint32_t>(ctx, (size_t)nplanes * 65536);
     rank_req* rd = arena_take_t<rank_req>(ctx, 64);
+    uint32_t* scratch = sb ? reinterpret_cast<uint32_t*>(amt_arena_take(ctx, sb)) : nullptr;
     AMT_TRY(amt_param_upload(ctx, rd, reqs, sizeof(rank_req) * nq));
-    AMT_TRY(hist_u16_launch(ctx, in, hist, nplanes, n));
+    AMT_TRY(hist_u16_launch(ctx, in, hist, nplanes, n, scratch));
     hipLaunchKernelGGL(percentile_u16_kernel, dim3(nplanes), dim3(1024), 0, ctx->stream, hist, rd, nq, out_dev);
     AMT_LAUNCH_CHECK();
     return AMT_OK;

@@ -36,11 +36,19 @@ _PIPE_CHUNKS = 8      # chunks per transfer: the DMA of one overlaps the host-si
 
 
 def _pool4():
+    """The host-copy threads shared by every context of the process (staging copies, conversions, extrema): four when
+    one thread drives the GPU, more when the process may run several worker threads with a context each
+    (AMT_COPY_THREADS; default = half the cores this process may use, between 4 and 16)."""
     global _copy_pool
     if _copy_pool is None:
         from concurrent.futures import ThreadPoolExecutor
 
-        _copy_pool = ThreadPoolExecutor(max_workers=4, thread_name_prefix="amt-copy")
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            cores = os.cpu_count() or 4
+        nthreads = int(os.environ.get("AMT_COPY_THREADS", str(max(4, min(16, cores // 2)))))
+        _copy_pool = ThreadPoolExecutor(max_workers=max(1, nthreads), thread_name_prefix="amt-copy")
     return _copy_pool
 
 
@@ -91,7 +99,8 @@ class _ResultPool:
     page-locked blocks that become the returned arrays: a fresh pageable array costs 8,192 page faults (2-3 ms,
     more than the 0.6 ms the bus takes) before the copy out of a staging buffer can even land.  At most
     AMT_RESULT_PINNED_BYTES (default 1 GiB; 0 = off) are handed out at any time -- beyond that, and for anything
-    below 4 MB, results are ordinary arrays -- and up to 256 MiB of returned blocks are kept for the next call."""
+    below 4 MB, results are ordinary arrays -- and returned blocks are kept for the next call (up to half the budget,
+    at least 256 MiB)."""
 
     def __init__(self):
         # re-entrant: a block's __del__ (-> _put) can run from the garbage collector at any allocation, including
@@ -101,7 +110,10 @@ class _ResultPool:
         self.kept = 0
         self.out = 0
         self.cap_out = int(os.environ.get("AMT_RESULT_PINNED_BYTES", str(1 << 30)))
-        self.cap_keep = 256 << 20
+        # returned blocks kept for the next call: releasing one (hipHostFree) synchronises the device and allocating
+        # the next (hipHostMalloc) costs milliseconds, so a process that cycles through many label images keeps half
+        # its budget instead of the 256 MiB that serve one thread
+        self.cap_keep = max(256 << 20, self.cap_out // 2)
 
     def get(self, nbytes: int):
         size = (nbytes + (1 << 20) - 1) & ~((1 << 20) - 1)

@@ -282,7 +282,7 @@ class SegmentationModel:
                 cache.seg, cache.key = seg, key
                 cache.inp = ctx.empty((len(part), 1, H, W), np.uint16)
             for j, a in enumerate(part):  # each plane converted on its way through the page-locked staging buffer
-                ctx.asarray(a, dtype=np.uint16, out=cache.inp[j, 0])
+                ctx.asarray(a, dtype=np.uint16, out=cache.inp[j][0])
             seg.run_c3(cache.inp)
             nm = seg.nmarkers.numpy()
             if (nm < 0).any() or (nm > seg.max_cells).any():
@@ -307,8 +307,9 @@ class SegmentationModel:
             self._refuse_unused_classical(params, cellpose_kwargs)
             try:
                 done = self._batch_classical(intensities_batch, params)
-            except Exception:
-                done = None  # fall back to the per-image loop, which reports failures image by image
+            except Exception as e:  # fall back to the per-image loop, which reports failures image by image
+                logger.debug("batched classical path failed (%s: %s); segmenting image by image", type(e).__name__, e)
+                done = None
             if done is not None:
                 return done
         iterator = enumerate(intensities_batch)
@@ -322,7 +323,7 @@ class SegmentationModel:
         for i, intensities in iterator:
             try:
                 mask = self._segment_one(intensities, params, cellpose_kwargs)
-                masks.append(mask.astype(np.int64))
+                masks.append(mask.astype(np.int64, copy=False))
             except Exception as e:
                 warnings.warn(
                     f"Cellpose segmentation failed on image {i}: {e}",

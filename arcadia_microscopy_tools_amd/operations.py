@@ -318,10 +318,13 @@ def apply_threshold(
         elif method_lower == "mean":
             t = _thresholds.mean_from_hist(counts, centers)
         elif method_lower == "li":
-            t = _thresholds.li_from_hist(counts, centers, **kw)
+            t = _thresholds.li_from_hist(counts, centers, wrap_dtype=src_dtype, **kw)
         else:
             kw.pop("nbins", None)
             t = getattr(_thresholds, method_lower)(counts, centers, **kw)
+        if np.isnan(t):  # x > nan is False everywhere (li on a signed image that wrapped in its own dtype)
+            z = np.zeros(shape, dtype=bool)
+            return z if was_numpy else ctx.asarray(z)
         mask = hipops.greater_than(d, ctx.asarray(np.array([float(int(np.floor(t)) - offset)])))
     elif method_lower == "otsu":
         thr = hipops.threshold_otsu(d, nbins=int(kw.pop("nbins", 256)))

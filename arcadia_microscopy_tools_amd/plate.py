@@ -308,126 +308,123 @@ class PlateTables:
 class HostTables:
     """One GPU, no collective: the per-plate feature table delivered to the HOST, inside the step that produced it.
 
-    The same staging ring and pack kernel as ``PlateTables`` (one 256-byte row per cell), followed by what a single
-    rank's "exchange" is -- the copy of the rows that exist into page-locked host memory: the row COUNT travels first
-    (8 bytes), and one step later, when that copy has long finished and the next step is already enqueued, the host
-    reads it and enqueues the copy of exactly that many rows.  Everything runs on a side stream ordered behind the
-    compute streams with events; the host never waits for the step it has just enqueued.  No torch involved."""
+    Every segmenter (= context = HIP stream) compacts ITS fields of view to one 256-byte row per cell with the pack
+    kernel of ``PlateTables`` and copies the rows that exist into page-locked host memory -- all on its own stream:
+    the row COUNT travels first (8 bytes), and ``lag`` (two) steps later, when that copy has long finished and the
+    following steps are already enqueued, the host reads it and enqueues the copy of exactly that many rows.  The host
+    never waits for the step it has just enqueued, and no stream ever waits for another one (measured on the 48-FOV
+    plate: ordering one side stream behind the four compute streams cost 0.8 ms per 4.3 ms step before a single byte
+    moved; a copy of ~4 MB in each compute stream costs < 0.1 ms of that stream).  No torch involved.  The plate's table
+    is the concatenation of the segmenters' blocks, which own consecutive fields of view."""
 
-    def __init__(self, segs, slots: int = 3):
-        from .device import Context, DeviceArray, pinned_empty
+    def __init__(self, segs, slots: int = 4, lag: int = 2):
+        from .device import DeviceArray, pinned_empty
 
         self.segs = list(segs)
-        B = sum(s.B for s in self.segs)
         K, C = self.segs[0].max_cells, self.segs[0].C
         if any(s.max_cells != K or s.C != C for s in self.segs):
             raise ValueError("all segmenters must share max_cells and the channel count")
-        self.B, self.K, self.C = B, K, C
+        self.B, self.K, self.C = sum(s.B for s in self.segs), K, C
         self.ncols = packed_ncols(C)
-        self.slots = max(2, int(slots))
-        self.gctx = Context(self.segs[0].ctx.device)
-        g = self.gctx
-        self.n_table = B * K * _hip.RP_NCOLS * 8
-        self.n_itable = B * K * C * 4 * 8
-        self.n_cells = (B * 4 + 7) // 8 * 8
-        self.slot_bytes = self.n_table + self.n_itable + self.n_cells
-        self.staging = g.zeros((self.slots * self.slot_bytes,), np.uint8)
-        self.rows = [g.empty((max(B * K, 1), self.ncols), np.float64) for _ in range(self.slots)]
-        self.nrows = [g.zeros((1,), np.int64) for _ in range(self.slots)]
-        self._pin = [(pinned_empty((max(B * K, 1), self.ncols), np.float64), pinned_empty((1,), np.int64))
-                     for _ in range(self.slots)]
-        self.packed_ev = [g.event() for _ in range(self.slots)]
-        self.count_ev = [g.event() for _ in range(self.slots)]
-        self.rows_ev = [g.event() for _ in range(self.slots)]
-        self.used = [False] * self.slots
-        self.pending: list[int] = []      # steps whose rows have not been requested yet
-        self.counts: dict[int, int] = {}  # step -> rows delivered
-        self.bytes_delivered = 0
-        g.synchronize()
+        self.lag = max(1, int(lag))
+        self.slots = max(self.lag + 2, int(slots))
         self._DeviceArray = DeviceArray
-
-    def _offsets(self, slot: int, b0: int):
-        base = slot * self.slot_bytes
-        return (base + b0 * self.K * _hip.RP_NCOLS * 8,
-                base + self.n_table + b0 * self.K * self.C * 4 * 8,
-                base + self.n_table + self.n_itable + b0 * 4)
-
-    def point(self, step: int):
-        """Make the segmenters write the tables of step ``step`` into that step's staging block."""
-        DeviceArray = self._DeviceArray
-        slot = step % self.slots
-        ptr = self.staging.ptr
-        K, C = self.K, self.C
-        if self.used[slot]:  # the pack kernel of the block's previous use may still be reading it
-            for s in self.segs:
-                self.packed_ev[slot].wait(s.ctx)
+        self.parts = []
         b0 = 0
         for s in self.segs:
-            o_t, o_i, o_c = self._offsets(slot, b0)
-            s.table = DeviceArray(s.ctx, ptr + o_t, (s.B, K, _hip.RP_NCOLS), np.float64)
-            s.itable = DeviceArray(s.ctx, ptr + o_i, (s.B, K, C, 4), np.float64)
-            s.ncells = DeviceArray(s.ctx, ptr + o_c, (s.B,), np.int32)
+            c = s.ctx
+            n_table = s.B * K * _hip.RP_NCOLS * 8
+            n_itable = s.B * K * C * 4 * 8
+            n_cells = (s.B * 4 + 7) // 8 * 8
+            slot_bytes = n_table + n_itable + n_cells
+            self.parts.append(dict(
+                seg=s, b0=b0, n_table=n_table, n_itable=n_itable, slot_bytes=slot_bytes,
+                staging=c.zeros((self.slots * slot_bytes,), np.uint8),
+                rows=[c.empty((max(s.B * K, 1), self.ncols), np.float64) for _ in range(self.slots)],
+                nrows=[c.zeros((1,), np.int64) for _ in range(self.slots)],
+                pin=[(pinned_empty((max(s.B * K, 1), self.ncols), np.float64), pinned_empty((1,), np.int64))
+                     for _ in range(self.slots)],
+                count_ev=[c.event() for _ in range(self.slots)], rows_ev=[c.event() for _ in range(self.slots)]))
             b0 += s.B
-        self.used[slot] = True
+            c.synchronize()
+        self.pending: list[int] = []            # steps whose rows have not been requested yet
+        self.counts: dict[int, list[int]] = {}  # step -> rows delivered per segmenter
+        self.bytes_delivered = 0
+
+    def _views(self, p, slot):
+        s, K, C = p["seg"], self.K, self.C
+        base = p["staging"].ptr + slot * p["slot_bytes"]
+        D = self._DeviceArray
+        return (D(s.ctx, base, (s.B, K, _hip.RP_NCOLS), np.float64),
+                D(s.ctx, base + p["n_table"], (s.B, K, C, 4), np.float64),
+                D(s.ctx, base + p["n_table"] + p["n_itable"], (s.B,), np.int32))
+
+    def point(self, step: int):
+        """Make the segmenters write the tables of step ``step`` into that step's staging block (the pack kernel of
+        the block's previous use ran on the same stream: stream order protects it)."""
+        slot = step % self.slots
+        for p in self.parts:
+            s = p["seg"]
+            s.table, s.itable, s.ncells = self._views(p, slot)
 
     def deliver_step(self, step: int, fov_index0: int = 0):
-        """After the step's kernels have been enqueued: pack its block, send the row count to the host, and request the
-        rows of the step before."""
+        """After the step's kernels have been enqueued: every segmenter packs its block on its own stream and sends the
+        row count to the host; the rows of the step ``lag`` steps back are requested."""
         from . import hipops
 
-        DeviceArray = self._DeviceArray
         slot = step % self.slots
-        g = self.gctx
-        for s in self.segs:
-            g.wait_for(s.ctx)
-        # the slot's previous rows (step - slots) left on this same stream at least one step ago: stream order keeps
-        # that copy ahead of the pack kernel below
-        B, K, C = self.B, self.K, self.C
-        o_t, o_i, o_c = self._offsets(slot, 0)
-        ptr = self.staging.ptr
-        hipops.pack_plate_rows(
-            DeviceArray(g, ptr + o_t, (B, K, _hip.RP_NCOLS), np.float64),
-            DeviceArray(g, ptr + o_i, (B, K, C, 4), np.float64),
-            DeviceArray(g, ptr + o_c, (B,), np.int32), fov_index0=fov_index0,
-            out=self.rows[slot], nrows_out=self.nrows[slot])
-        self.packed_ev[slot].record(g)
-        g.copy_to_host_async(self._pin[slot][1].array, self.nrows[slot])
-        self.count_ev[slot].record(g)
-        self._request(flush=False)
+        for p in self.parts:
+            s = p["seg"]
+            t, it, nc = self._views(p, slot)
+            hipops.pack_plate_rows(t, it, nc, fov_index0=fov_index0 + p["b0"], out=p["rows"][slot], nrows_out=p["nrows"][slot])
+            s.ctx.copy_to_host_async(p["pin"][slot][1].array, p["nrows"][slot])
+            p["count_ev"][slot].record(s.ctx)
         self.pending.append(step)
+        self._request(flush=False)
 
     def _request(self, flush: bool):
-        """Enqueue the row copies of the pending steps (all of them with ``flush``, else all but none: the newest
-        step is appended after this call, so everything pending is at least one step old)."""
-        g = self.gctx
-        for step in self.pending:
+        """Enqueue the row copies of the pending steps: all of them with ``flush``, else all but the newest ``lag``."""
+        todo = self.pending if flush else self.pending[: max(0, len(self.pending) - self.lag)]
+        self.pending = self.pending[len(todo):]
+        for step in todo:
             slot = step % self.slots
-            self.count_ev[slot].synchronize()
-            n = int(self._pin[slot][1].array[0])
-            if n < 0:
-                raise RuntimeError("a field of view overflowed its feature table (row count -1); raise max_cells")
-            g.copy_to_host_async(self._pin[slot][0].array, self.rows[slot], n * self.ncols * 8)
-            self.rows_ev[slot].record(g)
-            self.counts[step] = n
-            self.bytes_delivered += n * self.ncols * 8
-        self.pending = []
+            counts = []
+            for p in self.parts:
+                p["count_ev"][slot].synchronize()
+                n = int(p["pin"][slot][1].array[0])
+                if n < 0:
+                    raise RuntimeError("a field of view overflowed its feature table (row count -1); raise max_cells")
+                p["seg"].ctx.copy_to_host_async(p["pin"][slot][0].array, p["rows"][slot], n * self.ncols * 8)
+                p["rows_ev"][slot].record(p["seg"].ctx)
+                counts.append(n)
+                self.bytes_delivered += n * self.ncols * 8
+            self.counts[step] = counts
 
     def flush(self):
         self._request(flush=True)
 
+    def synchronize(self):
+        for p in self.parts:
+            p["seg"].ctx.synchronize()
+
     def rows_of(self, step: int) -> np.ndarray:
-        """The delivered rows of ``step`` (a view of the page-locked block: valid until the slot is reused)."""
+        """The delivered rows of ``step``, the segmenters' blocks one after the other (a copy out of the page-locked
+        blocks, which are reused ``slots`` steps later)."""
         if step in self.pending:
             self.flush()
         slot = step % self.slots
-        self.rows_ev[slot].synchronize()
-        return self._pin[slot][0].array[: self.counts[step]]
+        out = []
+        for p, n in zip(self.parts, self.counts[step]):
+            p["rows_ev"][slot].synchronize()
+            out.append(p["pin"][slot][0].array[:n])
+        return np.concatenate(out) if out else np.zeros((0, self.ncols))
 
     def close(self):
-        self.gctx.synchronize()
-        for rows, cnt in self._pin:
-            rows.close()
-            cnt.close()
+        self.synchronize()
+        for p in self.parts:
+            for rows, cnt in p["pin"]:
+                rows.close()
+                cnt.close()
 
 
 def rows_to_table(rows: np.ndarray, channel_names) -> np.ndarray:

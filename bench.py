@@ -46,6 +46,9 @@ import time
 # (and with torch + RCCL in the process, 8 measured 14 % slower than 16).
 # Must be set before the HIP runtime initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# page-locked result blocks handed out at any time (device._ResultPool): the api line's worker threads hold a few
+# int64 label images each (33.5 MB per 2048^2 image); beyond the budget results fall back to pageable arrays
+os.environ.setdefault("AMT_RESULT_PINNED_BYTES", str(4 << 30))
 
 import numpy as np  # noqa: E402
 
@@ -208,7 +211,7 @@ def parse_args():
                          "a8_exact) that are otherwise timed after the headline")
     ap.add_argument("--no-deliver", action="store_true",
                     help="N = 1: keep the feature tables on the device (by default every step packs its table and "
-                         "copies it to page-locked host memory inside the timed region, one step lagged)")
+                         "copies it to page-locked host memory inside the timed region, two steps lagged)")
     ap.add_argument("--tail-reps", type=int, default=0,
                     help="c3: time the watershed stage of a 32-FOV launch this many times over rotating windows of "
                          "the distinct FOVs and report p50 / p99 (flood time is set by the largest component)")
@@ -585,7 +588,7 @@ def run_api(args):
     S = args.size
     B = args.batch if args.batch != 192 else 48
     workers = int(os.environ.get("AMT_API_WORKERS", "8"))
-    per_call = int(os.environ.get("AMT_API_CHUNK", "6"))
+    per_call = int(os.environ.get("AMT_API_CHUNK", "4"))
     t0 = time.perf_counter()
     nuniq = max(1, min(args.unique, B))
     uniq = synth_fovs(list(range(nuniq)), S)
@@ -599,7 +602,7 @@ def run_api(args):
         out = []
         for f, m in zip(chunk, masks):
             sm = SegmentationMask(m, {c: f[i] for i, c in enumerate(chans)})
-            out.append((m, sm.cell_properties))
+            out.append((int(m.max()), m if f is fovs[0] or f is fovs[min(B - 1, per_call + 1)] else None, sm.cell_properties))
         return out
 
     chunks = [fovs[i:i + per_call] for i in range(0, B, per_call)]
@@ -615,7 +618,8 @@ def run_api(args):
     for k in (0, min(B - 1, per_call + 1)):
         m1 = model.segment(fovs[k][1])
         p1 = SegmentationMask(m1, {c: fovs[k][i] for i, c in enumerate(chans)}).cell_properties
-        equal = equal and np.array_equal(m1, res[k][0]) and all(np.array_equal(p1[c], res[k][1][c], equal_nan=True) for c in p1)
+        equal = (equal and res[k][1] is not None and np.array_equal(m1, res[k][1])
+                 and all(np.array_equal(p1[c], res[k][2][c], equal_nan=True) for c in p1))
     if not equal:
         raise RuntimeError("batch_segment + cell_properties differ from the per-image calls")
     # bytes that must cross the bus per FOV on this API: DAPI plane up, int64 labels down, labels (narrowed to int32 on
@@ -632,7 +636,7 @@ def run_api(args):
                                "the host -> SegmentationMask(labels, 4 channels).cell_properties -> feature dict on the host "
                                "(R/model.py:217-290, R/masks.py:247-328)",
                    "fovs_per_step": B, "worker_threads": workers, "images_per_batch_segment_call": per_call,
-                   "fov_shape": [4, S, S], "cells_per_fov_mean": float(np.mean([len(r[1]["label"]) for r in res]))},
+                   "fov_shape": [4, S, S], "cells_per_fov_mean": float(np.mean([len(r[2]["label"]) for r in res]))},
         "pcie_bound": {"h2d_bytes_per_fov": h2d, "d2h_bytes_per_fov": d2h, "assumed_GBps_per_direction": bus / 1e9,
                        "fov_per_s": bus / max(h2d, d2h),
                        "note": "labels travel host <-> device twice because the API hands int64 numpy label images from "
@@ -842,13 +846,13 @@ def run_chain(args):
         packed = PlateTables(segs, torch.device("cuda", device), cap_fovs=max_B, keep=2)
 
     # N = 1: there is no exchange, but the plate's feature table still has to reach the host -- every step packs
-    # its table and copies the rows that exist to page-locked host memory (plate.HostTables, one step lagged)
+    # its table and copies the rows that exist to page-locked host memory (plate.HostTables, two steps lagged)
     deliver = (not distributed) and args.workload == "c3" and not args.no_deliver
     host_tables = None
     if deliver:
         from arcadia_microscopy_tools_amd.plate import HostTables
 
-        host_tables = HostTables(segs, slots=3)
+        host_tables = HostTables(segs, slots=4, lag=2)
 
     def step(i=0):
         if gather:
@@ -873,8 +877,6 @@ def run_chain(args):
         else:
             for c in ctxs:
                 c.synchronize()
-            if deliver:
-                host_tables.gctx.synchronize()
 
     def barrier():
         if distributed:
@@ -947,7 +949,7 @@ def run_chain(args):
         if not np.array_equal(rows[:, 2: 2 + t_dev.shape[1]], t_dev, equal_nan=True):
             raise RuntimeError("the delivered feature table differs from the device tables")
         delivered = {"what": "packed per-cell rows (fov index, label, 14 morphology + 4 x 4 intensity columns) copied to "
-                             "page-locked host memory inside the timed region, one step lagged; label images stay in HBM",
+                             "page-locked host memory inside the timed region, two steps lagged; label images stay in HBM",
                      "rows_per_step": int(rows.shape[0]), "row_bytes": host_tables.ncols * 8,
                      "bytes_per_step": int(rows.shape[0]) * host_tables.ncols * 8}
         log(f"feature tables delivered to the host: {rows.shape[0]} rows per step")
