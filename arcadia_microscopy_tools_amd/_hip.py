@@ -119,6 +119,8 @@ _SIGS = {
     "amt_watershed_edt": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int]),
     "amt_watershed_f64": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int]),
     "amt_watershed_edt_cleared": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "amt_watershed_edt_cleared_sparse": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P,
+                                                 c_int]),
     "amt_watershed_edt_ex": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "amt_watershed_f64_ex": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "amt_regionprops": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int]),

@@ -63,7 +63,7 @@ __global__ void __launch_bounds__(1024) hist_u16_kernel(const uint16_t* __restri
 // 65536 bins as 16-bit counters (two per LDS word; a counter cannot overflow within a part of fewer than 65536
 // pixels), stores its 128 KiB as plain coalesced stores, and a second kernel adds the parts up.  A single full-range
 // 2048^2 plane: 82 us (round 2) -> 54 us (two windows) -> see DESIGN.md for this path.
-constexpr int HIST_PART_PX = 32760;   // multiple of 8 (16-byte loads), below 65536; 129 parts for a 2048^2 plane
+constexpr int HIST_PART_PX = 65528;   // multiple of 8 (16-byte loads), below 65536 (half-size parts: 28 -> 39 us per plane)
 constexpr int HIST_MAX_PARTS = 1024;  // 128 MiB of partial histograms at most
 
 __global__ void __launch_bounds__(1024) hist_u16_part_kernel(const uint16_t* __restrict__ in, uint32_t* __restrict__ partial,

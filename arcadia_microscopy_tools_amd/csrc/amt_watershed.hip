@@ -35,20 +35,30 @@
 #include <hip/hip_ext.h>
 
 // component classes
-enum { CLS_NONE = 0, CLS_UNIFORM = 1, CLS_S = 2, CLS_M = 3, CLS_M2 = 4, CLS_L = 5, CLS_X = 6, CLS_G = 7 };
-// LDS tile classes: max pixels of the bounding box, max d2 (bucket count - 1).  S / M / L are flooded by
+enum { CLS_NONE = 0, CLS_UNIFORM = 1, CLS_XS = 2, CLS_S = 3, CLS_M = 4, CLS_M2 = 5, CLS_L = 6, CLS_X = 7, CLS_G = 8 };
+// LDS tile classes: max pixels of the bounding box, max d2 (bucket count - 1).  XS / S / M / M2 / L are flooded by
 // ws_flood_batch_kernel (6 bytes of LDS per pixel + 8 per bucket), X -- the few boxes between L and the 15-bit
 // index limit -- by the one-pop-at-a-time ws_flood_lds_kernel (4 bytes per pixel).
+// Round 3: a class XS (1,280 px / 256 buckets, 9.2 KB: 17 workgroups per CU) for the 46 % of the synthetic plate's flooded
+// components that fit it was measured and is switched OFF (AMT_WS_XS_PX 0): occupancy does bound the small classes
+// (padding S: 10 workgroups per CU 468 us, 5 per CU 711 us), but every class launch has a floor of ~250 us -- its
+// longest component chain -- so splitting S (468 us) gave XS 255 + S 310 us, the stage stayed at 2.51 ms per 48 FOVs and
+// the 48-FOV plate's went from 1.07 to 1.16 ms.
+#ifndef AMT_WS_XS_PX
+#define AMT_WS_XS_PX 0
+#define AMT_WS_XS_NB 256
+#endif
 #ifndef AMT_WS_S_PX
 #define AMT_WS_S_PX 2048
 #define AMT_WS_S_NB 512
 #endif
 #ifndef AMT_WS_M_PX
 // 4,096 px (27 KB with the bucket words: five workgroups per CU).  Measured against 8,192 px / 1,024 buckets (two per
-// CU): watershed stage 1.86 -> 1.73 ms per 32 FOVs, 0.95 -> 0.79 ms per 12 FOVs; boxes above 4,096 px join class L
+// CU): watershed stage 1.86 -> 1.73 ms per 32 FOVs, 0.95 -> 0.79 ms per 12 FOVs; boxes above 4,096 px join class M2 / L
 #define AMT_WS_M_PX 4096
 #define AMT_WS_M_NB 512
 #endif
+constexpr int XS_PX = AMT_WS_XS_PX, XS_NB = AMT_WS_XS_NB;
 constexpr int S_PX = AMT_WS_S_PX, S_NB = AMT_WS_S_NB;
 constexpr int M_PX = AMT_WS_M_PX, M_NB = AMT_WS_M_NB;
 #ifndef AMT_WS_M2_PX
@@ -153,6 +163,7 @@ __global__ void __launch_bounds__(256) ws_rows_init_kernel(comp_row* __restrict_
 //   * marker pixels (sparse) update the marker count and label range;
 //   * max d2: only pixels that are >= their 4 neighbours inside the wave's 64 x 8 strip can be the component's
 //     maximum, so only those issue an atomicMax (the true maximum always passes the test).
+template <bool MARKER_PLANE>
 __global__ void __launch_bounds__(256) ws_stats_kernel(const int* __restrict__ d2, const int* __restrict__ L,
                                                        const int* __restrict__ T, const int* __restrict__ markers,
                                                        comp_row* __restrict__ rows, size_t row_stride, int H, int W,
@@ -171,7 +182,7 @@ __global__ void __launch_bounds__(256) ws_stats_kernel(const int* __restrict__ d
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const size_t i = base + (size_t)(yb + k) * W + x;
-        ms[k] = rs[k] >= 0 ? markers[i] : 0;
+        ms[k] = (MARKER_PLANE && rs[k] >= 0) ? markers[i] : 0;  // with a marker list the plane is not read at all
         vs[k] = 0;
     }
     // component row of every foreground pixel, gathered NOW with the marker / relief loads (a few hot lines: the
@@ -239,6 +250,30 @@ __global__ void __launch_bounds__(256) ws_stats_kernel(const int* __restrict__ d
     }
 }
 
+// marker statistics from the LIST of marker pixels (amt_label_sparse_reuse keeps it): a few thousand pixels per plane
+// instead of a 4-byte read of every pixel of the marker plane in ws_stats_kernel
+__global__ void __launch_bounds__(256) ws_marker_stats_kernel(const int* __restrict__ mk_list, const int* __restrict__ mk_count,
+                                                              int mk_cap, const int* __restrict__ markers,
+                                                              const int* __restrict__ L, const int* __restrict__ T,
+                                                              comp_row* __restrict__ rows, size_t row_stride, size_t n) {
+    const int plane = blockIdx.y;
+    const int cnt = mk_count[plane] < mk_cap ? mk_count[plane] : mk_cap;
+    const int* lst = mk_list + (size_t)plane * mk_cap;
+    const size_t base = (size_t)plane * n;
+    comp_row* prow = rows + (size_t)plane * row_stride;
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < cnt; k += gridDim.x * 256) {
+        const int p = lst[k];
+        const int r = L[base + p];
+        if (r < 0) continue;  // markers * mask: a marker pixel outside the mask does not exist
+        const int lab = markers[base + p];
+        if (lab == 0) continue;
+        comp_row* c = prow + (T[base + r] - 1);
+        atomicAdd(&c->mcnt, 1);
+        atomicMin(&c->labmin, lab);
+        atomicMax(&c->labmax, lab);
+    }
+}
+
 // classify components; publish marker-list sizes (moff) and queue sizes (boff) for the HBM path
 __global__ void __launch_bounds__(256) ws_classify_kernel(comp_row* __restrict__ rows, const int* __restrict__ ncomp,
                                                           int* __restrict__ moff, int* __restrict__ boff,
@@ -261,6 +296,7 @@ __global__ void __launch_bounds__(256) ws_classify_kernel(comp_row* __restrict__
         } else {
             const long long area = (long long)(c.x1 - c.x0 + 3) * (c.y1 - c.y0 + 3);  // with the sentinel ring
             if (c.labmax >= 0xFFFF) cls = CLS_G;  // labels are kept as 16-bit values in LDS
+            else if (area <= XS_PX && c.cmax < XS_NB) cls = CLS_XS;
             else if (area <= S_PX && c.cmax < S_NB) cls = CLS_S;
             else if (area <= M_PX && c.cmax < M_NB) cls = CLS_M;
             else if (area <= M2_PX && c.cmax < M2_NB) cls = CLS_M2;
@@ -273,9 +309,9 @@ __global__ void __launch_bounds__(256) ws_classify_kernel(comp_row* __restrict__
         // -1 = no marker at all (stays background)
         Fall[(size_t)blockIdx.y * n + c.root] = cls == CLS_UNIFORM ? c.labmin : (cls == CLS_NONE ? -1 : 0);
         if (cls == CLS_G) has_g[blockIdx.y] = 1;
-        if (cls >= CLS_S && cls <= CLS_X) {
+        if (cls >= CLS_XS && cls <= CLS_X) {
             // per-class worklist of this plane (order is irrelevant: components are independent)
-            const int k = cls - CLS_S;
+            const int k = cls - CLS_XS;
             const int pos = atomicAdd(&wl_count[k * nplanes + blockIdx.y], 1);
             wl[((size_t)k * nplanes + blockIdx.y) * row_stride + pos] = i;
         }
@@ -1011,117 +1047,191 @@ __global__ void __launch_bounds__(256) ws_global_init_kernel(const int* __restri
         out[base + i] = mask[base + i] ? markers[base + i] : 0;  // markers.astype(int32) * mask
 }
 
-struct gh_less {
-    __device__ __forceinline__ bool operator()(const hp_elem& a, const hp_elem& b) const {
-        return a.value < b.value || (a.value == b.value && a.age < b.age);
-    }
+// Round 3: the whole wave works on the ONE heap.  The heap's mechanics are scikit-image's, element for element; what
+// changed is how many memory round trips an operation takes:
+//   * an element is 16 bytes {key, age, index} with key = an unsigned code that orders like the relief (0x7fffffff - d2,
+//     or the order-preserving image of the float64), so "smaller" is two integer compares;
+//   * levels 0..12 of the heap (8,191 elements, 128 KB) live in LDS, deeper levels in HBM;
+//   * push: the ancestors of the new slot are known up front -- lane j loads ancestor j, one ballot tells how far the
+//     element rises, and the lanes shift the overtaken ancestors down in one round of stores (one round trip instead of
+//     one per level);
+//   * pop: the path down is data dependent, so 62 lanes fetch the whole 5-level subtree under the current position
+//     (1-2 round trips for the LDS levels + one for the HBM levels instead of 2 loads per level), the wave walks it with
+//     cross-lane reads, and the lanes on the path move their elements up in one round of stores;
+//   * the popped pixel's neighbours (mask, label, relief) are requested BEFORE the sift-down and arrive under it.
+// One wave per plane; round 2's one-lane version took 2.1 s per tied 2048^2 plane (4.9 us per pixel).
+struct gh_elem {
+    unsigned long long key;
+    unsigned age;
+    unsigned idx;
 };
+constexpr int GH_LDS_N = 8191;  // levels 0..12
 
 template <bool USE_D2>
 __global__ void __launch_bounds__(64) ws_global_kernel(const void* __restrict__ reliefall,
                                                        const uint8_t* __restrict__ maskall, int* __restrict__ outall,
                                                        hp_elem* __restrict__ heapall, const int* __restrict__ run,
                                                        int H, int W, size_t hstride, int conn) {
+    extern __shared__ __attribute__((aligned(16))) char gh_smem[];
+    gh_elem* sh = reinterpret_cast<gh_elem*>(gh_smem);
     const int plane = blockIdx.x;
     if (run && !run[plane]) return;
     const size_t n = (size_t)H * W;
     const uint8_t* mask = maskall + (size_t)plane * n;
     int* out = outall + (size_t)plane * n;
-    hp_elem* hp = heapall + (size_t)plane * hstride;
+    gh_elem* gh = reinterpret_cast<gh_elem*>(heapall + (size_t)plane * hstride);  // same 16 bytes per slot
     const double* rel = USE_D2 ? nullptr : (const double*)reliefall + (size_t)plane * n;
     const int* d2 = USE_D2 ? (const int*)reliefall + (size_t)plane * n : nullptr;
     const int lane = threadIdx.x;
-    gh_less smaller;
-    // -sqrt(d2) orders exactly like -d2 (and ties exactly when d2 ties): the integer is the key
-    auto value_of = [&](int p) -> double {
-        if (USE_D2) {
-            const int d = d2[p];
-            return -(double)(d < 0 ? 0 : d);
-        }
-        return rel[p];
+    constexpr unsigned long long INF = ~0ull;
+    auto key_of_d2 = [](int d) -> unsigned long long { return (unsigned long long)(0x7fffffffu - (unsigned)(d < 0 ? 0 : d)); };
+    auto key_of_f64 = [](double v) -> unsigned long long { return amt_f64_key(v + 0.0); };  // -0.0 orders like +0.0
+    auto ld = [&](int i) -> gh_elem { return i < GH_LDS_N ? sh[i] : gh[i]; };
+    auto st = [&](int i, const gh_elem& e) {
+        if (i < GH_LDS_N) sh[i] = e; else gh[i] = e;
     };
-    int items = 0;
-    auto push = [&](const hp_elem& e) {
-        int child = items++;
-        hp[child] = e;
-        while (child > 0) {
-            const int parent = (child + 1) / 2 - 1;
-            const hp_elem pe = hp[parent];
-            if (smaller(e, pe)) {
-                hp[child] = pe;
-                hp[parent] = e;
-                child = parent;
-            } else {
-                break;
-            }
+    auto less = [](unsigned long long ka, unsigned aa, unsigned long long kb, unsigned ab) -> bool {
+        return ka < kb || (ka == kb && aa < ab);
+    };
+    auto rl64 = [](unsigned long long v, int l) -> unsigned long long {
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+        return ((unsigned long long)hi << 32) | lo;
+    };
+    int items = 0;  // uniform
+    // ---- push: executed by the whole wave, e is uniform ----
+    auto push = [&](unsigned long long ekey, unsigned eage, unsigned eidx) {
+        const int c = items++;
+        const int depth = 31 - __clz(c + 1);  // number of ancestors of slot c
+        gh_elem a;
+        a.key = 0;
+        a.age = 0;
+        a.idx = 0;
+        const bool anc = lane >= 1 && lane <= depth;
+        if (anc) a = ld(((c + 1) >> lane) - 1);
+        const bool rises = anc && less(ekey, eage, a.key, a.age);
+        const unsigned long long m = __ballot(rises) >> 1;  // bit j-1: the element overtakes ancestor j
+        const int up = m == ~0ull ? 64 : __ffsll((long long)~m) - 1;  // consecutive overtaken ancestors from the bottom
+        if (anc && lane <= up) st(((c + 1) >> (lane - 1)) - 1, a);  // ancestor j moves down into slot of j - 1
+        if (lane == 0) {
+            gh_elem e;
+            e.key = ekey;
+            e.age = eage;
+            e.idx = eidx;
+            st(((c + 1) >> up) - 1, e);
         }
     };
-    auto pop = [&]() -> hp_elem {
-        const hp_elem top = hp[0];
-        hp_elem moved = hp[items - 1];
-        --items;
-        if (items > 0) {
-            hp[0] = moved;
-            int parent = 0, child = 1;
-            while (child < items) {
-                hp_elem ce = hp[child];
-                if (child + 1 < items) {
-                    const hp_elem c2 = hp[child + 1];
-                    if (smaller(c2, ce)) {
-                        ce = c2;
-                        ++child;
-                    }
-                }
-                if (smaller(ce, moved)) {
-                    hp[parent] = ce;
-                    hp[child] = moved;
-                    parent = child;
-                    child = 2 * child + 1;
-                } else {
-                    break;
-                }
-            }
-        }
-        return top;
-    };
-    // markers in raster order
+    // markers in raster order (age 0)
     for (size_t i0 = 0; i0 < n; i0 += 64) {
         const size_t i = i0 + lane;
         const int v = i < n ? out[i] : 0;
-        unsigned long long m = __ballot(v != 0);
-        if (lane == 0) {
-            while (m) {
-                const int b = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                hp_elem e;
-                e.index = (int)(i0 + b);
-                e.age = 0;
-                e.value = value_of(e.index);
-                push(e);
-            }
+        unsigned long long mk = __ballot(v != 0);
+        if (!mk) continue;
+        unsigned long long kv = 0;
+        if (v != 0) kv = USE_D2 ? key_of_d2(d2[i]) : key_of_f64(rel[i]);
+        while (mk) {
+            const int b = __ffsll((long long)mk) - 1;
+            mk &= mk - 1;
+            push(rl64(kv, b), 0u, (unsigned)(i0 + b));  // a wave's loads see its own earlier stores: no explicit wait
         }
     }
-    if (lane != 0) return;
-    const int dy1[4] = {-1, 0, 0, 1}, dx1[4] = {0, -1, 1, 0};
-    const int dy2[8] = {-1, 0, 0, 1, -1, -1, 1, 1}, dx2[8] = {0, 1, -1, 0, -1, 1, -1, 1};
     const int nnb = conn == 1 ? 4 : 8;
-    int age = 0;
+    // neighbour order: N, W, E, S (connectivity 1); N, E, W, S, NW, NE, SW, SE (connectivity 2, scikit-image 0.18.3)
+    int dy = 0, dx = 0;
+    if (conn == 1) {
+        dy = lane == 0 ? -1 : lane == 3 ? 1 : 0;
+        dx = lane == 1 ? -1 : lane == 2 ? 1 : 0;
+    } else {
+        const int dys[8] = {-1, 0, 0, 1, -1, -1, 1, 1}, dxs[8] = {0, 1, -1, 0, -1, 1, -1, 1};
+        dy = lane < 8 ? dys[lane & 7] : 0;
+        dx = lane < 8 ? dxs[lane & 7] : 0;
+    }
+    // relative position of this lane's node in a 5-level subtree: r = lane + 1 (1..62), level lv, offset o
+    const int r = lane + 1;
+    const int lv = 31 - __clz(r + 1);
+    const int o = r + 1 - (1 << lv);
+    unsigned age = 0;
     while (items > 0) {
-        const hp_elem e = pop();
-        const int p = e.index;
-        const int lab = out[p];
+        const gh_elem top = sh[0];
+        const int p = (int)top.idx;
         const int py = p / W, px = p - py * W;
-        for (int k = 0; k < nnb; ++k) {
-            const int qy = py + (conn == 1 ? dy1[k] : dy2[k]), qx = px + (conn == 1 ? dx1[k] : dx2[k]);
-            if (qy < 0 || qy >= H || qx < 0 || qx >= W) continue;
-            const int q = qy * W + qx;
-            if (!mask[q] || out[q] != 0) continue;
-            out[q] = lab;
-            hp_elem ne;
-            ne.value = value_of(q);
-            ne.age = ++age;
-            ne.index = q;
-            push(ne);
+        // neighbour data, requested now, consumed after the sift-down
+        const int qy = py + dy, qx = px + dx;
+        const bool inside = lane < nnb && qy >= 0 && qy < H && qx >= 0 && qx < W;
+        const int q = inside ? qy * W + qx : p;
+        const uint8_t qm = mask[q];
+        const int qo = out[q];
+        unsigned long long qk = 0;
+        if (USE_D2) qk = key_of_d2(d2[q]); else qk = key_of_f64(rel[q]);
+        const int lab = out[p];
+        // ---- pop ----
+        --items;
+        if (items > 0) {
+            const gh_elem last = ld(items);
+            int pos = 0;
+            while (true) {
+                // the 62 nodes of the five levels under pos
+                const long long ab = (((long long)pos + 1) << lv) - 1 + o;
+                const bool valid = lane < 62 && ab < (long long)items;
+                gh_elem e;
+                e.key = INF;
+                e.age = 0;
+                e.idx = 0;
+                if (valid) e = ld((int)ab);
+                int cur = 0;                 // relative index of the node `last` would sit in (0 = pos itself)
+                unsigned long long path = 0; // lanes whose element moves up to its parent
+                bool placed = false;
+#pragma unroll
+                for (int s5 = 0; s5 < 5; ++s5) {
+                    const int l = 2 * cur + 1;  // relative index of the left child; its lane is l - 1
+                    const unsigned long long kl = rl64(e.key, l - 1), kr = rl64(e.key, l);
+                    if (kl == INF) {
+                        placed = true;  // no child inside the heap
+                        break;
+                    }
+                    const unsigned al = (unsigned)__builtin_amdgcn_readlane((int)e.age, l - 1);
+                    const unsigned ar = (unsigned)__builtin_amdgcn_readlane((int)e.age, l);
+                    const bool right = kr != INF && less(kr, ar, kl, al);
+                    const unsigned long long kc = right ? kr : kl;
+                    const unsigned ac = right ? ar : al;
+                    if (!less(kc, ac, last.key, last.age)) {
+                        placed = true;
+                        break;
+                    }
+                    cur = right ? l + 1 : l;
+                    path |= 1ull << (cur - 1);
+                }
+                // lanes on the path hand their element to the parent slot
+                if ((path >> lane) & 1ull) {
+                    const int prel = (r - 1) >> 1;  // parent's relative index
+                    long long pab = pos;
+                    if (prel > 0) {
+                        const int plv = 31 - __clz(prel + 1);
+                        pab = (((long long)pos + 1) << plv) - 1 + (prel + 1 - (1 << plv));
+                    }
+                    st((int)pab, e);
+                }
+                long long cab = pos;
+                if (cur > 0) {
+                    const int clv = 31 - __clz(cur + 1);
+                    cab = (((long long)pos + 1) << clv) - 1 + (cur + 1 - (1 << clv));
+                }
+                if (placed) {
+                    if (lane == 0) st((int)cab, last);
+                    break;
+                }
+                pos = (int)cab;
+            }
+        }
+        // ---- spread: unlabelled masked neighbours take the label at push time, in neighbour order ----
+        unsigned long long claim = __ballot(inside && qm != 0 && qo == 0);
+        while (claim) {
+            const int k = __ffsll((long long)claim) - 1;
+            claim &= claim - 1;
+            const int qq = __builtin_amdgcn_readlane(q, k);
+            if (lane == 0) out[qq] = lab;
+            ++age;
+            push(rl64(qk, k), age, (unsigned)qq);
         }
     }
 }
@@ -1228,7 +1338,8 @@ static size_t ws_lds_pad() {
 static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const int32_t* markers,
                             const uint8_t* mask, int32_t* out, int nplanes, int H, int W, int seeds_first,
                             int connectivity, int tie_policy, int32_t* ties_dev, int32_t* fused_labels = nullptr,
-                            int32_t* fused_count = nullptr, const int32_t* nlabels_dev = nullptr, int max_label = 0) {
+                            int32_t* fused_count = nullptr, const int32_t* nlabels_dev = nullptr, int max_label = 0,
+                            const int32_t* mk_list = nullptr, const int32_t* mk_count = nullptr, int mk_cap = 0) {
     // fused_labels != nullptr: `out` is only the flood's scratch plane; the result is clear_border + relabel_sequential
     // of the watershed, written to fused_labels / fused_count (connectivity 1 only)
     AMT_TRY(amt_set_device(ctx));
@@ -1258,10 +1369,10 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
                            markers, mask, out, (const int*)nullptr, n);
         AMT_LAUNCH_CHECK();
         if (use_d2)
-            hipLaunchKernelGGL((ws_global_kernel<true>), dim3(nplanes), dim3(64), 0, ctx->stream, relief, mask, out, gheap,
+            hipLaunchKernelGGL((ws_global_kernel<true>), dim3(nplanes), dim3(64), GH_LDS_N * sizeof(gh_elem), ctx->stream, relief, mask, out, gheap,
                                (const int*)nullptr, H, W, n, 2);
         else
-            hipLaunchKernelGGL((ws_global_kernel<false>), dim3(nplanes), dim3(64), 0, ctx->stream, relief, mask, out, gheap,
+            hipLaunchKernelGGL((ws_global_kernel<false>), dim3(nplanes), dim3(64), GH_LDS_N * sizeof(gh_elem), ctx->stream, relief, mask, out, gheap,
                                (const int*)nullptr, H, W, n, 2);
         AMT_LAUNCH_CHECK();
         return AMT_OK;
@@ -1276,7 +1387,7 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     const int trows = amt_i_tile_rows(H);
     const size_t lcap = amt_i_rootlist_cap(W);
     const size_t nlist = (size_t)nplanes * trows;
-    size_t need = 5 * amt_align(np * 4) + amt_align(nlist * lcap * 4) + amt_align(nlist * 4) + 8 * amt_align(nr * 4) + amt_align(nr * sizeof(comp_row)) +
+    size_t need = 5 * amt_align(np * 4) + amt_align(nlist * lcap * 4) + amt_align(nlist * 4) + 9 * amt_align(nr * 4) + amt_align(nr * sizeof(comp_row)) +
                   9 * amt_align(nplanes * 4 * 16) + amt_align((size_t)nplanes * 4);
     need += use_d2 ? 2 * amt_align((size_t)nplanes * bstride * 4) : amt_align((size_t)nplanes * bstride * sizeof(hp_elem));
     // the sequential emulation's heap (every pixel is pushed at most once): the float64 path reuses its per-component
@@ -1298,10 +1409,10 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     comp_row* rows = arena_take_t<comp_row>(ctx, nr);
     int* btot = arena_take_t<int>(ctx, nplanes);
     int* mtot = arena_take_t<int>(ctx, nplanes);
-    // per plane: work counters of the L / M / S / G floods [0..4), has_g [4], worklist sizes S / M / M2 / L / X [5..10),
-    // number of components [10], work counters of the X [11] and M2 [12] floods
+    // per plane: work counters of the six LDS flood classes XS / S / M / M2 / L / X [0..6) and of the HBM flood [6],
+    // has_g [7], worklist sizes of the six classes [8..14), number of components [14]
     int* counters = arena_take_t<int>(ctx, (size_t)nplanes * 16);
-    int* wl = arena_take_t<int>(ctx, 5 * nr);  // worklists of the five LDS classes
+    int* wl = arena_take_t<int>(ctx, 6 * nr);  // worklists of the six LDS classes
     int* ties = ties_dev ? ties_dev : arena_take_t<int>(ctx, nplanes);
     int* P = fused_labels ? arena_take_t<int>(ctx, msz) : nullptr;
     int *head = nullptr, *tail = nullptr;
@@ -1316,7 +1427,7 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
         gheap = heap;  // bstride == n: the per-component heaps are dead when the emulation starts
     }
 
-    int* ncomp = counters + 10 * (size_t)nplanes;
+    int* ncomp = counters + 14 * (size_t)nplanes;
     hipLaunchKernelGGL(ws_zero_counters_kernel, dim3((nplanes * 16 + 63) / 64), dim3(64), 0, ctx->stream, counters,
                        nplanes * 16);
     AMT_LAUNCH_CHECK();
@@ -1332,11 +1443,21 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     AMT_TRY(amt_i_propagate_roots(ctx, T, L, rootlist, nroots, nplanes, H, W));
     hipLaunchKernelGGL(ws_rows_init_kernel, dim3(64, nplanes), dim3(256), 0, ctx->stream, rows, ncomp, row_stride);
     AMT_LAUNCH_CHECK();
-    int* has_g = counters + 4 * nplanes;
-    int* wl_count = counters + 5 * nplanes;  // [5][nplanes]
-    hipLaunchKernelGGL(ws_stats_kernel, dim3((W + 63) / 64, (H + 31) / 32, nplanes), dim3(256), 0, ctx->stream,
-                       use_d2 ? (const int*)relief : (const int*)nullptr, L, T, markers, rows, row_stride, H, W,
-                       use_d2 ? 1 : 0);
+    int* has_g = counters + 7 * nplanes;
+    int* wl_count = counters + 8 * nplanes;  // [6][nplanes]
+    if (mk_list) {
+        // the caller knows where the marker pixels are: the dense pass skips the marker plane
+        hipLaunchKernelGGL((ws_stats_kernel<false>), dim3((W + 63) / 64, (H + 31) / 32, nplanes), dim3(256), 0, ctx->stream,
+                           use_d2 ? (const int*)relief : (const int*)nullptr, L, T, markers, rows, row_stride, H, W,
+                           use_d2 ? 1 : 0);
+        AMT_LAUNCH_CHECK();
+        hipLaunchKernelGGL(ws_marker_stats_kernel, dim3(16, nplanes), dim3(256), 0, ctx->stream, mk_list, mk_count, mk_cap,
+                           markers, L, T, rows, row_stride, n);
+    } else {
+        hipLaunchKernelGGL((ws_stats_kernel<true>), dim3((W + 63) / 64, (H + 31) / 32, nplanes), dim3(256), 0, ctx->stream,
+                           use_d2 ? (const int*)relief : (const int*)nullptr, L, T, markers, rows, row_stride, H, W,
+                           use_d2 ? 1 : 0);
+    }
     AMT_LAUNCH_CHECK();
     hipLaunchKernelGGL(ws_classify_kernel, dim3(64, nplanes), dim3(256), 0, ctx->stream, rows, ncomp, moff, boff, has_g,
                        wl, wl_count, F, n, nplanes, row_stride, use_d2 ? 1 : 0);
@@ -1347,7 +1468,7 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     // such plane (its final pass derives every pixel from F and the flood's sparse writes): it seeds only planes that
     // hold a component for the HBM flood, which works in `out` itself
     hipLaunchKernelGGL(ws_seed_kernel, dim3(amt_grid_for(n, 1024, 4096), nplanes), dim3(256), 0, ctx->stream, markers, L, F,
-                       out, n, fused_labels ? (const int*)(counters + 4 * nplanes) : (const int*)nullptr);
+                       out, n, fused_labels ? (const int*)(counters + 7 * nplanes) : (const int*)nullptr);
     AMT_LAUNCH_CHECK();
     // ---- HBM-path bookkeeping (usually empty: only components too large for an LDS tile) ----
     AMT_TRY(amt_scan_excl_dev(ctx, moff, ncomp, row_stride, mtot, nplanes));
@@ -1358,6 +1479,7 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
                        has_g, row_stride, n);
     AMT_LAUNCH_CHECK();
     if (use_d2) {
+        const size_t ldsXS = (size_t)XS_PX * 6 + (size_t)XS_NB * 6;
         const size_t ldsS = (size_t)S_PX * 6 + (size_t)S_NB * 6;
         const size_t ldsM = (size_t)M_PX * 6 + (size_t)M_NB * 6;
         const size_t ldsM2 = (size_t)(M2_PX > 0 ? M2_PX : 64) * 6 + (size_t)M2_NB * 6;
@@ -1370,13 +1492,13 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
         AMT_TRY(amt_fork(ctx));
         // workgroups per plane and class (a workgroup only takes components of its own plane).  Measured: 2 x / 4 x as
         // many change nothing at 1, 12 or 32 planes per launch -- the chains per workgroup are not what bounds a class
-        const int gM = 64, gS = 128, gL = 16;
+        const int gXS = 96, gS = XS_PX > 0 ? 80 : 128, gM = XS_PX > 0 ? 48 : 64, gM2 = XS_PX > 0 ? 16 : 32, gL = 16;
         // Without auxiliary streams the classes still overlap: the first flood is an ordinary (barrier) launch, the
         // others carry hipExtAnyOrderLaunch -- their packets have no barrier bit, so the command processor dispatches
         // them while the earlier floods are still running; the next ordinary launch waits for all of them.
         const bool any = ctx->fork == 0 && ws_anyorder();
         int nflood = 0;
-        auto flood = [&](const void* fn, int gx, size_t lds, hipStream_t st, int cls_slot, int counter_slot) -> int {
+        auto flood = [&](const void* fn, int gx, size_t lds, hipStream_t st, int cls_slot) -> int {
             const int* a_d2 = (const int*)relief;
             const int* a_L = L;
             const int* a_T = T;
@@ -1384,27 +1506,28 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
             const comp_row* a_rows = rows;
             const int* a_wl = wl + (size_t)cls_slot * nplanes * row_stride;
             const int* a_wlc = wl_count + cls_slot * nplanes;
-            int* a_cnt = counters + counter_slot * nplanes;
+            int* a_cnt = counters + cls_slot * nplanes;  // the class's work counter
             size_t a_rs = row_stride;
             int a_H = H, a_W = W, a_sf = seeds_first;
             int* a_ties = ties;
             const int* a_mk = markers;
             void* args[] = {&a_d2, &a_L, &a_T, &a_out, &a_rows, &a_wl, &a_wlc, &a_cnt, &a_rs, &a_H, &a_W, &a_sf, &a_ties, &a_mk};
-            AMT_HIP_CHECK(hipExtLaunchKernel(fn, dim3(gx, nplanes), dim3(64), args, lds + (cls_slot <= 1 ? ws_lds_pad() : 0), st, nullptr, nullptr,
+            AMT_HIP_CHECK(hipExtLaunchKernel(fn, dim3(gx, nplanes), dim3(64), args, lds + (cls_slot <= 2 ? ws_lds_pad() : 0), st, nullptr, nullptr,
                                              (any && nflood > 0) ? (int)hipExtAnyOrderLaunch : 0));
             ++nflood;
             return AMT_OK;
         };
-        AMT_TRY(flood((const void*)ws_flood_batch_kernel<L_PX, L_NB>, gL, ldsL, ctx->stream, 3, 0));
-        AMT_TRY(flood((const void*)ws_flood_lds_kernel<X_PX, X_NB, CLS_X>, 8, ldsX, ctx->stream, 4, 11));
-        AMT_TRY(flood((const void*)ws_flood_batch_kernel<M2_PX, M2_NB>, 32, ldsM2, ctx->aux[2], 2, 12));
-        AMT_TRY(flood((const void*)ws_flood_batch_kernel<M_PX, M_NB>, gM, ldsM, ctx->aux[0], 1, 1));
-        AMT_TRY(flood((const void*)ws_flood_batch_kernel<S_PX, S_NB>, gS, ldsS, ctx->aux[1], 0, 2));
+        AMT_TRY(flood((const void*)ws_flood_batch_kernel<L_PX, L_NB>, gL, ldsL, ctx->stream, 4));
+        AMT_TRY(flood((const void*)ws_flood_lds_kernel<X_PX, X_NB, CLS_X>, 8, ldsX, ctx->stream, 5));
+        AMT_TRY(flood((const void*)ws_flood_batch_kernel<M2_PX, M2_NB>, gM2, ldsM2, ctx->aux[2], 3));
+        AMT_TRY(flood((const void*)ws_flood_batch_kernel<M_PX, M_NB>, gM, ldsM, ctx->aux[0], 2));
+        AMT_TRY(flood((const void*)ws_flood_batch_kernel<S_PX, S_NB>, gS, ldsS, ctx->aux[1], 1));
+        if (XS_PX > 0) AMT_TRY(flood((const void*)ws_flood_batch_kernel<(XS_PX > 0 ? XS_PX : 64), XS_NB>, gXS, ldsXS, ctx->aux[2], 0));
         {
             const int* a_d2 = (const int*)relief;
             void* args[] = {&a_d2, (void*)&mask, &out, &next, &head, &tail, &mlist, (void*)&rows, &moff, &boff, &ncomp, nullptr,
                             (void*)&row_stride, &H, &W, (void*)&n, (void*)&bstride, &seeds_first, &ties};
-            int* a_cnt = counters + 3 * nplanes;
+            int* a_cnt = counters + 6 * nplanes;
             args[11] = &a_cnt;
             AMT_HIP_CHECK(hipExtLaunchKernel((const void*)ws_flood_edt_kernel, dim3(4, nplanes), dim3(64), args, 0, ctx->aux[1],
                                              nullptr, nullptr, any ? (int)hipExtAnyOrderLaunch : 0));
@@ -1412,7 +1535,7 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
         AMT_TRY(amt_join(ctx));
     } else {
         hipLaunchKernelGGL(ws_flood_heap_kernel, dim3(64, nplanes), dim3(64), 0, ctx->stream, (const double*)relief,
-                           mask, out, heap, mlist, rows, moff, boff, ncomp, counters + 3 * nplanes, row_stride, H, W, n,
+                           mask, out, heap, mlist, rows, moff, boff, ncomp, counters + 6 * nplanes, row_stride, H, W, n,
                            bstride, ties);
     }
     AMT_LAUNCH_CHECK();
@@ -1422,10 +1545,10 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
                            markers, mask, out, (const int*)ties, n);
         AMT_LAUNCH_CHECK();
         if (use_d2)
-            hipLaunchKernelGGL((ws_global_kernel<true>), dim3(nplanes), dim3(64), 0, ctx->stream, relief, mask, out, gheap,
+            hipLaunchKernelGGL((ws_global_kernel<true>), dim3(nplanes), dim3(64), GH_LDS_N * sizeof(gh_elem), ctx->stream, relief, mask, out, gheap,
                                (const int*)ties, H, W, n, 1);
         else
-            hipLaunchKernelGGL((ws_global_kernel<false>), dim3(nplanes), dim3(64), 0, ctx->stream, relief, mask, out, gheap,
+            hipLaunchKernelGGL((ws_global_kernel<false>), dim3(nplanes), dim3(64), GH_LDS_N * sizeof(gh_elem), ctx->stream, relief, mask, out, gheap,
                                (const int*)ties, H, W, n, 1);
         AMT_LAUNCH_CHECK();
     }
@@ -1450,6 +1573,19 @@ extern "C" int amt_watershed_edt_cleared(amt_ctx* ctx, const int32_t* d2, const 
     AMT_REQUIRE(ws_scratch != labels_out, "watershed_edt_cleared: scratch and output must not alias");
     return watershed_common(ctx, d2, true, markers, mask, ws_scratch, nplanes, H, W, 1, 1, AMT_WS_TIES_EXACT, nullptr,
                             labels_out, count_dev, nlabels_dev, max_label);
+}
+
+extern "C" int amt_watershed_edt_cleared_sparse(amt_ctx* ctx, const int32_t* d2, const int32_t* markers,
+                                                const uint8_t* mask, int32_t* ws_scratch, int32_t* labels_out,
+                                                int32_t* count_dev, int nplanes, int H, int W, int max_label,
+                                                const int32_t* nlabels_dev, const int32_t* marker_list,
+                                                const int32_t* marker_count, int list_capacity) {
+    AMT_REQUIRE(ws_scratch && labels_out && count_dev && nlabels_dev && max_label >= 0 && marker_list && marker_count &&
+                    list_capacity > 0,
+                "watershed_edt_cleared_sparse: bad arguments");
+    AMT_REQUIRE(ws_scratch != labels_out, "watershed_edt_cleared_sparse: scratch and output must not alias");
+    return watershed_common(ctx, d2, true, markers, mask, ws_scratch, nplanes, H, W, 1, 1, AMT_WS_TIES_EXACT, nullptr,
+                            labels_out, count_dev, nlabels_dev, max_label, marker_list, marker_count, list_capacity);
 }
 
 extern "C" int amt_watershed_edt_ex(amt_ctx* ctx, const int32_t* d2, const int32_t* markers, const uint8_t* mask,

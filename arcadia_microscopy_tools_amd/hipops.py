@@ -790,7 +790,7 @@ def watershed_edt(d2: DeviceArray, markers: DeviceArray, mask: DeviceArray, seed
 
 
 def watershed_edt_cleared(d2: DeviceArray, markers: DeviceArray, mask: DeviceArray, nlabels: DeviceArray,
-                          max_label: int, scratch: DeviceArray, out=None, count=None):
+                          max_label: int, scratch: DeviceArray, out=None, count=None, marker_list=None):
     """``relabel_sequential(clear_border(watershed(seeded relief, markers, mask=mask)))`` in one call (the tail of
     config 3; R/masks.py:56,65): identical to ``watershed_edt(seeds_first=True)`` + ``clear_border_relabel`` but the
     watershed image is never written out.  ``markers`` are numbered 1..nlabels[plane]; ``scratch`` is an int32 plane
@@ -801,6 +801,17 @@ def watershed_edt_cleared(d2: DeviceArray, markers: DeviceArray, mask: DeviceArr
     c = _out(ctx, count, (n,), np.int32)
     if scratch.dtype != np.int32 or scratch.size != d2.size or scratch.ctx is not ctx:
         raise ValueError("scratch must be an int32 array of the batch's size on the same context")
+    if marker_list is not None:
+        # (list, counts) as label_sparse(keep=) leaves them: every non-zero pixel of `markers`; the component statistics
+        # then skip the marker plane
+        klist, kcount = marker_list
+        if klist.dtype != np.int32 or kcount.dtype != np.int32 or kcount.size != n or klist.size % n:
+            raise ValueError("marker_list must be (int32 (n, capacity), int32 (n,))")
+        _hip.check(_lib().amt_watershed_edt_cleared_sparse(ctx.handle, d2.ptr, markers.ptr, mask.ptr, scratch.ptr, o.ptr,
+                                                           c.ptr, n, H, W, int(max_label), nlabels.ptr, klist.ptr,
+                                                           kcount.ptr, klist.size // n),
+                   "amt_watershed_edt_cleared_sparse")
+        return o, c
     _hip.check(_lib().amt_watershed_edt_cleared(ctx.handle, d2.ptr, markers.ptr, mask.ptr, scratch.ptr, o.ptr, c.ptr, n, H,
                                                 W, int(max_label), nlabels.ptr), "amt_watershed_edt_cleared")
     return o, c

@@ -47,7 +47,7 @@ class FovSegmenter:
     def __init__(self, batch: int, C: int, H: int, W: int, *, sigma: float = 2.0, radius: int = 2,
                  min_distance: int = 5, max_cells: int = 4096, dapi_index: int = 1, ctx: Context | None = None,
                  props: bool = True, profile: bool = False, fused: bool = True, low_traffic: bool = False, bin_plane: bool = True,
-                 relief: str = "seeded", ties: str = "exact"):
+                 relief: str = "seeded", ties: str = "exact", marker_list: bool = True):
         self.ctx = ctx or get_context()
         self.B, self.C, self.H, self.W = int(batch), int(C), int(H), int(W)
         self.sigma, self.radius, self.min_distance = float(sigma), int(radius), int(min_distance)
@@ -64,6 +64,9 @@ class FovSegmenter:
         if relief == "plain":
             self.fused = False
         self.tied = None  # per-plane tie flags of the last plain-relief run
+        # marker_list: hand the watershed the list of marker pixels label_sparse keeps (its statistics pass then skips
+        # the marker plane); False = the round-2 call (A/B, identical labels)
+        self.marker_list = bool(marker_list)
         # low_traffic = Gaussian -> Otsu -> '>' through amt_gaussian_otsu_codes: the float64 smoothed planes are never
         # made (8 instead of 26 bytes of HBM traffic per pixel, 25 MB less memory per field of view; same masks, same
         # thresholds).  Off by default: the Gaussian is fp64-issue bound, so computing it twice costs more time than
@@ -195,7 +198,8 @@ class FovSegmenter:
             # (self.ws only receives the pixels of flooded components)
             self._stage("watershed_clear_relabel")
             hipops.watershed_edt_cleared(self.d2, self.markers, mask, self.nmarkers, self.max_cells, scratch=self.ws,
-                                         out=self.labels, count=self.ncells)
+                                         out=self.labels, count=self.ncells,
+                                         marker_list=self._marker_keep if self.marker_list else None)
         else:
             self._stage("watershed")
             if self.relief == "plain":

@@ -328,6 +328,15 @@ int amt_watershed_f64_ex(amt_ctx* ctx, const double* relief, const int32_t* mark
 int amt_watershed_edt_cleared(amt_ctx* ctx, const int32_t* d2, const int32_t* markers, const uint8_t* mask,
                               int32_t* ws_scratch, int32_t* labels_out, int32_t* count_dev, int nplanes, int H, int W,
                               int max_label, const int32_t* nlabels_dev);
+/* The same for callers that hold the LIST of marker pixels (the keep_list / keep_count amt_label_sparse_reuse leaves
+ * behind: marker_list[plane * list_capacity ...][0 .. marker_count[plane]) = flat indices of every non-zero pixel of the
+ * marker plane): the per-component marker statistics come from the list and the dense statistics pass does not read the
+ * marker plane (4 of its 12 bytes per pixel).  A plane whose list is incomplete (count above the capacity) gives
+ * undefined labels -- amt_label_sparse_reuse reports that plane with count -1. */
+int amt_watershed_edt_cleared_sparse(amt_ctx* ctx, const int32_t* d2, const int32_t* markers, const uint8_t* mask,
+                                     int32_t* ws_scratch, int32_t* labels_out, int32_t* count_dev, int nplanes, int H,
+                                     int W, int max_label, const int32_t* nlabels_dev, const int32_t* marker_list,
+                                     const int32_t* marker_count, int list_capacity);
 
 /* ---- region properties: R/masks.py:286-326 (regionprops_table) ------------------------------- */
 /* Morphology columns per label 1..max_label (row = label-1), float64, column order: */

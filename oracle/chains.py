@@ -34,12 +34,14 @@ def c2_chain(plane_u16: np.ndarray, sigma: float = 2.0, radius: int = 2):
     return skops.label(m)
 
 
-def c3_labels(dapi_u16: np.ndarray, sigma: float = 2.0, radius: int = 2, min_distance: int = 5):
-    """DAPI plane -> sequential int64 nuclei labels (edge cells removed). Also returns intermediates."""
+def c3_labels(dapi_u16: np.ndarray, sigma: float = 2.0, radius: int = 2, min_distance: int = 5, relief: str = "seeded"):
+    """DAPI plane -> sequential int64 nuclei labels (edge cells removed). Also returns intermediates.
+    ``relief``: "seeded" (the config-3 recipe, ``skops.seeded_flood_image``) or "plain" (SURVEY.md A.8 as written:
+    ``watershed(-edt, markers, mask)``, equal-valued markers ordered by scikit-image's heap)."""
     mask, _, _ = c2_mask(dapi_u16, sigma, radius)
     edt = skops.distance_transform_edt(mask)
     markers, _ = skops.peak_markers(edt, mask, min_distance)
-    relief = skops.seeded_flood_image(edt, markers)
+    relief = skops.seeded_flood_image(edt, markers) if relief == "seeded" else -edt
     ws = watershed(relief, markers, mask=mask, connectivity=1)
     cleared = skops.clear_border(ws)
     labels = skops.relabel_sequential(cleared).astype(np.int64) if cleared.max() > 0 else cleared.astype(np.int64)

@@ -363,3 +363,80 @@ def test_fused_watershed_tail_equals_separate_calls(ctx):
             assert int(b.ws.numpy()[k].max()) > int(lb[k].max()) > 0  # clear_border did drop frame-touching nuclei
             assert np.array_equal(la[k].astype(np.int64), chains.c3_labels(fovs[k, 1])[0])
         np.testing.assert_array_equal(a.table.numpy()[:, :8], b.table.numpy()[:, :8])
+
+
+def test_c3_plain_relief_exact_ties():
+    """SURVEY.md A.8 as written -- watershed(-edt, markers, mask) -- through the batch driver: planes whose markers tie
+    (on an EDT relief: nearly all) are re-flooded by the single-heap emulation and equal scikit-image's result
+    (oracle: the C restatement of its heap, pinned by tests/golden/watershed_cases.npz); bench.py reports this recipe
+    as sublines.a8_exact."""
+    from arcadia_microscopy_tools_amd import synth
+    from arcadia_microscopy_tools_amd.device import get_context
+    from arcadia_microscopy_tools_amd.segment import FovSegmenter
+    from oracle import chains
+
+    ctx = get_context()
+    fovs = np.stack([synth.synth_fov(40 + i, size=384) for i in range(3)])
+    seg = FovSegmenter(3, 4, 384, 384, ctx=ctx, relief="plain", ties="exact")
+    seg.run_c3(ctx.asarray(fovs))
+    got = seg.labels.numpy()
+    assert seg.tied.numpy().any()  # the recipe does tie on these planes
+    for b in range(3):
+        want, _ = chains.c3_labels(fovs[b, 1], relief="plain")
+        assert np.array_equal(got[b], want), (b, int((got[b] != want).sum()))
+    seeded = FovSegmenter(3, 4, 384, 384, ctx=ctx)
+    seeded.run_c3(ctx.asarray(fovs))
+    assert seeded.labels.numpy().max() == got.max()  # same markers, same number of nuclei; the borders may differ
+
+
+def test_host_tables_deliver_what_the_segmenters_computed():
+    """plate.HostTables (the N = 1 delivery bench.py times): two contexts, six steps with changing batches; the rows
+    that arrive on the host, two steps lagged, are the packed device tables of THAT step, in FOV order, and equal the
+    per-FOV oracle tables."""
+    from arcadia_microscopy_tools_amd import _hip, synth
+    from arcadia_microscopy_tools_amd.device import Context, get_context
+    from arcadia_microscopy_tools_amd.plate import HostTables, rows_to_table, plate_rows
+    from arcadia_microscopy_tools_amd.segment import DEFAULT_CHANNELS, FovSegmenter
+    from oracle import chains
+
+    dev = get_context().device
+    ctxs = [Context(dev), Context(dev)]
+    sizes = (2, 1)
+    segs = [FovSegmenter(n, 4, 256, 256, ctx=c, max_cells=512) for n, c in zip(sizes, ctxs)]
+    ht = HostTables(segs, slots=4, lag=2)
+    batches = [np.stack([synth.synth_fov(10 * step + i, size=256) for i in range(3)]) for step in range(6)]
+    kept = {}
+    for step, fovs in enumerate(batches):
+        ht.point(step)
+        off = 0
+        for sg in segs:
+            sg.run_c3(sg.ctx.asarray(fovs[off:off + sg.B]))
+            off += sg.B
+        ht.deliver_step(step, fov_index0=100 * step)
+        if step >= 2:  # the rows of step - 2 have been requested by now
+            kept[step - 2] = ht.rows_of(step - 2).copy()
+    ht.flush()
+    for step in (4, 5):
+        kept[step] = ht.rows_of(step).copy()
+    for step, fovs in enumerate(batches):
+        rows = kept[step]
+        assert rows.shape[1] == 2 + _hip.RP_NCOLS + 16
+        assert np.array_equal(np.unique(rows[:, 0]), 100 * step + np.arange(3))
+        table = rows_to_table(rows, DEFAULT_CHANNELS)
+        ref = []
+        for i in range(3):
+            lab, props = chains.c3_chain(fovs[i])
+            ref.append(props)
+        from arcadia_microscopy_tools_amd.plate import pack_rows
+        want = pack_rows([100 * step + i for i in range(3)], ref, DEFAULT_CHANNELS)
+        assert table.shape == want.shape, step
+        from arcadia_microscopy_tools_amd.plate import table_columns
+        cols = table_columns(DEFAULT_CHANNELS)
+        for j, name in enumerate(cols):
+            if name == "orientation":  # an axis: compared modulo pi, exactly symmetric regions left out (SURVEY.md A.9)
+                sym = np.isclose(np.abs(want[:, j]), np.pi / 4)
+                dd = (table[:, j] - want[:, j] + np.pi / 2) % np.pi - np.pi / 2
+                np.testing.assert_allclose(dd[~sym], 0, atol=1e-8, err_msg=f"{step} {name}")
+            else:
+                np.testing.assert_allclose(table[:, j], want[:, j], rtol=1e-5, atol=1e-6, err_msg=f"{step} {name}")
+    ht.close()
