@@ -77,6 +77,7 @@ _SIGS = {
     "amt_convert_u16_f64": (c_int, [_P, _P, c_double, _P, c_size_t]),
     "amt_add_scalar_f64": (c_int, [_P, _P, c_double, _P, c_size_t]),
     "amt_hist_u16": (c_int, [_P, _P, _P, c_int, c_size_t]),
+    "amt_hist_range_f64": (c_int, [_P, _P, ctypes.c_double, ctypes.c_int64, _P, c_int, c_size_t]),
     "amt_minmax_f64": (c_int, [_P, _P, _P, c_int, c_size_t]),
     "amt_hist_f64": (c_int, [_P, _P, _P, _P, c_int, c_int, c_size_t]),
     "amt_percentile_u16": (c_int, [_P, _P, _P, c_int, _P, c_int, c_size_t]),

@@ -381,6 +381,36 @@ extern "C" int amt_hist_f64(amt_ctx* ctx, const double* in, const double* minmax
 }
 
 // ------------------------------------------------------------------------------------------------
+// One bin per integer value over an arbitrary range: scikit-image's histogram of integer images
+// (SK/exposure/exposure.py:63-74: np.bincount(image - image_min, minlength = image_max - image_min + 1)) for images whose
+// range exceeds the 65,536 values amt_hist_u16 covers.  The image travels as float64 (integers are exact below 2^53);
+// counts go straight to global atomics -- with millions of bins per image they rarely collide.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) hist_range_kernel(const double* __restrict__ in, double lo, long long nbins,
+                                                         uint32_t* __restrict__ hist, size_t n) {
+    const double* src = in + (size_t)blockIdx.y * n;
+    uint32_t* h = hist + (size_t)blockIdx.y * (size_t)nbins;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const double d = src[i] - lo;
+        if (d >= 0.0 && d < (double)nbins) atomicAdd(&h[(long long)d], 1u);
+    }
+}
+
+extern "C" int amt_hist_range_f64(amt_ctx* ctx, const double* in, double lo, int64_t nbins, uint32_t* hist, int nplanes,
+                                  size_t n) {
+    AMT_TRY(amt_set_device(ctx));
+    AMT_REQUIRE(in && hist && nplanes >= 0 && nbins >= 1, "hist_range_f64: bad arguments");
+    AMT_REQUIRE(nbins <= (1ll << 28), "hist_range_f64: %lld bins are more than 2^28", (long long)nbins);
+    if (nplanes == 0) return AMT_OK;
+    AMT_HIP_CHECK(hipMemsetAsync(hist, 0, (size_t)nplanes * (size_t)nbins * sizeof(uint32_t), ctx->stream));
+    if (n == 0) return AMT_OK;
+    hipLaunchKernelGGL(hist_range_kernel, dim3(amt_grid_for(n, 256, 4096), nplanes), dim3(256), 0, ctx->stream, in, lo,
+                       (long long)nbins, hist, n);
+    AMT_LAUNCH_CHECK();
+    return AMT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Otsu (SK/filters/thresholding.py:336-348) on a histogram, one 1024-thread workgroup per plane.
 //   EXACT_INT: uint16 images -- bins image_min..image_max, bin centre = value; all cumulative sums
 //              are exact integers, so the parallel scan equals numpy's sequential float64 cumsum.

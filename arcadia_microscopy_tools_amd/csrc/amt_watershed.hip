@@ -35,7 +35,10 @@
 #include <hip/hip_ext.h>
 
 // component classes
-enum { CLS_NONE = 0, CLS_UNIFORM = 1, CLS_XS = 2, CLS_S = 3, CLS_M = 4, CLS_M2 = 5, CLS_L = 6, CLS_X = 7, CLS_G = 8 };
+// LB = an L component too large for a persistent flood workgroup that owns only half a CU's LDS (ws_flood_persist_kernel)
+enum { CLS_NONE = 0, CLS_UNIFORM = 1, CLS_XS = 2, CLS_S = 3, CLS_M = 4, CLS_M2 = 5, CLS_L = 6, CLS_X = 7, CLS_LB = 8, CLS_G = 9 };
+constexpr int WS_NLISTS = 7;  // worklists XS, S, M, M2, L, X, LB
+constexpr int WS_CTR = 24;    // ints per plane: work counters [0..7), HBM flood [7], has_g [8], list sizes [9..16), ncomp [16]
 // LDS tile classes: max pixels of the bounding box, max d2 (bucket count - 1).  XS / S / M / M2 / L are flooded by
 // ws_flood_batch_kernel (6 bytes of LDS per pixel + 8 per bucket), X -- the few boxes between L and the 15-bit
 // index limit -- by the one-pop-at-a-time ws_flood_lds_kernel (4 bytes per pixel).
@@ -279,7 +282,7 @@ __global__ void __launch_bounds__(256) ws_classify_kernel(comp_row* __restrict__
                                                           int* __restrict__ moff, int* __restrict__ boff,
                                                           int* __restrict__ has_g, int* __restrict__ wl,
                                                           int* __restrict__ wl_count, int* __restrict__ Fall, size_t n,
-                                                          int nplanes, size_t row_stride, int use_d2) {
+                                                          int nplanes, size_t row_stride, int use_d2, int pf_slots) {
     comp_row* r = rows + (size_t)blockIdx.y * row_stride;
     int* mo = moff + (size_t)blockIdx.y * row_stride;
     int* bo = boff + (size_t)blockIdx.y * row_stride;
@@ -300,7 +303,11 @@ __global__ void __launch_bounds__(256) ws_classify_kernel(comp_row* __restrict__
             else if (area <= S_PX && c.cmax < S_NB) cls = CLS_S;
             else if (area <= M_PX && c.cmax < M_NB) cls = CLS_M;
             else if (area <= M2_PX && c.cmax < M2_NB) cls = CLS_M2;
-            else if (area <= L_PX && c.cmax < L_NB) cls = CLS_L;
+            else if (area <= L_PX && c.cmax < L_NB) {
+                // bytes the persistent flood would reserve for it (6 per tile cell and per bucket, 2,560-byte slots)
+                const long long need = ((((area + 1) & ~1ll) + ((c.cmax + 2) & ~1)) * 6 + 2559) / 2560;
+                cls = (pf_slots > 0 && need > pf_slots) ? CLS_LB : CLS_L;
+            }
             else if (area <= X_PX && c.cmax < X_NB) cls = CLS_X;
             else cls = CLS_G;
         }
@@ -309,7 +316,7 @@ __global__ void __launch_bounds__(256) ws_classify_kernel(comp_row* __restrict__
         // -1 = no marker at all (stays background)
         Fall[(size_t)blockIdx.y * n + c.root] = cls == CLS_UNIFORM ? c.labmin : (cls == CLS_NONE ? -1 : 0);
         if (cls == CLS_G) has_g[blockIdx.y] = 1;
-        if (cls >= CLS_XS && cls <= CLS_X) {
+        if (cls >= CLS_XS && cls <= CLS_LB) {
             // per-class worklist of this plane (order is irrelevant: components are independent)
             const int k = cls - CLS_XS;
             const int pos = atomicAdd(&wl_count[k * nplanes + blockIdx.y], 1);
@@ -582,6 +589,242 @@ extern "C" int amt_ws_debug_reset() {
     return hipMemcpyToSymbol(HIP_SYMBOL(ws_dbg), z, 64) == hipSuccess ? 0 : -2;
 }
 #endif
+// One component, flooded by one wave in the LDS arrays it is given (cell: npx words, cnt: nb words, offs: nb halves, queue:
+// npx halves).  Shared by the per-class kernels (fixed layout per class) and the persistent kernel (layout per component).
+__device__ __forceinline__ void ws_flood_component(unsigned* cell, unsigned* cnt, unsigned short* offs, unsigned short* queue,
+                                                   const int* __restrict__ d2, const int* __restrict__ L,
+                                                   const int* __restrict__ T, int* __restrict__ out,
+                                                   const int* __restrict__ mk, const comp_row& cr, int c, int W,
+                                                   int seeds_first, int* __restrict__ ties, int plane, int lane) {
+    auto uni = [&](unsigned v) -> unsigned { return __builtin_amdgcn_readfirstlane(v); };
+    const int tw = cr.x1 - cr.x0 + 3, th = cr.y1 - cr.y0 + 3;  // padded tile
+    const int npx = tw * th;
+    const int nb = cr.cmax + 1;
+#ifdef WS_STATS
+    if (lane == 0) { atomicAdd(&ws_dbg[3], 1ull); atomicAdd(&ws_dbg[4], (unsigned long long)npx); atomicAdd(&ws_dbg[5], (unsigned long long)nb); }
+#endif
+    const unsigned inv_tw = 0xFFFFFFFFu / (unsigned)tw + 1u;  // i / tw == (i * inv_tw) >> 32 for i < 65536
+    for (int i = lane; i < nb; i += 64) cnt[i] = 0;
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    // ---- stage the bounding box + ring, histogram d2 over the component ----
+    // Eight tile cells per lane and round: 24 unconditional loads from clamped coordinates in flight, then the eight
+    // dependent tile-root -> component-id gathers; validity is applied where the values are used (a conditional load
+    // would put a wait behind each of them).  A 10,000-pixel box is staged in 20 round-trip pairs instead of 40.
+    constexpr int SU = 6;
+    for (int i0 = 0; i0 < npx; i0 += 64 * SU) {
+        int rr4[SU], o4[SU], d4[SU];
+        bool in4[SU];
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            const int i = i0 + u * 64 + lane;
+            const int ty = (int)(((unsigned long long)(unsigned)i * inv_tw) >> 32), tx = i - ty * tw;
+            in4[u] = i < npx && ty >= 1 && ty < th - 1 && tx >= 1 && tx < tw - 1;
+            int gy = cr.y0 + ty - 1, gx = cr.x0 + tx - 1;
+            gy = gy < cr.y0 ? cr.y0 : (gy > cr.y1 ? cr.y1 : gy);
+            gx = gx < cr.x0 ? cr.x0 : (gx > cr.x1 ? cr.x1 : gx);
+            const size_t g = (size_t)gy * W + gx;
+            rr4[u] = L[g];
+            o4[u] = mk[g];
+            d4[u] = d2[g];
+        }
+        int id4[SU];
+#pragma unroll
+        for (int u = 0; u < SU; ++u) id4[u] = T[rr4[u] < 0 ? 0 : rr4[u]];  // tile root -> component id (1-based)
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            const int i = i0 + u * 64 + lane;
+            if (i < npx) {
+                unsigned cv = 0xFFFFu;
+                if (in4[u] && rr4[u] >= 0 && id4[u] == c + 1) {
+                    const int d = d4[u] < 0 ? 0 : d4[u];
+                    cv = ((unsigned)o4[u] & 0xFFFFu) | ((unsigned)d << 16) | (o4[u] != 0 ? 0x80000000u : 0u);
+                    atomicAdd(&cnt[d], 1u);
+                }
+                cell[i] = cv;
+            }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    // ---- counts -> segment offsets (each lane owns a contiguous run of buckets), cursors = segment start ----
+    {
+        const int per = (nb + 63) / 64;
+        const int b0 = lane * per;
+        int sum = 0;
+        for (int j = 0; j < per; ++j) sum += (b0 + j < nb) ? (int)cnt[b0 + j] : 0;
+        int incl = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        int run = incl - sum;
+        for (int j = 0; j < per; ++j) {
+            if (b0 + j < nb) {
+                const int cj = (int)cnt[b0 + j];
+                offs[b0 + j] = (unsigned short)run;
+                cnt[b0 + j] = (unsigned)run | ((unsigned)run << 16);  // hd = tl = segment start
+                run += cj;
+            }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    int cur = -1;    // current bucket (-1: none yet)
+    int raise = -1;  // highest bucket that received a push since the last switch
+    const int offN = -tw, offW = -1, offE = 1, offS = tw;
+    // One step over the pixels p (one per active lane, lane order = pop order).  `limit`: the bucket the pixels
+    // were popped from (a target above it cuts the step) or a value above every bucket (marker spreading).
+    // Returns the number of lanes that took part.
+    auto step = [&](int p, bool active, int limit, bool marker_push) -> int {
+        unsigned cN = 0xFFFFu, cW = 0xFFFFu, cE = 0xFFFFu, cS = 0xFFFFu, cp = 0;
+        const int pa = active ? p : 0;
+        if (!marker_push) {
+            cN = cell[pa + offN];
+            cW = cell[pa + offW];
+            cE = cell[pa + offE];
+            cS = cell[pa + offS];
+        }
+        cp = cell[pa];
+        bool tN = active && !marker_push && (cN & 0xFFFFu) == 0, tW = active && !marker_push && (cW & 0xFFFFu) == 0;
+        bool tE = active && !marker_push && (cE & 0xFFFFu) == 0, tS = active && !marker_push && (cS & 0xFFFFu) == 0;
+        const int bN = (int)((cN >> 16) & 0x7FFF), bW = (int)((cW >> 16) & 0x7FFF);
+        const int bE = (int)((cE >> 16) & 0x7FFF), bS = (int)((cS >> 16) & 0x7FFF);
+        const bool higher = (tN && bN > limit) || (tW && bW > limit) || (tE && bE > limit) || (tS && bS > limit);
+        const unsigned long long hm = __ballot(higher);
+        const unsigned long long am = __ballot(active);
+        int took = __popcll(am);
+        if (hm) {
+            const int first = __ffsll((long long)hm) - 1;
+            took = __popcll(am & ((2ull << first) - 1ull));
+            if (lane > first) tN = tW = tE = tS = false;
+        }
+        bool wN = false, wW = false, wE = false, wS = false;
+        int qN = pa + offN, qW = pa + offW, qE = pa + offE, qS = pa + offS;
+        int dN = bN, dW = bW, dE = bE, dS = bS;
+        if (marker_push) {  // the pixel itself is queued (markers entering by value): one "claim" per lane, slot N
+            wN = active;
+            qN = pa;
+            dN = (int)((cp >> 16) & 0x7FFF);
+        } else if (__ballot(tN || tW || tE || tS)) {
+            // tickets: the smallest (lane, neighbour) pair holds the largest ticket
+            const unsigned tk = 0x100u - (unsigned)(lane * 4);
+            if (tN) atomicMax(&cell[qN], (cN & 0xFFFF0000u) | (tk - 0));
+            if (tW) atomicMax(&cell[qW], (cW & 0xFFFF0000u) | (tk - 1));
+            if (tE) atomicMax(&cell[qE], (cE & 0xFFFF0000u) | (tk - 2));
+            if (tS) atomicMax(&cell[qS], (cS & 0xFFFF0000u) | (tk - 3));
+            const unsigned rN = tN ? cell[qN] : 0, rW = tW ? cell[qW] : 0, rE = tE ? cell[qE] : 0,
+                           rS = tS ? cell[qS] : 0;
+            wN = tN && (rN & 0xFFFFu) == tk - 0;
+            wW = tW && (rW & 0xFFFFu) == tk - 1;
+            wE = tE && (rE & 0xFFFFu) == tk - 2;
+            wS = tS && (rS & 0xFFFFu) == tk - 3;
+            const unsigned lab = cp & 0xFFFFu;
+            if (wN) cell[qN] = (cN & 0xFFFF0000u) | lab;
+            if (wW) cell[qW] = (cW & 0xFFFF0000u) | lab;
+            if (wE) cell[qE] = (cE & 0xFFFF0000u) | lab;
+            if (wS) cell[qS] = (cS & 0xFFFF0000u) | lab;
+        }
+        // append the winners, one destination bucket at a time, in (lane, N-W-E-S) order.  Every bucket is handled
+        // once per step, so its cursor word is fetched for all claims up front (one LDS round trip, not one per
+        // bucket).  (Measured alternative: reserving slots with returning LDS atomics and ranking the tickets of a
+        // run afterwards was 3x slower -- the claims of a step go to FEW buckets, iso-distance contours, with many
+        // claims each.)
+        unsigned long long pend = __ballot(wN || wW || wE || wS);
+        unsigned hN = 0, hW = 0, hE = 0, hS = 0;
+        if (pend) {
+            hN = wN ? cnt[dN] : 0u;
+            hW = wW ? cnt[dW] : 0u;
+            hE = wE ? cnt[dE] : 0u;
+            hS = wS ? cnt[dS] : 0u;
+        }
+        const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#ifdef WS_STATS
+        if (lane == 0 && !marker_push) { atomicAdd(&ws_dbg[0], 1ull); atomicAdd(&ws_dbg[1], (unsigned long long)took); }
+#endif
+        while (pend) {
+#ifdef WS_STATS
+            if (lane == 0) atomicAdd(&ws_dbg[2], 1ull);
+#endif
+            const int l0 = __ffsll((long long)pend) - 1;
+            const int sel = wN ? dN : wW ? dW : wE ? dE : dS;  // this lane's first pending destination
+            const unsigned selh = wN ? hN : wW ? hW : wE ? hE : hS;
+            const int bsel = __builtin_amdgcn_readlane(sel, l0);
+            const unsigned ht = (unsigned)__builtin_amdgcn_readlane((int)selh, l0);
+            const bool mN = wN && dN == bsel, mW = wW && dW == bsel, mE = wE && dE == bsel, mS = wS && dS == bsel;
+            const unsigned long long sN = __ballot(mN), sW = __ballot(mW), sE = __ballot(mE), sS = __ballot(mS);
+            const int before = __popcll(sN & lt_mask) + __popcll(sW & lt_mask) + __popcll(sE & lt_mask) +
+                               __popcll(sS & lt_mask);
+            const int total = __popcll(sN) + __popcll(sW) + __popcll(sE) + __popcll(sS);
+            const int base = (int)(ht >> 16);
+            if (marker_push && ((ht >> 16) != (ht & 0xFFFFu) || total > 1) && lane == 0) ties[plane] = 1;
+            int r = base + before;
+            if (mN) queue[r++] = (unsigned short)qN;
+            if (mW) queue[r++] = (unsigned short)qW;
+            if (mE) queue[r++] = (unsigned short)qE;
+            if (mS) queue[r++] = (unsigned short)qS;
+            if (lane == l0) cnt[bsel] = (ht & 0xFFFFu) | ((unsigned)(base + total) << 16);
+            raise = bsel > raise ? bsel : raise;
+            wN = wN && !mN;
+            wW = wW && !mW;
+            wE = wE && !mE;
+            wS = wS && !mS;
+            pend = __ballot(wN || wW || wE || wS);
+        }
+        return took;
+    };
+    // ---- markers in raster order, 64 tile cells at a time ----
+    for (int i0 = 0; i0 < npx; i0 += 64) {
+        const int i = i0 + lane;
+        const bool ismk = i < npx && (cell[i] & 0x80000000u);
+        if (__ballot(ismk)) step(i, ismk, 0x7FFFFFFF, !seeds_first);
+    }
+    // ---- the flood ----
+    while (true) {
+        if (raise > cur) cur = raise;
+        raise = -1;
+        unsigned ht = cur >= 0 ? uni(cnt[cur]) : 0u;
+        if (cur < 0 || (ht & 0xFFFFu) == (ht >> 16)) {  // current bucket exhausted: walk down, 64 buckets a time
+            int found = -1;
+            int top = cur < 0 ? nb : cur;  // buckets below `top` are candidates
+            while (top > 0) {
+                const int bi = top - 1 - lane;
+                const unsigned h = bi >= 0 ? cnt[bi] : 0u;
+                const unsigned long long m = __ballot(bi >= 0 && (h & 0xFFFFu) != (h >> 16));
+                if (m) {
+                    found = top - 1 - (__ffsll((long long)m) - 1);
+                    break;
+                }
+                top -= 64;
+            }
+            if (found < 0) break;
+            cur = found;
+            ht = uni(cnt[cur]);
+        }
+        const int hd = (int)(ht & 0xFFFFu), tl = (int)(ht >> 16);
+        const int navail = tl - hd < 64 ? tl - hd : 64;
+        const bool active = lane < navail;
+        const int p = active ? (int)queue[hd + lane] : 0;
+        const int took = step(p, active, cur, false);  // pushes into the current bucket only move its tl
+        if (lane == 0) {
+            const unsigned now = cnt[cur];  // tl may have grown
+            cnt[cur] = (unsigned)(hd + took) | (now & 0xFFFF0000u);
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- write back ----
+    for (int i = lane; i < npx; i += 64) {
+        const unsigned lv = cell[i] & 0xFFFFu;
+        if (lv != 0xFFFFu) {
+            const int ty = (int)(((unsigned long long)(unsigned)i * inv_tw) >> 32), tx = i - ty * tw;
+            out[(size_t)(cr.y0 + ty - 1) * W + (cr.x0 + tx - 1)] = (int)lv;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 template <int TILE_PX, int NB>
 __global__ void __launch_bounds__(64) ws_flood_batch_kernel(const int* __restrict__ d2all, const int* __restrict__ Lall,
                                                             const int* __restrict__ Tall, int* __restrict__ outall,
@@ -606,7 +849,6 @@ __global__ void __launch_bounds__(64) ws_flood_batch_kernel(const int* __restric
     const int* mylist = wl + (size_t)plane * row_stride;
     const int nwork = wl_count[plane];
     const int lane = threadIdx.x;
-    auto uni = [&](unsigned v) -> unsigned { return __builtin_amdgcn_readfirstlane(v); };
     while (true) {
         int kk = 0;
         if (lane == 0) kk = atomicAdd(&counters[plane], 1);
@@ -614,228 +856,154 @@ __global__ void __launch_bounds__(64) ws_flood_batch_kernel(const int* __restric
         if (kk >= nwork) break;
         const int c = mylist[kk];
         const comp_row cr = rr[c];
-        const int tw = cr.x1 - cr.x0 + 3, th = cr.y1 - cr.y0 + 3;  // padded tile
-        const int npx = tw * th;
+        ws_flood_component(cell, cnt, offs, queue, d2, L, T, out, mk, cr, c, W, seeds_first, ties, plane, lane);
+    }
+}
+
+// ---- one launch for all LDS classes ---------------------------------------------------------------------------------
+// Round 3.  The per-class launches are bound by LDS capacity x time: every workgroup reserves its class's MAXIMUM (15 KB
+// for a component that needs 8), a class cannot finish before its longest component, and the classes compete for the same
+// LDS whichever way they are launched (in order 1.41 ms, overlapped 1.06 ms per 48 planes -- the sum barely moves).
+// Here ONE workgroup of 16 waves owns a CU's whole LDS and hands it out in 2,560-byte slots: a wave takes the next
+// component of a global list (largest classes first), reserves exactly the slots ITS box and buckets need (compare-and-
+// swap on a 64-bit mask of slots), floods with the same code as the class kernels, and returns the slots.
+//   * two lists: "big" (classes L, M2) and "small" (M, S, XS).  Wave 0 of a workgroup serves the big list first and the
+//     other waves wait for its first reservation, so a component that needs most of a CU starts at time zero instead of
+//     behind fifteen small ones; when a list runs dry its waves move to the other one.
+//   * a wave that finds the LDS full sleeps and retries; no wave waits while holding slots, so the workgroup always drains.
+constexpr int PF_SLOT = 2560;
+constexpr int PF_SLOTS_FULL = 63;            // data slots of a workgroup that owns a whole CU (the 64th: control words)
+constexpr int PF_SLOTS_HALF = 31;            // ... that owns half a CU: two such workgroups, or other kernels, share it
+constexpr int PF_WAVES = 16;                 // upper bound (launch bounds); the launch decides
+constexpr int PF_NCLS = 5;                   // XS, S, M, M2, L (worklist slots 0..4)
+
+// idx[c * (nplanes + 1) + plane] = components of class c in the planes before `plane` (the last entry: all of them);
+// ctl[0] / ctl[1] = cursors of the big / small list (zeroed), ctl[2] / ctl[3] = their lengths
+__global__ void __launch_bounds__(64) ws_flood_index_kernel(const int* __restrict__ wl_count, int* __restrict__ idx,
+                                                            int* __restrict__ ctl, int nplanes) {
+    __shared__ int tot[PF_NCLS];
+    if (threadIdx.x < PF_NCLS) {
+        const int c = threadIdx.x;
+        int run = 0;
+        for (int p = 0; p < nplanes; ++p) {
+            idx[c * (nplanes + 1) + p] = run;
+            run += wl_count[c * nplanes + p];
+        }
+        idx[c * (nplanes + 1) + nplanes] = run;
+        tot[c] = run;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ctl[0] = 0;
+        ctl[1] = 0;
+        ctl[2] = tot[4] + tot[3];           // big: L then M2
+        ctl[3] = tot[2] + tot[1] + tot[0];  // small: M, S, XS
+    }
+}
+
+__global__ void __launch_bounds__(PF_WAVES * 64) ws_flood_persist_kernel(
+    const int* __restrict__ d2all, const int* __restrict__ Lall, const int* __restrict__ Tall, int* __restrict__ outall,
+    const comp_row* __restrict__ rows, const int* __restrict__ wl, const int* __restrict__ idx, int* __restrict__ ctl,
+    size_t row_stride, int H, int W, int seeds_first, int* __restrict__ ties, const int* __restrict__ mkall, int nplanes,
+    int pf_slots) {
+    extern __shared__ __attribute__((aligned(16))) char pf_smem[];
+    unsigned long long* slotmask = reinterpret_cast<unsigned long long*>(pf_smem + (size_t)pf_slots * PF_SLOT);
+    int* first_done = reinterpret_cast<int*>(slotmask + 1);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) {
+        *slotmask = ~0ull << pf_slots;  // bit s set = slot s taken; the slots from pf_slots on do not exist (control block)
+        *first_done = 0;
+    }
+    __syncthreads();
+    const size_t n = (size_t)H * W;
+    const int nbig = ctl[2], nsmall = ctl[3];
+    // class order inside a list and the list each wave starts with
+    int list = wave == 0 ? 0 : 1;
+    bool first = true;
+    int dry = 0;  // lists found empty
+    while (dry < 2) {
+        int g = 0;
+        if (lane == 0) g = atomicAdd(&ctl[list], 1);
+        g = __builtin_amdgcn_readfirstlane(g);
+        if (g >= (list == 0 ? nbig : nsmall)) {
+            if (first && wave == 0 && lane == 0) __hip_atomic_store(first_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            first = false;
+            ++dry;
+            list ^= 1;
+            continue;
+        }
+        // item g of the list -> class, plane, component
+        int cls, within = g;
+        if (list == 0) {
+            const int nL = idx[4 * (nplanes + 1) + nplanes];
+            cls = within < nL ? 4 : 3;
+            if (cls == 3) within -= nL;
+        } else {
+            const int nM = idx[2 * (nplanes + 1) + nplanes], nS = idx[1 * (nplanes + 1) + nplanes];
+            cls = within < nM ? 2 : (within < nM + nS ? 1 : 0);
+            within -= cls == 2 ? 0 : (cls == 1 ? nM : nM + nS);
+        }
+        const int* ci = idx + cls * (nplanes + 1);
+        int lo = 0, hi = nplanes - 1;  // the last plane whose offset is <= within
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (ci[mid] <= within) lo = mid; else hi = mid - 1;
+        }
+        const int plane = lo;
+        const int c = wl[((size_t)cls * nplanes + plane) * row_stride + (within - ci[plane])];
+        const comp_row cr = rows[(size_t)plane * row_stride + c];
+        const int npx = (cr.x1 - cr.x0 + 3) * (cr.y1 - cr.y0 + 3);
         const int nb = cr.cmax + 1;
-#ifdef WS_STATS
-        if (lane == 0) { atomicAdd(&ws_dbg[3], 1ull); atomicAdd(&ws_dbg[4], (unsigned long long)npx); atomicAdd(&ws_dbg[5], (unsigned long long)nb); }
-#endif
-        const unsigned inv_tw = 0xFFFFFFFFu / (unsigned)tw + 1u;  // i / tw == (i * inv_tw) >> 32 for i < 65536
-        for (int i = lane; i < nb; i += 64) cnt[i] = 0;
-        __builtin_amdgcn_s_waitcnt(0);
-        __builtin_amdgcn_wave_barrier();
-        // ---- stage the bounding box + ring, histogram d2 over the component ----
-        for (int i0 = 0; i0 < npx; i0 += 256) {
-            int rr4[4], o4[4], d4[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * 64 + lane;
-                const int ty = (int)(((unsigned long long)(unsigned)i * inv_tw) >> 32), tx = i - ty * tw;
-                rr4[u] = -1;
-                o4[u] = 0;
-                d4[u] = 0;
-                if (i < npx && ty >= 1 && ty < th - 1 && tx >= 1 && tx < tw - 1) {
-                    const size_t g = (size_t)(cr.y0 + ty - 1) * W + (cr.x0 + tx - 1);
-                    rr4[u] = L[g];
-                    o4[u] = mk[g];
-                    d4[u] = d2[g];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) rr4[u] = rr4[u] >= 0 ? T[rr4[u]] : 0;  // tile root -> component id (1-based)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * 64 + lane;
-                if (i < npx) {
-                    unsigned cv = 0xFFFFu;
-                    if (rr4[u] == c + 1) {
-                        const int d = d4[u] < 0 ? 0 : d4[u];
-                        cv = ((unsigned)o4[u] & 0xFFFFu) | ((unsigned)d << 16) | (o4[u] != 0 ? 0x80000000u : 0u);
-                        atomicAdd(&cnt[d], 1u);
-                    }
-                    cell[i] = cv;
-                }
-            }
+        const int npx2 = (npx + 1) & ~1, nb2 = (nb + 1) & ~1;  // keep every array 4-byte aligned
+        const int need = (npx2 * 6 + nb2 * 6 + PF_SLOT - 1) / PF_SLOT;  // slots
+        // the other waves of the workgroup hold back until wave 0 has placed its first (big) component
+        if (wave != 0 && first) {
+            while (__hip_atomic_load(first_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(8);
+            first = false;
         }
-        __builtin_amdgcn_s_waitcnt(0);
-        __builtin_amdgcn_wave_barrier();
-        // ---- counts -> segment offsets (each lane owns a contiguous run of buckets), cursors = segment start ----
-        {
-            const int per = (nb + 63) / 64;
-            const int b0 = lane * per;
-            int sum = 0;
-            for (int j = 0; j < per; ++j) sum += (b0 + j < nb) ? (int)cnt[b0 + j] : 0;
-            int incl = sum;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int t = __shfl_up(incl, o);
-                if (lane >= o) incl += t;
-            }
-            int run = incl - sum;
-            for (int j = 0; j < per; ++j) {
-                if (b0 + j < nb) {
-                    const int cj = (int)cnt[b0 + j];
-                    offs[b0 + j] = (unsigned short)run;
-                    cnt[b0 + j] = (unsigned)run | ((unsigned)run << 16);  // hd = tl = segment start
-                    run += cj;
+        int pos = -1;
+        if (lane == 0) {
+            const unsigned long long want = need >= 64 ? ~0ull : ((1ull << need) - 1ull);
+            while (true) {
+                const unsigned long long m = __hip_atomic_load(slotmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                unsigned long long x = ~m;  // free slots; bit i of x survives iff slots i .. i + need - 1 are free
+                for (int rem = need - 1, sh = 1; rem > 0; sh <<= 1) {
+                    const int t = sh < rem ? sh : rem;
+                    x &= x >> t;
+                    rem -= t;
                 }
-            }
-        }
-        __builtin_amdgcn_s_waitcnt(0);
-        __builtin_amdgcn_wave_barrier();
-        int cur = -1;    // current bucket (-1: none yet)
-        int raise = -1;  // highest bucket that received a push since the last switch
-        const int offN = -tw, offW = -1, offE = 1, offS = tw;
-        // One step over the pixels p (one per active lane, lane order = pop order).  `limit`: the bucket the pixels
-        // were popped from (a target above it cuts the step) or a value above every bucket (marker spreading).
-        // Returns the number of lanes that took part.
-        auto step = [&](int p, bool active, int limit, bool marker_push) -> int {
-            unsigned cN = 0xFFFFu, cW = 0xFFFFu, cE = 0xFFFFu, cS = 0xFFFFu, cp = 0;
-            const int pa = active ? p : 0;
-            if (!marker_push) {
-                cN = cell[pa + offN];
-                cW = cell[pa + offW];
-                cE = cell[pa + offE];
-                cS = cell[pa + offS];
-            }
-            cp = cell[pa];
-            bool tN = active && !marker_push && (cN & 0xFFFFu) == 0, tW = active && !marker_push && (cW & 0xFFFFu) == 0;
-            bool tE = active && !marker_push && (cE & 0xFFFFu) == 0, tS = active && !marker_push && (cS & 0xFFFFu) == 0;
-            const int bN = (int)((cN >> 16) & 0x7FFF), bW = (int)((cW >> 16) & 0x7FFF);
-            const int bE = (int)((cE >> 16) & 0x7FFF), bS = (int)((cS >> 16) & 0x7FFF);
-            const bool higher = (tN && bN > limit) || (tW && bW > limit) || (tE && bE > limit) || (tS && bS > limit);
-            const unsigned long long hm = __ballot(higher);
-            const unsigned long long am = __ballot(active);
-            int took = __popcll(am);
-            if (hm) {
-                const int first = __ffsll((long long)hm) - 1;
-                took = __popcll(am & ((2ull << first) - 1ull));
-                if (lane > first) tN = tW = tE = tS = false;
-            }
-            bool wN = false, wW = false, wE = false, wS = false;
-            int qN = pa + offN, qW = pa + offW, qE = pa + offE, qS = pa + offS;
-            int dN = bN, dW = bW, dE = bE, dS = bS;
-            if (marker_push) {  // the pixel itself is queued (markers entering by value): one "claim" per lane, slot N
-                wN = active;
-                qN = pa;
-                dN = (int)((cp >> 16) & 0x7FFF);
-            } else if (__ballot(tN || tW || tE || tS)) {
-                // tickets: the smallest (lane, neighbour) pair holds the largest ticket
-                const unsigned tk = 0x100u - (unsigned)(lane * 4);
-                if (tN) atomicMax(&cell[qN], (cN & 0xFFFF0000u) | (tk - 0));
-                if (tW) atomicMax(&cell[qW], (cW & 0xFFFF0000u) | (tk - 1));
-                if (tE) atomicMax(&cell[qE], (cE & 0xFFFF0000u) | (tk - 2));
-                if (tS) atomicMax(&cell[qS], (cS & 0xFFFF0000u) | (tk - 3));
-                const unsigned rN = tN ? cell[qN] : 0, rW = tW ? cell[qW] : 0, rE = tE ? cell[qE] : 0,
-                               rS = tS ? cell[qS] : 0;
-                wN = tN && (rN & 0xFFFFu) == tk - 0;
-                wW = tW && (rW & 0xFFFFu) == tk - 1;
-                wE = tE && (rE & 0xFFFFu) == tk - 2;
-                wS = tS && (rS & 0xFFFFu) == tk - 3;
-                const unsigned lab = cp & 0xFFFFu;
-                if (wN) cell[qN] = (cN & 0xFFFF0000u) | lab;
-                if (wW) cell[qW] = (cW & 0xFFFF0000u) | lab;
-                if (wE) cell[qE] = (cE & 0xFFFF0000u) | lab;
-                if (wS) cell[qS] = (cS & 0xFFFF0000u) | lab;
-            }
-            // append the winners, one destination bucket at a time, in (lane, N-W-E-S) order.  Every bucket is handled
-            // once per step, so its cursor word is fetched for all claims up front (one LDS round trip, not one per
-            // bucket).  (Measured alternative: reserving slots with returning LDS atomics and ranking the tickets of a
-            // run afterwards was 3x slower -- the claims of a step go to FEW buckets, iso-distance contours, with many
-            // claims each.)
-            unsigned long long pend = __ballot(wN || wW || wE || wS);
-            unsigned hN = 0, hW = 0, hE = 0, hS = 0;
-            if (pend) {
-                hN = wN ? cnt[dN] : 0u;
-                hW = wW ? cnt[dW] : 0u;
-                hE = wE ? cnt[dE] : 0u;
-                hS = wS ? cnt[dS] : 0u;
-            }
-            const unsigned long long lt_mask = (1ull << lane) - 1ull;
-#ifdef WS_STATS
-            if (lane == 0 && !marker_push) { atomicAdd(&ws_dbg[0], 1ull); atomicAdd(&ws_dbg[1], (unsigned long long)took); }
-#endif
-            while (pend) {
-#ifdef WS_STATS
-                if (lane == 0) atomicAdd(&ws_dbg[2], 1ull);
-#endif
-                const int l0 = __ffsll((long long)pend) - 1;
-                const int sel = wN ? dN : wW ? dW : wE ? dE : dS;  // this lane's first pending destination
-                const unsigned selh = wN ? hN : wW ? hW : wE ? hE : hS;
-                const int bsel = __builtin_amdgcn_readlane(sel, l0);
-                const unsigned ht = (unsigned)__builtin_amdgcn_readlane((int)selh, l0);
-                const bool mN = wN && dN == bsel, mW = wW && dW == bsel, mE = wE && dE == bsel, mS = wS && dS == bsel;
-                const unsigned long long sN = __ballot(mN), sW = __ballot(mW), sE = __ballot(mE), sS = __ballot(mS);
-                const int before = __popcll(sN & lt_mask) + __popcll(sW & lt_mask) + __popcll(sE & lt_mask) +
-                                   __popcll(sS & lt_mask);
-                const int total = __popcll(sN) + __popcll(sW) + __popcll(sE) + __popcll(sS);
-                const int base = (int)(ht >> 16);
-                if (marker_push && ((ht >> 16) != (ht & 0xFFFFu) || total > 1) && lane == 0) ties[plane] = 1;
-                int r = base + before;
-                if (mN) queue[r++] = (unsigned short)qN;
-                if (mW) queue[r++] = (unsigned short)qW;
-                if (mE) queue[r++] = (unsigned short)qE;
-                if (mS) queue[r++] = (unsigned short)qS;
-                if (lane == l0) cnt[bsel] = (ht & 0xFFFFu) | ((unsigned)(base + total) << 16);
-                raise = bsel > raise ? bsel : raise;
-                wN = wN && !mN;
-                wW = wW && !mW;
-                wE = wE && !mE;
-                wS = wS && !mS;
-                pend = __ballot(wN || wW || wE || wS);
-            }
-            return took;
-        };
-        // ---- markers in raster order, 64 tile cells at a time ----
-        for (int i0 = 0; i0 < npx; i0 += 64) {
-            const int i = i0 + lane;
-            const bool ismk = i < npx && (cell[i] & 0x80000000u);
-            if (__ballot(ismk)) step(i, ismk, 0x7FFFFFFF, !seeds_first);
-        }
-        // ---- the flood ----
-        while (true) {
-            if (raise > cur) cur = raise;
-            raise = -1;
-            unsigned ht = cur >= 0 ? uni(cnt[cur]) : 0u;
-            if (cur < 0 || (ht & 0xFFFFu) == (ht >> 16)) {  // current bucket exhausted: walk down, 64 buckets a time
-                int found = -1;
-                int top = cur < 0 ? nb : cur;  // buckets below `top` are candidates
-                while (top > 0) {
-                    const int bi = top - 1 - lane;
-                    const unsigned h = bi >= 0 ? cnt[bi] : 0u;
-                    const unsigned long long m = __ballot(bi >= 0 && (h & 0xFFFFu) != (h >> 16));
-                    if (m) {
-                        found = top - 1 - (__ffsll((long long)m) - 1);
+                if (x) {
+                    const int at = __ffsll((long long)x) - 1;
+                    unsigned long long expect = m;
+                    if (__hip_atomic_compare_exchange_strong(slotmask, &expect, m | (want << at), __ATOMIC_RELAXED,
+                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                        pos = at;
                         break;
                     }
-                    top -= 64;
+                } else {
+                    __builtin_amdgcn_s_sleep(16);
                 }
-                if (found < 0) break;
-                cur = found;
-                ht = uni(cnt[cur]);
-            }
-            const int hd = (int)(ht & 0xFFFFu), tl = (int)(ht >> 16);
-            const int navail = tl - hd < 64 ? tl - hd : 64;
-            const bool active = lane < navail;
-            const int p = active ? (int)queue[hd + lane] : 0;
-            const int took = step(p, active, cur, false);  // pushes into the current bucket only move its tl
-            if (lane == 0) {
-                const unsigned now = cnt[cur];  // tl may have grown
-                cnt[cur] = (unsigned)(hd + took) | (now & 0xFFFF0000u);
-            }
-            __builtin_amdgcn_s_waitcnt(0);
-        }
-        __builtin_amdgcn_wave_barrier();
-        // ---- write back ----
-        for (int i = lane; i < npx; i += 64) {
-            const unsigned lv = cell[i] & 0xFFFFu;
-            if (lv != 0xFFFFu) {
-                const int ty = (int)(((unsigned long long)(unsigned)i * inv_tw) >> 32), tx = i - ty * tw;
-                out[(size_t)(cr.y0 + ty - 1) * W + (cr.x0 + tx - 1)] = (int)lv;
             }
         }
-        __builtin_amdgcn_wave_barrier();
+        pos = __builtin_amdgcn_readfirstlane(pos);
+        if (first && wave == 0) {
+            if (lane == 0) __hip_atomic_store(first_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            first = false;
+        }
+        unsigned* cell = reinterpret_cast<unsigned*>(pf_smem + (size_t)pos * PF_SLOT);
+        unsigned* cnt = cell + npx2;
+        unsigned short* offs = reinterpret_cast<unsigned short*>(cnt + nb2);
+        unsigned short* queue = offs + nb2;
+        ws_flood_component(cell, cnt, offs, queue, d2all + (size_t)plane * n, Lall + (size_t)plane * n, Tall + (size_t)plane * n,
+                           outall + (size_t)plane * n, mkall + (size_t)plane * n, cr, c, W, seeds_first, ties, plane, lane);
+        __builtin_amdgcn_s_waitcnt(0);
+        if (lane == 0) {
+            const unsigned long long want = need >= 64 ? ~0ull : ((1ull << need) - 1ull);
+            __hip_atomic_fetch_and(slotmask, ~(want << pos), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
     }
+    // a workgroup whose wave 0 never placed anything must not leave its siblings waiting (they only wait while `first`)
+    if (wave == 0 && lane == 0) __hip_atomic_store(first_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 // ---- HBM bucket-queue flood (components too large for an LDS tile) ---------------------------------
@@ -1324,6 +1492,36 @@ static bool ws_anyorder() {
     return v == 1;
 }
 
+// AMT_WS_PERSIST: 0 = the per-class flood launches of round 2, 1 = one persistent launch, a workgroup per CU with all
+// its LDS, 2 = two workgroups per CU with half the LDS each (A/B switch; identical results)
+static int ws_persist() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("AMT_WS_PERSIST");
+        v = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
+    }
+    return v;
+}
+// AMT_WS_PF_SLOTS: 2,560-byte LDS slots of a mode-1 workgroup (8..63; fewer leave LDS on the CU for other kernels)
+static int ws_pf_slots() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("AMT_WS_PF_SLOTS");
+        v = e ? atoi(e) : PF_SLOTS_FULL;
+        if (v < 8 || v > PF_SLOTS_FULL) v = PF_SLOTS_FULL;
+    }
+    return v;
+}
+static int ws_pf_waves() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("AMT_WS_PF_WAVES");
+        v = e ? atoi(e) : 10;
+        if (v < 1 || v > PF_WAVES) v = 10;
+    }
+    return v;
+}
+
 // AMT_WS_LDS_PAD=bytes: extra dynamic LDS per flood workgroup (occupancy experiments only)
 static size_t ws_lds_pad() {
     static long v = -1;
@@ -1387,8 +1585,9 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     const int trows = amt_i_tile_rows(H);
     const size_t lcap = amt_i_rootlist_cap(W);
     const size_t nlist = (size_t)nplanes * trows;
-    size_t need = 5 * amt_align(np * 4) + amt_align(nlist * lcap * 4) + amt_align(nlist * 4) + 9 * amt_align(nr * 4) + amt_align(nr * sizeof(comp_row)) +
-                  9 * amt_align(nplanes * 4 * 16) + amt_align((size_t)nplanes * 4);
+    size_t need = 5 * amt_align(np * 4) + amt_align(nlist * lcap * 4) + amt_align(nlist * 4) + 10 * amt_align(nr * 4) + amt_align(nr * sizeof(comp_row)) +
+                  9 * amt_align(nplanes * 4 * WS_CTR) + amt_align((size_t)nplanes * 4) + amt_align((size_t)PF_NCLS * (nplanes + 1) * 4) +
+                  amt_align(64);
     need += use_d2 ? 2 * amt_align((size_t)nplanes * bstride * 4) : amt_align((size_t)nplanes * bstride * sizeof(hp_elem));
     // the sequential emulation's heap (every pixel is pushed at most once): the float64 path reuses its per-component
     // heap space, the bucket path needs it extra -- and only when ties are to be resolved exactly
@@ -1411,8 +1610,10 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     int* mtot = arena_take_t<int>(ctx, nplanes);
     // per plane: work counters of the six LDS flood classes XS / S / M / M2 / L / X [0..6) and of the HBM flood [6],
     // has_g [7], worklist sizes of the six classes [8..14), number of components [14]
-    int* counters = arena_take_t<int>(ctx, (size_t)nplanes * 16);
-    int* wl = arena_take_t<int>(ctx, 6 * nr);  // worklists of the six LDS classes
+    int* counters = arena_take_t<int>(ctx, (size_t)nplanes * WS_CTR);
+    int* wl = arena_take_t<int>(ctx, (size_t)WS_NLISTS * nr);  // worklists of the LDS classes
+    int* pf_idx = arena_take_t<int>(ctx, (size_t)PF_NCLS * (nplanes + 1));  // the persistent flood's item index
+    int* pf_ctl = arena_take_t<int>(ctx, 16);
     int* ties = ties_dev ? ties_dev : arena_take_t<int>(ctx, nplanes);
     int* P = fused_labels ? arena_take_t<int>(ctx, msz) : nullptr;
     int *head = nullptr, *tail = nullptr;
@@ -1427,9 +1628,9 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
         gheap = heap;  // bstride == n: the per-component heaps are dead when the emulation starts
     }
 
-    int* ncomp = counters + 14 * (size_t)nplanes;
-    hipLaunchKernelGGL(ws_zero_counters_kernel, dim3((nplanes * 16 + 63) / 64), dim3(64), 0, ctx->stream, counters,
-                       nplanes * 16);
+    int* ncomp = counters + 16 * (size_t)nplanes;
+    hipLaunchKernelGGL(ws_zero_counters_kernel, dim3((nplanes * WS_CTR + 63) / 64), dim3(64), 0, ctx->stream, counters,
+                       nplanes * WS_CTR);
     AMT_LAUNCH_CHECK();
     hipLaunchKernelGGL(ws_set_flags_kernel, dim3((nplanes + 63) / 64), dim3(64), 0, ctx->stream, ties, nplanes, 0);
     AMT_LAUNCH_CHECK();
@@ -1443,8 +1644,10 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     AMT_TRY(amt_i_propagate_roots(ctx, T, L, rootlist, nroots, nplanes, H, W));
     hipLaunchKernelGGL(ws_rows_init_kernel, dim3(64, nplanes), dim3(256), 0, ctx->stream, rows, ncomp, row_stride);
     AMT_LAUNCH_CHECK();
-    int* has_g = counters + 7 * nplanes;
-    int* wl_count = counters + 8 * nplanes;  // [6][nplanes]
+    int* has_g = counters + 8 * nplanes;
+    int* wl_count = counters + 9 * nplanes;  // [WS_NLISTS][nplanes]
+    const int pf_mode = use_d2 ? ws_persist() : 0;  // 0 = class launches, 1 = a whole CU per workgroup, 2 = half a CU
+    const int pf_slots = pf_mode == 1 ? ws_pf_slots() : (pf_mode == 2 ? PF_SLOTS_HALF : 0);
     if (mk_list) {
         // the caller knows where the marker pixels are: the dense pass skips the marker plane
         hipLaunchKernelGGL((ws_stats_kernel<false>), dim3((W + 63) / 64, (H + 31) / 32, nplanes), dim3(256), 0, ctx->stream,
@@ -1460,7 +1663,7 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     }
     AMT_LAUNCH_CHECK();
     hipLaunchKernelGGL(ws_classify_kernel, dim3(64, nplanes), dim3(256), 0, ctx->stream, rows, ncomp, moff, boff, has_g,
-                       wl, wl_count, F, n, nplanes, row_stride, use_d2 ? 1 : 0);
+                       wl, wl_count, F, n, nplanes, row_stride, use_d2 ? 1 : 0, pf_slots);
     AMT_LAUNCH_CHECK();
     AMT_TRY(amt_i_propagate_roots(ctx, F, L, rootlist, nroots, nplanes, H, W));
     dim3 g1(amt_grid_for(n, 256, 4096), nplanes);
@@ -1468,7 +1671,7 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     // such plane (its final pass derives every pixel from F and the flood's sparse writes): it seeds only planes that
     // hold a component for the HBM flood, which works in `out` itself
     hipLaunchKernelGGL(ws_seed_kernel, dim3(amt_grid_for(n, 1024, 4096), nplanes), dim3(256), 0, ctx->stream, markers, L, F,
-                       out, n, fused_labels ? (const int*)(counters + 7 * nplanes) : (const int*)nullptr);
+                       out, n, fused_labels ? (const int*)has_g : (const int*)nullptr);
     AMT_LAUNCH_CHECK();
     // ---- HBM-path bookkeeping (usually empty: only components too large for an LDS tile) ----
     AMT_TRY(amt_scan_excl_dev(ctx, moff, ncomp, row_stride, mtot, nplanes));
@@ -1517,17 +1720,51 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
             ++nflood;
             return AMT_OK;
         };
-        AMT_TRY(flood((const void*)ws_flood_batch_kernel<L_PX, L_NB>, gL, ldsL, ctx->stream, 4));
+        const bool persist = pf_mode != 0;
+        if (persist) {
+            // one persistent launch for the five batch classes, then LB (L boxes beyond a workgroup that owns less than a
+            // whole CU), X and the HBM flood beside it.  Mode 1 (default): a workgroup of 10 waves per CU with all its
+            // LDS; mode 2: two workgroups per CU with half each.  Measured on one box (watershed stage per 48 FOVs in one
+            // context / 48-FOV plate / 192-FOV default, FOV/s): class launches 2.53 ms / 10.4 k / 11.5-11.7 k; whole CU,
+            // 8 waves 2.11 / 10.4 k / 11.3 k; 10 waves 2.02 / 10.4 k / 11.6 k; 16 waves 2.10; 46 slots 2.16 / 10.2 k /
+            // 10.9 k; half a CU x 2 2.26 / 10.4 k / 11.1 k.  The stage gains 0.5 ms; with four contexts side by side the
+            // floods were already hidden behind the other contexts' streaming kernels, so the totals do not move.
+            hipLaunchKernelGGL(ws_flood_index_kernel, dim3(1), dim3(64), 0, ctx->stream, wl_count, pf_idx, pf_ctl, nplanes);
+            AMT_LAUNCH_CHECK();
+            const int* a_d2 = (const int*)relief;
+            const int* a_L = L;
+            const int* a_T = T;
+            int* a_out = out;
+            const comp_row* a_rows = rows;
+            const int* a_wl = wl;
+            const int* a_idx = pf_idx;
+            int* a_ctl = pf_ctl;
+            size_t a_rs = row_stride;
+            int a_H = H, a_W = W, a_sf = seeds_first, a_np = nplanes, a_slots = pf_slots;
+            int* a_ties = ties;
+            const int* a_mk = markers;
+            void* args[] = {&a_d2, &a_L, &a_T, &a_out, &a_rows, &a_wl, &a_idx, &a_ctl, &a_rs, &a_H, &a_W, &a_sf, &a_ties, &a_mk,
+                            &a_np, &a_slots};
+            const int wgs = pf_mode == 1 ? ctx->num_cus : 2 * ctx->num_cus;
+            AMT_HIP_CHECK(hipExtLaunchKernel((const void*)ws_flood_persist_kernel, dim3(wgs), dim3(ws_pf_waves() * 64), args,
+                                             (size_t)(pf_slots + 1) * PF_SLOT, ctx->stream, nullptr, nullptr, 0));
+            ++nflood;
+            if (pf_slots < PF_SLOTS_FULL) AMT_TRY(flood((const void*)ws_flood_batch_kernel<L_PX, L_NB>, gL, ldsL, ctx->stream, 6));
+        } else {
+            AMT_TRY(flood((const void*)ws_flood_batch_kernel<L_PX, L_NB>, gL, ldsL, ctx->stream, 4));
+        }
         AMT_TRY(flood((const void*)ws_flood_lds_kernel<X_PX, X_NB, CLS_X>, 8, ldsX, ctx->stream, 5));
+        if (!persist) {
         AMT_TRY(flood((const void*)ws_flood_batch_kernel<M2_PX, M2_NB>, gM2, ldsM2, ctx->aux[2], 3));
         AMT_TRY(flood((const void*)ws_flood_batch_kernel<M_PX, M_NB>, gM, ldsM, ctx->aux[0], 2));
         AMT_TRY(flood((const void*)ws_flood_batch_kernel<S_PX, S_NB>, gS, ldsS, ctx->aux[1], 1));
         if (XS_PX > 0) AMT_TRY(flood((const void*)ws_flood_batch_kernel<(XS_PX > 0 ? XS_PX : 64), XS_NB>, gXS, ldsXS, ctx->aux[2], 0));
+        }
         {
             const int* a_d2 = (const int*)relief;
             void* args[] = {&a_d2, (void*)&mask, &out, &next, &head, &tail, &mlist, (void*)&rows, &moff, &boff, &ncomp, nullptr,
                             (void*)&row_stride, &H, &W, (void*)&n, (void*)&bstride, &seeds_first, &ties};
-            int* a_cnt = counters + 6 * nplanes;
+            int* a_cnt = counters + 7 * nplanes;
             args[11] = &a_cnt;
             AMT_HIP_CHECK(hipExtLaunchKernel((const void*)ws_flood_edt_kernel, dim3(4, nplanes), dim3(64), args, 0, ctx->aux[1],
                                              nullptr, nullptr, any ? (int)hipExtAnyOrderLaunch : 0));
@@ -1535,7 +1772,7 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
         AMT_TRY(amt_join(ctx));
     } else {
         hipLaunchKernelGGL(ws_flood_heap_kernel, dim3(64, nplanes), dim3(64), 0, ctx->stream, (const double*)relief,
-                           mask, out, heap, mlist, rows, moff, boff, ncomp, counters + 6 * nplanes, row_stride, H, W, n,
+                           mask, out, heap, mlist, rows, moff, boff, ncomp, counters + 7 * nplanes, row_stride, H, W, n,
                            bstride, ties);
     }
     AMT_LAUNCH_CHECK();

@@ -277,6 +277,18 @@ def histogram_u16(a: DeviceArray, out: DeviceArray | None = None) -> DeviceArray
     return o
 
 
+def histogram_range(a: DeviceArray, lo: int, nbins: int) -> DeviceArray:
+    """One bin per integer ``lo .. lo + nbins - 1`` of an integer-valued float64 array (per plane): scikit-image's
+    histogram of integer images whose range exceeds uint16 (SK/exposure/exposure.py:63-74)."""
+    ctx = a.ctx
+    if a.dtype != np.float64:
+        raise TypeError("histogram_range expects the float64 image an integer image beyond uint16 travels as")
+    n, H, W = _planes(a)
+    o = ctx.empty((n, int(nbins)), np.uint32)
+    _hip.check(_lib().amt_hist_range_f64(ctx.handle, a.ptr, float(lo), int(nbins), o.ptr, n, H * W), "amt_hist_range_f64")
+    return o
+
+
 def minmax(a: DeviceArray, out: DeviceArray | None = None) -> DeviceArray:
     ctx = a.ctx
     n, H, W = _planes(a)

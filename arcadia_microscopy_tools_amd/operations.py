@@ -16,7 +16,8 @@ or one per axis), ``threshold_local`` filters every axis with its Gaussian; its 
 dtypes: uint8 / uint16 / float64 are computed as the reference computes them (bit-exact).  Other integer
 types are converted on upload: to uint16 when the values fit (exact), otherwise to float64 (exact below 2^53).  The
 histogram thresholds bin integers one bin per value as scikit-image does: an integer image beyond the uint16 range
-travels as ``x - min`` when its RANGE fits 65,536 values, and is refused when it does not.
+travels as ``x - min`` when its RANGE fits 65,536 values, as float64 with one device bin per value up to a range of
+2^26 values (``amt_hist_range_f64``), and is refused beyond that (scikit-image itself would need gigabytes per array).
 Where scikit-image's result depends on the dtype itself -- ``img_as_float`` inside the Gaussians of the DoG, Sauvola's
 default ``r`` -- the CALLER's dtype decides (``_img_as_float_plan``, ``_sauvola_r``), not the type the data travels as.
 float32 / float16 are computed in float64: numpy / scikit-image keep float32 arithmetic for them, so results agree
@@ -32,6 +33,8 @@ from . import _thresholds, hipops
 from .device import DeviceArray, get_context
 from .pipeline import device_operator
 from .typing import BoolArray, Float64Array, ScalarArray
+
+_MAX_INTEGER_BINS = 1 << 26  # one uint32 bin per integer value: 256 MB on the device, 512 MB per float64 host array
 
 _SUPPORTED_METHODS = ("otsu", "li", "yen", "isodata", "mean", "minimum", "triangle", "local", "niblack", "sauvola")
 
@@ -61,10 +64,16 @@ def _to_device(intensities, what: str, integer_histogram: bool = False, shifted:
             # subtract in a type that holds the whole range: int8 [-128, 127] - (-128) overflows int8 itself
             wide = a if a.dtype == np.uint64 else a.astype(np.int64)
             a = (wide - wide.dtype.type(lo)).astype(np.uint16)
+        elif integer_histogram and shifted is not None and hi - lo < _MAX_INTEGER_BINS:
+            # one bin per value over a range beyond uint16: the image travels as float64 (exact below 2^53) and is
+            # binned by amt_hist_range_f64; shifted[1] tells the caller the range
+            shifted[0] = lo
+            shifted.append(hi - lo + 1)
+            a = a.astype(np.float64)
         elif integer_histogram:
             raise NotImplementedError(
-                f"{what}: integer image with values in [{lo}, {hi}]: scikit-image bins integers one bin per value, "
-                "which the device path does for the uint16 range only"
+                f"{what}: integer image with values in [{lo}, {hi}]: scikit-image bins integers one bin per value "
+                f"({hi - lo + 1:,} bins here); the device path stops at {_MAX_INTEGER_BINS:,}"
             )
         else:
             a = a.astype(np.float64)
@@ -297,6 +306,7 @@ def apply_threshold(
     d, was_numpy = _to_device(intensities, "apply_threshold", integer_histogram=hist_method,
                               shifted=shifted if hist_method else None)
     offset = int(shifted[0])
+    wide_bins = int(shifted[1]) if len(shifted) > 1 else 0  # integer image beyond a 65,536-value range
     shape = d.shape
     if d.ndim != 2 and method_lower not in ("local", "niblack", "sauvola"):
         d = _flat(d)  # global methods: ONE threshold from the histogram of the whole stack
@@ -306,7 +316,26 @@ def apply_threshold(
         z = np.zeros(shape, dtype=bool)
         return z if was_numpy else ctx.asarray(z)
     kw = dict(kwargs)
-    if offset:
+    if wide_bins:
+        # scikit-image's histogram of such an image has one bin per integer from min to max; the counts come from the
+        # device, the selection runs on them with the same numpy expressions, and x > t is exact on the float64 image
+        counts = hipops.histogram_range(_flat(d), offset, wide_bins).numpy()[0].astype(np.int64)
+        centers = np.arange(offset, offset + wide_bins)
+        if method_lower == "otsu":
+            kw.pop("nbins", None)
+            t = _thresholds.otsu(counts, centers)
+        elif method_lower == "mean":
+            t = _thresholds.mean_from_hist(counts, centers)
+        elif method_lower == "li":
+            t = _thresholds.li_from_hist(counts, centers, wrap_dtype=src_dtype, **kw)
+        else:
+            kw.pop("nbins", None)
+            t = getattr(_thresholds, method_lower)(counts, centers, **kw)
+        if np.isnan(t):
+            z = np.zeros(shape, dtype=bool)
+            return z if was_numpy else ctx.asarray(z)
+        mask = hipops.greater_than(d, ctx.asarray(np.array([float(t)])))
+    elif offset:
         # integer image beyond uint16 whose range fits: histogram of x - min on the device, the reference's threshold
         # from (counts, arange(min, max + 1)) on the host, and x > t  <=>  x - min > floor(t) - min for integers
         hist = hipops.histogram_u16(d).numpy()[0]

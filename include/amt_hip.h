@@ -151,6 +151,10 @@ int amt_add_scalar_f64(amt_ctx* ctx, const double* in, double s, double* out, si
 /* ---- statistics: np.percentile (R/operations.py:47,94), histogram (SK/exposure/exposure.py) -- */
 /* One 65536-bin histogram per plane (uint32 counts), bin = pixel value. */
 int amt_hist_u16(amt_ctx* ctx, const uint16_t* in, uint32_t* hist, int nplanes, size_t n);
+/* One bin per integer value lo .. lo + nbins - 1 of an integer-valued float64 image (scikit-image's histogram of
+ * integer images, SK/exposure/exposure.py:63-74, for ranges beyond uint16): hist = nplanes x nbins uint32; values outside
+ * the range are not counted.  nbins <= 2^28. */
+int amt_hist_range_f64(amt_ctx* ctx, const double* in, double lo, int64_t nbins, uint32_t* hist, int nplanes, size_t n);
 /* minmax_dev[plane] = {min, max} */
 int amt_minmax_f64(amt_ctx* ctx, const double* in, double* minmax_dev, int nplanes, size_t n);
 /* np.histogram(x, bins=nbins, range=(min,max)) counts per plane; edges follow np.linspace. */

@@ -555,8 +555,13 @@ def test_operators_on_stacks_and_other_dtypes():
     wide = (t3[0].astype(np.int64) - 30000) * 1000
     p = np.percentile(wide, (1, 99))
     assert np.array_equal(rescale_by_percentile(wide, (1, 99)), skops.rescale_intensity(wide, (p[0], p[1]), (0, 1)))
+    # a range of 7.6 million values: one device bin per value (round 3; round 2 refused it), same thresholds as the
+    # reference's histogram of the integer image
+    for method in ("otsu", "mean", "li", "yen", "isodata", "triangle"):
+        want = wide > getattr(skops, "threshold_" + method)(wide)
+        assert np.array_equal(apply_threshold(wide, method), want), ("wide", method)
     with pytest.raises(NotImplementedError, match="one bin per value"):
-        apply_threshold(wide, "otsu")  # range of 40 million values: refused
+        apply_threshold(wide * 16, "otsu")  # 122 million values: beyond the 2^26 bins the device path takes
     # integer images beyond uint16 whose RANGE fits 65,536 values: binned from min to max like scikit-image
     for shift, dt in ((100000, np.int32), (3_000_000_000, np.int64), (-20000, np.int32), (70000, np.uint32)):
         y = (t3[0].astype(np.int64) + shift).astype(dt)
