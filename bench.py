@@ -490,7 +490,9 @@ def run_c5(args, json_fd):
     def step():
         with torch.no_grad():
             y = net(x)
-        hipops.cellpose_masks(dP, pr, 0.0, 200, out=labels, count=counts)
+        # CellposeModel.eval's own post-processing: 200 flow steps, flow-error filter at the reference's default 0.4
+        # (R/model.py:69), size floor 15 and hole filling
+        hipops.cellpose_masks(dP, pr, 0.0, 200, out=labels, count=counts, flow_threshold=0.4, fill_holes=True)
         return y
 
     def sync():
@@ -530,7 +532,7 @@ def run_c5(args, json_fd):
     post = []
     for _ in range(3):
         tm.start()
-        hipops.cellpose_masks(dP, pr, 0.0, 200, out=labels, count=counts)
+        hipops.cellpose_masks(dP, pr, 0.0, 200, out=labels, count=counts, flow_threshold=0.4, fill_holes=True)
         tm.stop()
         ctx.synchronize()
         post.append(tm.elapsed_ms())
@@ -550,7 +552,9 @@ def run_c5(args, json_fd):
                             "post-processing in HIP",
                 "network": "random-weight stand-in of Cellpose's published residual U-Net (6.6 M parameters); real "
                            "weights are unobtainable offline -- throughput only, no accuracy claim",
-                "tiles_per_gpu_per_step": T, "tile_shape": [2, S, S], "niter": 200,
+                "tiles_per_gpu_per_step": T, "tile_shape": [2, S, S], "niter": 200, "flow_threshold": 0.4,
+                "postprocessing": "follow flows, seeds, size ceiling, flow-error filter (float64 heat diffusion per mask), "
+                                  "size floor 15, hole filling (amt_cellpose_masks_ex)",
                 "postprocessing_input": "synthetic flow fields (~1,200 disks per tile), resident on the device",
                 "masks_per_tile_mean": float(nmask.mean()),
             },
@@ -655,7 +659,7 @@ def run_api(args):
 def run_a8(args):
     """The config-3 chain with the PLAIN -EDT relief and ties='exact': planes in which two markers of
     one component carry the same value (on an EDT relief: nearly all) are re-flooded by the sequential emulation of
-    scikit-image's single heap (bit-identical; one lane per plane).  A short run: ``--batch`` FOVs (8 when left at the
+    scikit-image's single heap (bit-identical; one wave per plane).  A short run: ``--batch`` FOVs (48 when left at the
     default) per step."""
     from arcadia_microscopy_tools_amd.device import Context, set_default_device
     from arcadia_microscopy_tools_amd.segment import FovSegmenter
@@ -663,7 +667,7 @@ def run_a8(args):
     set_default_device(0)
     ctx = Context(0)
     S = args.size
-    B = args.batch if args.batch != 192 else 8
+    B = args.batch if args.batch != 192 else 48  # one wave per plane does the heap: planes are the only parallelism
     nuniq = max(1, min(args.unique, B))
     uniq = synth_fovs(list(range(nuniq)), S)
     d = ctx.asarray(np.stack([uniq[i % nuniq] for i in range(B)]))

@@ -11,9 +11,10 @@ def main():
     print(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py {args}")
     with open(path, newline="") as f:
         rows = list(csv.DictReader(f))
-    note = "# one launch = one stage kernel over a batch of 32 planes of 2048x2048"
+    note = sys.argv[3] if len(sys.argv) > 3 else "# one launch = one stage kernel over the batch of 2048x2048 planes named in the command"
     if any("ws_flood" in r["Name"] for r in rows):
-        note += "; the ws_flood_* classes of one chain run concurrently (main + three auxiliary streams)"
+        note += ("; rocprofv3's kernel trace serialises the launches, so ws_flood_persist_kernel / ws_flood_lds_kernel / "
+                 "ws_flood_edt_kernel (any-order launches that overlap in an unprofiled run) appear one after the other")
     print(note)
     print("kernel,calls,avg_us,total_ms,pct")
     if True:
