@@ -772,7 +772,7 @@ def run_sublines(args) -> dict:
     attempt("unique64", lambda: run_chain(_sub_args(args, unique=64, steps=5, warmup=1, **dict(quick, tail_reps=24))))
     attempt("prep", lambda: run_ops(_sub_args(args, workload="prep", steps=10, warmup=2, no_cpu=True)))
     attempt("filters", lambda: run_ops(_sub_args(args, workload="filters", steps=10, warmup=2, no_cpu=True)))
-    attempt("api", lambda: run_api(_sub_args(args, steps=3, warmup=1)))
+    attempt("api", lambda: run_api(_sub_args(args, steps=5, warmup=2)))
     attempt("a8_exact", lambda: run_a8(_sub_args(args, steps=1, warmup=1)))
     return subs
 
