@@ -86,8 +86,10 @@ int amt_i_ccl_roots(amt_ctx* ctx, const void* in, int in_dtype, int* L, int* blk
 // listed roots themselves and resolve a pixel as L[L[p]].
 int amt_i_tile_rows(int H);
 size_t amt_i_rootlist_cap(int W);
+// multi (nullable): one int of scratch; with it a 0 / 1 mask takes the bit-parallel tile kernel (other byte values
+// are detected and redone by the pixel kernel)
 int amt_i_ccl_tileroots_u8(amt_ctx* ctx, const uint8_t* in, int* L, int* rootlist, int* nroots, int nplanes, int H,
-                           int W);
+                           int W, int* multi = nullptr);
 // A[t] = A[L[t]] for every listed tile root t (lists compressed): a pixel then reaches its component's entry of A
 // with one hop through its tile root
 int amt_i_propagate_roots(amt_ctx* ctx, int* A, const int* L, const int* rootlist, const int* nroots, int nplanes, int H,

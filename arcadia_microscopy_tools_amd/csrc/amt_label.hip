@@ -9,6 +9,8 @@
 // first pixel in raster order), so the raster numbering is a prefix sum over the root flags.
 #include "amt_internal.h"
 
+#include <type_traits>
+
 __device__ __forceinline__ int uf_find(const int* __restrict__ L, int a) {
     int p = L[a];
     while (p != a) {
@@ -134,18 +136,18 @@ __device__ __forceinline__ void ccl_stitch_rows(int* L, int p, int pitch, int la
 // tile row keeps the reserving atomics of a plane off a single address) -- callers that only need roots compressed
 // walk these lists instead of the whole plane.
 template <typename T, bool CONN8>
-__global__ void __launch_bounds__(256) ccl_tile_kernel(const T* __restrict__ in, int* __restrict__ Lall, int H, int W,
-                                                       int* __restrict__ rootlist, int* __restrict__ nroots,
-                                                       size_t cap) {
+__device__ __forceinline__ void ccl_tile_do(const T* __restrict__ in, int* __restrict__ Lall, int H, int W,
+                                            int* __restrict__ rootlist, int* __restrict__ nroots, size_t cap, int bx, int by,
+                                            int bz, int ntr) {
     __shared__ __attribute__((aligned(16))) int S[TILE_R * 64];
     typedef typename ccl_wide<T>::type V;
     constexpr V NOVAL = ccl_wide<T>::NOVAL;
     __shared__ V vlast[4][64];
     const size_t n = (size_t)H * W;
-    const T* img = in + (size_t)blockIdx.z * n;
-    int* L = Lall + (size_t)blockIdx.z * n;
+    const T* img = in + (size_t)bz * n;
+    int* L = Lall + (size_t)bz * n;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int x0 = blockIdx.x * 64, ty0 = blockIdx.y * TILE_R;
+    const int x0 = bx * 64, ty0 = by * TILE_R;
     const int x = x0 + lane;
     const int xc = x < W ? x : W - 1;
     const int r0 = wave * STRIP_R;  // first tile row of this wave
@@ -211,7 +213,7 @@ __global__ void __launch_bounds__(256) ccl_tile_kernel(const T* __restrict__ in,
         __syncthreads();
         if (threadIdx.x == 0) {
             const int tot = s_wroots[0] + s_wroots[1] + s_wroots[2] + s_wroots[3];
-            s_base = tot ? atomicAdd(&nroots[blockIdx.z * gridDim.y + blockIdx.y], tot) : 0;
+            s_base = tot ? atomicAdd(&nroots[bz * ntr + by], tot) : 0;
         }
     }
     __syncthreads();
@@ -237,7 +239,7 @@ __global__ void __launch_bounds__(256) ccl_tile_kernel(const T* __restrict__ in,
         for (int i = 0; i < 4; ++i) o[i] = rr[i] >= 0 ? (ty0 + (rr[i] >> 6)) * W + x0 + (rr[i] & 63) : -1;
         if (y < H) {
             const size_t idx = (size_t)y * W + xg;
-            if (xg + 3 < W && (((size_t)blockIdx.z * n + idx) & 3) == 0) {
+            if (xg + 3 < W && (((size_t)bz * n + idx) & 3) == 0) {
                 *reinterpret_cast<int4*>(L + idx) = make_int4(o[0], o[1], o[2], o[3]);
             } else {
 #pragma unroll
@@ -252,12 +254,223 @@ __global__ void __launch_bounds__(256) ccl_tile_kernel(const T* __restrict__ in,
                 const unsigned long long m = __ballot(is_root);
                 if (is_root) {
                     const size_t pos = (size_t)run + __popcll(m & ((1ull << lane) - 1ull));
+                    if (pos < cap) rootlist[((size_t)bz * ntr + by) * cap + pos] = o[i];
+                }
+                run += __popcll(m);
+            }
+        }
+    }
+}
+
+template <typename T, bool CONN8>
+__global__ void __launch_bounds__(256) ccl_tile_kernel(const T* __restrict__ in, int* __restrict__ Lall, int H, int W,
+                                                       int* __restrict__ rootlist, int* __restrict__ nroots,
+                                                       size_t cap) {
+    ccl_tile_do<T, CONN8>(in, Lall, H, W, rootlist, nroots, cap, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y);
+}
+
+// the fallback behind ccl_tile_bits_kernel: a few hundred workgroups that leave at once unless that kernel gave up
+// (*only_if != 0), and then walk over all tiles
+template <typename T, bool CONN8>
+__global__ void __launch_bounds__(256) ccl_tile_fallback_kernel(const T* __restrict__ in, int* __restrict__ Lall, int H, int W,
+                                                                int* __restrict__ rootlist, int* __restrict__ nroots,
+                                                                size_t cap, const int* __restrict__ only_if, int ntx,
+                                                                int ntr, int nplanes) {
+    if (!*only_if) return;
+    const int total = ntx * ntr * nplanes;
+    for (int t = blockIdx.x; t < total; t += gridDim.x) {
+        const int bx = t % ntx, by = (t / ntx) % ntr, bz = t / (ntx * ntr);
+        ccl_tile_do<T, CONN8>(in, Lall, H, W, rootlist, nroots, cap, bx, by, bz, ntr);
+        __syncthreads();
+    }
+}
+
+// ---- the same tile labelling for 0 / 1 byte masks, bit-parallel (round 3) --------------------------------------------
+// ccl_tile_kernel spends ~78 lane-operations per pixel (four waves per tile, a lane per pixel and row): the pass was
+// bound by vector-instruction issue, not by LDS or HBM.  For a MASK the rows of a 64 x 64 tile are 64-bit words, and
+// everything that is not the final write-out can be done on words by ONE wave with a lane per ROW:
+//   * the lane loads its row's 64 bytes (four 16-byte loads) and squeezes them into a word (a multiply per four bytes);
+//   * run heads = w & ~(w << 1); every RUN is an element of the tile's LDS union-find (8 KB: a row has at most 32 runs;
+//     ids in raster order of the runs' first pixels, so the root is again the component's first pixel);
+//   * the lane stitches its runs to the row above (the neighbour lane's word): the runs of `above` that meet a run --
+//     widened by one column for 8-connectivity -- are the 1-segments of (run & above), one union each;
+//   * heads are compressed, and the write-out maps lanes to four consecutive pixels of a row as before; a pixel finds
+//     its run's head by a count-leading-zeros on its row's word.
+// Values other than 0 / 1 (a uint8 image labelled "by equal value") set *multi, the caller resets the root lists and
+// ccl_tile_kernel redoes the planes.  Requires W % 16 == 0 and 16-byte aligned rows (the host checks).
+__device__ __forceinline__ int ccl_run_start(unsigned long long w, int x) {
+    const unsigned long long z = ~w & ((1ull << x) - 1ull);  // zeros below x
+    return z ? 64 - __clzll((long long)z) : 0;
+}
+
+// union-find over RUNS: entry of run id (row << 5 | ordinal of the run in its row; a row has at most 32 runs) =
+// parent id << 6 | the parent run's first column -- ids grow in raster order of the runs' first pixels, so "smaller entry
+// wins" is "smaller id wins", and a find returns the root's position along with its id
+__device__ __forceinline__ int ccl_rfind(int* S, int id) {
+    int e = __hip_atomic_load(&S[id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while ((e >> 6) != id) {
+        id = e >> 6;
+        e = __hip_atomic_load(&S[id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    return e;
+}
+__device__ __forceinline__ void ccl_runion(int* S, int a, int b) {
+    while (true) {
+        int ea = ccl_rfind(S, a), eb = ccl_rfind(S, b);
+        if (ea == eb) return;
+        if (ea < eb) {
+            const int t = ea;
+            ea = eb;
+            eb = t;
+        }
+        const int old = atomicMin(&S[ea >> 6], eb);  // hang the later root below the earlier one
+        if (old == ea) return;
+        a = old >> 6;  // somebody moved it meanwhile: retry from there
+        b = eb >> 6;
+    }
+}
+
+template <bool CONN8>
+__global__ void __launch_bounds__(64) ccl_tile_bits_kernel(const uint8_t* __restrict__ in, int* __restrict__ Lall, int H,
+                                                           int W, int* __restrict__ rootlist, int* __restrict__ nroots,
+                                                           size_t cap, int* __restrict__ multi) {
+    __shared__ int S[64 * 32];  // 8 KB: eighteen tiles per CU
+    __shared__ unsigned long long bits[64];
+    const size_t n = (size_t)H * W;
+    const uint8_t* img = in + (size_t)blockIdx.z * n;
+    int* L = Lall + (size_t)blockIdx.z * n;
+    const int lane = threadIdx.x;
+    const int x0 = blockIdx.x * 64, ty0 = blockIdx.y * 64;
+    // ---- the lane's row as a word ----
+    unsigned long long w = 0;
+    unsigned other = 0;
+    {
+        const int y = ty0 + lane;
+        const uint8_t* rowp = img + (size_t)(y < H ? y : H - 1) * W;
+        uint4 q[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int xs = x0 + 16 * j;
+            q[j] = *reinterpret_cast<const uint4*>(rowp + (xs < W ? xs : 0));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned v[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
+            unsigned sixteen = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                other |= v[k] & 0xFEFEFEFEu;
+                sixteen |= (((v[k] & 0x01010101u) * 0x01020408u) >> 24) << (4 * k);  // byte i -> bit i
+            }
+            if (x0 + 16 * j < W) w |= (unsigned long long)(sixteen & 0xFFFFu) << (16 * j);
+        }
+        if (y >= H) {
+            w = 0;
+            other = 0;
+        }
+    }
+    if (__ballot(other != 0) && lane == 0) atomicOr(multi, 1);
+    bits[lane] = w;
+    // ---- runs: their own parents ----
+    const unsigned long long heads = w & ~(w << 1);
+    {
+        int j = 0;
+        for (unsigned long long h = heads; h; h &= h - 1, ++j) {
+            const int b = __ffsll((long long)h) - 1;
+            S[lane * 32 + j] = ((lane * 32 + j) << 6) | b;
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    // ---- stitch to the row above ----
+    {
+        unsigned long long above = __shfl_up(w, 1);
+        if (lane == 0) above = 0;
+        const unsigned long long aheads = above & ~(above << 1);
+        int j = 0;
+        for (unsigned long long h = heads; h && above; h &= h - 1, ++j) {
+            const int b = __ffsll((long long)h) - 1;
+            const unsigned long long t = w >> b;
+            const int len = ~t ? __ffsll((long long)~t) - 1 : 64;  // trailing ones: the run's length
+            unsigned long long rm = (len >= 64 ? ~0ull : ((1ull << len) - 1ull)) << b;
+            if (CONN8) rm |= (rm << 1) | (rm >> 1);
+            const unsigned long long ov = rm & above;
+            for (unsigned long long oh = ov & ~(ov << 1); oh; oh &= oh - 1) {
+                const int c = __ffsll((long long)oh) - 1;  // a pixel of the run above: its ordinal = heads at or below c
+                const int aj = __popcll(aheads & ((2ull << c) - 1ull)) - 1;
+                ccl_runion(S, lane * 32 + j, (lane - 1) * 32 + aj);
+            }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    // ---- compress the runs, count the roots, reserve the tile's slice of its tile row's list ----
+    int nroot = 0;
+    {
+        int j = 0;
+        for (unsigned long long h = heads; h; h &= h - 1, ++j) {
+            const int own = lane * 32 + j;
+            const int e = ccl_rfind(S, own);
+            if ((e >> 6) != own) S[own] = e;
+            nroot += (e >> 6) == own;
+        }
+    }
+    int run = 0;
+    if (rootlist) {
+        int tot = nroot;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) tot += __shfl_xor(tot, o);
+        int base = 0;
+        if (lane == 0 && tot) base = atomicAdd(&nroots[blockIdx.z * gridDim.y + blockIdx.y], tot);
+        run = __builtin_amdgcn_readfirstlane(base);
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    // ---- write-out: a lane owns four consecutive pixels of a row ----
+    const int c4 = (lane & 15) * 4, rsub = lane >> 4;
+    const int xg = x0 + c4;
+#pragma unroll 4
+    for (int j = 0; j < 16; ++j) {
+        const int row = rsub + 4 * j;
+        const int y = ty0 + row;
+        const unsigned long long ww = bits[row];
+        const unsigned long long hw = ww & ~(ww << 1);
+        int o[4];
+        bool isroot[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int x = c4 + i;
+            o[i] = -1;
+            isroot[i] = false;
+            if ((ww >> x) & 1ull) {
+                const int id = row * 32 + __popcll(hw & ((2ull << x) - 1ull)) - 1;  // the pixel's run
+                const int e = S[id];                                                // runs point straight at the root run now
+                o[i] = (ty0 + (e >> 11)) * W + x0 + (e & 63);
+                isroot[i] = (e >> 6) == id && (e & 63) == x;                        // the first pixel of a root run
+            }
+        }
+        if (y < H && xg < W) {  // W % 16 == 0: the four pixels are inside the image together
+            const size_t idx = (size_t)y * W + xg;
+            *reinterpret_cast<int4*>(L + idx) = make_int4(o[0], o[1], o[2], o[3]);
+        }
+        if (rootlist) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned long long m = __ballot(isroot[i]);
+                if (isroot[i]) {
+                    const size_t pos = (size_t)run + __popcll(m & ((1ull << lane) - 1ull));
                     if (pos < cap) rootlist[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * cap + pos] = o[i];
                 }
                 run += __popcll(m);
             }
         }
     }
+}
+
+// the fallback's preparation: if the bit kernel met a byte other than 0 / 1, forget the roots it listed
+__global__ void ccl_reset_lists_kernel(int* __restrict__ nroots, size_t nlist, const int* __restrict__ multi) {
+    if (!*multi) return;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nlist; i += (size_t)gridDim.x * blockDim.x) nroots[i] = 0;
 }
 
 // blockIdx.y selects the job: [0, nrow_jobs) = strip-boundary rows, the rest = segment-boundary columns
@@ -415,8 +628,20 @@ int amt_i_ccl_roots(amt_ctx* ctx, const void* in, int in_dtype, int* L, int* blk
 int amt_i_tile_rows(int H) { return (H + TILE_R - 1) / TILE_R; }
 size_t amt_i_rootlist_cap(int W) { return (size_t)TILE_R * W; }
 
+// AMT_CCL_BITS=0: the pixel-per-lane tile kernel for masks too (A/B switch; identical results)
+static bool ccl_bits_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("AMT_CCL_BITS");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
+}
+
+// multi (nullable): one int of scratch; with it, uint8 inputs take the bit-parallel tile kernel first
 template <typename T, bool CONN8>
-static int ccl_tileroots(amt_ctx* ctx, const T* in, int* L, int* rootlist, int* nroots, int nplanes, int H, int W) {
+static int ccl_tileroots(amt_ctx* ctx, const T* in, int* L, int* rootlist, int* nroots, int nplanes, int H, int W,
+                         int* multi = nullptr) {
     const size_t cap = amt_i_rootlist_cap(W);
     const int segs = (W + 63) / 64;
     dim3 gs(segs, (H + TILE_R - 1) / TILE_R, nplanes);
@@ -425,8 +650,26 @@ static int ccl_tileroots(amt_ctx* ctx, const T* in, int* L, int* rootlist, int* 
     const int ncol_jobs = H * ((W - 1) / 64);
     const int ncol_blocks = (ncol_jobs + 256 * segs - 1) / (256 * segs);
     dim3 gb(segs, nrow_blocks + ncol_blocks, nplanes);
-    hipLaunchKernelGGL((ccl_tile_kernel<T, CONN8>), gs, dim3(256), 0, ctx->stream, in, L, H, W, rootlist, nroots, cap);
-    AMT_LAUNCH_CHECK();
+    bool done = false;
+    if (std::is_same<T, uint8_t>::value && multi && ccl_bits_enabled() && W % 16 == 0 &&
+        (reinterpret_cast<uintptr_t>(in) & 15) == 0 && ((size_t)H * W) % 16 == 0) {
+        // masks: the bit-parallel tile kernel; a plane batch that turns out to hold other byte values is redone below
+        AMT_HIP_CHECK(hipMemsetAsync(multi, 0, sizeof(int), ctx->stream));
+        hipLaunchKernelGGL((ccl_tile_bits_kernel<CONN8>), gs, dim3(64), 0, ctx->stream, (const uint8_t*)in, L, H, W, rootlist,
+                           nroots, cap, multi);
+        AMT_LAUNCH_CHECK();
+        hipLaunchKernelGGL(ccl_reset_lists_kernel, dim3(8), dim3(256), 0, ctx->stream, nroots,
+                           (size_t)nplanes * gs.y, (const int*)multi);
+        AMT_LAUNCH_CHECK();
+        hipLaunchKernelGGL((ccl_tile_fallback_kernel<T, CONN8>), dim3(512), dim3(256), 0, ctx->stream, in, L, H, W, rootlist,
+                           nroots, cap, (const int*)multi, (int)gs.x, (int)gs.y, nplanes);
+        AMT_LAUNCH_CHECK();
+        done = true;
+    }
+    if (!done) {
+        hipLaunchKernelGGL((ccl_tile_kernel<T, CONN8>), gs, dim3(256), 0, ctx->stream, in, L, H, W, rootlist, nroots, cap);
+        AMT_LAUNCH_CHECK();
+    }
     if (gb.y > 0) {
         hipLaunchKernelGGL((ccl_border_kernel<T, CONN8>), gb, dim3(256), 0, ctx->stream, in, L, H, W, nrow_blocks);
         AMT_LAUNCH_CHECK();
@@ -435,8 +678,8 @@ static int ccl_tileroots(amt_ctx* ctx, const T* in, int* L, int* rootlist, int* 
 }
 
 int amt_i_ccl_tileroots_u8(amt_ctx* ctx, const uint8_t* in, int* L, int* rootlist, int* nroots, int nplanes, int H,
-                           int W) {
-    return ccl_tileroots<uint8_t, false>(ctx, in, L, rootlist, nroots, nplanes, H, W);
+                           int W, int* multi) {
+    return ccl_tileroots<uint8_t, false>(ctx, in, L, rootlist, nroots, nplanes, H, W, multi);
 }
 
 // A[t] = A[component root of t] for every listed tile root t (the lists must be compressed already): afterwards a
@@ -567,8 +810,9 @@ extern "C" int amt_label(amt_ctx* ctx, const void* in, int in_dtype, int32_t* ou
     const size_t nwords = (n + 63) / 64;
     AMT_TRY(amt_arena_begin(ctx, 2 * amt_align((size_t)nplanes * n * 4) + amt_align(nlist * cap * 4) +
                                      amt_align((size_t)nplanes * nblk * 4) + amt_align(nlist * 4) +
-                                     amt_align((size_t)nplanes * nwords * 8)));
+                                     amt_align((size_t)nplanes * nwords * 8) + amt_align(64)));
     int* L = arena_take_t<int>(ctx, (size_t)nplanes * n);
+    int* multi = arena_take_t<int>(ctx, 16);  // "a byte other than 0 / 1 was seen" (ccl_tile_bits_kernel)
     int* T = arena_take_t<int>(ctx, (size_t)nplanes * n);
     int* rootlist = arena_take_t<int>(ctx, nlist * cap);
     int* blk = arena_take_t<int>(ctx, (size_t)nplanes * nblk);
@@ -580,9 +824,9 @@ extern "C" int amt_label(amt_ctx* ctx, const void* in, int in_dtype, int32_t* ou
     // tile-local union-find + seams; only the listed tile roots are compressed, pixels resolve in two hops
     if (in_dtype == AMT_U8) {
         if (connectivity == 2)
-            AMT_TRY((ccl_tileroots<uint8_t, true>(ctx, (const uint8_t*)in, L, rootlist, nroots, nplanes, H, W)));
+            AMT_TRY((ccl_tileroots<uint8_t, true>(ctx, (const uint8_t*)in, L, rootlist, nroots, nplanes, H, W, multi)));
         else
-            AMT_TRY((ccl_tileroots<uint8_t, false>(ctx, (const uint8_t*)in, L, rootlist, nroots, nplanes, H, W)));
+            AMT_TRY((ccl_tileroots<uint8_t, false>(ctx, (const uint8_t*)in, L, rootlist, nroots, nplanes, H, W, multi)));
     } else {
         if (connectivity == 2)
             AMT_TRY((ccl_tileroots<int32_t, true>(ctx, (const int32_t*)in, L, rootlist, nroots, nplanes, H, W)));

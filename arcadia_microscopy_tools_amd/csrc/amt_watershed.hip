@@ -236,6 +236,18 @@ __global__ void __launch_bounds__(256) ws_stats_kernel(const int* __restrict__ d
         // inside the strip's eight rows that spares four of five y atomics (the strip's first / last row always asks)
         const unsigned long long ab = __ballot(r >= 0 && k > 0 && rs[k > 0 ? k - 1 : 0] >= 0 && ts[k > 0 ? k - 1 : 0] == ts[k]);
         const unsigned long long bl = __ballot(r >= 0 && k < 7 && rs[k < 7 ? k + 1 : 7] >= 0 && ts[k < 7 ? k + 1 : 7] == ts[k]);
+        // The same idea for the x extent (round 3; it cut the pass's ~5 M atomics per 48 planes): a run that starts at
+        // column a cannot set the component's x0 if the pixel right above its first pixel belongs to the component (that
+        // row's run starts at <= a) or the pixel below-left does (that row's run starts at < a) -- "above: <=, below: <"
+        // cannot point in a circle, so every chain of such rows ends at one that asks.  Mirrored for x1 at the run's
+        // LAST pixel.  Rows 0 / 7 of the strip know only one neighbour row and ask unless that one covers them.
+        const int cme = r >= 0 ? ts[k] : 0;
+        const int cab = (k > 0 && rs[k > 0 ? k - 1 : 0] >= 0) ? ts[k > 0 ? k - 1 : 0] : 0;   // component right above
+        const int cbe = (k < 7 && rs[k < 7 ? k + 1 : 7] >= 0) ? ts[k < 7 ? k + 1 : 7] : 0;   // ... right below
+        const int cbl = amt_lane_left(cbe), cbr = amt_lane_right(cbe);                       // below-left / below-right
+        const int right = amt_lane_right(r);
+        const bool tail = r >= 0 && (lane == 63 || right != r);
+        if (tail && !(cab == cme || (lane < 63 && cbr == cme))) atomicMax(&(prow + (cme - 1))->x1, x);
         if (head) {
             const unsigned long long later = hb & ~((2ull << lane) - 1ull);
             const int end_lane = later ? (__ffsll((long long)later) - 2) : 63;
@@ -245,8 +257,7 @@ __global__ void __launch_bounds__(256) ws_stats_kernel(const int* __restrict__ d
             // the run that starts at the component root itself: the one pixel that is its own parent (r = L[pixel])
             if ((size_t)r == (size_t)(yb + k) * W + x) c->root = r;
             if (!use_d2) atomicAdd(&c->cmax, len);
-            atomicMin(&c->x0, x);
-            atomicMax(&c->x1, x + len - 1);
+            if (!(cab == cme || (lane > 0 && cbl == cme))) atomicMin(&c->x0, x);
             if (!(ab & run)) atomicMin(&c->y0, yb + k);
             if (!(bl & run)) atomicMax(&c->y1, yb + k);
         }
@@ -1637,7 +1648,7 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     // components of the mask with dense ids in T (the order of the ids is irrelevant: components are
     // independent work items and nothing in the output depends on their numbering)
     AMT_HIP_CHECK(hipMemsetAsync(nroots, 0, nlist * 4, ctx->stream));
-    AMT_TRY(amt_i_ccl_tileroots_u8(ctx, mask, L, rootlist, nroots, nplanes, H, W));
+    AMT_TRY(amt_i_ccl_tileroots_u8(ctx, mask, L, rootlist, nroots, nplanes, H, W, pf_ctl + 8));
     hipLaunchKernelGGL(ws_roots_kernel, dim3(4, trows, nplanes), dim3(256), 0, ctx->stream, L, T, rootlist, nroots, ncomp,
                        lcap, n);
     AMT_LAUNCH_CHECK();
@@ -1666,12 +1677,14 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
                        wl, wl_count, F, n, nplanes, row_stride, use_d2 ? 1 : 0, pf_slots);
     AMT_LAUNCH_CHECK();
     AMT_TRY(amt_i_propagate_roots(ctx, F, L, rootlist, nroots, nplanes, H, W));
-    dim3 g1(amt_grid_for(n, 256, 4096), nplanes);
+    // the marker lists of the HBM flood's components: nearly always no plane has one, and 4,096 workgroups per plane
+    // that only read a flag and leave cost 43 us per 48 planes -- 128 (grid-stride) do when a plane does have one
+    dim3 g1(amt_grid_for(n, 256, 128), nplanes);
     // the seed pass gives `out` its final value everywhere except in flooded components.  The fused path needs no
     // such plane (its final pass derives every pixel from F and the flood's sparse writes): it seeds only planes that
-    // hold a component for the HBM flood, which works in `out` itself
-    hipLaunchKernelGGL(ws_seed_kernel, dim3(amt_grid_for(n, 1024, 4096), nplanes), dim3(256), 0, ctx->stream, markers, L, F,
-                       out, n, fused_labels ? (const int*)has_g : (const int*)nullptr);
+    // hold a component for the HBM flood, which works in `out` itself -- same consideration for its grid
+    hipLaunchKernelGGL(ws_seed_kernel, dim3(amt_grid_for(n, 1024, fused_labels ? 128 : 4096), nplanes), dim3(256), 0,
+                       ctx->stream, markers, L, F, out, n, fused_labels ? (const int*)has_g : (const int*)nullptr);
     AMT_LAUNCH_CHECK();
     // ---- HBM-path bookkeeping (usually empty: only components too large for an LDS tile) ----
     AMT_TRY(amt_scan_excl_dev(ctx, moff, ncomp, row_stride, mtot, nplanes));

@@ -295,6 +295,24 @@ def test_label_random(ctx, ops):
     vals = rng.integers(0, 4, (60, 90)).astype(np.int32)
     lab, cnt = ops.label(ctx.asarray(vals))
     assert np.array_equal(lab.numpy(), skops.label(vals))
+    # uint8 images that are NOT 0 / 1 masks are labelled by equal value too: widths that take the bit-parallel mask
+    # kernel must notice and fall back (ccl_tile_bits_kernel -> ccl_tile_fallback_kernel); a batch mixes both kinds
+    for shape in ((64, 96), (130, 256)):
+        v8 = rng.integers(0, 4, shape).astype(np.uint8)
+        for conn in (1, 2):
+            lab, cnt = ops.label(ctx.asarray(v8), connectivity=conn)
+            assert np.array_equal(lab.numpy(), skops.label(v8.astype(np.int32), conn)), (shape, conn)
+        both = np.stack([v8, (v8 > 1).astype(np.uint8)])
+        lab, cnt = ops.label(ctx.asarray(both), connectivity=2)
+        for b in range(2):
+            assert np.array_equal(lab.numpy()[b], skops.label(both[b].astype(np.int32), 2)), (shape, b)
+    # masks whose width is a multiple of 16 (the bit-parallel kernel), incl. tiles cut by the image's edge
+    for shape, p in (((64, 64), 0.5), ((70, 144), 0.6), ((200, 80), 0.45), ((3, 16), 0.7), ((129, 2048), 0.55)):
+        m = rng.random(shape) < p
+        for conn in (1, 2):
+            lab, cnt = ops.label(ctx.asarray(m), connectivity=conn)
+            ref = skops.label(m, conn)
+            assert cnt.numpy()[0] == ref.max() and np.array_equal(lab.numpy(), ref), (shape, conn)
     # empty
     lab, cnt = ops.label(ctx.asarray(np.zeros((20, 20), bool)))
     assert cnt.numpy()[0] == 0 and lab.numpy().max() == 0
