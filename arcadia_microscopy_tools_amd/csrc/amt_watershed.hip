@@ -1278,6 +1278,11 @@ __global__ void __launch_bounds__(64) ws_global_kernel(const void* __restrict__ 
         return ((unsigned long long)hi << 32) | lo;
     };
     int items = 0;  // uniform
+    gh_elem tail;            // the element in slot items - 1 when tail_valid (uniform)
+    tail.key = 0;
+    tail.age = 0;
+    tail.idx = 0;
+    bool tail_valid = false;
     // ---- push: executed by the whole wave, e is uniform ----
     auto push = [&](unsigned long long ekey, unsigned eage, unsigned eidx) {
         const int c = items++;
@@ -1298,6 +1303,18 @@ __global__ void __launch_bounds__(64) ws_global_kernel(const void* __restrict__ 
             e.age = eage;
             e.idx = eidx;
             st(((c + 1) >> up) - 1, e);
+        }
+        // what now sits in the LAST slot (c): the new element, or its parent if it rose -- the next pop moves exactly
+        // this element to the root and need not fetch it from HBM
+        tail_valid = true;
+        if (up == 0) {
+            tail.key = ekey;
+            tail.age = eage;
+            tail.idx = eidx;
+        } else {
+            tail.key = rl64(a.key, 1);
+            tail.age = (unsigned)__builtin_amdgcn_readlane((int)a.age, 1);
+            tail.idx = (unsigned)__builtin_amdgcn_readlane((int)a.idx, 1);
         }
     };
     // markers in raster order (age 0)
@@ -1345,8 +1362,10 @@ __global__ void __launch_bounds__(64) ws_global_kernel(const void* __restrict__ 
         const int lab = out[p];
         // ---- pop ----
         --items;
+        if (items == 0) tail_valid = false;
         if (items > 0) {
-            const gh_elem last = ld(items);
+            const gh_elem last = tail_valid ? tail : ld(items);
+            tail_valid = false;
             int pos = 0;
             while (true) {
                 // the 62 nodes of the five levels under pos
