@@ -240,6 +240,19 @@ def launch_ranks_if_needed(args):
     sys.exit(subprocess.call(cmd))
 
 
+def _cpu_c3_worker(job):
+    """One field of view through the oracle's config-3 chain in a WORKER PROCESS (spawned: no GIL shared with its
+    siblings, no HIP state inherited): generates the FOV itself, returns the seconds the chain took."""
+    index, size = job
+    from arcadia_microscopy_tools_amd import synth
+    from oracle import chains
+
+    fov = synth.synth_fov(index, size=size)
+    t0 = time.perf_counter()
+    chains.c3_chain(fov)
+    return time.perf_counter() - t0
+
+
 def cpu_baseline(fovs: np.ndarray, workload: str, n_single: int):
     """Time the CPU oracle (numpy/scipy restatement of the reference's scikit-image path, kind 'port') on a
     bounded sample of the same workload: single thread, then all host cores with the reference's own
@@ -281,6 +294,27 @@ def cpu_baseline(fovs: np.ndarray, workload: str, n_single: int):
     with ThreadPoolExecutor(max_workers=cores) as ex:
         list(ex.map(fn, sample))
     tall = time.perf_counter() - t0
+    procs = None
+    if workload == "c3":
+        # the same sample with one PROCESS per core: what the host can do when Python's lock is out of the way (the
+        # reference itself offers threads only, R/pipeline.py:145, so this is an upper bound on its own CPU path)
+        try:
+            import multiprocessing as mp
+            from concurrent.futures import ProcessPoolExecutor
+
+            # an executor, not mp.Pool: a worker that dies raises BrokenProcessPool instead of being respawned for ever
+            with ProcessPoolExecutor(max_workers=cores, mp_context=mp.get_context("spawn")) as pool:
+                list(pool.map(_cpu_c3_worker, [(0, 256)] * cores, timeout=180))  # start the workers outside the timed part
+                t0 = time.perf_counter()
+                secs = list(pool.map(_cpu_c3_worker, [(i, fovs.shape[-1]) for i in range(cores)], timeout=300))
+                tproc = time.perf_counter() - t0
+            # the workers also generate their FOV (~0.5 s each, not part of the chain): the chains ran side by side and
+            # the slowest one bounds them
+            procs = {"value": cores / max(1e-9, max(secs)), "cores": cores,
+                     "sample": f"{cores} FOVs, one spawned process each, slowest chain {max(secs):.2f} s, "
+                               f"{tproc:.1f} s with the FOV generation"}
+        except Exception as e:  # a box that forbids child processes keeps the thread figure
+            procs = {"error": f"{type(e).__name__}: {e}"}
     return {
         "value": n_single / t1,
         "unit": unit,
@@ -290,6 +324,7 @@ def cpu_baseline(fovs: np.ndarray, workload: str, n_single: int):
                   f"{t1:.1f} s",
         "all_cores": {"value": len(sample) / tall, "cores": cores,
                       "sample": f"{len(sample)} FOVs, ThreadPoolExecutor(max_workers={cores}), {tall:.1f} s"},
+        "all_cores_processes": procs,
     }
 
 
@@ -1117,6 +1152,9 @@ def run_chain(args):
             out["cpu_baseline"] = cpu_baseline(np.stack(uniq), args.workload, args.cpu_fovs)
             out["gpu_over_cpu_1thread"] = out["value"] / out["cpu_baseline"]["value"]
             out["gpu_over_cpu_all_cores"] = out["value"] / out["cpu_baseline"]["all_cores"]["value"]
+            pr = out["cpu_baseline"].get("all_cores_processes")
+            if pr and "value" in pr:
+                out["gpu_over_cpu_all_cores_processes"] = out["value"] / pr["value"]
     if host_tables is not None:
         host_tables.close()
     if distributed:
