@@ -62,6 +62,7 @@ _SIGS = {
     "amt_event_sync": (c_int, [_P, _P]),
     "amt_event_destroy": (c_int, [_P, _P]),
     "amt_host_alloc": (c_int, [c_size_t, POINTER(c_void_p)]),
+    "amt_host_copy": (c_int, [c_void_p, c_void_p, c_size_t]),
     "amt_host_free": (c_int, [_P]),
     "amt_timer_create": (c_int, [_P, POINTER(c_void_p)]),
     "amt_timer_start": (c_int, [_P, _P]),

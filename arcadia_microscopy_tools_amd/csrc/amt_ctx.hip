@@ -321,6 +321,34 @@ extern "C" int amt_host_free(void* hptr) {
     return AMT_OK;
 }
 
+// Host memcpy with streaming stores: a staging block is written once and next read by the DMA engine, so pulling its
+// lines into the cache first (what an ordinary store does) only doubles the destination's traffic.  Plain host code.
+extern "C" int amt_host_copy(void* dst, const void* src, size_t bytes) {
+    AMT_REQUIRE((dst && src) || bytes == 0, "amt_host_copy: null pointer");
+    typedef long long v2di __attribute__((vector_size(16)));
+    unsigned char* d = (unsigned char*)dst;
+    const unsigned char* s = (const unsigned char*)src;
+    size_t head = ((uintptr_t)d & 15) ? 16 - ((uintptr_t)d & 15) : 0;
+    if (head > bytes) head = bytes;
+    memcpy(d, s, head);
+    d += head, s += head, bytes -= head;
+    size_t i = 0;
+    for (; i + 64 <= bytes; i += 64) {
+        v2di a, b, c, e;
+        memcpy(&a, s + i, 16);
+        memcpy(&b, s + i + 16, 16);
+        memcpy(&c, s + i + 32, 16);
+        memcpy(&e, s + i + 48, 16);
+        __builtin_nontemporal_store(a, (v2di*)(d + i));
+        __builtin_nontemporal_store(b, (v2di*)(d + i + 16));
+        __builtin_nontemporal_store(c, (v2di*)(d + i + 32));
+        __builtin_nontemporal_store(e, (v2di*)(d + i + 48));
+    }
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);  // streaming stores are weakly ordered: drain them before returning
+    memcpy(d + i, s + i, bytes - i);
+    return AMT_OK;
+}
+
 struct amt_timer {
     hipEvent_t start, stop;
 };

@@ -68,7 +68,11 @@ def _host_copy(dst: np.ndarray, src: np.ndarray) -> None:
 def _stage_chunk(dst: np.ndarray, src: np.ndarray, stats: bool):
     """One chunk of a staged upload: convert / copy into the page-locked buffer and, on request, the chunk's extrema
     (the chunk is still in cache: the constructor checks of a label image cost no second pass over it)."""
-    np.copyto(dst, src, casting="unsafe")
+    if dst.dtype == src.dtype and dst.nbytes >= (1 << 16):
+        # streaming stores (amt_host_copy): the staging block is read next by the DMA engine, not by this core
+        _hip.check(_hip.load_library().amt_host_copy(dst.ctypes.data, src.ctypes.data, dst.nbytes), "amt_host_copy")
+    else:
+        np.copyto(dst, src, casting="unsafe")
     return (src.min(), src.max()) if stats else None
 
 

@@ -207,6 +207,39 @@ class SegmentationMask:
         object.__setattr__(self, "_mask_max", mx)
         object.__setattr__(self, "_sealed", True)
 
+    @classmethod
+    def _from_device(cls, labels, num_cells: int, morph: np.ndarray, inten, intensity_image_dict=None,
+                     outline_extractor="cellpose", property_names=None, intensity_property_names=None):
+        """A mask whose label plane was COMPUTED on the device (``SegmentationModel.batch_masks``): ``labels`` is the
+        int32 plane after edge-cell removal and sequential numbering, ``morph`` / ``inten`` the feature rows of its
+        ``num_cells`` cells.  Equal in every derived attribute to ``SegmentationMask(labels.numpy_int64(), ...)``;
+        ``mask_image`` is that same label image, downloaded when it is first read."""
+        if num_cells <= 0:
+            raise ValueError("mask_image contains no cells (all values are 0)")
+        self = object.__new__(cls)
+        channels = _checked_intensities(intensity_image_dict, tuple(labels.shape[-2:]))
+        if property_names is None:
+            property_names = list(DEFAULT_CELL_PROPERTY_NAMES)
+        if intensity_property_names is None:
+            intensity_property_names = list(DEFAULT_INTENSITY_PROPERTY_NAMES) if channels else []
+        given = (channels, True, outline_extractor, property_names, intensity_property_names)
+        for name, value in zip(cls._CTOR_FIELDS[1:], given):
+            object.__setattr__(self, name, value)
+        d = self.__dict__
+        d["_mask_max"] = int(num_cells)
+        d["_labels_device"] = (labels, int(num_cells))
+        d["_rows"] = (morph, inten)
+        d["_sealed"] = True
+        return self
+
+    def __getattr__(self, name):
+        # only reached for attributes that are not set: the lazily downloaded label image of a device-born mask
+        if name == "mask_image" and "_rows" in self.__dict__:
+            image = self.__dict__["_labels_device"][0].numpy_int64()
+            self.__dict__["mask_image"] = image
+            return image
+        raise AttributeError(f"{type(self).__name__!s} object has no attribute {name!r}")
+
     def __setattr__(self, name, value):
         if name in self._CTOR_FIELDS and self.__dict__.get("_sealed", False):
             raise AttributeError(
@@ -216,6 +249,10 @@ class SegmentationMask:
 
     def __repr__(self):
         chans = [c.name for c in self.intensity_image_dict] if self.intensity_image_dict else []
+        if "mask_image" not in self.__dict__:  # device-born: do not download the image for a repr
+            shape = tuple(self.__dict__["_labels_device"][0].shape[-2:])
+            return (f"SegmentationMask(shape={shape}, dtype=int64, channels={chans}, "
+                    f"remove_edge_cells={self.remove_edge_cells}, outline_extractor={self.outline_extractor!r})")
         return (f"SegmentationMask(shape={self.mask_image.shape}, dtype={self.mask_image.dtype}, channels={chans}, "
                 f"remove_edge_cells={self.remove_edge_cells}, outline_extractor={self.outline_extractor!r})")
 
@@ -263,6 +300,12 @@ class SegmentationMask:
 
         assert self.property_names is not None
         assert self.intensity_property_names is not None
+        if "_rows" in self.__dict__:  # measured by the chain that made the labels (SegmentationModel.batch_masks)
+            morph, inten = self.__dict__["_rows"]
+            names = [c.name for c in self.intensity_image_dict] if self.intensity_image_dict else []
+            use = inten if (names and self.intensity_property_names) else None
+            return assemble_cell_properties(morph, use, names, list(self.property_names),
+                                            list(self.intensity_property_names))
         lab, k = self._labels_device
         k = int(k)
         inten = None
@@ -339,7 +382,7 @@ class SegmentationMask:
                 f"with min={min_value}, max={max_value}."
             )
         # the survivors keep their pixels; numbering restarts at 1 and edge cells are NOT re-examined
-        settings = {name: getattr(self, name) for name in self._CTOR_FIELDS}
+        settings = {name: getattr(self, name) for name in self._CTOR_FIELDS[1:]}
         settings.update(mask_image=new_label_image, remove_edge_cells=False,
                         property_names=list(self.property_names),
                         intensity_property_names=list(self.intensity_property_names))

@@ -293,6 +293,87 @@ class SegmentationModel:
                 out.append(labels[j].numpy_int64())
         return out
 
+    def batch_masks(self, intensities_batch: Sequence[np.ndarray], channels, nuclear=0,
+                    cell_diameter_px: float | None = None, batch_size: int | None = None, *,
+                    remove_edge_cells: bool = True, outline_extractor: str = "cellpose", property_names=None,
+                    intensity_property_names=None) -> list:
+        """``batch_segment`` and the ``SegmentationMask`` of every image in one call (an addition to the reference's
+        interface; the two-call form stays available and gives the same results).
+
+        intensities_batch   images of shape (C, height, width), one plane per entry of ``channels``
+        channels            the ``Channel`` of every plane (keys of each mask's ``intensity_image_dict``)
+        nuclear             index (or ``Channel``) of the plane that is segmented
+
+        Returns, per image, ``SegmentationMask(self.segment(image[nuclear]), dict(zip(channels, image)),
+        remove_edge_cells=..., ...)`` -- the same label image, cell count, outlines and ``cell_properties`` -- or
+        ``None`` with a ``SegmentationWarning`` where that construction fails (no cells).  With
+        ``backend="classical"`` and uint8 / uint16 images of one shape every image crosses the bus ONCE: labels and
+        feature rows stay where the chain made them, only the rows come to the host (``maskbatch.MaskBatcher``), and
+        ``mask_image`` (there: the label image after edge-cell removal) / ``label_image`` are downloaded on first
+        access."""
+        from .masks import SegmentationMask
+
+        channels = list(channels)
+        nuc = channels.index(nuclear) if nuclear in channels and not isinstance(nuclear, (int, np.integer)) else int(nuclear)
+        if not 0 <= nuc < len(channels):
+            raise ValueError(f"nuclear must name one of the {len(channels)} channels, got {nuclear!r}")
+        params = self._resolve_and_validate_parameters(cell_diameter_px, None, None, None, batch_size)
+        mask_kw = dict(outline_extractor=outline_extractor, property_names=property_names,
+                       intensity_property_names=intensity_property_names)
+        images = [np.asarray(im) for im in intensities_batch]
+        for im in images:
+            if im.ndim != 3 or im.shape[0] != len(channels):
+                raise ValueError(f"expected images of shape ({len(channels)}, height, width), got {im.shape}")
+        rows = None
+        if (self.backend == "classical" and remove_edge_cells and images
+                and all(im.dtype in (np.uint8, np.uint16) and im.shape == images[0].shape for im in images)):
+            rows = self._masks_classical(images, nuc, params)
+        out: list = []
+        if rows is not None:
+            for im, (lab, k, morph, inten) in zip(images, rows):
+                if k <= 0:
+                    warnings.warn("no cells in an image of the batch (or none away from the frame): None at its index",
+                                  SegmentationWarning, stacklevel=2)
+                    out.append(None)
+                    continue
+                out.append(SegmentationMask._from_device(lab, k, morph, inten, dict(zip(channels, im)), **mask_kw))
+            return out
+        labels = self.batch_segment([im[nuc] for im in images], cell_diameter_px=cell_diameter_px,
+                                    batch_size=batch_size, show_progress=False)
+        for i, (im, lab) in enumerate(zip(images, labels)):
+            try:
+                mask = None if lab is None else SegmentationMask(lab, dict(zip(channels, im)),
+                                                                 remove_edge_cells=remove_edge_cells, **mask_kw)
+                if mask is not None:
+                    mask.num_cells  # edge-cell removal may leave nothing: found here, not on a later access
+            except ValueError as e:
+                warnings.warn(f"no SegmentationMask for image {i}: {e}", SegmentationWarning, stacklevel=2)
+                mask = None
+            out.append(mask)
+        return out
+
+    def _masks_classical(self, images, nuclear: int, params: CellposeParams):
+        """The one-pass route of ``batch_masks``; None when a table of the chain overflowed (dense noise)."""
+        import threading
+
+        from .device import get_context
+        from .maskbatch import MaskBatcher
+
+        C, H, W = images[0].shape
+        ctx = get_context()
+        min_distance = max(1, int(round(params["diameter"] / 6.0)))
+        chunk = max(1, min(int(params["batch_size"]), len(images)))
+        cache = self.__dict__.setdefault("_mask_cache", threading.local())
+        key = (chunk, C, H, W, nuclear, min_distance, self.sigma, self.opening_radius, id(ctx))
+        mb = getattr(cache, "mb", None)
+        if mb is None or cache.key != key:
+            if mb is not None:
+                mb.close()
+            mb = MaskBatcher(chunk, C, H, W, nuclear=nuclear, sigma=self.sigma, radius=self.opening_radius,
+                             min_distance=min_distance, ctx=ctx)
+            cache.mb, cache.key = mb, key
+        return mb.run(images)
+
     def batch_segment(self, intensities_batch: Sequence[Float64Array], cell_diameter_px: float | None = None,
                       flow_threshold: float | None = None, cellprob_threshold: float | None = None,
                       num_iterations: int | None = None, batch_size: int | None = None,

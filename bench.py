@@ -635,6 +635,7 @@ def run_api(args):
     fovs = [uniq[i % nuniq] for i in range(B)]
     chans = (BRIGHTFIELD, DAPI, FITC, TRITC)
     model = SegmentationModel(backend="classical")
+    bus_rate = 53e9  # measured host-link rate of this box class (tools/xfer_probe.py; PCIe Gen5 x16: 63 GB/s nominal)
 
     def work(chunk):
         masks = model.batch_segment([f[1] for f in chunk], batch_size=len(chunk), show_progress=False)
@@ -661,11 +662,50 @@ def run_api(args):
                  and all(np.array_equal(p1[c], res[k][2][c], equal_nan=True) for c in p1))
     if not equal:
         raise RuntimeError("batch_segment + cell_properties differ from the per-image calls")
+    # ---- the same results through the one-call form (an addition to the reference's interface): every image crosses
+    # the bus once, labels + rows stay on the device, only the rows of the cells that exist come home ----
+    mask_chunk = int(os.environ.get("AMT_API_MASK_CHUNK", "8"))
+    mworkers = int(os.environ.get("AMT_API_MASK_WORKERS", "2"))
+    MB = int(os.environ.get("AMT_API_MASK_FOVS", "192"))  # FOVs per step of this form (a plate's worth per call)
+    mfovs = [uniq[i % nuniq] for i in range(MB)]
+    share = -(-MB // mworkers)
+    shares = [mfovs[i:i + share] for i in range(0, MB, share)]
+
+    def mwork(part):
+        masks = model.batch_masks(part, chans, nuclear=DAPI, batch_size=mask_chunk)
+        return [(m, m.cell_properties) for m in masks]
+
+    with ThreadPoolExecutor(max_workers=mworkers) as ex:
+        for _ in range(max(1, args.warmup)):
+            mres = [r for part in ex.map(mwork, shares) for r in part]
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            mres = [r for part in ex.map(mwork, shares) for r in part]
+        m_elapsed = time.perf_counter() - t0
+    for k in (0, min(MB - 1, per_call + 1)):
+        m1 = model.segment(mfovs[k][1])
+        sm = SegmentationMask(m1, {c: mfovs[k][i] for i, c in enumerate(chans)})
+        p1 = sm.cell_properties
+        if not (np.array_equal(sm.label_image, mres[k][0].label_image)
+                and list(p1) == list(mres[k][1])
+                and all(np.array_equal(p1[c], mres[k][1][c], equal_nan=True) for c in p1)):
+            raise RuntimeError("batch_masks differs from segment + SegmentationMask")
+    one_call = {
+        "value": MB * args.steps / m_elapsed, "unit": "FOV/s", "ms_per_step": m_elapsed / args.steps * 1e3,
+        "fovs_per_step": MB,
+        "workload": "host numpy FOVs -> SegmentationModel(backend='classical').batch_masks(images, channels, "
+                    "nuclear=DAPI) -> SegmentationMask objects (labels on the device, downloaded on access) -> "
+                    ".cell_properties of every mask on the host",
+        "worker_threads": mworkers, "images_per_chunk": mask_chunk,
+        "pcie_bound_fov_per_s": bus_rate / (S * S * 8), "h2d_bytes_per_fov": S * S * 8,
+        "results_equal_two_calls": True,
+    }
+    del mres
     # bytes that must cross the bus per FOV on this API: DAPI plane up, int64 labels down, labels (narrowed to int32 on
     # their way into the staging buffer) + four uint16 planes up
     h2d = S * S * (2 + 4 + 4 * 2)
     d2h = S * S * 8
-    bus = 53e9  # measured host-link rate of this box class (tools/xfer_probe.py; PCIe Gen5 x16: 63 GB/s nominal)
+    bus = bus_rate
     return {
         "metric": "fields-of-view/sec through the reference-level API on host arrays (batch_segment + cell_properties)",
         "value": B * args.steps / elapsed, "unit": "FOV/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -685,6 +725,7 @@ def run_api(args):
         # 67, four planes staged and sent 100 -- the worker threads saturate host memory before they saturate the bus
         "host_memory_traffic_bytes_per_fov": S * S * (6 + 8 + 8 + 16 + 24),
         "results_equal_per_image_calls": True, "host_gen_s": gen_s,
+        "one_call": one_call,
     }
 
 
@@ -774,7 +815,8 @@ def _sub_args(args, **kw):
 def _brief(line: dict) -> dict:
     """What a supplementary line keeps of a full bench line."""
     keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "cpu_baseline",
-            "pcie_bound", "results_equal_per_image_calls", "note", "tied_plane_fraction", "delivered_to_host")
+            "pcie_bound", "results_equal_per_image_calls", "note", "tied_plane_fraction", "delivered_to_host",
+            "one_call")
     out = {k: line[k] for k in keep if k in line}
     r = out.get("roofline")
     if isinstance(r, dict):
@@ -796,6 +838,8 @@ def run_sublines(args) -> dict:
             subs[name] = _brief(fn())
             subs[name]["wall_s"] = time.perf_counter() - t0
             log(f"subline {name}: {subs[name]['value']:.1f} {subs[name]['unit']} ({subs[name]['wall_s']:.1f} s)")
+            if "one_call" in subs[name]:
+                log(f"subline {name}, one-call form (batch_masks): {subs[name]['one_call']['value']:.1f} FOV/s")
         except Exception as e:  # a supplementary line must not take the headline down with it
             subs[name] = {"error": f"{type(e).__name__}: {e}"}
             log(f"subline {name} FAILED: {subs[name]['error']}")

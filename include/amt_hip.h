@@ -93,6 +93,8 @@ int amt_event_destroy(amt_ctx* ctx, void* event);
 /* pinned host staging buffers for the FOV feeder */
 int amt_host_alloc(size_t bytes, void** hptr);
 int amt_host_free(void* hptr);
+/* host memcpy with streaming stores, for filling a staging block the DMA engine reads next (thread-safe, no GPU call) */
+int amt_host_copy(void* dst, const void* src, size_t bytes);
 /* HIP-event timing on the context's stream (bench.py roofline: kernel time measured live) */
 int amt_timer_create(amt_ctx* ctx, void** timer);
 int amt_timer_start(amt_ctx* ctx, void* timer);

@@ -261,6 +261,79 @@ def test_segmentation_model_classical():
     assert all(np.array_equal(g, model.segment(im)) for g, im in zip(got8, imgs8))
 
 
+def test_batch_masks_equal_the_two_calls():
+    """``SegmentationModel.batch_masks`` (one pass over the bus, labels and rows kept on the device) gives exactly what
+    ``segment`` + ``SegmentationMask`` give image by image: label image, count, outlines, every property column."""
+    import warnings as w
+
+    from arcadia_microscopy_tools_amd import synth
+    from arcadia_microscopy_tools_amd.exceptions import SegmentationWarning
+    from arcadia_microscopy_tools_amd.model import SegmentationModel
+
+    chans = (BRIGHTFIELD, DAPI, FITC, TRITC)
+    model = SegmentationModel(backend="classical")
+    fovs = [synth.synth_fov(20 + i, size=320) for i in range(5)]
+
+    def two_calls(f, **kw):
+        return SegmentationMask(model.segment(f[1]), dict(zip(chans, f)), **kw)
+
+    def same(a, b):
+        assert a.num_cells == b.num_cells
+        assert np.array_equal(a.label_image, b.label_image) and a.label_image.dtype == np.int64
+        pa, pb = a.cell_properties, b.cell_properties
+        assert list(pa) == list(pb)
+        for c in pa:
+            assert pa[c].dtype == pb[c].dtype and np.array_equal(pa[c], pb[c], equal_nan=True), c
+        assert np.array_equal(a.centroids_yx, b.centroids_yx)
+
+    want = [two_calls(f) for f in fovs]
+    for bs in (2, 8, 1):  # 5 images: short last chunk / one chunk / image by image
+        got = model.batch_masks(fovs, chans, nuclear=DAPI, batch_size=bs)
+        assert len(got) == 5
+        for g, t in zip(got, want):
+            same(g, t)
+    g0 = got[0]
+    # the image the mask was built from is the processed label image, fetched on first access; immutability holds
+    assert "mask_image" not in g0.__dict__ and "shape=(320, 320)" in repr(g0)
+    assert np.array_equal(g0.mask_image, want[0].label_image)
+    with pytest.raises(AttributeError, match="Cannot modify"):
+        g0.mask_image = g0.mask_image
+    with pytest.raises(AttributeError):
+        g0.no_such_attribute
+    assert [o.tolist() for o in g0.cell_outlines] == [o.tolist() for o in want[0].cell_outlines]
+    f1, f2 = g0.filter("area", min_value=60.0), want[0].filter("area", min_value=60.0)
+    assert np.array_equal(f1.label_image, f2.label_image)
+    um1, um2 = g0.convert_properties_to_microns(0.33), want[0].convert_properties_to_microns(0.33)
+    assert all(np.array_equal(um1[c], um2[c], equal_nan=True) for c in um2)
+    # chosen columns, nuclear channel by index, uint8 planes
+    kw = dict(property_names=["label", "area", "circularity"], intensity_property_names=["intensity_mean"])
+    got = model.batch_masks(fovs[:2], chans, nuclear=1, **kw)
+    for g, f in zip(got, fovs):
+        same(g, two_calls(f, **kw))
+    f8 = [(f >> 6).astype(np.uint8) for f in fovs[:3]]
+    for g, f in zip(model.batch_masks(f8, chans, nuclear=DAPI, batch_size=2), f8):
+        same(g, two_calls(f))
+    # an image without cells: None + warning at its index, the others unaffected
+    blank = np.zeros_like(fovs[0])
+    with w.catch_warnings(record=True) as rec:
+        w.simplefilter("always")
+        got = model.batch_masks([fovs[0], blank, fovs[1]], chans, nuclear=DAPI, batch_size=2)
+    assert got[1] is None and any(issubclass(r.category, SegmentationWarning) for r in rec)
+    same(got[0], want[0])
+    same(got[2], want[1])
+    # what the one-pass route does not take goes through the two calls: edge cells kept, float images
+    got = model.batch_masks(fovs[:2], chans, nuclear=DAPI, remove_edge_cells=False)
+    for g, f in zip(got, fovs):
+        same(g, two_calls(f, remove_edge_cells=False))
+    ff = [f.astype(np.float64) for f in fovs[:2]]
+    for g, f in zip(model.batch_masks(ff, chans, nuclear=DAPI), ff):
+        same(g, two_calls(f))
+    with pytest.raises(ValueError, match="expected images of shape"):
+        model.batch_masks([fovs[0][1]], chans)
+    with pytest.raises(ValueError, match="nuclear must name"):
+        model.batch_masks(fovs[:1], chans, nuclear=7)
+
+
 def test_stream_rule_at_the_boundary():
     """include/amt_hip.h, "Streams": an amt_* call runs on the stream of the context it is given, so an array produced
     on another context must be bound (``DeviceArray.on``) and ordered (``Context.wait_for`` / ``Event``) first.  The
