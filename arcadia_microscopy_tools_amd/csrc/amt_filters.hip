@@ -40,13 +40,13 @@ __device__ __forceinline__ double cvt_f64<double>(double v, double scale) {
     return v;
 }
 
-// eight outputs at positions o .. o+7 of a line; `at(i)` returns sample i (already converted); `w` = the
+// RUNTIME radius.  Eight outputs at positions o .. o+7 of a line; `at(i)` returns sample i (already converted); `w` = the
 // 2r+1 weights IN LDS (scalar loads share their counter with LDS reads and return out of order, so a scalar
 // weight load inside the steps forces a full wait on the in-flight LDS reads; LDS weight reads stay in order).
 // The two samples that enter the windows are requested TWO steps ahead (software pipeline), so the LDS latency
 // hides behind 48 float64 operations even with a single wave per SIMD.
 template <typename F>
-__device__ __forceinline__ void blocked8(F at, int o, const double* w, int r, double acc[8]) {
+__device__ __forceinline__ void blocked8_rot(F at, int o, const double* w, int r, double acc[8]) {
     double L[8], Rw[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -89,6 +89,111 @@ __device__ __forceinline__ void blocked8(F at, int o, const double* w, int r, do
     if (st + 5 < r) AMT_BLOCKED8_STEP(5, st + 5)
     if (st + 6 < r) AMT_BLOCKED8_STEP(6, st + 6)
 #undef AMT_BLOCKED8_STEP
+}
+
+// COMPILE-TIME radius RC (the reference's own preprocessing: sigma 16 -> r = 64), everything unrolled.
+// Steps come in blocks of eight.  Within a block the left window at step s is the last 8 - s samples of the block's
+// OLD eight samples followed by the first s of its NEW eight (the right window mirrors that), so output k reads
+// old[k + s] or new[k + s - 8] -- static register names, nothing is inserted or rotated.  The next block's NEW samples
+// are requested one block ahead, each into the register its predecessor vacated (old[s] is dead after step s): a
+// request is ~800 clocks old when it is used and no value is ever copied.  Round 2's form kept ONE rotating window and
+// replaced all sixteen live slots in every block; the compiler paid for that with 18 register moves per 192 float64
+// operations at the loop's back edge (ISA of conv_h8g_kernel) plus waits on samples requested two steps ahead.
+// With the block loop unrolled completely no value crosses a back edge; with a runtime radius the same source needs
+// 160 registers and is slower than the rotating form above (measured), so that one keeps serving the other radii.
+// Measured (32 planes of 2048^2, r = 64): vertical 1,130 -> 1,076 us, horizontal 1,300 -> 1,241 us.
+template <int RC, typename F>
+__device__ __forceinline__ void blocked8(F at, int o, const double* w, int r_, double acc[8]) {
+    if constexpr (RC == 0) {
+        blocked8_rot(at, o, w, r_, acc);
+        return;
+    }
+    constexpr int r = RC ? RC : 16;
+    static_assert(RC == 0 || RC >= 8, "block-ahead requests stay inside the chunk's samples for r >= 8 only");
+    double LA[8], RA[8], LB[8], RB[8];
+    // every sample index is written as b + a non-negative constant, b = o - r made opaque: LDS instructions take
+    // unsigned immediate offsets only, and the compiler otherwise spends a vector add on every request left of o
+    int b = o - r;
+    asm volatile("" : "+v"(b));
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        acc[k] = at(b + r + k) * w[r];
+        LA[k] = at(b + k);
+        RA[k] = at(b + 2 * r + k);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        LB[k] = at(b + k + 8);
+        RB[k] = at(b + 2 * r + k - 8);
+    }
+    // neither the optimiser nor the scheduler may move an LDS read or a step's arithmetic across a step boundary: the
+    // (empty) statement orders memory operations and "rewrites" the eight sums, so each step's operations sit between
+    // two of them.  Left alone, instruction selection puts every request of an unrolled block first and the arithmetic
+    // after (458 - 512 registers, spills)
+#define AMT_B8_FENCE                                                                                       \
+    asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]),    \
+                      "+v"(acc[6]), "+v"(acc[7])::"memory");                                                \
+    __builtin_amdgcn_sched_barrier(0);
+    // one step at distance j = r - st, s = st & 7; Lo / Ro: the block's old samples, Ln / Rn: its new ones
+#define AMT_B8_STEP(Lo, Ln, Ro, Rn, s, st)                                                            \
+    {                                                                                                 \
+        const double wj = wnext;                                                                      \
+        wnext = w[(st) + 1]; /* asked for a step ahead (w[r] exists: the centre weight) */            \
+        double t_[8];                                                                                 \
+        _Pragma("unroll") for (int k = 0; k < 8; ++k)                                                 \
+            t_[k] = (k + (s) < 8 ? Lo[(k + (s)) & 7] : Ln[(k + (s)) & 7]) +                            \
+                    (k - (s) >= 0 ? Ro[(k - (s)) & 7] : Rn[(k - (s)) & 7]);                            \
+        _Pragma("unroll") for (int k = 0; k < 8; ++k) t_[k] = t_[k] * wj;                             \
+        _Pragma("unroll") for (int k = 0; k < 8; ++k) acc[k] += t_[k];                                \
+        AMT_B8_FENCE /* requests stay where the pipeline puts them (register pressure) */              \
+    }
+    // after step s of the block that starts at st0: old[s] (left) and old[7 - s] (right) are dead and receive the
+    // samples the block after the next one calls new
+#define AMT_B8_FETCH(Lo, Ro, s, st0)                                                                  \
+    {                                                                                                 \
+        Lo[s] = at(b + (st0) + 16 + (s));                                                               \
+        Ro[7 - (s)] = at(b + 2 * r - (st0) - 16 + 7 - (s));                                               \
+        AMT_B8_FENCE                                                                                  \
+    }
+#define AMT_B8_BLOCK(Lo, Ln, Ro, Rn, st0)                                                             \
+    AMT_B8_STEP(Lo, Ln, Ro, Rn, 0, (st0) + 0) AMT_B8_FETCH(Lo, Ro, 0, st0)                             \
+    AMT_B8_STEP(Lo, Ln, Ro, Rn, 1, (st0) + 1) AMT_B8_FETCH(Lo, Ro, 1, st0)                             \
+    AMT_B8_STEP(Lo, Ln, Ro, Rn, 2, (st0) + 2) AMT_B8_FETCH(Lo, Ro, 2, st0)                             \
+    AMT_B8_STEP(Lo, Ln, Ro, Rn, 3, (st0) + 3) AMT_B8_FETCH(Lo, Ro, 3, st0)                             \
+    AMT_B8_STEP(Lo, Ln, Ro, Rn, 4, (st0) + 4) AMT_B8_FETCH(Lo, Ro, 4, st0)                             \
+    AMT_B8_STEP(Lo, Ln, Ro, Rn, 5, (st0) + 5) AMT_B8_FETCH(Lo, Ro, 5, st0)                             \
+    AMT_B8_STEP(Lo, Ln, Ro, Rn, 6, (st0) + 6) AMT_B8_FETCH(Lo, Ro, 6, st0)                             \
+    AMT_B8_STEP(Lo, Ln, Ro, Rn, 7, (st0) + 7) AMT_B8_FETCH(Lo, Ro, 7, st0)
+#define AMT_B8_TAIL(Lo, Ln, Ro, Rn, st0)                                                              \
+    if ((st0) + 0 < r) AMT_B8_STEP(Lo, Ln, Ro, Rn, 0, (st0) + 0)                                       \
+    if ((st0) + 1 < r) AMT_B8_STEP(Lo, Ln, Ro, Rn, 1, (st0) + 1)                                       \
+    if ((st0) + 2 < r) AMT_B8_STEP(Lo, Ln, Ro, Rn, 2, (st0) + 2)                                       \
+    if ((st0) + 3 < r) AMT_B8_STEP(Lo, Ln, Ro, Rn, 3, (st0) + 3)                                       \
+    if ((st0) + 4 < r) AMT_B8_STEP(Lo, Ln, Ro, Rn, 4, (st0) + 4)                                       \
+    if ((st0) + 5 < r) AMT_B8_STEP(Lo, Ln, Ro, Rn, 5, (st0) + 5)                                       \
+    if ((st0) + 6 < r) AMT_B8_STEP(Lo, Ln, Ro, Rn, 6, (st0) + 6)
+    // a block that starts at st0 fetches x[o - r + st0 + 16 .. + 23] and x[o + r - st0 - 16 .. - 9]: with st0 + 8 <= r
+    // (and r >= 8, this path's radii start at 13) every fetched index lies in [o - 8, o + 15], inside the samples the
+    // eight outputs read anyway
+    int st = 0;
+    double wnext = w[0];
+#pragma unroll
+    for (; st + 16 <= r; st += 16) {
+        AMT_B8_BLOCK(LA, LB, RA, RB, st)
+        AMT_B8_BLOCK(LB, LA, RB, RA, st + 8)
+    }
+    if (st + 8 <= r) {
+        AMT_B8_BLOCK(LA, LB, RA, RB, st)
+        st += 8;
+        AMT_B8_TAIL(LB, LA, RB, RA, st)
+    } else {
+        AMT_B8_TAIL(LA, LB, RA, RB, st)
+    }
+#undef AMT_B8_STEP
+#undef AMT_B8_FENCE
+#undef AMT_B8_FETCH
+#undef AMT_B8_BLOCK
+#undef AMT_B8_TAIL
 }
 
 template <typename TIn>
@@ -135,9 +240,9 @@ __global__ void __launch_bounds__(256) conv_v8_kernel(const TIn* __restrict__ in
         if (y0 + q0 >= H) break;
         double acc[8];
         if (has_out)
-            blocked8(at, q0 + r, wl, r, acc);
+            blocked8_rot(at, q0 + r, wl, r, acc);
         else
-            blocked8(at_in, q0 + r, wl, r, acc);
+            blocked8_rot(at_in, q0 + r, wl, r, acc);
         if (x < W) {
 #pragma unroll
             for (int k = 0; k < 8; ++k)
@@ -191,7 +296,7 @@ __global__ void __launch_bounds__(256) conv_h8_kernel(const double* __restrict__
     const int y = y0 + lane;
     for (int c = wave; c * 8 < TW; c += 4) {
         double res[8];
-        blocked8(at, c * 8 + r, wl, r, res);
+        blocked8_rot(at, c * 8 + r, wl, r, res);
         const int x = x0 + c * 8;
         if (y < H && x < W) {
             double* dst = out + plane + (size_t)y * W + x;
@@ -666,7 +771,7 @@ static int launch_fused(amt_ctx* ctx, const TIn* in, double scale, double* out, 
 // ------------------------------------------------------------------------------------------------
 constexpr int H8G_CP = 256, H8G_PITCH = 258;
 
-template <int H8G_ROWS>
+template <int H8G_ROWS, int RC = 0>
 __global__ void __launch_bounds__(256) conv_h8g_kernel(const double* __restrict__ in, double* out, int H, int W,
                                                        const double* __restrict__ wts, int r, int mode, double cval,
                                                        int TW, const double* minuend, int remap) {
@@ -730,7 +835,7 @@ __global__ void __launch_bounds__(256) conv_h8g_kernel(const double* __restrict_
         const int cw = cb + half;                       // this lane group's chunk
         const int c = cw < nchunks ? cw : nchunks - 1;  // an idle half recomputes the last chunk and stores nothing
         double res[8];
-        blocked8(at, c * 8 + r, wl, r, res);
+        blocked8<RC>(at, c * 8 + r, wl, r, res);
         const int x = x0 + c * 8;
         if (cw < nchunks && y < H && x < W) {
             double* dst = out + plane + (size_t)y * W + x;
@@ -757,7 +862,7 @@ __global__ void __launch_bounds__(256) conv_h8g_kernel(const double* __restrict_
     }
 }
 
-template <typename TIn>
+template <typename TIn, int RC = 0>
 __global__ void __launch_bounds__(256) conv_v8g_kernel(const TIn* __restrict__ in, double scale,
                                                        double* __restrict__ out, int H, int W,
                                                        const double* __restrict__ wts, int r, int mode, double cval,
@@ -803,9 +908,9 @@ __global__ void __launch_bounds__(256) conv_v8g_kernel(const TIn* __restrict__ i
         if (y0 + q0 >= H) break;
         double acc[8];
         if (has_out)
-            blocked8(at, q0 + r, wl, r, acc);
+            blocked8<RC>(at, q0 + r, wl, r, acc);
         else
-            blocked8(at_in, q0 + r, wl, r, acc);
+            blocked8<RC>(at_in, q0 + r, wl, r, acc);
 #pragma unroll
         for (int k = 0; k < 8; ++k)
             if (y0 + q0 + k < H) out[plane + (size_t)(y0 + q0 + k) * W + x] = acc[k];
@@ -841,13 +946,18 @@ static int gaussian_typed(amt_ctx* ctx, const TIn* in, double scale, double* out
     const bool aligned = (reinterpret_cast<uintptr_t>(in) & 15) == 0 && (reinterpret_cast<uintptr_t>(tmp) & 15) == 0 &&
                          (in_stride * sizeof(TIn)) % 16 == 0 && getenv("AMT_GAUSS_NO_GLDS") == nullptr;
     bool v_done = false, h_done = false;
+    const bool no_rc = getenv("AMT_GAUSS_NO_RC") != nullptr;  // A/B: the runtime-radius instances for r = 64 too
     if (aligned && W % 64 == 0 && H > 2 * r) {  // vertical pass, LDS-DMA staging
         int TH = sizeof(TIn) == 2 ? 128 : 64;
         const int rows_pad = (TH + 2 * r + 7) & ~7;
         const size_t smem0 = (size_t)rows_pad * 64 * sizeof(TIn) + (size_t)(2 * r + 1) * 8 + (size_t)(TH + 2 * r);
         dim3 g0(W / 64, (H + TH - 1) / TH, nplanes);
-        hipLaunchKernelGGL((conv_v8g_kernel<TIn>), g0, dim3(256), smem0, ctx->stream, in, scale, tmp, H, W, wdev, r, mode,
-                           cval, TH, in_stride);
+        if (r == 64 && !no_rc)
+            hipLaunchKernelGGL((conv_v8g_kernel<TIn, 64>), g0, dim3(256), smem0, ctx->stream, in, scale, tmp, H, W, wdev, r,
+                               mode, cval, TH, in_stride);
+        else
+            hipLaunchKernelGGL((conv_v8g_kernel<TIn>), g0, dim3(256), smem0, ctx->stream, in, scale, tmp, H, W, wdev, r,
+                               mode, cval, TH, in_stride);
         AMT_LAUNCH_CHECK();
         v_done = true;
     }
@@ -872,8 +982,12 @@ static int gaussian_typed(amt_ctx* ctx, const TIn* in, double scale, double* out
         const size_t smem1 = (size_t)ROWS * H8G_PITCH * sizeof(double) + (size_t)(2 * r + 1) * 8;
         dim3 g1((W + TW - 1) / TW, (H + ROWS - 1) / ROWS, nplanes);
         const int remap = (g1.x * g1.y) % 8 == 0;
-        hipLaunchKernelGGL(conv_h8g_kernel<ROWS>, g1, dim3(256), smem1, ctx->stream, tmp, out, H, W, wdev, r, mode, cval,
-                           TW, minuend, remap);
+        if (r == 64 && !no_rc)
+            hipLaunchKernelGGL((conv_h8g_kernel<ROWS, 64>), g1, dim3(256), smem1, ctx->stream, tmp, out, H, W, wdev, r, mode,
+                               cval, TW, minuend, remap);
+        else
+            hipLaunchKernelGGL((conv_h8g_kernel<ROWS>), g1, dim3(256), smem1, ctx->stream, tmp, out, H, W, wdev, r, mode,
+                               cval, TW, minuend, remap);
         AMT_LAUNCH_CHECK();
         h_done = true;
     }

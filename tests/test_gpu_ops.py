@@ -69,6 +69,12 @@ def test_gaussian_wide_radius_lds_dma_paths(ctx, ops):
         assert np.array_equal(out[0], ndi.gaussian_filter(f[0], 7.0, mode=mode, cval=-1.5)), mode
     out = ops.difference_of_gaussians(d, 0.6, 16.0).numpy()
     assert np.array_equal(out[0], skops.difference_of_gaussians(u[0], 0.6, 16.0))
+    # r = 64 has instances of its own (compile-time radius, fully unrolled): float64 input, rows that end inside a tile
+    f2 = rng.random((2, 150, 448))
+    for mode in ("reflect", "constant", "nearest"):
+        out = ops.gaussian(ctx.asarray(f2), 16.0, mode=mode, cval=0.5).numpy()
+        for b in range(2):
+            assert np.array_equal(out[b], ndi.gaussian_filter(f2[b], 16.0, mode=mode, cval=0.5)), (mode, b)
 
 
 def test_dog_bit_exact(ctx, ops, golden):
