@@ -63,6 +63,8 @@ _SIGS = {
     "amt_event_destroy": (c_int, [_P, _P]),
     "amt_host_alloc": (c_int, [c_size_t, POINTER(c_void_p)]),
     "amt_host_copy": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "amt_host_minmax_int": (c_int, [c_void_p, c_int, c_int, c_size_t, c_void_p]),
+    "amt_host_narrow_i64_i32": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "amt_host_free": (c_int, [_P]),
     "amt_timer_create": (c_int, [_P, POINTER(c_void_p)]),
     "amt_timer_start": (c_int, [_P, _P]),
@@ -187,6 +189,14 @@ def hip_runtime() -> str:
     return _runtime
 
 
+# entry points that may wait (for the device, the allocator or host memory): the interpreter lock is released around them
+_BLOCKING = frozenset((
+    "amt_sync", "amt_event_sync", "amt_memcpy_h2d", "amt_memcpy_d2h", "amt_memcpy_d2d", "amt_host_alloc", "amt_host_free",
+    "amt_host_copy", "amt_host_minmax_int", "amt_host_narrow_i64_i32", "amt_ctx_create", "amt_ctx_create_on_stream",
+    "amt_ctx_destroy", "amt_malloc", "amt_free", "amt_timer_elapsed_ms",
+))
+
+
 def load_library():
     """Load libamt_hip.so and declare every prototype.  Raises HipUnavailableError if it is missing."""
     global _lib
@@ -203,12 +213,20 @@ def load_library():
         _share_hip_runtime_with_torch()
         try:
             lib = ctypes.CDLL(LIB_PATH)
+            quick = ctypes.PyDLL(LIB_PATH) if os.environ.get("AMT_GIL", "keep") == "keep" else lib
         except OSError as e:  # missing ROCm runtime etc.
             raise HipUnavailableError(f"cannot load {LIB_PATH}: {e}") from e
         for name, (res, args) in _SIGS.items():
-            fn = getattr(lib, name)  # AttributeError = header / library mismatch: fail loudly
-            fn.restype = res
-            fn.argtypes = args
+            for handle in {id(lib): lib, id(quick): quick}.values():
+                fn = getattr(handle, name)  # AttributeError = header / library mismatch: fail loudly
+                fn.restype = res
+                fn.argtypes = args
+            if name not in _BLOCKING:
+                # enqueue-only entry points (a few microseconds each) are called WITHOUT releasing the interpreter
+                # lock: a chain is ~50 such calls, and worker threads that drop and re-take the lock around each of
+                # them spend their time handing it to one another (tools/api_profile.py: four workers were no faster
+                # than one).  Calls that wait for the device or move host memory keep releasing it.
+                setattr(lib, name, getattr(quick, name))
         _lib = lib
     return _lib
 

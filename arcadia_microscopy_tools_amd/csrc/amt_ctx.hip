@@ -349,6 +349,81 @@ extern "C" int amt_host_copy(void* dst, const void* src, size_t bytes) {
     return AMT_OK;
 }
 
+// Extrema of an integer host array in ONE foreign call (the Python layer's worker threads otherwise make dozens of
+// short numpy calls per label image and queue for the interpreter lock between them).  itemsize 1 / 2 / 4 / 8.
+template <typename T>
+static void host_minmax(const T* p, size_t n, int64_t out[2]) {
+    T lo[4] = {p[0], p[0], p[0], p[0]}, hi[4] = {p[0], p[0], p[0], p[0]};
+    size_t i = 0;
+    for (; i + 4 <= n; i += 4)
+        for (int k = 0; k < 4; ++k) {
+            const T v = p[i + k];
+            lo[k] = v < lo[k] ? v : lo[k];
+            hi[k] = v > hi[k] ? v : hi[k];
+        }
+    for (; i < n; ++i) {
+        lo[0] = p[i] < lo[0] ? p[i] : lo[0];
+        hi[0] = p[i] > hi[0] ? p[i] : hi[0];
+    }
+    for (int k = 1; k < 4; ++k) {
+        lo[0] = lo[k] < lo[0] ? lo[k] : lo[0];
+        hi[0] = hi[k] > hi[0] ? hi[k] : hi[0];
+    }
+    out[0] = (int64_t)lo[0];
+    out[1] = (int64_t)hi[0];
+}
+
+extern "C" int amt_host_minmax_int(const void* src, int itemsize, int is_signed, size_t n, int64_t* out) {
+    AMT_REQUIRE(src && out && n > 0, "amt_host_minmax_int: empty input");
+    switch (itemsize * 2 + (is_signed ? 1 : 0)) {
+        case 2: host_minmax((const uint8_t*)src, n, out); break;
+        case 3: host_minmax((const int8_t*)src, n, out); break;
+        case 4: host_minmax((const uint16_t*)src, n, out); break;
+        case 5: host_minmax((const int16_t*)src, n, out); break;
+        case 8: host_minmax((const uint32_t*)src, n, out); break;
+        case 9: host_minmax((const int32_t*)src, n, out); break;
+        case 17: host_minmax((const int64_t*)src, n, out); break;
+        default: AMT_REQUIRE(false, "amt_host_minmax_int: unsupported element type (itemsize %d, signed %d)", itemsize, is_signed);
+    }
+    return AMT_OK;
+}
+
+// int64 -> int32 (label images travel as int32) with streaming stores, and the extrema of the SOURCE values in the
+// same pass when `minmax` is given.  Values are truncated like a C cast; callers check the range from the extrema.
+extern "C" int amt_host_narrow_i64_i32(int32_t* dst, const int64_t* src, size_t n, int64_t* minmax) {
+    AMT_REQUIRE((dst && src) || n == 0, "amt_host_narrow_i64_i32: null pointer");
+    int64_t lo = n ? src[0] : 0, hi = lo;
+    size_t i = 0;
+    typedef int v4si __attribute__((vector_size(16)));
+    if (((uintptr_t)dst & 15) == 0) {
+        for (; i + 4 <= n; i += 4) {
+            const int64_t a = src[i], b = src[i + 1], c = src[i + 2], d = src[i + 3];
+            if (minmax) {
+                const int64_t l1 = a < b ? a : b, l2 = c < d ? c : d, h1 = a > b ? a : b, h2 = c > d ? c : d;
+                const int64_t l = l1 < l2 ? l1 : l2, h = h1 > h2 ? h1 : h2;
+                lo = l < lo ? l : lo;
+                hi = h > hi ? h : hi;
+            }
+            const v4si v = {(int)a, (int)b, (int)c, (int)d};
+            __builtin_nontemporal_store(v, (v4si*)(dst + i));
+        }
+        __atomic_thread_fence(__ATOMIC_SEQ_CST);
+    }
+    for (; i < n; ++i) {
+        const int64_t a = src[i];
+        if (minmax) {
+            lo = a < lo ? a : lo;
+            hi = a > hi ? a : hi;
+        }
+        dst[i] = (int32_t)a;
+    }
+    if (minmax) {
+        minmax[0] = lo;
+        minmax[1] = hi;
+    }
+    return AMT_OK;
+}
+
 struct amt_timer {
     hipEvent_t start, stop;
 };

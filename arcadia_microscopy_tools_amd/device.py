@@ -65,15 +65,36 @@ def _host_copy(dst: np.ndarray, src: np.ndarray) -> None:
         f.result()
 
 
+def host_extrema(a: np.ndarray):
+    """(min, max) of a C-contiguous integer array through ONE foreign call (``amt_host_minmax_int``), or None when the
+    element type has no such path (floats, uint64, strided views): callers then use numpy."""
+    if a.dtype.kind not in "iub" or a.dtype == np.uint64 or not a.flags["C_CONTIGUOUS"] or a.size == 0:
+        return None
+    out = np.empty(2, np.int64)
+    _hip.check(_hip.load_library().amt_host_minmax_int(a.ctypes.data, a.dtype.itemsize, int(a.dtype.kind == "i"),
+                                                       a.size, out.ctypes.data), "amt_host_minmax_int")
+    return int(out[0]), int(out[1])
+
+
 def _stage_chunk(dst: np.ndarray, src: np.ndarray, stats: bool):
     """One chunk of a staged upload: convert / copy into the page-locked buffer and, on request, the chunk's extrema
-    (the chunk is still in cache: the constructor checks of a label image cost no second pass over it)."""
+    (the chunk is still in cache: the constructor checks of a label image cost no second pass over it).  The common
+    cases are one foreign call each -- a worker thread that makes many short numpy calls queues for the interpreter
+    lock between them when other worker threads do the same."""
+    lib = _hip.load_library()
+    if dst.dtype == np.int32 and src.dtype == np.int64 and dst.nbytes >= (1 << 16):
+        mm = np.empty(2, np.int64) if stats else None
+        _hip.check(lib.amt_host_narrow_i64_i32(dst.ctypes.data, src.ctypes.data, src.size,
+                                               None if mm is None else mm.ctypes.data), "amt_host_narrow_i64_i32")
+        return (mm[0], mm[1]) if stats else None
     if dst.dtype == src.dtype and dst.nbytes >= (1 << 16):
         # streaming stores (amt_host_copy): the staging block is read next by the DMA engine, not by this core
-        _hip.check(_hip.load_library().amt_host_copy(dst.ctypes.data, src.ctypes.data, dst.nbytes), "amt_host_copy")
+        _hip.check(lib.amt_host_copy(dst.ctypes.data, src.ctypes.data, dst.nbytes), "amt_host_copy")
     else:
         np.copyto(dst, src, casting="unsafe")
-    return (src.min(), src.max()) if stats else None
+    if not stats:
+        return None
+    return host_extrema(src) or (src.min(), src.max())
 
 
 def _chunks(n: int):

@@ -118,17 +118,21 @@ def _extract_outlines_cellpose(label_image):
 
 
 def _extrema(a: np.ndarray):
-    """(min, max) of a 2-D array.  Planes of a megapixel and more are reduced band by band on the host-copy threads
-    (numpy releases the GIL), each band in pieces of 256 KB whose minimum AND maximum are taken while the piece is
-    still in cache: the image crosses the memory bus once, not twice (a 2048^2 int64 label image is 33 MB, and with a
-    worker thread per context the host's memory bandwidth is what bounds the reference-level calls)."""
-    if a.size < (1 << 20) or a.shape[0] < 8:
-        return a.min(), a.max()
-    from .device import _pool4
+    """(min, max) of a 2-D array.  Planes of a megapixel and more are reduced band by band on the host-copy threads:
+    integer images with one foreign call per band (``device.host_extrema``), other element types with numpy in pieces
+    of 256 KB whose minimum AND maximum are taken while the piece is in cache.  The image crosses the memory bus once
+    (a 2048^2 int64 label image is 33 MB, and with a worker thread per context the host's memory system and the
+    interpreter lock are what bound the reference-level calls)."""
+    from .device import _pool4, host_extrema
 
+    if a.size < (1 << 20) or a.shape[0] < 8:
+        return host_extrema(a) or (a.min(), a.max())
     rows = max(1, (256 << 10) // max(1, a.shape[1] * a.itemsize))
 
     def band(b):
+        got = host_extrema(b)
+        if got is not None:
+            return got
         mn, mx = b[:1].min(), b[:1].max()
         for r in range(0, b.shape[0], rows):
             piece = b[r:r + rows]
@@ -139,6 +143,27 @@ def _extrema(a: np.ndarray):
     futs = [_pool4().submit(band, a[r:r + step]) for r in range(0, a.shape[0], step)]
     parts = [f.result() for f in futs]
     return min(p[0] for p in parts), max(p[1] for p in parts)
+
+
+def _as_one_block(planes):
+    """The (C, Y, X) array whose channels ``planes`` are, when they lie back to back in memory (the usual case:
+    ``{channel: fov[i]}`` of one acquisition); None otherwise."""
+    p0 = planes[0]
+    if len(planes) < 2 or any(p.dtype != p0.dtype or p.shape != p0.shape or not p.flags["C_CONTIGUOUS"] for p in planes):
+        return None
+    if any(p.ctypes.data != p0.ctypes.data + c * p0.nbytes for c, p in enumerate(planes)):
+        return None
+    base = p0.base
+    while base is not None and not (isinstance(base, np.ndarray) and base.flags["C_CONTIGUOUS"]
+                                    and base.ctypes.data <= p0.ctypes.data
+                                    and base.ctypes.data + base.nbytes >= planes[-1].ctypes.data + p0.nbytes):
+        base = getattr(base, "base", None)
+    if base is None or any(p.base is None for p in planes):
+        return None
+    # a view of the owner that covers exactly the planes (no copy): the owner keeps the memory alive
+    flat = base.reshape(-1).view(np.uint8)
+    o = p0.ctypes.data - base.ctypes.data
+    return flat[o:o + len(planes) * p0.nbytes].view(p0.dtype).reshape((len(planes),) + p0.shape)
 
 
 def _check_label_plane(mask_image):
@@ -322,8 +347,12 @@ class SegmentationMask:
             exact = all(p.dtype in (np.uint8, np.uint16) for p in planes)
             dt = np.uint16 if exact else np.float64
             stack = ctx.empty((len(planes),) + tuple(lab.shape[-2:]), dt)
-            for c, p in enumerate(planes):
-                ctx.asarray(p, out=stack[c])  # converted to ``dt`` on its way through the staging buffer
+            whole = _as_one_block(planes)
+            if whole is not None:  # the planes are the channels of ONE (C, Y, X) array: one staged transfer
+                ctx.asarray(whole, out=stack)
+            else:
+                for c, p in enumerate(planes):
+                    ctx.asarray(p, out=stack[c])  # converted to ``dt`` on its way through the staging buffer
             if exact and lab.size == stack.size // len(planes):
                 # morphology + intensities share the bounding-box pass and the per-label scan
                 m, it = hipops.regionprops_full(lab.reshape((1,) + tuple(lab.shape[-2:])),

@@ -95,6 +95,11 @@ int amt_host_alloc(size_t bytes, void** hptr);
 int amt_host_free(void* hptr);
 /* host memcpy with streaming stores, for filling a staging block the DMA engine reads next (thread-safe, no GPU call) */
 int amt_host_copy(void* dst, const void* src, size_t bytes);
+/* host helpers of the constructor checks and the label upload of SegmentationMask (R/masks.py:169-176: "non-negative",
+   "contains no cells"): extrema of an integer array in one call -> out[2] = {min, max}; int64 -> int32 narrowing into a
+   staging block with the source extrema from the same pass (minmax may be NULL) */
+int amt_host_minmax_int(const void* src, int itemsize, int is_signed, size_t n, int64_t* out);
+int amt_host_narrow_i64_i32(int32_t* dst, const int64_t* src, size_t n, int64_t* minmax);
 /* HIP-event timing on the context's stream (bench.py roofline: kernel time measured live) */
 int amt_timer_create(amt_ctx* ctx, void** timer);
 int amt_timer_start(amt_ctx* ctx, void* timer);
