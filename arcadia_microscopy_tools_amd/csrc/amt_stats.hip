@@ -1157,15 +1157,21 @@ __global__ void __launch_bounds__(1024) pq_sample_kernel(const double* __restric
 // the bracket's list with ONE global atomic per flush: a per-wave global atomic on the list counter would serialise
 // ~50,000 atomics per plane on one address.  (Measured alternative: a stage per wave with the fill level in a register
 // and no block barriers ran 1.7x slower, 803 vs 476 us per 32 planes.)
-constexpr int PQ_STAGE = 2048;  // >= 2 x the 1024 keys a block can add between two flush checks
+constexpr int PQ_STAGE = 2048;  // keys of one bracket a block stages in LDS (it meets ~230 on average; the rest overflow to the list)
 constexpr int PQ_GROUP = 4;     // brackets per classify launch (LDS: PQ_GROUP x PQ_STAGE keys)
+// NQ: brackets of this launch (1 .. PQ_GROUP), unrolled exactly, so that one or two brackets spill nothing.  VEC2: the plane
+// is read in 16-byte pairs (even n, aligned base).  A thread has PQ_VPT samples of one iteration in flight and the next
+// iteration's PQ_VPT requested: with four samples per thread a wave waited a full memory round trip per 2 KB (5 us under
+// load, 40 us per block, 2.1 TB/s -- rocprofv3 counters: 27 vector instructions per 64 samples, waves idle 70 %).
+constexpr int PQ_VPT = 8;
+template <int NQ, bool VEC2>
 __global__ void __launch_bounds__(256) pq_classify_kernel(const double* __restrict__ in, pq_bracket* __restrict__ br,
                                                           int nq_all, int j0, unsigned long long* __restrict__ lists,
-                                                          size_t cap, size_t n) {
+                                                          size_t cap, size_t n, uint4* __restrict__ partial) {
     // brackets j0 .. j0 + nq - 1 of the plane's nq_all
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     unsigned long long* stage = reinterpret_cast<unsigned long long*>(smem_raw);  // nq x PQ_STAGE keys
-    const int nq = min(PQ_GROUP, nq_all - j0);
+    constexpr int nq = NQ;
     br += j0;
     lists += (size_t)j0 * cap;
     __shared__ pq_bracket sb[8];
@@ -1178,87 +1184,145 @@ __global__ void __launch_bounds__(256) pq_classify_kernel(const double* __restri
     __syncthreads();
     const double* src = in + (size_t)plane * n;
     const int lane = threadIdx.x & 63;
-    unsigned c_below[8], c_eqa[8], c_eqb[8];
+    // The comparisons are the only per-lane work: a compare writes a 64-lane mask, and counting, combining and
+    // ranking masks is scalar arithmetic that the vector unit never sees.  (The first version kept per-lane counters
+    // and one LDS atomic per value: ~250 vector instructions per 256 samples and bracket, and the pass was bound by
+    // instruction issue at 2.3 TB/s.)  Brackets live in scalar registers; an open end is a sentinel + a uniform flag.
+    unsigned long long A[NQ], Bk[NQ];
+    bool HA[NQ], HB[NQ], SAME[NQ];
+    unsigned w_below[NQ], w_eqa[NQ], w_eqb[NQ];  // wave-uniform counts
 #pragma unroll
-    for (int j = 0; j < 8; ++j) c_below[j] = c_eqa[j] = c_eqb[j] = 0;
-    const size_t per_iter = (size_t)gridDim.x * 1024;
-    const size_t iters = (n + per_iter - 1) / per_iter;  // the same for every thread: the flush needs block barriers
-    auto flush = [&](bool force) {
+    for (int j = 0; j < NQ; ++j) {
+        A[j] = sb[j].a;
+        Bk[j] = sb[j].b;
+        HA[j] = sb[j].has_a != 0;
+        HB[j] = sb[j].has_b != 0;
+        SAME[j] = HA[j] && A[j] == Bk[j];
+        w_below[j] = w_eqa[j] = w_eqb[j] = 0;
+    }
+    const size_t per_iter = (size_t)gridDim.x * 256 * PQ_VPT;
+    const size_t iters = (n + per_iter - 1) / per_iter;
+    // No barrier inside the walk: the waves of a block run freely and their loads stay in flight (a flush check per
+    // 1,024 samples cost two block barriers each and held the pass at 2.3 TB/s).  The stage is emptied once, at the end.
+    auto flush = [&]() {
         __syncthreads();
         for (int j = 0; j < nq; ++j) {
-            const unsigned fill = s_fill[j];  // uniform
-            if (fill == 0 || (!force && fill <= PQ_STAGE - 1024)) continue;
+            const unsigned fill = min(s_fill[j], (unsigned)PQ_STAGE);  // uniform; reservations beyond the stage went to the list
+            if (fill == 0) continue;
             if (threadIdx.x == 0) s_base[j] = atomicAdd(&br[(size_t)plane * nq_all + j].n_in, fill);
             __syncthreads();
             const size_t base = s_base[j];
             for (unsigned i = threadIdx.x; i < fill; i += 256)
                 if (base + i < cap) lists[((size_t)plane * nq_all + j) * cap + base + i] = stage[(size_t)j * PQ_STAGE + i];
             __syncthreads();
-            if (threadIdx.x == 0) s_fill[j] = 0;
         }
-        __syncthreads();
     };
-    for (size_t it = 0; it < iters; ++it) {
-        const size_t i0 = it * per_iter + (size_t)blockIdx.x * 1024 + threadIdx.x;
-        double raw4[4];
-        bool ok4[4];
+    // the samples of iteration it + 1 are requested before those of iteration it are processed; sample u of thread t
+    // is element u * 256 + t of the block's run (scalar) or pair (u / 2) * 256 + t, half u & 1 (VEC2)
+    double nxt[PQ_VPT];
+    auto index_of = [&](size_t it, int u) -> size_t {
+        const size_t run = it * per_iter + (size_t)blockIdx.x * (256 * PQ_VPT);
+        return VEC2 ? run + (size_t)(u >> 1) * 512 + 2 * threadIdx.x + (u & 1) : run + (size_t)u * 256 + threadIdx.x;
+    };
+    auto request = [&](size_t it) {
+        if constexpr (VEC2) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {  // unconditional loads from clamped indices, all in flight
-            const size_t i = i0 + (size_t)u * 256;
-            ok4[u] = i < n;
-            raw4[u] = src[ok4[u] ? i : n - 1];
+            for (int p2 = 0; p2 < PQ_VPT / 2; ++p2) {  // unconditional loads from clamped (even) indices, all in flight
+                const size_t i = index_of(it, 2 * p2);
+                const double2 v = *reinterpret_cast<const double2*>(src + (i + 1 < n ? i : n - 2));
+                nxt[2 * p2] = v.x;
+                nxt[2 * p2 + 1] = v.y;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < PQ_VPT; ++u) {
+                const size_t i = index_of(it, u);
+                nxt[u] = src[i < n ? i : n - 1];
+            }
         }
+    };
+    request(0);
+    const unsigned long long lanes_below = (1ull << lane) - 1ull;
+    for (size_t it = 0; it < iters; ++it) {
+        unsigned long long k4[PQ_VPT], okm[PQ_VPT];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const unsigned long long k = amt_f64_key(raw4[u]);
+        for (int u = 0; u < PQ_VPT; ++u) {
+            okm[u] = __ballot(index_of(it, u) < n);
+            k4[u] = amt_f64_key(nxt[u]);
+        }
+        if (it + 1 < iters) request(it + 1);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                if (j >= nq) break;
-                const unsigned long long a = sb[j].a, b = sb[j].b;
-                const bool ha = sb[j].has_a, hb = sb[j].has_b;
-                c_below[j] += ok4[u] && ha && k < a;
-                c_eqa[j] += ok4[u] && ha && k == a;
-                c_eqb[j] += ok4[u] && hb && k == b && !(ha && a == b);
-                const bool inside = ok4[u] && (!ha || k > a) && (!hb || k < b);
-                const unsigned long long m = __ballot(inside);
-                if (m) {
-                    unsigned base = 0;
-                    const int leader = __ffsll((long long)m) - 1;
-                    if (lane == leader) base = atomicAdd(&s_fill[j], (unsigned)__popcll(m));
-                    base = __shfl(base, leader);
-                    // a block adds at most 1024 keys per iteration and flushes above PQ_STAGE - 1024: the stage cannot
-                    // overflow, the bound is only a guard
-                    const unsigned pos = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
-                    if (inside && pos < (unsigned)PQ_STAGE) stage[(size_t)j * PQ_STAGE + pos] = k;
+        for (int j = 0; j < NQ; ++j) {
+            unsigned long long ins[PQ_VPT];
+            unsigned total = 0;
+#pragma unroll
+            for (int u = 0; u < PQ_VPT; ++u) {
+                const unsigned long long k = k4[u];
+                const unsigned long long lt_a = __ballot(k < A[j]) & okm[u], eq_a = __ballot(k == A[j]) & okm[u];
+                const unsigned long long lt_b = __ballot(k < Bk[j]) & okm[u], eq_b = __ballot(k == Bk[j]) & okm[u];
+                const unsigned long long gt_a = okm[u] & ~lt_a & ~eq_a;
+                ins[u] = (HA[j] ? gt_a : okm[u]) & (HB[j] ? lt_b : okm[u]);
+                w_below[j] += HA[j] ? (unsigned)__popcll(lt_a) : 0u;
+                w_eqa[j] += HA[j] ? (unsigned)__popcll(eq_a) : 0u;
+                w_eqb[j] += (HB[j] && !SAME[j]) ? (unsigned)__popcll(eq_b) : 0u;
+                total += (unsigned)__popcll(ins[u]);
+            }
+            if (total) {  // uniform: ONE stage reservation per wave, bracket and PQ_VPT values
+                unsigned base = 0;
+                if (lane == 0) base = atomicAdd(&s_fill[j], total);
+                base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+                if (base + total <= (unsigned)PQ_STAGE) {
+#pragma unroll
+                    for (int u = 0; u < PQ_VPT; ++u) {
+                        const unsigned pos = base + (unsigned)__popcll(ins[u] & lanes_below);
+                        if ((ins[u] >> lane) & 1ull) stage[(size_t)j * PQ_STAGE + pos] = k4[u];
+                        base += (unsigned)__popcll(ins[u]);
+                    }
+                } else {
+                    // the stage is full (a block meets ~230 keys of a bracket on average; this is a plane whose values
+                    // are sorted in space): what still fits goes to the stage, the rest straight to the list
+                    unsigned long long ov[PQ_VPT];
+                    unsigned nover = 0, b2 = base;
+#pragma unroll
+                    for (int u = 0; u < PQ_VPT; ++u) {
+                        const unsigned pos = b2 + (unsigned)__popcll(ins[u] & lanes_below);
+                        const bool mine = (ins[u] >> lane) & 1ull;
+                        if (mine && pos < (unsigned)PQ_STAGE) stage[(size_t)j * PQ_STAGE + pos] = k4[u];
+                        ov[u] = __ballot(mine && pos >= (unsigned)PQ_STAGE);
+                        nover += (unsigned)__popcll(ov[u]);
+                        b2 += (unsigned)__popcll(ins[u]);
+                    }
+                    unsigned gb = 0;
+                    if (lane == 0) gb = atomicAdd(&br[(size_t)plane * nq_all + j].n_in, nover);
+                    gb = (unsigned)__builtin_amdgcn_readfirstlane((int)gb);
+#pragma unroll
+                    for (int u = 0; u < PQ_VPT; ++u) {
+                        const size_t pos = (size_t)gb + (unsigned)__popcll(ov[u] & lanes_below);
+                        if (((ov[u] >> lane) & 1ull) && pos < cap)
+                            lists[((size_t)plane * nq_all + j) * cap + pos] = k4[u];
+                        gb += (unsigned)__popcll(ov[u]);
+                    }
                 }
             }
         }
-        flush(false);
     }
-    flush(true);
+    flush();
+    if (lane == 0) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        if (j >= nq) break;
-        unsigned v0 = c_below[j], v1 = c_eqa[j], v2 = c_eqb[j];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            v0 += __shfl_xor(v0, o);
-            v1 += __shfl_xor(v1, o);
-            v2 += __shfl_xor(v2, o);
-        }
-        if (lane == 0) {
-            atomicAdd(&sc[j][0], v0);
-            atomicAdd(&sc[j][1], v1);
-            atomicAdd(&sc[j][2], v2);
+        for (int j = 0; j < NQ; ++j) {
+            if (w_below[j]) atomicAdd(&sc[j][0], w_below[j]);
+            if (w_eqa[j]) atomicAdd(&sc[j][1], w_eqa[j]);
+            if (w_eqb[j]) atomicAdd(&sc[j][2], w_eqb[j]);
         }
     }
     __syncthreads();
-    if (threadIdx.x < nq) {
-        pq_bracket* g = &br[(size_t)plane * nq_all + threadIdx.x];
-        if (sc[threadIdx.x][0]) atomicAdd(&g->below, sc[threadIdx.x][0]);
-        if (sc[threadIdx.x][1]) atomicAdd(&g->eq_a, sc[threadIdx.x][1]);
-        if (sc[threadIdx.x][2]) atomicAdd(&g->eq_b, sc[threadIdx.x][2]);
-    }
+    // The block's counts go to a slot of its own and pq_resolve adds the slots up.  Atomics of every block of a plane
+    // on the bracket's one cache line cost ~0.4 us EACH, one after the other (measured: 128 / 512 / 2,048 blocks per
+    // plane -> 0.55 / 0.8 / 3.3 ms per 32 planes): that line, not the 1 GB read, was what bounded this pass.  The list
+    // cursor (one returning atomic per block and bracket) is all that still meets there.
+    if (threadIdx.x < nq)
+        partial[((size_t)plane * nq_all + j0 + threadIdx.x) * gridDim.x + blockIdx.x] =
+            make_uint4(sc[threadIdx.x][0], sc[threadIdx.x][1], sc[threadIdx.x][2], 0u);
 }
 
 // k-th smallest (0-based) of `cnt` keys produced by `key_at(i)`, all of which share the bits above byte `first_pass`;
@@ -1319,9 +1383,13 @@ __device__ void pq_list_select(const unsigned long long* __restrict__ lst, size_
         return pq_block_select([&](size_t i) { return lst[i]; }, c, r, prefix, first, lh, &sh64[0], &sh64[1]);
     };
     if (c <= (size_t)PQ_BUF) {  // sort the list outright
-        for (int i = t; i < PQ_BUF; i += 1024) B[i] = (size_t)i < c ? lst[i] : ~0ull;
+        const int cap2 = c <= 2048 ? 2048 : c <= 4096 ? 4096 : c <= 8192 ? 8192 : PQ_BUF;
+        for (int i = t; i < cap2; i += 1024) B[i] = (size_t)i < c ? lst[i] : ~0ull;
         __syncthreads();
-        pq_block_sort<PQ_BUF>(B);
+        if (cap2 == 2048) pq_block_sort<2048>(B);
+        else if (cap2 == 4096) pq_block_sort<4096>(B);
+        else if (cap2 == 8192) pq_block_sort<8192>(B);
+        else pq_block_sort<PQ_BUF>(B);
         out2[0] = B[r0];
         out2[1] = two ? B[r0 + 1] : B[r0];
         __syncthreads();
@@ -1344,23 +1412,35 @@ __device__ void pq_list_select(const unsigned long long* __restrict__ lst, size_
     __syncthreads();
     const int lane = t & 63;
     unsigned cb = 0, ca = 0, ce = 0;
-    const size_t iters = (c + 1023) / 1024;
+    // one block walks the whole list (a few per cent of the plane): eight entries per thread in flight, or the walk is
+    // a chain of ~100 dependent memory round trips
+    constexpr int LU = 8;
+    const size_t iters = (c + 1024 * LU - 1) / (1024 * LU);
     for (size_t it = 0; it < iters; ++it) {
-        const size_t i = it * 1024 + t;
-        const bool ok = i < c;
-        const unsigned long long k = lst[ok ? i : c - 1];
-        cb += ok && ha && k < a2;
-        ca += ok && ha && k == a2;
-        ce += ok && hb && k == b2 && !(ha && a2 == b2);
-        const bool inside = ok && (!ha || k > a2) && (!hb || k < b2);
-        const unsigned long long m = __ballot(inside);
-        if (m) {
-            unsigned base = 0;
-            const int leader = __ffsll((long long)m) - 1;
-            if (lane == leader) base = atomicAdd(&sh32[3], (unsigned)__popcll(m));
-            base = __shfl(base, leader);
-            const unsigned pos = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
-            if (inside && pos < (unsigned)PQ_BUF) B[pos] = k;
+        unsigned long long k8[LU];
+#pragma unroll
+        for (int u = 0; u < LU; ++u) {
+            const size_t i = (it * LU + u) * 1024 + t;
+            k8[u] = lst[i < c ? i : c - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < LU; ++u) {
+            const size_t i = (it * LU + u) * 1024 + t;
+            const bool ok = i < c;
+            const unsigned long long k = k8[u];
+            cb += ok && ha && k < a2;
+            ca += ok && ha && k == a2;
+            ce += ok && hb && k == b2 && !(ha && a2 == b2);
+            const bool inside = ok && (!ha || k > a2) && (!hb || k < b2);
+            const unsigned long long m = __ballot(inside);
+            if (m) {
+                unsigned base = 0;
+                const int leader = __ffsll((long long)m) - 1;
+                if (lane == leader) base = atomicAdd(&sh32[3], (unsigned)__popcll(m));
+                base = __shfl(base, leader);
+                const unsigned pos = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+                if (inside && pos < (unsigned)PQ_BUF) B[pos] = k;
+            }
         }
     }
 #pragma unroll
@@ -1378,11 +1458,15 @@ __device__ void pq_list_select(const unsigned long long* __restrict__ lst, size_
     const unsigned long long e0 = sh32[0], e1 = e0 + sh32[1], fill = sh32[3], e2 = e1 + fill, e3 = e2 + sh32[2];
     __syncthreads();
     const bool sortable = fill <= (unsigned long long)PQ_BUF;
-    if (sortable) {
-        for (int i = t; i < PQ_BUF; i += 1024)
+    if (sortable) {  // sort the smallest power of two that holds the keys (uniform choice)
+        const int cap2 = fill <= 2048 ? 2048 : fill <= 4096 ? 4096 : fill <= 8192 ? 8192 : PQ_BUF;
+        for (int i = t; i < cap2; i += 1024)
             if ((unsigned long long)i >= fill) B[i] = ~0ull;
         __syncthreads();
-        pq_block_sort<PQ_BUF>(B);
+        if (cap2 == 2048) pq_block_sort<2048>(B);
+        else if (cap2 == 4096) pq_block_sort<4096>(B);
+        else if (cap2 == 8192) pq_block_sort<8192>(B);
+        else pq_block_sort<PQ_BUF>(B);
     }
     for (int w = 0; w < 2; ++w) {
         const unsigned long long r = r0 + (unsigned long long)(w && two ? 1 : 0);
@@ -1399,14 +1483,40 @@ __device__ void pq_list_select(const unsigned long long* __restrict__ lst, size_
 __global__ void __launch_bounds__(1024) pq_resolve_kernel(const double* __restrict__ in, const rank_req* __restrict__ reqs,
                                                           const pq_bracket* __restrict__ br, int nq,
                                                           const unsigned long long* __restrict__ lists, size_t cap,
-                                                          sel_state* __restrict__ res, size_t n) {
+                                                          sel_state* __restrict__ res, size_t n,
+                                                          const uint4* __restrict__ partial, int nparts) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     unsigned long long* B = reinterpret_cast<unsigned long long*>(smem_raw);  // PQ_BUF keys
     __shared__ uint32_t lh[256];
     __shared__ unsigned long long sh64[2];
     __shared__ unsigned sh32[4];
     const int j = blockIdx.x, plane = blockIdx.y;
-    const pq_bracket b = br[(size_t)plane * nq + j];
+    pq_bracket b = br[(size_t)plane * nq + j];
+    {  // the per-block counts of the classify pass, added up (see there)
+        __shared__ unsigned s_sum[3];
+        if (threadIdx.x < 3) s_sum[threadIdx.x] = 0;
+        __syncthreads();
+        unsigned c0 = 0, c1 = 0, c2 = 0;
+        for (int i = threadIdx.x; i < nparts; i += 1024) {
+            const uint4 p = partial[((size_t)plane * nq + j) * nparts + i];
+            c0 += p.x, c1 += p.y, c2 += p.z;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            c0 += __shfl_xor(c0, o);
+            c1 += __shfl_xor(c1, o);
+            c2 += __shfl_xor(c2, o);
+        }
+        if ((threadIdx.x & 63) == 0 && (c0 | c1 | c2)) {
+            atomicAdd(&s_sum[0], c0);
+            atomicAdd(&s_sum[1], c1);
+            atomicAdd(&s_sum[2], c2);
+        }
+        __syncthreads();
+        b.below = s_sum[0];
+        b.eq_a = s_sum[1];
+        b.eq_b = s_sum[2];
+    }
     const unsigned long long* lst = lists + ((size_t)plane * nq + j) * cap;
     const double* src = in + (size_t)plane * n;
     const unsigned long long rlo = (unsigned long long)reqs[j].lo, rhi = (unsigned long long)reqs[j].hi;
@@ -1466,23 +1576,44 @@ extern "C" int amt_percentile_f64(amt_ctx* ctx, const double* in, const double* 
     if (n < PQ_MIN_N) return percentile_f64_radix(ctx, in, reqs, nq, out_dev, nplanes, n);
     const size_t cap = n / 8 + 4096;
     const size_t nbr = (size_t)nplanes * nq;
+    // blocks per plane of the classify pass: enough of them to fill the chip over all planes, few enough that their list
+    // cursors do not queue on the bracket's cache line
+    static const int pq_grid_env = getenv("AMT_PQ_GRID") ? atoi(getenv("AMT_PQ_GRID")) : 0;  // A/B
+    int want = pq_grid_env > 0 ? pq_grid_env : 4096 / nplanes;
+    want = want < 64 ? 64 : (want > 256 && pq_grid_env <= 0 ? 256 : want);
+    const unsigned gparts = amt_grid_for(n, 256 * PQ_VPT, (unsigned)want);
     AMT_TRY(amt_arena_begin(ctx, amt_align(sizeof(rank_req) * 8) + amt_align(sizeof(pq_bracket) * nbr) +
-                                     amt_align(nbr * cap * 8) + amt_align(sizeof(sel_state) * 2 * nbr)));
+                                     amt_align(nbr * cap * 8) + amt_align(sizeof(sel_state) * 2 * nbr) +
+                                     amt_align(sizeof(uint4) * nbr * gparts)));
     rank_req* rd = arena_take_t<rank_req>(ctx, 8);
     pq_bracket* br = arena_take_t<pq_bracket>(ctx, nbr);
     unsigned long long* lists = arena_take_t<unsigned long long>(ctx, nbr * cap);
     sel_state* res = arena_take_t<sel_state>(ctx, 2 * nbr);
+    uint4* partial = arena_take_t<uint4>(ctx, nbr * gparts);
     AMT_TRY(amt_param_upload(ctx, rd, reqs, sizeof(rank_req) * nq));
     hipLaunchKernelGGL(pq_sample_kernel, dim3(nplanes), dim3(1024), (size_t)PQ_M * 8, ctx->stream, in, rd, nq, br, n);
     AMT_LAUNCH_CHECK();
     for (int j0 = 0; j0 < nq; j0 += PQ_GROUP) {  // one full read per group of four percentiles
         const int nj = nq - j0 < PQ_GROUP ? nq - j0 : PQ_GROUP;
-        hipLaunchKernelGGL(pq_classify_kernel, dim3(amt_grid_for(n, 256 * 16, 512), nplanes), dim3(256),
-                           (size_t)nj * PQ_STAGE * 8, ctx->stream, in, br, nq, j0, lists, cap, n);
+        const dim3 gc(gparts, nplanes);
+        const size_t sm = (size_t)nj * PQ_STAGE * 8;
+        const bool vec2 = n % 2 == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0;
+#define AMT_PQ_CLASSIFY(NQ_)                                                                                          \
+    if (vec2)                                                                                                         \
+        hipLaunchKernelGGL((pq_classify_kernel<NQ_, true>), gc, dim3(256), sm, ctx->stream, in, br, nq, j0, lists, cap, n, partial); \
+    else                                                                                                              \
+        hipLaunchKernelGGL((pq_classify_kernel<NQ_, false>), gc, dim3(256), sm, ctx->stream, in, br, nq, j0, lists, cap, n, partial);
+        switch (nj) {
+            case 1: AMT_PQ_CLASSIFY(1) break;
+            case 2: AMT_PQ_CLASSIFY(2) break;
+            case 3: AMT_PQ_CLASSIFY(3) break;
+            default: AMT_PQ_CLASSIFY(4) break;
+        }
+#undef AMT_PQ_CLASSIFY
         AMT_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(pq_resolve_kernel, dim3(nq, nplanes), dim3(1024), (size_t)PQ_BUF * 8, ctx->stream, in, rd, br, nq, lists,
-                       cap, res, n);
+                       cap, res, n, partial, (int)gparts);
     AMT_LAUNCH_CHECK();
     hipLaunchKernelGGL(sel_finish_kernel, dim3((nplanes * nq + 63) / 64), dim3(64), 0, ctx->stream, res, rd, nq, nplanes,
                        out_dev);

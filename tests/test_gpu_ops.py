@@ -188,6 +188,25 @@ def test_percentile_f64_sampled_path(ctx, ops):
     # one big plane at the benchmark size, heavy ties included
     big = np.clip(rng.normal(-0.5, 1.0, (2048, 2048)), 0, None)
     assert np.array_equal(ops.percentile(ctx.asarray(big), (1, 99)).numpy()[0], np.percentile(big, (1, 99)))
+    # an odd number of samples (scalar loads instead of 16-byte pairs), planes that start at odd element offsets
+    odd = rng.normal(0.0, 1.0, (3, 257, 257))
+    got = ops.percentile(ctx.asarray(odd), (1, 50, 99)).numpy()
+    for b in range(3):
+        assert np.array_equal(got[b], np.percentile(odd[b], (1, 50, 99))), b
+    # values sorted in space: whole 1,024-sample runs of a block fall inside one bracket, its LDS stage fills up and the
+    # rest of its keys go straight to the list (a sorted megapixel; a ramp repeated with the period of the block stride,
+    # so that EVERY run of some blocks lies inside the bracket; the same descending)
+    ramp = np.sort(rng.normal(0.0, 1.0, 1 << 18))
+    srt = np.stack([
+        np.sort(rng.random(1 << 20)).reshape(1024, 1024),
+        np.tile(ramp, 4).reshape(1024, 1024),
+        np.tile(ramp[::-1], 4).reshape(1024, 1024) * 3.0 - 1.0,
+    ])
+    ds = ctx.asarray(srt)
+    for q in ((90,), (1, 99), (0.5, 25, 50, 99.9), (10, 20, 30, 40, 60)):
+        got = ops.percentile(ds, q).numpy()
+        for b in range(srt.shape[0]):
+            assert np.array_equal(got[b], np.atleast_1d(np.percentile(srt[b], q))), (b, q)
 
 
 def test_binary_morphology(ctx, ops, golden):
