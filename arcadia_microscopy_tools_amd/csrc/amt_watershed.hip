@@ -1269,8 +1269,9 @@ __global__ void __launch_bounds__(64) ws_global_kernel(const void* __restrict__ 
     auto st = [&](int i, const gh_elem& e) {
         if (i < GH_LDS_N) sh[i] = e; else gh[i] = e;
     };
+    // integer relief: the 31-bit code and the age are ONE 64-bit key (code << 32 | age), "smaller" is one compare
     auto less = [](unsigned long long ka, unsigned aa, unsigned long long kb, unsigned ab) -> bool {
-        return ka < kb || (ka == kb && aa < ab);
+        return USE_D2 ? ka < kb : (ka < kb || (ka == kb && aa < ab));
     };
     auto rl64 = [](unsigned long long v, int l) -> unsigned long long {
         const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l);
@@ -1324,11 +1325,21 @@ __global__ void __launch_bounds__(64) ws_global_kernel(const void* __restrict__ 
         unsigned long long mk = __ballot(v != 0);
         if (!mk) continue;
         unsigned long long kv = 0;
-        if (v != 0) kv = USE_D2 ? key_of_d2(d2[i]) : key_of_f64(rel[i]);
+        if (v != 0) kv = USE_D2 ? key_of_d2(d2[i]) << 32 : key_of_f64(rel[i]);
+        // heap entries carry the pixel as (y << 16 | x): the flood needs both coordinates of every popped pixel, and a
+        // division per pop is ~40 dependent instructions of a wave that runs alone
+        const size_t iy = i0 / (size_t)W;
+        int ly = (int)iy, lx = (int)(i0 - iy * (size_t)W) + lane;
+        while (lx >= W) {
+            lx -= W;
+            ++ly;
+        }
+        const unsigned pk = ((unsigned)ly << 16) | (unsigned)lx;
         while (mk) {
             const int b = __ffsll((long long)mk) - 1;
             mk &= mk - 1;
-            push(rl64(kv, b), 0u, (unsigned)(i0 + b));  // a wave's loads see its own earlier stores: no explicit wait
+            // a wave's loads see its own earlier stores: no explicit wait
+            push(rl64(kv, b), 0u, (unsigned)__builtin_amdgcn_readlane((int)pk, b));
         }
     }
     const int nnb = conn == 1 ? 4 : 8;
@@ -1347,14 +1358,23 @@ __global__ void __launch_bounds__(64) ws_global_kernel(const void* __restrict__ 
     const int lv = 31 - __clz(r + 1);
     const int o = r + 1 - (1 << lv);
     unsigned age = 0;
+#ifdef WS_STATS
+    unsigned long long g_pop = 0, g_push = 0, g_rl = 0, g_rg = 0, g_npush = 0, g_npop = 0, g_nr = 0;
+    const unsigned long long g_t0 = __builtin_readcyclecounter();
+#define GCLK() __builtin_readcyclecounter()
+#endif
     while (items > 0) {
+#ifdef WS_STATS
+        const unsigned long long g_a = GCLK();
+#endif
         const gh_elem top = sh[0];
-        const int p = (int)top.idx;
-        const int py = p / W, px = p - py * W;
+        const int py = (int)(top.idx >> 16), px = (int)(top.idx & 0xffffu);
+        const int p = py * W + px;
         // neighbour data, requested now, consumed after the sift-down
         const int qy = py + dy, qx = px + dx;
         const bool inside = lane < nnb && qy >= 0 && qy < H && qx >= 0 && qx < W;
         const int q = inside ? qy * W + qx : p;
+        const unsigned qpk = ((unsigned)qy << 16) | (unsigned)qx;
         const uint8_t qm = mask[q];
         const int qo = out[q];
         unsigned long long qk = 0;
@@ -1368,59 +1388,81 @@ __global__ void __launch_bounds__(64) ws_global_kernel(const void* __restrict__ 
             tail_valid = false;
             int pos = 0;
             while (true) {
+#ifdef WS_STATS
+                const unsigned long long g_r0 = GCLK();
+                const bool g_glob = (((pos + 1) << 5) - 1) >= GH_LDS_N;
+#endif
                 // the 62 nodes of the five levels under pos
-                const long long ab = (((long long)pos + 1) << lv) - 1 + o;
-                const bool valid = lane < 62 && ab < (long long)items;
+                const int ab = ((pos + 1) << lv) - 1 + o;  // slots stay far below 2^31 (a plane has < 2^26 pixels)
+                const bool valid = lane < 62 && ab < items;
                 gh_elem e;
                 e.key = INF;
                 e.age = 0;
                 e.idx = 0;
-                if (valid) e = ld((int)ab);
+                if (valid) e = ld(ab);
+                // Which child every node of the subtree prefers, and which nodes are smaller than `last`, for all 62 nodes
+                // AT ONCE (two ballots); the walk itself is then bit arithmetic on the two masks.  (Walking with cross-lane
+                // reads cost ~30 dependent vector instructions per level, 17 levels per pop: most of the 3.7 us per pixel.)
+                // Lane L holds relative node L + 1, whose children sit in lanes 2 L + 2 and 2 L + 3; lane 63 stands in for
+                // the subtree's root (children: lanes 0 and 1).  A missing node carries the key INF: never preferred, never
+                // smaller than `last`.
+                const int cl = lane == 63 ? 0 : 2 * lane + 2;
+                const bool has_kids = lane == 63 || lane < 30;
+                const int cls = has_kids ? cl : 0;
+                const unsigned kl_lo = (unsigned)__shfl((int)(unsigned)e.key, cls), kl_hi = (unsigned)__shfl((int)(unsigned)(e.key >> 32), cls);
+                const unsigned kr_lo = (unsigned)__shfl((int)(unsigned)e.key, cls + 1), kr_hi = (unsigned)__shfl((int)(unsigned)(e.key >> 32), cls + 1);
+                const unsigned al = (unsigned)__shfl((int)e.age, cls), ar = (unsigned)__shfl((int)e.age, cls + 1);
+                const unsigned long long kl = ((unsigned long long)kl_hi << 32) | kl_lo, kr = ((unsigned long long)kr_hi << 32) | kr_lo;
+                const unsigned long long RM = __ballot(has_kids && less(kr, ar, kl, al));  // right child strictly smaller
+                const unsigned long long LT = __ballot(lane < 62 && less(e.key, e.age, last.key, last.age));
                 int cur = 0;                 // relative index of the node `last` would sit in (0 = pos itself)
                 unsigned long long path = 0; // lanes whose element moves up to its parent
                 bool placed = false;
 #pragma unroll
                 for (int s5 = 0; s5 < 5; ++s5) {
-                    const int l = 2 * cur + 1;  // relative index of the left child; its lane is l - 1
-                    const unsigned long long kl = rl64(e.key, l - 1), kr = rl64(e.key, l);
-                    if (kl == INF) {
-                        placed = true;  // no child inside the heap
+                    const int rbit = (int)((RM >> (cur == 0 ? 63 : cur - 1)) & 1ull);
+                    const int c = 2 * cur + 1 + rbit;  // the preferred child (relative index; its lane is c - 1)
+                    if (!((LT >> (c - 1)) & 1ull)) {
+                        placed = true;  // no child, or none smaller than `last`
                         break;
                     }
-                    const unsigned al = (unsigned)__builtin_amdgcn_readlane((int)e.age, l - 1);
-                    const unsigned ar = (unsigned)__builtin_amdgcn_readlane((int)e.age, l);
-                    const bool right = kr != INF && less(kr, ar, kl, al);
-                    const unsigned long long kc = right ? kr : kl;
-                    const unsigned ac = right ? ar : al;
-                    if (!less(kc, ac, last.key, last.age)) {
-                        placed = true;
-                        break;
-                    }
-                    cur = right ? l + 1 : l;
+                    cur = c;
                     path |= 1ull << (cur - 1);
                 }
                 // lanes on the path hand their element to the parent slot
                 if ((path >> lane) & 1ull) {
                     const int prel = (r - 1) >> 1;  // parent's relative index
-                    long long pab = pos;
+                    int pab = pos;
                     if (prel > 0) {
                         const int plv = 31 - __clz(prel + 1);
-                        pab = (((long long)pos + 1) << plv) - 1 + (prel + 1 - (1 << plv));
+                        pab = ((pos + 1) << plv) - 1 + (prel + 1 - (1 << plv));
                     }
-                    st((int)pab, e);
+                    st(pab, e);
                 }
-                long long cab = pos;
+                int cab = pos;
                 if (cur > 0) {
                     const int clv = 31 - __clz(cur + 1);
-                    cab = (((long long)pos + 1) << clv) - 1 + (cur + 1 - (1 << clv));
+                    cab = ((pos + 1) << clv) - 1 + (cur + 1 - (1 << clv));
                 }
+#ifdef WS_STATS
+                {
+                    const unsigned long long d = GCLK() - g_r0;
+                    if (g_glob) g_rg += d; else g_rl += d;
+                    ++g_nr;
+                }
+#endif
                 if (placed) {
-                    if (lane == 0) st((int)cab, last);
+                    if (lane == 0) st(cab, last);
                     break;
                 }
-                pos = (int)cab;
+                pos = cab;
             }
         }
+#ifdef WS_STATS
+        g_pop += GCLK() - g_a;
+        ++g_npop;
+        const unsigned long long g_b = GCLK();
+#endif
         // ---- spread: unlabelled masked neighbours take the label at push time, in neighbour order ----
         unsigned long long claim = __ballot(inside && qm != 0 && qo == 0);
         while (claim) {
@@ -1429,9 +1471,22 @@ __global__ void __launch_bounds__(64) ws_global_kernel(const void* __restrict__ 
             const int qq = __builtin_amdgcn_readlane(q, k);
             if (lane == 0) out[qq] = lab;
             ++age;
-            push(rl64(qk, k), age, (unsigned)qq);
+            push(USE_D2 ? (rl64(qk, k) << 32) | age : rl64(qk, k), age, (unsigned)__builtin_amdgcn_readlane((int)qpk, k));
+#ifdef WS_STATS
+            ++g_npush;
+#endif
         }
+#ifdef WS_STATS
+        g_push += GCLK() - g_b;
+#endif
     }
+#ifdef WS_STATS
+    if (lane == 0 && plane == 0) {
+        ws_dbg[0] = g_npop, ws_dbg[1] = g_pop, ws_dbg[2] = g_npush, ws_dbg[3] = g_push;
+        ws_dbg[4] = g_nr, ws_dbg[5] = g_rg, ws_dbg[6] = g_rl, ws_dbg[7] = GCLK() - g_t0;
+    }
+#undef GCLK
+#endif
 }
 
 __global__ void ws_set_flags_kernel(int* f, int n, int v) {
@@ -1585,6 +1640,9 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     const size_t np = (size_t)nplanes * n;
     // seeds_first cannot tie (marker pixels are spread first, in raster order, before anything is queued by value)
     const bool exact = tie_policy == AMT_WS_TIES_EXACT && !seeds_first;
+    // the single-heap emulation packs a pixel as (y << 16 | x) and keeps heap slots in 32-bit arithmetic
+    AMT_REQUIRE(!(exact || connectivity == 2) || (H <= 65535 && W <= 65535 && n <= ((size_t)1 << 26)),
+                "watershed: exact tie handling / connectivity 2 support planes of at most 2^26 pixels, got %d x %d", H, W);
     if (connectivity == 2) {
         // 8-connected floods: no component decomposition here -- every plane goes through the sequential emulation
         AMT_TRY(amt_arena_begin(ctx, amt_align(np * sizeof(hp_elem)) + amt_align((size_t)nplanes * 4)));

@@ -933,7 +933,8 @@ def run_chain(args):
             c.set_fork(args.aux_streams)
     parts = [d_fovs[bounds[i]:bounds[i + 1]] for i in range(nstreams)]
     segs = [FovSegmenter(bounds[i + 1] - bounds[i], 4, S, S, ctx=ctxs[i], max_cells=args.max_cells,
-                         bin_plane=os.environ.get("AMT_BENCH_NO_BINS") != "1")
+                         bin_plane=os.environ.get("AMT_BENCH_NO_BINS") != "1",
+                         low_traffic=os.environ.get("AMT_BENCH_LOW_TRAFFIC") == "1")
             for i in range(nstreams)]
     packed = None
     gather = distributed and args.workload == "c3" and not args.no_gather and os.environ.get("AMT_BENCH_NO_GATHER") != "1"
@@ -1056,7 +1057,8 @@ def run_chain(args):
     # one launch of the timed region covers the FOVs of ONE stream: profile that launch size
     PB = bounds[1] - bounds[0]
     prof = FovSegmenter(PB, 4, S, S, ctx=ctx, profile=True, max_cells=args.max_cells,
-                        bin_plane=os.environ.get("AMT_BENCH_NO_BINS") != "1")
+                        bin_plane=os.environ.get("AMT_BENCH_NO_BINS") != "1",
+                        low_traffic=os.environ.get("AMT_BENCH_LOW_TRAFFIC") == "1")
     d_prof = d_fovs[:PB]
     stage_ms: dict[str, list[float]] = {}
     reps = 3
