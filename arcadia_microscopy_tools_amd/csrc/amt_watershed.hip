@@ -1293,17 +1293,19 @@ __global__ void __launch_bounds__(64) ws_global_kernel(const void* __restrict__ 
         a.age = 0;
         a.idx = 0;
         const bool anc = lane >= 1 && lane <= depth;
+        // (the ancestors below the LDS levels were written by this CU a moment ago and come from its L1: keeping them
+        // in registers from one push to the next, or requesting them ahead, was measured and bought nothing)
         if (anc) a = ld(((c + 1) >> lane) - 1);
         const bool rises = anc && less(ekey, eage, a.key, a.age);
         const unsigned long long m = __ballot(rises) >> 1;  // bit j-1: the element overtakes ancestor j
         const int up = m == ~0ull ? 64 : __ffsll((long long)~m) - 1;  // consecutive overtaken ancestors from the bottom
         if (anc && lane <= up) st(((c + 1) >> (lane - 1)) - 1, a);  // ancestor j moves down into slot of j - 1
         if (lane == 0) {
-            gh_elem e;
-            e.key = ekey;
-            e.age = eage;
-            e.idx = eidx;
-            st(((c + 1) >> up) - 1, e);
+            gh_elem en;
+            en.key = ekey;
+            en.age = eage;
+            en.idx = eidx;
+            st(((c + 1) >> up) - 1, en);
         }
         // what now sits in the LAST slot (c): the new element, or its parent if it rose -- the next pop moves exactly
         // this element to the root and need not fetch it from HBM
@@ -1357,6 +1359,22 @@ __global__ void __launch_bounds__(64) ws_global_kernel(const void* __restrict__ 
     const int r = lane + 1;
     const int lv = 31 - __clz(r + 1);
     const int o = r + 1 - (1 << lv);
+    // The preference bits (RM below: bit 2 a + 1 = "relative node a prefers its right child", a = 0: the subtree's root)
+    // that put THIS lane's node on the min-child path: every ancestor must prefer the child on the way down to it.
+    unsigned long long need_r = 0, need_l = 0;
+    {
+        int c = r;
+        while (c > 0 && lane < 62) {
+            const int par = (c - 1) >> 1;
+            const unsigned long long bit = 1ull << (2 * par + 1);
+            if (c == 2 * par + 2) need_r |= bit; else need_l |= bit;
+            c = par;
+        }
+    }
+    // slot of this lane's node's parent: ((pos + 1) << par_lv) - 1 + par_off (par_lv = 0, par_off = 0: pos itself)
+    const int prel = (r - 1) >> 1;
+    const int par_lv = prel > 0 ? 31 - __clz(prel + 1) : 0;
+    const int par_off = prel > 0 ? prel + 1 - (1 << par_lv) : 0;
     unsigned age = 0;
 #ifdef WS_STATS
     unsigned long long g_pop = 0, g_push = 0, g_rl = 0, g_rg = 0, g_npush = 0, g_npop = 0, g_nr = 0;
@@ -1401,44 +1419,26 @@ __global__ void __launch_bounds__(64) ws_global_kernel(const void* __restrict__ 
                 e.idx = 0;
                 if (valid) e = ld(ab);
                 // Which child every node of the subtree prefers, and which nodes are smaller than `last`, for all 62 nodes
-                // AT ONCE (two ballots); the walk itself is then bit arithmetic on the two masks.  (Walking with cross-lane
-                // reads cost ~30 dependent vector instructions per level, 17 levels per pop: most of the 3.7 us per pixel.)
-                // Lane L holds relative node L + 1, whose children sit in lanes 2 L + 2 and 2 L + 3; lane 63 stands in for
-                // the subtree's root (children: lanes 0 and 1).  A missing node carries the key INF: never preferred, never
-                // smaller than `last`.
-                const int cl = lane == 63 ? 0 : 2 * lane + 2;
-                const bool has_kids = lane == 63 || lane < 30;
-                const int cls = has_kids ? cl : 0;
-                const unsigned kl_lo = (unsigned)__shfl((int)(unsigned)e.key, cls), kl_hi = (unsigned)__shfl((int)(unsigned)(e.key >> 32), cls);
-                const unsigned kr_lo = (unsigned)__shfl((int)(unsigned)e.key, cls + 1), kr_hi = (unsigned)__shfl((int)(unsigned)(e.key >> 32), cls + 1);
-                const unsigned al = (unsigned)__shfl((int)e.age, cls), ar = (unsigned)__shfl((int)e.age, cls + 1);
-                const unsigned long long kl = ((unsigned long long)kl_hi << 32) | kl_lo, kr = ((unsigned long long)kr_hi << 32) | kr_lo;
-                const unsigned long long RM = __ballot(has_kids && less(kr, ar, kl, al));  // right child strictly smaller
+                // AT ONCE (two ballots); the path is then bit arithmetic on the masks.  (Walking with cross-lane reads cost
+                // ~30 dependent vector instructions per level, 17 levels per pop: most of the 3.7 us per pixel.)
+                // Lane L holds relative node L + 1, so siblings sit in lanes (2 i, 2 i + 1): the RIGHT child (odd lane)
+                // compares itself with its left neighbour -- one lane shift, no LDS crossbar.  RM bit 2 a + 1 = "node a
+                // prefers its right child".  A missing node carries the key INF: never preferred, never smaller than `last`.
+                const unsigned long long kleft = ((unsigned long long)(unsigned)amt_lane_left((int)(unsigned)(e.key >> 32)) << 32) |
+                                                 (unsigned)amt_lane_left((int)(unsigned)e.key);
+                const unsigned aleft = (unsigned)amt_lane_left((int)e.age);
+                const unsigned long long RM = __ballot((lane & 1) && lane < 62 && less(e.key, e.age, kleft, aleft));
                 const unsigned long long LT = __ballot(lane < 62 && less(e.key, e.age, last.key, last.age));
-                int cur = 0;                 // relative index of the node `last` would sit in (0 = pos itself)
-                unsigned long long path = 0; // lanes whose element moves up to its parent
-                bool placed = false;
-#pragma unroll
-                for (int s5 = 0; s5 < 5; ++s5) {
-                    const int rbit = (int)((RM >> (cur == 0 ? 63 : cur - 1)) & 1ull);
-                    const int c = 2 * cur + 1 + rbit;  // the preferred child (relative index; its lane is c - 1)
-                    if (!((LT >> (c - 1)) & 1ull)) {
-                        placed = true;  // no child, or none smaller than `last`
-                        break;
-                    }
-                    cur = c;
-                    path |= 1ull << (cur - 1);
-                }
+                // the min-child path through the five levels, all at once: a node is on it iff all its ancestors prefer
+                // the child that leads to it; the path's elements move up as far as they are smaller than `last` (one
+                // node per level, and lanes are numbered level by level: "above the first that is not" = lower lanes)
+                const unsigned long long onpath = __ballot(lane < 62 && (RM & need_r) == need_r && (RM & need_l) == 0ull);
+                const unsigned long long blocked = onpath & ~LT;
+                const bool placed = blocked != 0ull;  // a child is missing or not smaller than `last`: it settles here
+                const unsigned long long path = placed ? onpath & ((blocked & (0ull - blocked)) - 1ull) : onpath;
+                const int cur = path ? 64 - __clzll((long long)path) : 0;  // relative index of the node `last` would sit in
                 // lanes on the path hand their element to the parent slot
-                if ((path >> lane) & 1ull) {
-                    const int prel = (r - 1) >> 1;  // parent's relative index
-                    int pab = pos;
-                    if (prel > 0) {
-                        const int plv = 31 - __clz(prel + 1);
-                        pab = ((pos + 1) << plv) - 1 + (prel + 1 - (1 << plv));
-                    }
-                    st(pab, e);
-                }
+                if ((path >> lane) & 1ull) st(((pos + 1) << par_lv) - 1 + par_off, e);
                 int cab = pos;
                 if (cur > 0) {
                     const int clv = 31 - __clz(cur + 1);
