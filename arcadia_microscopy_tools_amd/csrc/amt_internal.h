@@ -88,6 +88,7 @@ int amt_i_tile_rows(int H);
 size_t amt_i_rootlist_cap(int W);
 // multi (nullable): one int of scratch; with it a 0 / 1 mask takes the bit-parallel tile kernel (other byte values
 // are detected and redone by the pixel kernel)
+size_t amt_i_ccl_scratch_ints(int nplanes, int H, int W);  // ints of scratch behind `multi`
 int amt_i_ccl_tileroots_u8(amt_ctx* ctx, const uint8_t* in, int* L, int* rootlist, int* nroots, int nplanes, int H,
                            int W, int* multi = nullptr);
 // A[t] = A[L[t]] for every listed tile root t (lists compressed): a pixel then reaches its component's entry of A

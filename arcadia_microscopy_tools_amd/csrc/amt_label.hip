@@ -333,7 +333,8 @@ __device__ __forceinline__ void ccl_runion(int* S, int a, int b) {
 template <bool CONN8>
 __global__ void __launch_bounds__(64) ccl_tile_bits_kernel(const uint8_t* __restrict__ in, int* __restrict__ Lall, int H,
                                                            int W, int* __restrict__ rootlist, int* __restrict__ nroots,
-                                                           size_t cap, int* __restrict__ multi) {
+                                                           size_t cap, int* __restrict__ multi,
+                                                           unsigned long long* __restrict__ colbits) {
     __shared__ int S[64 * 32];  // 8 KB: eighteen tiles per CU
     __shared__ unsigned long long bits[64];
     const size_t n = (size_t)H * W;
@@ -371,6 +372,16 @@ __global__ void __launch_bounds__(64) ccl_tile_bits_kernel(const uint8_t* __rest
     }
     if (__ballot(other != 0) && lane == 0) atomicOr(multi, 1);
     bits[lane] = w;
+    {
+        // the tile's first and last column, a bit per row: all the seam pass needs to stitch this tile to its left and
+        // right neighbours (reading those two columns from the image costs a 64-byte line per PIXEL: 8 MB per plane)
+        const unsigned long long lc = __ballot((w & 1ull) != 0), rc = __ballot((w >> 63) != 0);
+        if (lane == 0) {
+            unsigned long long* cb = colbits + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 2;
+            cb[0] = lc;
+            cb[1] = rc;
+        }
+    }
     // ---- runs: their own parents ----
     const unsigned long long heads = w & ~(w << 1);
     {
@@ -476,7 +487,7 @@ __global__ void ccl_reset_lists_kernel(int* __restrict__ nroots, size_t nlist, c
 // blockIdx.y selects the job: [0, nrow_jobs) = strip-boundary rows, the rest = segment-boundary columns
 template <typename T, bool CONN8>
 __global__ void __launch_bounds__(256) ccl_border_kernel(const T* __restrict__ in, int* __restrict__ Lall, int H, int W,
-                                                         int nrow_blocks) {
+                                                         int nrow_blocks, const int* __restrict__ cols_only_if = nullptr) {
     const size_t n = (size_t)H * W;
     const T* img = in + (size_t)blockIdx.z * n;
     int* L = Lall + (size_t)blockIdx.z * n;
@@ -494,6 +505,7 @@ __global__ void __launch_bounds__(256) ccl_border_kernel(const T* __restrict__ i
         ccl_stitch_rows<CONN8, false>(L, y * W + xc, W, lane, v, up, NOVAL);
     } else {
         // column pairs (x-1, x) with x a multiple of 64; one thread per (row, boundary)
+        if (cols_only_if && !*cols_only_if) return;  // ccl_border_cols_bits_kernel does them from the tiles' column bits
         const int nbound = (W - 1) / 64;  // boundaries at x = 64, 128, ...
         const int t = (((int)blockIdx.y - nrow_blocks) * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
         if (nbound == 0 || t >= H * nbound) return;
@@ -505,6 +517,37 @@ __global__ void __launch_bounds__(256) ccl_border_kernel(const T* __restrict__ i
             if (vb != 0 && img[pa - W] == vb) uf_union(L, pb, pa - W);  // NW of b
             if (va != 0 && img[pb - W] == va) uf_union(L, pa, pb - W);  // NE of a
         }
+    }
+}
+
+// The column seams of a 0 / 1 mask from the column bits ccl_tile_bits_kernel left: a wave per (tile boundary, tile row),
+// a lane per row.  Stands down when the batch held other byte values (the byte version above then runs).
+template <bool CONN8>
+__global__ void __launch_bounds__(256) ccl_border_cols_bits_kernel(const unsigned long long* __restrict__ colbits,
+                                                                   int* __restrict__ Lall, int H, int W, int segs, int trows,
+                                                                   const int* __restrict__ multi) {
+    if (*multi) return;
+    const int lane = threadIdx.x & 63;
+    const int job = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (job >= (segs - 1) * trows) return;  // whole wave
+    const int bx = job % (segs - 1) + 1, ty = job / (segs - 1);
+    const unsigned long long* cb = colbits + ((size_t)blockIdx.z * trows + ty) * segs * 2;
+    const unsigned long long ra = cb[(bx - 1) * 2 + 1], lb = cb[bx * 2];  // a = last column of the left tile, b = first of the right
+    int* L = Lall + (size_t)blockIdx.z * H * W;
+    const int y = ty * 64 + lane, x = bx * 64;
+    const int pb = y * W + x, pa = pb - 1;
+    const bool va = (ra >> lane) & 1ull, vb = (lb >> lane) & 1ull;  // rows beyond H carry zero bits
+    if (va && vb) uf_union(L, pb, pa);
+    if (CONN8) {
+        // the row above: the lane below this one, or the last row of the tile row above
+        unsigned long long ra_up = ra << 1, lb_up = lb << 1;
+        if (ty > 0) {
+            const unsigned long long* cu = cb - (size_t)segs * 2;
+            ra_up |= cu[(bx - 1) * 2 + 1] >> 63;
+            lb_up |= cu[bx * 2] >> 63;
+        }
+        if (vb && ((ra_up >> lane) & 1ull)) uf_union(L, pb, pa - W);  // NW of b
+        if (va && ((lb_up >> lane) & 1ull)) uf_union(L, pa, pb - W);  // NE of a
     }
 }
 
@@ -638,7 +681,12 @@ static bool ccl_bits_enabled() {
     return v == 1;
 }
 
-// multi (nullable): one int of scratch; with it, uint8 inputs take the bit-parallel tile kernel first
+// ints of scratch behind `multi`: the flag (16 ints) + two 64-bit column words per tile
+size_t amt_i_ccl_scratch_ints(int nplanes, int H, int W) {
+    return 16 + (size_t)nplanes * ((W + 63) / 64) * ((H + TILE_R - 1) / TILE_R) * 4;
+}
+
+// multi (nullable): amt_i_ccl_scratch_ints of scratch; with it, uint8 inputs take the bit-parallel tile kernel first
 template <typename T, bool CONN8>
 static int ccl_tileroots(amt_ctx* ctx, const T* in, int* L, int* rootlist, int* nroots, int nplanes, int H, int W,
                          int* multi = nullptr) {
@@ -656,7 +704,7 @@ static int ccl_tileroots(amt_ctx* ctx, const T* in, int* L, int* rootlist, int* 
         // masks: the bit-parallel tile kernel; a plane batch that turns out to hold other byte values is redone below
         AMT_HIP_CHECK(hipMemsetAsync(multi, 0, sizeof(int), ctx->stream));
         hipLaunchKernelGGL((ccl_tile_bits_kernel<CONN8>), gs, dim3(64), 0, ctx->stream, (const uint8_t*)in, L, H, W, rootlist,
-                           nroots, cap, multi);
+                           nroots, cap, multi, reinterpret_cast<unsigned long long*>(multi + 16));
         AMT_LAUNCH_CHECK();
         hipLaunchKernelGGL(ccl_reset_lists_kernel, dim3(8), dim3(256), 0, ctx->stream, nroots,
                            (size_t)nplanes * gs.y, (const int*)multi);
@@ -671,8 +719,18 @@ static int ccl_tileroots(amt_ctx* ctx, const T* in, int* L, int* rootlist, int* 
         AMT_LAUNCH_CHECK();
     }
     if (gb.y > 0) {
-        hipLaunchKernelGGL((ccl_border_kernel<T, CONN8>), gb, dim3(256), 0, ctx->stream, in, L, H, W, nrow_blocks);
+        // with the bit kernel's column words the byte version only stitches the rows (its column jobs leave at once
+        // unless the batch turned out to hold other byte values)
+        hipLaunchKernelGGL((ccl_border_kernel<T, CONN8>), gb, dim3(256), 0, ctx->stream, in, L, H, W, nrow_blocks,
+                           done ? (const int*)multi : (const int*)nullptr);
         AMT_LAUNCH_CHECK();
+        if (done && segs > 1) {
+            const int jobs = (segs - 1) * (int)gs.y;
+            hipLaunchKernelGGL((ccl_border_cols_bits_kernel<CONN8>), dim3((jobs + 3) / 4, 1, nplanes), dim3(256), 0, ctx->stream,
+                               reinterpret_cast<const unsigned long long*>(multi + 16), L, H, W, segs, (int)gs.y,
+                               (const int*)multi);
+            AMT_LAUNCH_CHECK();
+        }
     }
     return AMT_OK;
 }
@@ -810,9 +868,11 @@ extern "C" int amt_label(amt_ctx* ctx, const void* in, int in_dtype, int32_t* ou
     const size_t nwords = (n + 63) / 64;
     AMT_TRY(amt_arena_begin(ctx, 2 * amt_align((size_t)nplanes * n * 4) + amt_align(nlist * cap * 4) +
                                      amt_align((size_t)nplanes * nblk * 4) + amt_align(nlist * 4) +
-                                     amt_align((size_t)nplanes * nwords * 8) + amt_align(64)));
+                                     amt_align((size_t)nplanes * nwords * 8) +
+                                     amt_align(amt_i_ccl_scratch_ints(nplanes, H, W) * 4)));
     int* L = arena_take_t<int>(ctx, (size_t)nplanes * n);
-    int* multi = arena_take_t<int>(ctx, 16);  // "a byte other than 0 / 1 was seen" (ccl_tile_bits_kernel)
+    // "a byte other than 0 / 1 was seen" + the tiles' column words (ccl_tile_bits_kernel)
+    int* multi = arena_take_t<int>(ctx, amt_i_ccl_scratch_ints(nplanes, H, W));
     int* T = arena_take_t<int>(ctx, (size_t)nplanes * n);
     int* rootlist = arena_take_t<int>(ctx, nlist * cap);
     int* blk = arena_take_t<int>(ctx, (size_t)nplanes * nblk);

@@ -1682,6 +1682,8 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     if (exact && use_d2) need += amt_align(np * sizeof(hp_elem));
     const size_t msz = (size_t)nplanes * ((size_t)max_label + 1);
     if (fused_labels) need += amt_align(msz * 4);
+    const size_t ccl_ints = amt_i_ccl_scratch_ints(nplanes, H, W);
+    need += amt_align(ccl_ints * 4);
     AMT_TRY(amt_arena_begin(ctx, need));
     int* L = arena_take_t<int>(ctx, np);
     int* T = arena_take_t<int>(ctx, np);
@@ -1702,6 +1704,7 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     int* wl = arena_take_t<int>(ctx, (size_t)WS_NLISTS * nr);  // worklists of the LDS classes
     int* pf_idx = arena_take_t<int>(ctx, (size_t)PF_NCLS * (nplanes + 1));  // the persistent flood's item index
     int* pf_ctl = arena_take_t<int>(ctx, 16);
+    int* ccl_scratch = arena_take_t<int>(ctx, ccl_ints);  // the tile labelling's flag + the tiles' column words
     int* ties = ties_dev ? ties_dev : arena_take_t<int>(ctx, nplanes);
     int* P = fused_labels ? arena_take_t<int>(ctx, msz) : nullptr;
     int *head = nullptr, *tail = nullptr;
@@ -1725,7 +1728,7 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     // components of the mask with dense ids in T (the order of the ids is irrelevant: components are
     // independent work items and nothing in the output depends on their numbering)
     AMT_HIP_CHECK(hipMemsetAsync(nroots, 0, nlist * 4, ctx->stream));
-    AMT_TRY(amt_i_ccl_tileroots_u8(ctx, mask, L, rootlist, nroots, nplanes, H, W, pf_ctl + 8));
+    AMT_TRY(amt_i_ccl_tileroots_u8(ctx, mask, L, rootlist, nroots, nplanes, H, W, ccl_scratch));
     hipLaunchKernelGGL(ws_roots_kernel, dim3(4, trows, nplanes), dim3(256), 0, ctx->stream, L, T, rootlist, nroots, ncomp,
                        lcap, n);
     AMT_LAUNCH_CHECK();
