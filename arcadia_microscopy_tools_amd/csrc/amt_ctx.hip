@@ -33,6 +33,17 @@ static int ctx_create_common(int device, hipStream_t stream, bool own, amt_ctx**
         return AMT_ENODEV;
     }
     AMT_REQUIRE(device >= 0 && device < n, "amt_ctx_create: device %d out of range (have %d)", device, n);
+    {
+        // AMT_SYNC_MODE=yield|block: how a host thread waits in amt_sync (default: the runtime's choice, a spin).  Only
+        // takes effect if nothing has initialised the device yet (A/B switch for many worker threads on few cores)
+        static bool once = false;
+        const char* m = getenv("AMT_SYNC_MODE");
+        if (!once && m) {
+            once = true;
+            (void)hipSetDeviceFlags(m[0] == 'b' ? hipDeviceScheduleBlockingSync : m[0] == 'y' ? hipDeviceScheduleYield : hipDeviceScheduleSpin);
+            (void)hipGetLastError();
+        }
+    }
     AMT_HIP_CHECK(hipSetDevice(device));
     amt_ctx* c = new amt_ctx();
     c->device = device;
