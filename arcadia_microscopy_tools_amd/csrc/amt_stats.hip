@@ -100,19 +100,26 @@ __global__ void __launch_bounds__(1024) hist_u16_part_kernel(const uint16_t* __r
     for (int i = threadIdx.x; i < 8192; i += 1024) out[i] = l4[i];
 }
 
-// hist[plane][2 w], [2 w + 1] = sum over the plane's parts of the two 16-bit halves of word w
+// hist[plane][2 w], [2 w + 1] = sum over the plane's parts of the two 16-bit halves of word w.  Four lanes share a word
+// and take every fourth part (the sums meet through two lane exchanges): a thread that walks all ~64 parts alone waits
+// for them a few at a time (10 us per single plane; 5 with four lanes per word).
 __global__ void __launch_bounds__(256) hist_u16_reduce_kernel(const uint32_t* __restrict__ partial, uint32_t* __restrict__ hist,
                                                               int parts) {
     const int plane = blockIdx.y;
-    const int w = blockIdx.x * 256 + threadIdx.x;  // 0 .. 32767
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int w = t >> 2, q = t & 3;  // word 0 .. 32767, quarter of the parts
     const uint32_t* p = partial + (size_t)plane * parts * 32768 + w;
     uint32_t lo = 0, hi = 0;
-    for (int k = 0; k < parts; ++k) {
+    for (int k = q; k < parts; k += 4) {
         const uint32_t v = p[(size_t)k * 32768];
         lo += v & 0xffffu;
         hi += v >> 16;
     }
-    reinterpret_cast<uint2*>(hist + (size_t)plane * 65536)[w] = make_uint2(lo, hi);
+    lo += __shfl_xor(lo, 1);
+    hi += __shfl_xor(hi, 1);
+    lo += __shfl_xor(lo, 2);
+    hi += __shfl_xor(hi, 2);
+    if (q == 0) reinterpret_cast<uint2*>(hist + (size_t)plane * 65536)[w] = make_uint2(lo, hi);
 }
 
 // bytes of scratch hist_u16_launch wants for this call (0: it takes the two-window kernel)
@@ -134,7 +141,7 @@ static int hist_u16_launch(amt_ctx* ctx, const uint16_t* in, uint32_t* hist, int
         hipLaunchKernelGGL(hist_u16_part_kernel, dim3(nplanes * parts), dim3(1024), 32768 * sizeof(uint32_t), ctx->stream, in,
                            scratch, n, parts);
         AMT_LAUNCH_CHECK();
-        hipLaunchKernelGGL(hist_u16_reduce_kernel, dim3(128, nplanes), dim3(256), 0, ctx->stream, scratch, hist, parts);
+        hipLaunchKernelGGL(hist_u16_reduce_kernel, dim3(512, nplanes), dim3(256), 0, ctx->stream, scratch, hist, parts);
         AMT_LAUNCH_CHECK();
         return AMT_OK;
     }
