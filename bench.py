@@ -847,22 +847,23 @@ def run_sublines(args) -> dict:
 
     quick = dict(no_cpu=True, no_h2d=True, no_sublines=True, tail_reps=0)
     attempt("c2", lambda: run_chain(_sub_args(args, workload="c2", steps=10, warmup=2, **quick)))
-    attempt("plate48", lambda: run_chain(_sub_args(args, plate=48, steps=20, warmup=3, **quick)))
-    attempt("unique64", lambda: run_chain(_sub_args(args, unique=64, steps=5, warmup=1, **dict(quick, tail_reps=24))))
-    attempt("prep", lambda: run_ops(_sub_args(args, workload="prep", steps=10, warmup=2, no_cpu=True)))
-    attempt("filters", lambda: run_ops(_sub_args(args, workload="filters", steps=10, warmup=2, no_cpu=True)))
-    def api_in_child():
-        # the reference-level calls are bound by the HOST (page-locked pools, copy threads, allocator state): measured in
-        # a fresh process, as a user's script would run them, not in the heap this command has churned for a minute
-        cmd = [sys.executable, os.path.abspath(__file__), "--workload", "api", "--steps", "5", "--warmup", "2",
-               "--size", str(args.size), "--unique", str(min(args.unique, 8))]
+    def in_child(*argv):
+        # a fresh process, as a user's script would be: no heap this command has churned for a minute, no idle contexts
+        # and streams of the lines before (measured: the 48-FOV plate 9.8 k FOV/s in here, 10.6-11.1 k on its own)
+        cmd = [sys.executable, os.path.abspath(__file__), *argv, "--size", str(args.size), "--unique", str(min(args.unique, 8))]
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
         lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
         if r.returncode != 0 or not lines:
             raise RuntimeError(f"child exited with {r.returncode}: {r.stderr.decode()[-300:]}")
         return json.loads(lines[-1])
 
-    attempt("api", api_in_child)
+    attempt("plate48", lambda: in_child("--plate", "48", "--steps", "60", "--warmup", "5", "--no-sublines", "--no-cpu",
+                                        "--no-h2d"))
+    attempt("unique64", lambda: run_chain(_sub_args(args, unique=64, steps=5, warmup=1, **dict(quick, tail_reps=24))))
+    attempt("prep", lambda: run_ops(_sub_args(args, workload="prep", steps=10, warmup=2, no_cpu=True)))
+    attempt("filters", lambda: run_ops(_sub_args(args, workload="filters", steps=10, warmup=2, no_cpu=True)))
+    # the reference-level calls are bound by the HOST (page-locked pools, copy threads, allocator state): a child too
+    attempt("api", lambda: in_child("--workload", "api", "--steps", "5", "--warmup", "2"))
     attempt("a8_exact", lambda: run_a8(_sub_args(args, steps=1, warmup=1)))
     return subs
 
