@@ -330,60 +330,40 @@ __device__ __forceinline__ void ccl_runion(int* S, int a, int b) {
     }
 }
 
-template <bool CONN8>
-__global__ void __launch_bounds__(64) ccl_tile_bits_kernel(const uint8_t* __restrict__ in, int* __restrict__ Lall, int H,
-                                                           int W, int* __restrict__ rootlist, int* __restrict__ nroots,
-                                                           size_t cap, int* __restrict__ multi,
-                                                           unsigned long long* __restrict__ colbits) {
-    __shared__ int S[64 * 32];  // 8 KB: eighteen tiles per CU
-    __shared__ unsigned long long bits[64];
-    const size_t n = (size_t)H * W;
-    const uint8_t* img = in + (size_t)blockIdx.z * n;
-    int* L = Lall + (size_t)blockIdx.z * n;
-    const int lane = threadIdx.x;
-    const int x0 = blockIdx.x * 64, ty0 = blockIdx.y * 64;
-    // ---- the lane's row as a word ----
+// the lane's row of a 64 x 64 tile as a word (bit i = byte i is 1); `other` collects bits of bytes that are not 0 / 1
+__device__ __forceinline__ unsigned long long ccl_bits_load_row(const uint8_t* __restrict__ img, int H, int W, int x0, int y,
+                                                                unsigned& other) {
     unsigned long long w = 0;
-    unsigned other = 0;
-    {
-        const int y = ty0 + lane;
-        const uint8_t* rowp = img + (size_t)(y < H ? y : H - 1) * W;
-        uint4 q[4];
+    other = 0;
+    const uint8_t* rowp = img + (size_t)(y < H ? y : H - 1) * W;
+    uint4 q[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int xs = x0 + 16 * j;
-            q[j] = *reinterpret_cast<const uint4*>(rowp + (xs < W ? xs : 0));
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const unsigned v[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
-            unsigned sixteen = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                other |= v[k] & 0xFEFEFEFEu;
-                sixteen |= (((v[k] & 0x01010101u) * 0x01020408u) >> 24) << (4 * k);  // byte i -> bit i
-            }
-            if (x0 + 16 * j < W) w |= (unsigned long long)(sixteen & 0xFFFFu) << (16 * j);
-        }
-        if (y >= H) {
-            w = 0;
-            other = 0;
-        }
+    for (int j = 0; j < 4; ++j) {
+        const int xs = x0 + 16 * j;
+        q[j] = *reinterpret_cast<const uint4*>(rowp + (xs < W ? xs : 0));
     }
-    if (__ballot(other != 0) && lane == 0) atomicOr(multi, 1);
-    bits[lane] = w;
-    {
-        // the tile's first and last column, a bit per row: all the seam pass needs to stitch this tile to its left and
-        // right neighbours (reading those two columns from the image costs a 64-byte line per PIXEL: 8 MB per plane)
-        const unsigned long long lc = __ballot((w & 1ull) != 0), rc = __ballot((w >> 63) != 0);
-        if (lane == 0) {
-            unsigned long long* cb = colbits + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 2;
-            cb[0] = lc;
-            cb[1] = rc;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned v[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
+        unsigned sixteen = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            other |= v[k] & 0xFEFEFEFEu;
+            sixteen |= (((v[k] & 0x01010101u) * 0x01020408u) >> 24) << (4 * k);  // byte i -> bit i
         }
+        if (x0 + 16 * j < W) w |= (unsigned long long)(sixteen & 0xFFFFu) << (16 * j);
     }
-    // ---- runs: their own parents ----
-    const unsigned long long heads = w & ~(w << 1);
+    if (y >= H) {
+        w = 0;
+        other = 0;
+    }
+    return w;
+}
+
+// the tile's union-find over runs (a lane per row): own parents, stitched to the row above, compressed -- afterwards
+// S[run] = the entry of the run's tile root.  Returns the number of root runs of the lane's row.
+template <bool CONN8>
+__device__ __forceinline__ int ccl_bits_unionfind(int* S, unsigned long long w, unsigned long long heads, int lane) {
     {
         int j = 0;
         for (unsigned long long h = heads; h; h &= h - 1, ++j) {
@@ -393,7 +373,6 @@ __global__ void __launch_bounds__(64) ccl_tile_bits_kernel(const uint8_t* __rest
     }
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
-    // ---- stitch to the row above ----
     {
         unsigned long long above = __shfl_up(w, 1);
         if (lane == 0) above = 0;
@@ -415,7 +394,6 @@ __global__ void __launch_bounds__(64) ccl_tile_bits_kernel(const uint8_t* __rest
     }
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
-    // ---- compress the runs, count the roots, reserve the tile's slice of its tile row's list ----
     int nroot = 0;
     {
         int j = 0;
@@ -426,6 +404,40 @@ __global__ void __launch_bounds__(64) ccl_tile_bits_kernel(const uint8_t* __rest
             nroot += (e >> 6) == own;
         }
     }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    return nroot;
+}
+
+template <bool CONN8>
+__global__ void __launch_bounds__(64) ccl_tile_bits_kernel(const uint8_t* __restrict__ in, int* __restrict__ Lall, int H,
+                                                           int W, int* __restrict__ rootlist, int* __restrict__ nroots,
+                                                           size_t cap, int* __restrict__ multi,
+                                                           unsigned long long* __restrict__ colbits) {
+    __shared__ int S[64 * 32];  // 8 KB: eighteen tiles per CU
+    __shared__ unsigned long long bits[64];
+    const size_t n = (size_t)H * W;
+    const uint8_t* img = in + (size_t)blockIdx.z * n;
+    int* L = Lall + (size_t)blockIdx.z * n;
+    const int lane = threadIdx.x;
+    const int x0 = blockIdx.x * 64, ty0 = blockIdx.y * 64;
+    unsigned other;
+    const unsigned long long w = ccl_bits_load_row(img, H, W, x0, ty0 + lane, other);
+    if (__ballot(other != 0) && lane == 0) atomicOr(multi, 1);
+    bits[lane] = w;
+    {
+        // the tile's first and last column, a bit per row: all the seam pass needs to stitch this tile to its left and
+        // right neighbours (reading those two columns from the image costs a 64-byte line per PIXEL: 8 MB per plane)
+        const unsigned long long lc = __ballot((w & 1ull) != 0), rc = __ballot((w >> 63) != 0);
+        if (lane == 0) {
+            unsigned long long* cb = colbits + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 2;
+            cb[0] = lc;
+            cb[1] = rc;
+        }
+    }
+    const unsigned long long heads = w & ~(w << 1);
+    const int nroot = ccl_bits_unionfind<CONN8>(S, w, heads, lane);
+    // ---- reserve the tile's slice of its tile row's list ----
     int run = 0;
     if (rootlist) {
         int tot = nroot;
@@ -478,6 +490,218 @@ __global__ void __launch_bounds__(64) ccl_tile_bits_kernel(const uint8_t* __rest
     }
 }
 
+// ---- run tables instead of a parent plane (round 3) -------------------------------------------------------------------
+// amt_label on a 0 / 1 mask used to move 13 bytes per pixel: the tile pass wrote an int32 parent per pixel (4), the
+// numbering pass read it back (4) and wrote the labels (4).  A tile's labelling IS its run table, so the tile pass now
+// leaves only that: the 64 row words (512 B), one 16-bit entry per run = (row << 6 | column) of the run's tile root
+// (runs in raster order; ~100 per tile on nuclei masks, at most 2,048), the run count, and L[p] = p at the tile roots
+// themselves -- the union-find of the seams and the raster numbering only ever touch tile roots.  The seams are stitched
+// from the row words (a wave per tile boundary), and the last pass expands (row words, run table, rank of every tile
+// root) into labels: 1 + ~0.2 bytes read and 4 written per pixel.
+constexpr int RT_CAP = 2048;  // runs per tile: 64 rows x at most 32 runs
+
+__device__ __forceinline__ int ccl_wave_incl_scan(int v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(v, o);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+template <bool CONN8>
+__global__ void __launch_bounds__(64) ccl_tile_runs_kernel(const uint8_t* __restrict__ in, int* __restrict__ Lall, int H,
+                                                           int W, int* __restrict__ rootlist, int* __restrict__ nroots,
+                                                           size_t cap, int* __restrict__ multi,
+                                                           unsigned long long* __restrict__ tbits,
+                                                           unsigned short* __restrict__ rtab, int* __restrict__ nruns) {
+    __shared__ int S[64 * 32];
+    const size_t n = (size_t)H * W;
+    const uint8_t* img = in + (size_t)blockIdx.z * n;
+    int* L = Lall + (size_t)blockIdx.z * n;
+    const int lane = threadIdx.x;
+    const int x0 = blockIdx.x * 64, ty0 = blockIdx.y * 64;
+    const size_t tile = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    unsigned other;
+    const unsigned long long w = ccl_bits_load_row(img, H, W, x0, ty0 + lane, other);
+    if (__ballot(other != 0) && lane == 0) atomicOr(multi, 1);
+    tbits[tile * 64 + lane] = w;
+    const unsigned long long heads = w & ~(w << 1);
+    const int nroot = ccl_bits_unionfind<CONN8>(S, w, heads, lane);
+    // compact run ordinals (raster order) and the tile's slice of its tile row's root list
+    const int cnt = __popcll(heads);
+    const int incl = ccl_wave_incl_scan(cnt, lane);
+    const int rincl = ccl_wave_incl_scan(nroot, lane);
+    const int tot = __shfl(rincl, 63);
+    int base = 0;
+    if (lane == 0 && tot) base = atomicAdd(&nroots[blockIdx.z * gridDim.y + blockIdx.y], tot);
+    size_t pos = (size_t)__builtin_amdgcn_readfirstlane(base) + (rincl - nroot);
+    unsigned short* rt = rtab + tile * RT_CAP + (incl - cnt);
+    int j = 0;
+    for (unsigned long long h = heads; h; h &= h - 1, ++j) {
+        const int own = lane * 32 + j;
+        const int e = S[own];  // the root run's entry: id << 6 | first column, id = row << 5 | ordinal in the row
+        rt[j] = (unsigned short)(((e >> 11) << 6) | (e & 63));
+        if ((e >> 6) == own) {
+            const int pix = (ty0 + lane) * W + x0 + (e & 63);
+            L[pix] = pix;
+            if (pos < cap) rootlist[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * cap + pos] = pix;
+            ++pos;
+        }
+    }
+    if (lane == 63) nruns[tile] = incl;
+}
+
+__device__ __forceinline__ int ccl_rt_root(const unsigned short* __restrict__ rtab, size_t tile, int k, int ty, int bx,
+                                           int W) {
+    const int e = rtab[tile * RT_CAP + k];
+    return (ty * 64 + (e >> 6)) * W + bx * 64 + (e & 63);
+}
+
+// The seams from the tiles' row words: a wave per tile boundary.  jobs [0, segs * (trows - 1)): the row pair across a
+// horizontal boundary, a lane per column; the rest: the column pair across a vertical boundary, a lane per row (with
+// the two diagonal pairs at the corner where four tiles meet).  A union is skipped where a neighbouring lane's union
+// implies it (same run pair, or pixels that are vertical / horizontal neighbours inside their own tiles).
+template <bool CONN8>
+__global__ void __launch_bounds__(256) ccl_seams_runs_kernel(const unsigned long long* __restrict__ tbits,
+                                                             const unsigned short* __restrict__ rtab,
+                                                             const int* __restrict__ nruns, int* __restrict__ Lall, int H,
+                                                             int W, int segs, int trows, const int* __restrict__ multi) {
+    if (*multi) return;
+    const int lane = threadIdx.x & 63;
+    const int job = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nrowjobs = segs * (trows - 1);
+    if (job >= nrowjobs + (segs - 1) * trows) return;  // whole wave
+    int* L = Lall + (size_t)blockIdx.z * H * W;
+    const size_t t0 = (size_t)blockIdx.z * trows * segs;
+    if (job < nrowjobs) {
+        const int bx = job % segs, ty = job / segs + 1;
+        const size_t A = t0 + (size_t)(ty - 1) * segs + bx, B = A + segs;
+        const unsigned long long wa = tbits[A * 64 + 63], wb = tbits[B * 64];
+        const unsigned long long reach = CONN8 ? (wa | (wa << 1) | (wa >> 1)) : wa;
+        if (!(reach & wb)) return;
+        const unsigned long long ha = wa & ~(wa << 1), hb = wb & ~(wb << 1);
+        const int offA = nruns[A] - __popcll(ha);
+        const unsigned long long upto = (2ull << lane) - 1ull;
+        if (!((wa >> lane) & 1ull)) return;
+        const int ka = offA + __popcll(ha & upto) - 1;
+        int kb0 = -1, kb1 = -1;  // ordinals of the runs of B's first row to join
+        if (!CONN8) {
+            const unsigned long long ov = wa & wb;
+            if (((ov & ~(ov << 1)) >> lane) & 1ull) kb0 = __popcll(hb & upto) - 1;
+        } else {
+            const bool al = lane > 0 && ((wa >> (lane - 1)) & 1ull);
+            const bool bl = lane > 0 && ((wb >> (lane - 1)) & 1ull), bc = (wb >> lane) & 1ull;
+            const bool br = lane < 63 && ((wb >> (lane + 1)) & 1ull);
+            if (bc && !al) kb0 = __popcll(hb & upto) - 1;
+            else if (bl && !bc && !al) kb0 = __popcll(hb & (upto >> 1)) - 1;
+            if (br && !bc) kb1 = __popcll(hb & ((4ull << lane) - 1ull)) - 1;
+        }
+        if (kb0 < 0 && kb1 < 0) return;
+        const int pa = ccl_rt_root(rtab, A, ka, ty - 1, bx, W);
+        if (kb0 >= 0) uf_union(L, pa, ccl_rt_root(rtab, B, kb0, ty, bx, W));
+        if (kb1 >= 0) uf_union(L, pa, ccl_rt_root(rtab, B, kb1, ty, bx, W));
+    } else {
+        const int cj = job - nrowjobs;
+        const int bx = cj % (segs - 1) + 1, ty = cj / (segs - 1);
+        const size_t A = t0 + (size_t)ty * segs + bx - 1, B = A + 1;
+        const unsigned long long wA = tbits[A * 64 + lane], wB = tbits[B * 64 + lane];
+        const bool a = (wA >> 63) & 1ull, b = wB & 1ull;
+        const unsigned long long anya = __ballot(a), anyb = __ballot(b);
+        // whole wave: every pair has a pixel of THIS tile row (4-connected: one on either side)
+        if (CONN8 ? (!anya && !anyb) : (!anya || !anyb)) return;
+        const int cA = __popcll(wA & ~(wA << 1)), cB = __popcll(wB & ~(wB << 1));
+        const int kA = ccl_wave_incl_scan(cA, lane) - 1;       // the row's last run in A (it ends at column 63 if a)
+        const int kB = ccl_wave_incl_scan(cB, lane) - cB;      // the row's first run in B (it starts at column 0 if b)
+        // the row above: the lane below this one, or row 63 of the tiles above
+        bool a_up = __shfl_up((int)a, 1), b_up = __shfl_up((int)b, 1);
+        int kA_up = __shfl_up(kA, 1), kB_up = __shfl_up(kB, 1);
+        size_t A_up = A, B_up = B;
+        int ty_up = ty;
+        if (lane == 0) {
+            a_up = b_up = false;
+            if (CONN8 && ty > 0) {
+                A_up = A - segs;
+                B_up = B - segs;
+                ty_up = ty - 1;
+                const unsigned long long ua = tbits[A_up * 64 + 63], ub = tbits[B_up * 64 + 63];
+                a_up = (ua >> 63) & 1ull;
+                b_up = ub & 1ull;
+                kA_up = nruns[A_up] - 1;                               // the tile's very last run
+                kB_up = nruns[B_up] - __popcll(ub & ~(ub << 1));       // the first run of its last row
+            }
+        }
+        if (a && b && !(a_up && b_up)) uf_union(L, ccl_rt_root(rtab, A, kA, ty, bx - 1, W), ccl_rt_root(rtab, B, kB, ty, bx, W));
+        if (CONN8) {
+            if (b && a_up && !a && !b_up)  // north-west of b
+                uf_union(L, ccl_rt_root(rtab, B, kB, ty, bx, W), ccl_rt_root(rtab, A_up, kA_up, ty_up, bx - 1, W));
+            if (a && b_up && !b && !a_up)  // north-east of a
+                uf_union(L, ccl_rt_root(rtab, A, kA, ty, bx - 1, W), ccl_rt_root(rtab, B_up, kB_up, ty_up, bx, W));
+        }
+    }
+}
+
+// labels from (row words, run table, T at the tile roots): a wave per tile, four tiles per workgroup.  T[tile root] is
+// what the caller wants written for the root's component (the raster rank in amt_label).
+__global__ void __launch_bounds__(256) ccl_expand_runs_kernel(const unsigned long long* __restrict__ tbits,
+                                                              const unsigned short* __restrict__ rtab,
+                                                              const int* __restrict__ nruns, const int* __restrict__ Tall,
+                                                              int* __restrict__ outall, int H, int W, int segs, int trows,
+                                                              int ntiles, const int* __restrict__ multi) {
+    if (*multi) return;
+    __shared__ int lab_s[4][RT_CAP];
+    __shared__ unsigned long long bits_s[4][64];
+    __shared__ int off_s[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int t = blockIdx.x * 4 + wv;
+    if (t >= ntiles) return;  // whole wave
+    const int bx = t % segs, ty = (t / segs) % trows, plane = t / (segs * trows);
+    const size_t n = (size_t)H * W;
+    const int* T = Tall + (size_t)plane * n;
+    int* out = outall + (size_t)plane * n;
+    const int x0 = bx * 64, ty0 = ty * 64;
+    const int c4 = (lane & 15) * 4, rsub = lane >> 4;
+    const int xg = x0 + c4;
+    const int nr = nruns[t];
+    if (nr == 0) {  // uniform: nothing but background
+        if (xg < W) {
+#pragma unroll 4
+            for (int j = 0; j < 16; ++j) {
+                const int y = ty0 + rsub + 4 * j;
+                if (y < H) *reinterpret_cast<int4*>(out + (size_t)y * W + xg) = make_int4(0, 0, 0, 0);
+            }
+        }
+        return;
+    }
+    const unsigned long long w = tbits[(size_t)t * 64 + lane];
+    const int cnt = __popcll(w & ~(w << 1));
+    bits_s[wv][lane] = w;
+    off_s[wv][lane] = ccl_wave_incl_scan(cnt, lane) - cnt;
+    for (int k = lane; k < nr; k += 64) lab_s[wv][k] = T[ccl_rt_root(rtab, (size_t)t, k, ty, bx, W)];
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    if (xg >= W) return;
+#pragma unroll 4
+    for (int j = 0; j < 16; ++j) {
+        const int row = rsub + 4 * j;
+        const int y = ty0 + row;
+        const unsigned long long ww = bits_s[wv][row];
+        const unsigned long long hw = ww & ~(ww << 1);
+        const unsigned nib = (unsigned)(ww >> c4) & 15u, hnib = (unsigned)(hw >> c4) & 15u;
+        int4 o = make_int4(0, 0, 0, 0);
+        if (nib) {
+            // the run of pixel c4 + i = heads at or before it, minus one
+            const int k0 = off_s[wv][row] + __popcll(hw & ((1ull << c4) - 1ull)) - 1;
+            const int* lb = lab_s[wv];
+            if (nib & 1u) o.x = lb[k0 + (int)(hnib & 1u)];
+            if (nib & 2u) o.y = lb[k0 + __popc(hnib & 3u)];
+            if (nib & 4u) o.z = lb[k0 + __popc(hnib & 7u)];
+            if (nib & 8u) o.w = lb[k0 + __popc(hnib)];
+        }
+        if (y < H) *reinterpret_cast<int4*>(out + (size_t)y * W + xg) = o;
+    }
+}
+
 // the fallback's preparation: if the bit kernel met a byte other than 0 / 1, forget the roots it listed
 __global__ void ccl_reset_lists_kernel(int* __restrict__ nroots, size_t nlist, const int* __restrict__ multi) {
     if (!*multi) return;
@@ -487,7 +711,9 @@ __global__ void ccl_reset_lists_kernel(int* __restrict__ nroots, size_t nlist, c
 // blockIdx.y selects the job: [0, nrow_jobs) = strip-boundary rows, the rest = segment-boundary columns
 template <typename T, bool CONN8>
 __global__ void __launch_bounds__(256) ccl_border_kernel(const T* __restrict__ in, int* __restrict__ Lall, int H, int W,
-                                                         int nrow_blocks, const int* __restrict__ cols_only_if = nullptr) {
+                                                         int nrow_blocks, const int* __restrict__ cols_only_if = nullptr,
+                                                         const int* __restrict__ all_only_if = nullptr) {
+    if (all_only_if && !*all_only_if) return;  // the run-table path stitched the seams (amt_label on a 0 / 1 mask)
     const size_t n = (size_t)H * W;
     const T* img = in + (size_t)blockIdx.z * n;
     int* L = Lall + (size_t)blockIdx.z * n;
@@ -681,6 +907,16 @@ static bool ccl_bits_enabled() {
     return v == 1;
 }
 
+// AMT_CCL_RUNS=0: amt_label keeps the parent plane for masks too (A/B switch; identical results)
+static bool ccl_runs_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("AMT_CCL_RUNS");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
+}
+
 // ints of scratch behind `multi`: the flag (16 ints) + two 64-bit column words per tile
 size_t amt_i_ccl_scratch_ints(int nplanes, int H, int W) {
     return 16 + (size_t)nplanes * ((W + 63) / 64) * ((H + TILE_R - 1) / TILE_R) * 4;
@@ -819,7 +1055,9 @@ __global__ void __launch_bounds__(256) roots_rank_kernel(int* __restrict__ Tall,
 
 // out = rank of the component of every pixel: pixel -> tile root, whose T entry was copied from the component root
 __global__ void __launch_bounds__(256) apply_rank_kernel(const int* __restrict__ L, const int* __restrict__ T,
-                                                         int* __restrict__ out, size_t n) {
+                                                         int* __restrict__ out, size_t n,
+                                                         const int* __restrict__ only_if = nullptr) {
+    if (only_if && !*only_if) return;
     const size_t base = (size_t)blockIdx.y * n;
     for (size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i0 < n; i0 += (size_t)gridDim.x * 1024) {
         if (i0 + 3 < n && ((base + i0) & 3) == 0) {
@@ -866,10 +1104,13 @@ extern "C" int amt_label(amt_ctx* ctx, const void* in, int in_dtype, int32_t* ou
     const size_t cap = amt_i_rootlist_cap(W);
     const size_t nlist = (size_t)nplanes * trows;
     const size_t nwords = (n + 63) / 64;
+    const size_t ntiles_all = (size_t)nplanes * trows * ((W + 63) / 64);  // run tables of the 0 / 1 mask path
     AMT_TRY(amt_arena_begin(ctx, 2 * amt_align((size_t)nplanes * n * 4) + amt_align(nlist * cap * 4) +
                                      amt_align((size_t)nplanes * nblk * 4) + amt_align(nlist * 4) +
                                      amt_align((size_t)nplanes * nwords * 8) +
-                                     amt_align(amt_i_ccl_scratch_ints(nplanes, H, W) * 4)));
+                                     amt_align(amt_i_ccl_scratch_ints(nplanes, H, W) * 4) +
+                                     amt_align(ntiles_all * 64 * 8) + amt_align(ntiles_all * RT_CAP * 2) +
+                                     amt_align(ntiles_all * 4)));
     int* L = arena_take_t<int>(ctx, (size_t)nplanes * n);
     // "a byte other than 0 / 1 was seen" + the tiles' column words (ccl_tile_bits_kernel)
     int* multi = arena_take_t<int>(ctx, amt_i_ccl_scratch_ints(nplanes, H, W));
@@ -882,6 +1123,74 @@ extern "C" int amt_label(amt_ctx* ctx, const void* in, int in_dtype, int32_t* ou
     AMT_HIP_CHECK(hipMemsetAsync(nroots, 0, nlist * 4, ctx->stream));
     AMT_HIP_CHECK(hipMemsetAsync(bitmap, 0, (size_t)nplanes * nwords * 8, ctx->stream));
     // tile-local union-find + seams; only the listed tile roots are compressed, pixels resolve in two hops
+    const int segs = (W + 63) / 64;
+    const int ntiles = nplanes * trows * segs;
+    const bool runs = in_dtype == AMT_U8 && ccl_runs_enabled() && W % 16 == 0 &&
+                      (reinterpret_cast<uintptr_t>(in) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
+                      n % 16 == 0 && (size_t)ntiles * 64 < 0x7fffffffull;
+    if (runs) {
+        // 0 / 1 masks: run tables instead of a parent plane.  A batch that turns out to hold other byte values raises
+        // *multi; every run-table kernel then stands down and the byte kernels -- which otherwise leave at once -- redo it
+        unsigned long long* tbits = arena_take_t<unsigned long long>(ctx, (size_t)ntiles * 64);
+        unsigned short* rtab = arena_take_t<unsigned short>(ctx, (size_t)ntiles * RT_CAP);
+        int* nruns = arena_take_t<int>(ctx, (size_t)ntiles);
+        const uint8_t* in8 = (const uint8_t*)in;
+        const bool c8 = connectivity == 2;
+        AMT_HIP_CHECK(hipMemsetAsync(multi, 0, sizeof(int), ctx->stream));
+        dim3 gs(segs, trows, nplanes);
+        if (c8)
+            hipLaunchKernelGGL((ccl_tile_runs_kernel<true>), gs, dim3(64), 0, ctx->stream, in8, L, H, W, rootlist, nroots, cap,
+                               multi, tbits, rtab, nruns);
+        else
+            hipLaunchKernelGGL((ccl_tile_runs_kernel<false>), gs, dim3(64), 0, ctx->stream, in8, L, H, W, rootlist, nroots, cap,
+                               multi, tbits, rtab, nruns);
+        AMT_LAUNCH_CHECK();
+        hipLaunchKernelGGL(ccl_reset_lists_kernel, dim3(8), dim3(256), 0, ctx->stream, nroots, nlist, (const int*)multi);
+        AMT_LAUNCH_CHECK();
+        const int nrow_jobs = (H - 1) / TILE_R;
+        const int nrow_blocks = (nrow_jobs + 3) / 4;
+        const int ncol_jobs = H * ((W - 1) / 64);
+        const int ncol_blocks = (ncol_jobs + 256 * segs - 1) / (256 * segs);
+        dim3 gb(segs, nrow_blocks + ncol_blocks, nplanes);
+        if (c8) {
+            hipLaunchKernelGGL((ccl_tile_fallback_kernel<uint8_t, true>), dim3(512), dim3(256), 0, ctx->stream, in8, L, H, W,
+                               rootlist, nroots, cap, (const int*)multi, segs, trows, nplanes);
+            if (gb.y > 0)
+                hipLaunchKernelGGL((ccl_border_kernel<uint8_t, true>), gb, dim3(256), 0, ctx->stream, in8, L, H, W, nrow_blocks,
+                                   (const int*)nullptr, (const int*)multi);
+        } else {
+            hipLaunchKernelGGL((ccl_tile_fallback_kernel<uint8_t, false>), dim3(512), dim3(256), 0, ctx->stream, in8, L, H, W,
+                               rootlist, nroots, cap, (const int*)multi, segs, trows, nplanes);
+            if (gb.y > 0)
+                hipLaunchKernelGGL((ccl_border_kernel<uint8_t, false>), gb, dim3(256), 0, ctx->stream, in8, L, H, W, nrow_blocks,
+                                   (const int*)nullptr, (const int*)multi);
+        }
+        AMT_LAUNCH_CHECK();
+        const int jobs = segs * (trows - 1) + (segs - 1) * trows;
+        if (jobs > 0) {
+            if (c8)
+                hipLaunchKernelGGL((ccl_seams_runs_kernel<true>), dim3((jobs + 3) / 4, 1, nplanes), dim3(256), 0, ctx->stream,
+                                   tbits, rtab, nruns, L, H, W, segs, trows, (const int*)multi);
+            else
+                hipLaunchKernelGGL((ccl_seams_runs_kernel<false>), dim3((jobs + 3) / 4, 1, nplanes), dim3(256), 0, ctx->stream,
+                                   tbits, rtab, nruns, L, H, W, segs, trows, (const int*)multi);
+            AMT_LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(roots_compress_count_kernel, dim3(4, trows, nplanes), dim3(256), 0, ctx->stream, L, rootlist,
+                           nroots, blk, bitmap, cap, n, nblk);
+        AMT_LAUNCH_CHECK();
+        AMT_TRY(amt_scan_excl(ctx, blk, nblk, (size_t)nblk, count_dev, nplanes));
+        hipLaunchKernelGGL(roots_rank_kernel, dim3(4, trows, nplanes), dim3(256), 0, ctx->stream, T, L, rootlist, nroots,
+                           blk, bitmap, cap, n, nblk);
+        AMT_LAUNCH_CHECK();
+        hipLaunchKernelGGL(ccl_expand_runs_kernel, dim3((ntiles + 3) / 4), dim3(256), 0, ctx->stream, tbits, rtab, nruns, T, out,
+                           H, W, segs, trows, ntiles, (const int*)multi);
+        AMT_LAUNCH_CHECK();
+        hipLaunchKernelGGL(apply_rank_kernel, dim3(amt_grid_for(n, 1024, 256), nplanes), dim3(256), 0, ctx->stream, L, T, out, n,
+                           (const int*)multi);
+        AMT_LAUNCH_CHECK();
+        return AMT_OK;
+    }
     if (in_dtype == AMT_U8) {
         if (connectivity == 2)
             AMT_TRY((ccl_tileroots<uint8_t, true>(ctx, (const uint8_t*)in, L, rootlist, nroots, nplanes, H, W, multi)));
