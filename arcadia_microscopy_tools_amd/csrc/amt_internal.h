@@ -91,6 +91,15 @@ size_t amt_i_rootlist_cap(int W);
 size_t amt_i_ccl_scratch_ints(int nplanes, int H, int W);  // ints of scratch behind `multi`
 int amt_i_ccl_tileroots_u8(amt_ctx* ctx, const uint8_t* in, int* L, int* rootlist, int* nroots, int nplanes, int H,
                            int W, int* multi = nullptr);
+// Run tables of a 0 / 1 (or truth-value) mask, per 64 x 64 tile t = (plane * tile_rows + tile_row) * segments + segment:
+//   tbits[t * 64 + row]   the row's 64 pixels as a word (bit i = column i)
+//   rtab[t * RT_CAP + k]  for the tile's k-th run in raster order: (row << 6 | column) of the first pixel of its TILE ROOT
+//   nruns[t]              number of runs
+// A pixel's run: runs of the rows above (prefix sum of the rows' head counts) + heads at or before it in its own row.
+constexpr int RT_CAP = 2048;  // 64 rows x at most 32 runs
+bool amt_i_ccl_runs_ok(const void* in, int H, int W, int nplanes);
+int amt_i_ccl_tileroots_runs_u8(amt_ctx* ctx, const uint8_t* in, int* L, int* rootlist, int* nroots, int nplanes, int H,
+                                int W, unsigned long long* tbits, unsigned short* rtab, int* nruns);
 // A[t] = A[L[t]] for every listed tile root t (lists compressed): a pixel then reaches its component's entry of A
 // with one hop through its tile root
 int amt_i_propagate_roots(amt_ctx* ctx, int* A, const int* L, const int* rootlist, const int* nroots, int nplanes, int H,
@@ -108,6 +117,20 @@ int amt_i_drop_and_scan(amt_ctx* ctx, int* P, int max_label, int* count_dev, int
 // amt_lane_left / lane 63 of amt_lane_right receive 0, every caller masks those lanes itself.  All 64 lanes must be
 // active (call from wave-uniform control flow only).
 #ifdef __HIPCC__
+__device__ __forceinline__ int ccl_wave_incl_scan(int v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(v, o);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+// flat index (inside its plane) of the tile root of run k of tile (ty, bx)
+__device__ __forceinline__ int ccl_rt_root(const unsigned short* __restrict__ rtab, size_t tile, int k, int ty, int bx,
+                                           int W) {
+    const int e = rtab[tile * RT_CAP + k];
+    return (ty * 64 + (e >> 6)) * W + bx * 64 + (e & 63);
+}
 __device__ __forceinline__ int amt_lane_left(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }
 __device__ __forceinline__ int amt_lane_right(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false); }
 __device__ __forceinline__ long long amt_lane_left(long long v) {

@@ -331,6 +331,8 @@ __device__ __forceinline__ void ccl_runion(int* S, int a, int b) {
 }
 
 // the lane's row of a 64 x 64 tile as a word (bit i = byte i is 1); `other` collects bits of bytes that are not 0 / 1
+// NONZERO: bit i = byte i is not 0 (a watershed's mask is a truth value; `other` stays 0)
+template <bool NONZERO = false>
 __device__ __forceinline__ unsigned long long ccl_bits_load_row(const uint8_t* __restrict__ img, int H, int W, int x0, int y,
                                                                 unsigned& other) {
     unsigned long long w = 0;
@@ -348,8 +350,10 @@ __device__ __forceinline__ unsigned long long ccl_bits_load_row(const uint8_t* _
         unsigned sixteen = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            other |= v[k] & 0xFEFEFEFEu;
-            sixteen |= (((v[k] & 0x01010101u) * 0x01020408u) >> 24) << (4 * k);  // byte i -> bit i
+            unsigned one = v[k] & 0x01010101u;
+            if (NONZERO) one = ((((v[k] & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v[k]) >> 7) & 0x01010101u;
+            else other |= v[k] & 0xFEFEFEFEu;
+            sixteen |= ((one * 0x01020408u) >> 24) << (4 * k);  // byte i -> bit i
         }
         if (x0 + 16 * j < W) w |= (unsigned long long)(sixteen & 0xFFFFu) << (16 * j);
     }
@@ -498,24 +502,18 @@ __global__ void __launch_bounds__(64) ccl_tile_bits_kernel(const uint8_t* __rest
 // themselves -- the union-find of the seams and the raster numbering only ever touch tile roots.  The seams are stitched
 // from the row words (a wave per tile boundary), and the last pass expands (row words, run table, rank of every tile
 // root) into labels: 1 + ~0.2 bytes read and 4 written per pixel.
-constexpr int RT_CAP = 2048;  // runs per tile: 64 rows x at most 32 runs
+// (RT_CAP, ccl_wave_incl_scan, ccl_rt_root: amt_internal.h -- the watershed reads the tables too)
 
-__device__ __forceinline__ int ccl_wave_incl_scan(int v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(v, o);
-        if (lane >= o) v += t;
-    }
-    return v;
-}
-
-template <bool CONN8>
+// WS: the watershed's variant -- the mask is a truth value (no fallback, multi unused), the parent plane is written as
+// well (the floods and the sparse look-ups of that stage still read it)
+template <bool CONN8, bool WS = false>
 __global__ void __launch_bounds__(64) ccl_tile_runs_kernel(const uint8_t* __restrict__ in, int* __restrict__ Lall, int H,
                                                            int W, int* __restrict__ rootlist, int* __restrict__ nroots,
                                                            size_t cap, int* __restrict__ multi,
                                                            unsigned long long* __restrict__ tbits,
                                                            unsigned short* __restrict__ rtab, int* __restrict__ nruns) {
     __shared__ int S[64 * 32];
+    __shared__ unsigned long long bits[WS ? 64 : 1];
     const size_t n = (size_t)H * W;
     const uint8_t* img = in + (size_t)blockIdx.z * n;
     int* L = Lall + (size_t)blockIdx.z * n;
@@ -523,9 +521,10 @@ __global__ void __launch_bounds__(64) ccl_tile_runs_kernel(const uint8_t* __rest
     const int x0 = blockIdx.x * 64, ty0 = blockIdx.y * 64;
     const size_t tile = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     unsigned other;
-    const unsigned long long w = ccl_bits_load_row(img, H, W, x0, ty0 + lane, other);
-    if (__ballot(other != 0) && lane == 0) atomicOr(multi, 1);
+    const unsigned long long w = ccl_bits_load_row<WS>(img, H, W, x0, ty0 + lane, other);
+    if (!WS && __ballot(other != 0) && lane == 0) atomicOr(multi, 1);
     tbits[tile * 64 + lane] = w;
+    if (WS) bits[lane] = w;
     const unsigned long long heads = w & ~(w << 1);
     const int nroot = ccl_bits_unionfind<CONN8>(S, w, heads, lane);
     // compact run ordinals (raster order) and the tile's slice of its tile row's root list
@@ -544,18 +543,40 @@ __global__ void __launch_bounds__(64) ccl_tile_runs_kernel(const uint8_t* __rest
         rt[j] = (unsigned short)(((e >> 11) << 6) | (e & 63));
         if ((e >> 6) == own) {
             const int pix = (ty0 + lane) * W + x0 + (e & 63);
-            L[pix] = pix;
+            if (!WS) L[pix] = pix;
             if (pos < cap) rootlist[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * cap + pos] = pix;
             ++pos;
         }
     }
     if (lane == 63) nruns[tile] = incl;
-}
-
-__device__ __forceinline__ int ccl_rt_root(const unsigned short* __restrict__ rtab, size_t tile, int k, int ty, int bx,
-                                           int W) {
-    const int e = rtab[tile * RT_CAP + k];
-    return (ty * 64 + (e >> 6)) * W + bx * 64 + (e & 63);
+    if (!WS) return;
+    // ---- the parent plane: a lane owns four consecutive pixels of a row, every pixel points at its tile root ----
+    const int c4 = (lane & 15) * 4, rsub = lane >> 4;
+    const int xg = x0 + c4;
+    if (xg >= W) return;
+#pragma unroll 4
+    for (int jj = 0; jj < 16; ++jj) {
+        const int row = rsub + 4 * jj;
+        const int y = ty0 + row;
+        const unsigned long long ww = bits[row];
+        const unsigned long long hw = ww & ~(ww << 1);
+        const unsigned nib = (unsigned)(ww >> c4) & 15u;
+        int4 o = make_int4(-1, -1, -1, -1);
+        if (nib) {
+            int oo[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int x = c4 + i;
+                oo[i] = -1;
+                if ((nib >> i) & 1u) {
+                    const int e = S[row * 32 + __popcll(hw & ((2ull << x) - 1ull)) - 1];
+                    oo[i] = (ty0 + (e >> 11)) * W + x0 + (e & 63);
+                }
+            }
+            o = make_int4(oo[0], oo[1], oo[2], oo[3]);
+        }
+        if (y < H) *reinterpret_cast<int4*>(L + (size_t)y * W + xg) = o;
+    }
 }
 
 // The seams from the tiles' row words: a wave per tile boundary.  jobs [0, segs * (trows - 1)): the row pair across a
@@ -567,7 +588,7 @@ __global__ void __launch_bounds__(256) ccl_seams_runs_kernel(const unsigned long
                                                              const unsigned short* __restrict__ rtab,
                                                              const int* __restrict__ nruns, int* __restrict__ Lall, int H,
                                                              int W, int segs, int trows, const int* __restrict__ multi) {
-    if (*multi) return;
+    if (multi && *multi) return;
     const int lane = threadIdx.x & 63;
     const int job = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int nrowjobs = segs * (trows - 1);
@@ -642,14 +663,16 @@ __global__ void __launch_bounds__(256) ccl_seams_runs_kernel(const unsigned long
 }
 
 // labels from (row words, run table, T at the tile roots): a wave per tile, four tiles per workgroup.  T[tile root] is
-// what the caller wants written for the root's component (the raster rank in amt_label).
+// what the caller wants written for the root's component (the raster rank in amt_label).  Tiles with more than XR_CAP runs
+// (noise) gather per pixel instead of through LDS.
+constexpr int XR_CAP = 512;
 __global__ void __launch_bounds__(256) ccl_expand_runs_kernel(const unsigned long long* __restrict__ tbits,
                                                               const unsigned short* __restrict__ rtab,
                                                               const int* __restrict__ nruns, const int* __restrict__ Tall,
                                                               int* __restrict__ outall, int H, int W, int segs, int trows,
                                                               int ntiles, const int* __restrict__ multi) {
     if (*multi) return;
-    __shared__ int lab_s[4][RT_CAP];
+    __shared__ int lab_s[4][XR_CAP];
     __shared__ unsigned long long bits_s[4][64];
     __shared__ int off_s[4][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -677,10 +700,14 @@ __global__ void __launch_bounds__(256) ccl_expand_runs_kernel(const unsigned lon
     const int cnt = __popcll(w & ~(w << 1));
     bits_s[wv][lane] = w;
     off_s[wv][lane] = ccl_wave_incl_scan(cnt, lane) - cnt;
-    for (int k = lane; k < nr; k += 64) lab_s[wv][k] = T[ccl_rt_root(rtab, (size_t)t, k, ty, bx, W)];
+    const bool fast = nr <= XR_CAP;
+    if (fast)
+        for (int k = lane; k < nr; k += 64) lab_s[wv][k] = T[ccl_rt_root(rtab, (size_t)t, k, ty, bx, W)];
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
     if (xg >= W) return;
+    const int* lb = lab_s[wv];
+    auto lab = [&](int k) -> int { return fast ? lb[k] : T[ccl_rt_root(rtab, (size_t)t, k, ty, bx, W)]; };
 #pragma unroll 4
     for (int j = 0; j < 16; ++j) {
         const int row = rsub + 4 * j;
@@ -692,11 +719,10 @@ __global__ void __launch_bounds__(256) ccl_expand_runs_kernel(const unsigned lon
         if (nib) {
             // the run of pixel c4 + i = heads at or before it, minus one
             const int k0 = off_s[wv][row] + __popcll(hw & ((1ull << c4) - 1ull)) - 1;
-            const int* lb = lab_s[wv];
-            if (nib & 1u) o.x = lb[k0 + (int)(hnib & 1u)];
-            if (nib & 2u) o.y = lb[k0 + __popc(hnib & 3u)];
-            if (nib & 4u) o.z = lb[k0 + __popc(hnib & 7u)];
-            if (nib & 8u) o.w = lb[k0 + __popc(hnib)];
+            if (nib & 1u) o.x = lab(k0 + (int)(hnib & 1u));
+            if (nib & 2u) o.y = lab(k0 + __popc(hnib & 3u));
+            if (nib & 4u) o.z = lab(k0 + __popc(hnib & 7u));
+            if (nib & 8u) o.w = lab(k0 + __popc(hnib));
         }
         if (y < H) *reinterpret_cast<int4*>(out + (size_t)y * W + xg) = o;
     }
@@ -897,21 +923,21 @@ int amt_i_ccl_roots(amt_ctx* ctx, const void* in, int in_dtype, int* L, int* blk
 int amt_i_tile_rows(int H) { return (H + TILE_R - 1) / TILE_R; }
 size_t amt_i_rootlist_cap(int W) { return (size_t)TILE_R * W; }
 
-// AMT_CCL_BITS=0: the pixel-per-lane tile kernel for masks too (A/B switch; identical results)
-static bool ccl_bits_enabled() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("AMT_CCL_BITS");
-        v = (e && e[0] == '0') ? 0 : 1;
-    }
-    return v == 1;
-}
-
 // AMT_CCL_RUNS=0: amt_label keeps the parent plane for masks too (A/B switch; identical results)
 static bool ccl_runs_enabled() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("AMT_CCL_RUNS");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
+}
+
+// AMT_CCL_BITS=0: the pixel-per-lane tile kernel for masks too (A/B switch; identical results)
+static bool ccl_bits_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("AMT_CCL_BITS");
         v = (e && e[0] == '0') ? 0 : 1;
     }
     return v == 1;
@@ -967,6 +993,28 @@ static int ccl_tileroots(amt_ctx* ctx, const T* in, int* L, int* rootlist, int* 
                                (const int*)multi);
             AMT_LAUNCH_CHECK();
         }
+    }
+    return AMT_OK;
+}
+
+// the watershed's labelling of its mask (4-connected components of the NON-ZERO bytes): parent plane + root lists as
+// amt_i_ccl_tileroots_u8 leaves them, and the run tables beside them (amt_internal.h)
+bool amt_i_ccl_runs_ok(const void* in, int H, int W, int nplanes) {
+    return ccl_runs_enabled() && W % 16 == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0 && ((size_t)H * W) % 16 == 0 &&
+           (size_t)nplanes * amt_i_tile_rows(H) * ((W + 63) / 64) * 64 < 0x7fffffffull;
+}
+
+int amt_i_ccl_tileroots_runs_u8(amt_ctx* ctx, const uint8_t* in, int* L, int* rootlist, int* nroots, int nplanes, int H,
+                                int W, unsigned long long* tbits, unsigned short* rtab, int* nruns) {
+    const int segs = (W + 63) / 64, trows = amt_i_tile_rows(H);
+    hipLaunchKernelGGL((ccl_tile_runs_kernel<false, true>), dim3(segs, trows, nplanes), dim3(64), 0, ctx->stream, in, L, H, W,
+                       rootlist, nroots, amt_i_rootlist_cap(W), (int*)nullptr, tbits, rtab, nruns);
+    AMT_LAUNCH_CHECK();
+    const int jobs = segs * (trows - 1) + (segs - 1) * trows;
+    if (jobs > 0) {
+        hipLaunchKernelGGL((ccl_seams_runs_kernel<false>), dim3((jobs + 3) / 4, 1, nplanes), dim3(256), 0, ctx->stream, tbits,
+                           rtab, nruns, L, H, W, segs, trows, (const int*)nullptr);
+        AMT_LAUNCH_CHECK();
     }
     return AMT_OK;
 }

@@ -128,16 +128,30 @@ __global__ void __launch_bounds__(256) ws_roots_kernel(int* __restrict__ Lall, i
     int* T = Tall + (size_t)plane * n;
     const int cnt = nroots[shard] < (int)cap ? nroots[shard] : (int)cap;
     const int* lst = rootlist + (size_t)shard * cap;
-    for (int k = blockIdx.x * 256 + threadIdx.x; k < cnt; k += gridDim.x * 256) {
-        const int t = lst[k];
-        int r = L[t];
-        int p = L[r];
-        while (p != r) {  // roots only ever point at smaller indices: the chain ends at the component root
-            r = p;
-            p = L[r];
+    const int lane = threadIdx.x & 63;
+    for (int k0 = blockIdx.x * 256; k0 < cnt; k0 += gridDim.x * 256) {  // block-uniform bounds: the ballot below is whole-wave
+        const int k = k0 + threadIdx.x;
+        bool is_root = false;
+        int t = 0;
+        if (k < cnt) {
+            t = lst[k];
+            int r = L[t];
+            int p = L[r];
+            while (p != r) {  // roots only ever point at smaller indices: the chain ends at the component root
+                r = p;
+                p = L[r];
+            }
+            if (r != t) L[t] = r;
+            else is_root = true;
         }
-        if (r != t) L[t] = r;
-        else T[t] = atomicAdd(&ncomp[plane], 1) + 1;
+        // one counter per plane: a returning atomic per ROOT queued ~1,000 deep on one address; now one per wave
+        const unsigned long long m = __ballot(is_root);
+        if (m) {
+            int base = 0;
+            if (lane == __ffsll((long long)m) - 1) base = atomicAdd(&ncomp[plane], __popcll(m));
+            base = __shfl(base, __ffsll((long long)m) - 1);
+            if (is_root) T[t] = base + __popcll(m & ((1ull << lane) - 1ull)) + 1;
+        }
     }
 }
 
@@ -264,6 +278,137 @@ __global__ void __launch_bounds__(256) ws_stats_kernel(const int* __restrict__ d
     }
 }
 
+// ---- the same statistics from the mask's run tables (round 3; amt_internal.h) ------------------------------------------
+// ws_stats_kernel reads the parent plane (4 bytes per pixel) only to learn which component a pixel belongs to, and asks
+// for a component's row once per pixel.  A tile's run table says the same with one entry per RUN: a wave per tile, first
+// a lane per run (component id of the run's tile root; the ordinal of the root's own run), then
+//   * a lane per ROW: bounding box from the run's ends, with the filters of ws_stats_kernel expressed on row words (a run
+//     with a mask pixel right above / below it cannot be its component's first / last row, ...), and the component root;
+//   * a lane per four pixels: d2 is read only where the mask is set, maxima are folded per TILE ROOT in LDS, one global
+//     atomic per tile root.
+// Tiles with more than SR_CAP runs (noise) take a per-run path without LDS tables.
+constexpr int SR_CAP = 512;
+
+__global__ void __launch_bounds__(256) ws_stats_runs_kernel(const int* __restrict__ d2all, const unsigned long long* __restrict__ tbits,
+                                                            const unsigned short* __restrict__ rtab,
+                                                            const int* __restrict__ nruns, const int* __restrict__ Lall,
+                                                            const int* __restrict__ Tall, comp_row* __restrict__ rows,
+                                                            size_t row_stride, int H, int W, int segs, int trows, int ntiles) {
+    __shared__ int comp_s[4][SR_CAP];
+    __shared__ int cm_s[4][SR_CAP];
+    __shared__ unsigned short kr_s[4][SR_CAP];
+    __shared__ unsigned long long bits_s[4][64];
+    __shared__ int off_s[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int t = blockIdx.x * 4 + wv;
+    if (t >= ntiles) return;  // whole wave
+    const int nr = nruns[t];
+    if (nr == 0) return;
+    const int bx = t % segs, ty = (t / segs) % trows, plane = t / (segs * trows);
+    const size_t n = (size_t)H * W;
+    const int* T = Tall + (size_t)plane * n;
+    const int* L = Lall + (size_t)plane * n;
+    const int* d2 = d2all + (size_t)plane * n;
+    comp_row* prow = rows + (size_t)plane * row_stride;
+    const int x0 = bx * 64, ty0 = ty * 64;
+    const unsigned long long w = tbits[(size_t)t * 64 + lane];
+    const unsigned long long heads = w & ~(w << 1);
+    const int cnt = __popcll(heads);
+    const int off = ccl_wave_incl_scan(cnt, lane) - cnt;
+    bits_s[wv][lane] = w;
+    off_s[wv][lane] = off;
+    const bool fast = nr <= SR_CAP;
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    if (fast) {
+        for (int k = lane; k < nr; k += 64) {
+            const int e = rtab[(size_t)t * RT_CAP + k];
+            const int rrow = e >> 6, rcol = e & 63;
+            comp_s[wv][k] = T[(ty0 + rrow) * W + x0 + rcol];
+            const unsigned long long rw = bits_s[wv][rrow];
+            kr_s[wv][k] = (unsigned short)(off_s[wv][rrow] + __popcll((rw & ~(rw << 1)) & ((2ull << rcol) - 1ull)) - 1);
+            cm_s[wv][k] = 0;
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+    }
+    // ---- a lane per row: run geometry ----
+    {
+        const int y = ty0 + lane;
+        const unsigned long long above = lane > 0 ? bits_s[wv][lane - 1] : 0ull;   // row 0 / 63 of the tile: unknown, always ask
+        const unsigned long long below = lane < 63 ? bits_s[wv][lane + 1] : 0ull;
+        int j = 0;
+        for (unsigned long long h = heads; h; h &= h - 1, ++j) {
+            const int b = __ffsll((long long)h) - 1;
+            const unsigned long long tt = w >> b;
+            const int len = ~tt ? __ffsll((long long)~tt) - 1 : 64;
+            const unsigned long long rm = (len >= 64 ? ~0ull : ((1ull << len) - 1ull)) << b;
+            const int k = off + j;
+            const int e = rtab[(size_t)t * RT_CAP + k];
+            const int c = fast ? comp_s[wv][k] : T[(ty0 + (e >> 6)) * W + x0 + (e & 63)];
+            comp_row* cr = prow + (c - 1);
+            const int last = b + len - 1;
+            if (!(above & rm)) atomicMin(&cr->y0, y);
+            if (!(below & rm)) atomicMax(&cr->y1, y);
+            // x0: a mask pixel right above the run's first pixel, or below it AND below-left of it, belongs to a run of
+            // this component that starts at <= / < this one; mirrored for x1 ("above: <=, below: <" cannot form a circle)
+            if (!(((above >> b) & 1ull) || (b > 0 && ((below >> (b - 1)) & 3ull) == 3ull))) atomicMin(&cr->x0, x0 + b);
+            if (!(((above >> last) & 1ull) || (last < 63 && ((below >> last) & 3ull) == 3ull))) atomicMax(&cr->x1, x0 + last);
+            if (e == ((lane << 6) | b)) {  // the tile root's own run; the component's root is its own parent
+                const int p = y * W + x0 + b;
+                if (L[p] == p) cr->root = p;
+            }
+            if (!fast) {
+                int m = 0;
+                for (int x = b; x <= last; ++x) {
+                    const int v = d2[(size_t)y * W + x0 + x];
+                    m = v > m ? v : m;
+                }
+                if (m > 0) atomicMax(&cr->cmax, m);
+            }
+        }
+    }
+    if (!fast) return;
+    // ---- a lane per four pixels: max d2 per tile root ----
+    const int c4 = (lane & 15) * 4, rsub = lane >> 4;
+    const int xg = x0 + c4;
+    int4 v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int row = rsub + 4 * j;
+        const unsigned nib = (unsigned)(bits_s[wv][row] >> c4) & 15u;
+        v[j] = make_int4(0, 0, 0, 0);
+        if (nib) v[j] = *reinterpret_cast<const int4*>(d2 + (size_t)(ty0 + row) * W + xg);  // mask bits exist inside the image only
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int row = rsub + 4 * j;
+        const unsigned long long ww = bits_s[wv][row];
+        const unsigned nib = (unsigned)(ww >> c4) & 15u;
+        if (!nib) continue;
+        const unsigned long long hw = ww & ~(ww << 1);
+        const unsigned hnib = (unsigned)(hw >> c4) & 15u;
+        const int k0 = off_s[wv][row] + __popcll(hw & ((1ull << c4) - 1ull)) - 1;  // the run open at the nibble's left edge
+        const int vv[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+        const int first = __ffs((int)nib) - 1;
+        if ((hnib >> (first + 1)) == 0u) {
+            // one run in these four pixels (the usual case): one LDS atomic
+            int m = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) m = ((nib >> i) & 1u) && vv[i] > m ? vv[i] : m;
+            if (m > 0) atomicMax(&cm_s[wv][kr_s[wv][k0 + __popc(hnib & ((2u << first) - 1u))]], m);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (((nib >> i) & 1u) && vv[i] > 0) atomicMax(&cm_s[wv][kr_s[wv][k0 + __popc(hnib & ((2u << i) - 1u))]], vv[i]);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    for (int k = lane; k < nr; k += 64)
+        if (kr_s[wv][k] == k && cm_s[wv][k] > 0) atomicMax(&(prow + (comp_s[wv][k] - 1))->cmax, cm_s[wv][k]);
+}
+
 // marker statistics from the LIST of marker pixels (amt_label_sparse_reuse keeps it): a few thousand pixels per plane
 // instead of a 4-byte read of every pixel of the marker plane in ws_stats_kernel
 __global__ void __launch_bounds__(256) ws_marker_stats_kernel(const int* __restrict__ mk_list, const int* __restrict__ mk_count,
@@ -298,10 +443,15 @@ __global__ void __launch_bounds__(256) ws_classify_kernel(comp_row* __restrict__
     int* mo = moff + (size_t)blockIdx.y * row_stride;
     int* bo = boff + (size_t)blockIdx.y * row_stride;
     const int nc = ncomp[blockIdx.y];
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < nc; i += gridDim.x * 256) {
-        comp_row c = r[i];
+    const int lane = threadIdx.x & 63;
+    for (int i0 = blockIdx.x * 256; i0 < nc; i0 += gridDim.x * 256) {  // block-uniform bounds: whole-wave ballots below
+        const int i = i0 + threadIdx.x;
+        const bool live = i < nc;
+        comp_row c = r[live ? i : 0];
         int cls;
-        if (c.mcnt == 0) {
+        if (!live) {
+            cls = CLS_NONE;
+        } else if (c.mcnt == 0) {
             cls = CLS_NONE;
         } else if (c.labmin == c.labmax) {
             cls = CLS_UNIFORM;
@@ -322,19 +472,28 @@ __global__ void __launch_bounds__(256) ws_classify_kernel(comp_row* __restrict__
             else if (area <= X_PX && c.cmax < X_NB) cls = CLS_X;
             else cls = CLS_G;
         }
-        r[i].cls = cls;
-        // per-root fill value: the label of a single-label component, 0 = flooded (labels come from the flood),
-        // -1 = no marker at all (stays background)
-        Fall[(size_t)blockIdx.y * n + c.root] = cls == CLS_UNIFORM ? c.labmin : (cls == CLS_NONE ? -1 : 0);
-        if (cls == CLS_G) has_g[blockIdx.y] = 1;
-        if (cls >= CLS_XS && cls <= CLS_LB) {
-            // per-class worklist of this plane (order is irrelevant: components are independent)
-            const int k = cls - CLS_XS;
-            const int pos = atomicAdd(&wl_count[k * nplanes + blockIdx.y], 1);
-            wl[((size_t)k * nplanes + blockIdx.y) * row_stride + pos] = i;
+        if (live) {
+            r[i].cls = cls;
+            // per-root fill value: the label of a single-label component, 0 = flooded (labels come from the flood),
+            // -1 = no marker at all (stays background)
+            Fall[(size_t)blockIdx.y * n + c.root] = cls == CLS_UNIFORM ? c.labmin : (cls == CLS_NONE ? -1 : 0);
+            if (cls == CLS_G) has_g[blockIdx.y] = 1;
+            mo[i] = cls == CLS_G ? c.mcnt : 0;
+            bo[i] = cls == CLS_G ? (use_d2 ? c.cmax + 1 : c.cmax) : 0;
         }
-        mo[i] = cls == CLS_G ? c.mcnt : 0;
-        bo[i] = cls == CLS_G ? (use_d2 ? c.cmax + 1 : c.cmax) : 0;
+        // per-class worklists of this plane (order is irrelevant: components are independent).  One slot counter per
+        // class and plane: a returning atomic per COMPONENT queued hundreds deep on one address (the kernel took 60 us
+        // for 50,000 components); a wave now reserves its slots with one atomic per class it holds
+        for (int k = 0; k <= CLS_LB - CLS_XS; ++k) {
+            const unsigned long long m = __ballot(live && cls == CLS_XS + k);
+            if (!m) continue;
+            const int leader = __ffsll((long long)m) - 1;
+            int base = 0;
+            if (lane == leader) base = atomicAdd(&wl_count[k * nplanes + blockIdx.y], __popcll(m));
+            base = __shfl(base, leader);
+            if (live && cls == CLS_XS + k)
+                wl[((size_t)k * nplanes + blockIdx.y) * row_stride + base + __popcll(m & ((1ull << lane) - 1ull))] = i;
+        }
     }
 }
 
@@ -1567,6 +1726,114 @@ __global__ void __launch_bounds__(256) ws_final_kernel(const int* __restrict__ L
     }
 }
 
+// ws_final_kernel from the run tables: a wave per tile turns (row words, run table, the final label of every tile root,
+// the label map) into final labels -- the parent plane is not read; the flood's plane only where a flooded component has
+// pixels.  ws_final_map_kernel first replaces F at every listed tile root by what its pixels are to receive (the mapped
+// label of a single-label component, -1 = flooded: look in the flood's plane, 0 = background), so that a run costs ONE
+// gather here.  The write-out keeps to the rule of this file: all loads of eight rows are in flight (the flood plane's,
+// predicated, and then the map's) before the first store.
+__global__ void __launch_bounds__(256) ws_final_map_kernel(int* __restrict__ Fall, const int* __restrict__ map,
+                                                           const int* __restrict__ rootlist, const int* __restrict__ nroots,
+                                                           size_t cap, size_t n, int max_label) {
+    const int plane = blockIdx.z, shard = plane * gridDim.y + blockIdx.y;
+    int* F = Fall + (size_t)plane * n;
+    const int* M = map + (size_t)plane * (max_label + 1);
+    const int cnt = nroots[shard] < (int)cap ? nroots[shard] : (int)cap;
+    const int* lst = rootlist + (size_t)shard * cap;
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < cnt; k += gridDim.x * 256) {
+        const int t = lst[k], f = F[t];
+        F[t] = f > 0 ? ((unsigned)(f - 1) < (unsigned)max_label ? M[f] : 0) : (f == 0 ? -1 : 0);
+    }
+}
+
+__global__ void __launch_bounds__(256) ws_final_runs_kernel(const unsigned long long* __restrict__ tbits,
+                                                            const unsigned short* __restrict__ rtab,
+                                                            const int* __restrict__ nruns, const int* __restrict__ Fall,
+                                                            const int* __restrict__ wsall, const int* __restrict__ map,
+                                                            int* __restrict__ outall, int H, int W, int segs, int trows,
+                                                            int ntiles, int max_label) {
+    __shared__ int lab_s[4][SR_CAP];
+    __shared__ unsigned long long bits_s[4][64];
+    __shared__ int off_s[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int t = blockIdx.x * 4 + wv;
+    if (t >= ntiles) return;  // whole wave
+    const int bx = t % segs, ty = (t / segs) % trows, plane = t / (segs * trows);
+    const size_t n = (size_t)H * W;
+    const int* F = Fall + (size_t)plane * n;
+    const int* ws = wsall + (size_t)plane * n;
+    const int* M = map + (size_t)plane * (max_label + 1);
+    int* out = outall + (size_t)plane * n;
+    const unsigned ml = (unsigned)max_label;
+    const int x0 = bx * 64, ty0 = ty * 64;
+    const int c4 = (lane & 15) * 4, rsub = lane >> 4;
+    const int xg = x0 + c4;
+    const int nr = nruns[t];
+    if (nr == 0) {  // uniform: nothing but background
+        if (xg < W) {
+#pragma unroll 4
+            for (int j = 0; j < 16; ++j) {
+                const int y = ty0 + rsub + 4 * j;
+                if (y < H) *reinterpret_cast<int4*>(out + (size_t)y * W + xg) = make_int4(0, 0, 0, 0);
+            }
+        }
+        return;
+    }
+    const unsigned long long w = tbits[(size_t)t * 64 + lane];
+    const int cnt = __popcll(w & ~(w << 1));
+    bits_s[wv][lane] = w;
+    off_s[wv][lane] = ccl_wave_incl_scan(cnt, lane) - cnt;
+    const bool fast = nr <= SR_CAP;  // otherwise (noise): a gather per pixel
+    if (fast)
+        for (int k = lane; k < nr; k += 64) lab_s[wv][k] = F[ccl_rt_root(rtab, (size_t)t, k, ty, bx, W)];
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    if (xg >= W) return;
+    const int* lb = lab_s[wv];
+    auto lab = [&](int k) -> int { return fast ? lb[k] : F[ccl_rt_root(rtab, (size_t)t, k, ty, bx, W)]; };
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        int4 o[8], f[8];
+        bool need[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int row = rsub + 4 * (half * 8 + q);
+            const unsigned long long ww = bits_s[wv][row];
+            const unsigned long long hw = ww & ~(ww << 1);
+            const unsigned nib = (unsigned)(ww >> c4) & 15u, hnib = (unsigned)(hw >> c4) & 15u;
+            o[q] = make_int4(0, 0, 0, 0);
+            if (nib) {
+                const int k0 = off_s[wv][row] + __popcll(hw & ((1ull << c4) - 1ull)) - 1;
+                if (nib & 1u) o[q].x = lab(k0 + (int)(hnib & 1u));
+                if (nib & 2u) o[q].y = lab(k0 + __popc(hnib & 3u));
+                if (nib & 4u) o[q].z = lab(k0 + __popc(hnib & 7u));
+                if (nib & 8u) o[q].w = lab(k0 + __popc(hnib));
+            }
+            need[q] = (o[q].x | o[q].y | o[q].z | o[q].w) < 0;  // pixels of a flooded component: labels in the flood's plane
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int y = ty0 + rsub + 4 * (half * 8 + q);
+            f[q] = make_int4(0, 0, 0, 0);
+            if (need[q]) f[q] = *reinterpret_cast<const int4*>(ws + (size_t)y * W + xg);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (need[q]) {
+                if (o[q].x < 0) o[q].x = (unsigned)(f[q].x - 1) < ml ? M[f[q].x] : 0;
+                if (o[q].y < 0) o[q].y = (unsigned)(f[q].y - 1) < ml ? M[f[q].y] : 0;
+                if (o[q].z < 0) o[q].z = (unsigned)(f[q].z - 1) < ml ? M[f[q].z] : 0;
+                if (o[q].w < 0) o[q].w = (unsigned)(f[q].w - 1) < ml ? M[f[q].w] : 0;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int y = ty0 + rsub + 4 * (half * 8 + q);
+            if (y < H) *reinterpret_cast<int4*>(out + (size_t)y * W + xg) = o[q];
+        }
+    }
+}
+
 // AMT_WS_ANYORDER=0 keeps the flood classes of a context without auxiliary streams strictly in order (A/B switch)
 static bool ws_anyorder() {
     static int v = -1;
@@ -1605,6 +1872,16 @@ static int ws_pf_waves() {
         if (v < 1 || v > PF_WAVES) v = 10;
     }
     return v;
+}
+
+// AMT_WS_RUNS=0: the fused chain reads the parent plane in its statistics and final passes (A/B switch; same results)
+static bool ws_runs_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("AMT_WS_RUNS");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
 }
 
 // AMT_WS_LDS_PAD=bytes: extra dynamic LDS per flood workgroup (occupancy experiments only)
@@ -1684,6 +1961,14 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     if (fused_labels) need += amt_align(msz * 4);
     const size_t ccl_ints = amt_i_ccl_scratch_ints(nplanes, H, W);
     need += amt_align(ccl_ints * 4);
+    // the fused chain's path (d2 relief, marker list, clear_border + relabel fused): the mask's run tables serve the
+    // statistics and the final mapping instead of the parent plane (AMT_WS_RUNS=0: the parent plane everywhere)
+    const int segs = (W + 63) / 64;
+    const int ntiles = nplanes * trows * segs;
+    const bool runs = use_d2 && fused_labels && mk_list && ws_runs_enabled() && amt_i_ccl_runs_ok(mask, H, W, nplanes) &&
+                      (reinterpret_cast<uintptr_t>(fused_labels) & 15) == 0 && (reinterpret_cast<uintptr_t>(relief) & 15) == 0 &&
+                      (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+    if (runs) need += amt_align((size_t)ntiles * 64 * 8) + amt_align((size_t)ntiles * RT_CAP * 2) + amt_align((size_t)ntiles * 4);
     AMT_TRY(amt_arena_begin(ctx, need));
     int* L = arena_take_t<int>(ctx, np);
     int* T = arena_take_t<int>(ctx, np);
@@ -1707,6 +1992,9 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     int* ccl_scratch = arena_take_t<int>(ctx, ccl_ints);  // the tile labelling's flag + the tiles' column words
     int* ties = ties_dev ? ties_dev : arena_take_t<int>(ctx, nplanes);
     int* P = fused_labels ? arena_take_t<int>(ctx, msz) : nullptr;
+    unsigned long long* tbits = runs ? arena_take_t<unsigned long long>(ctx, (size_t)ntiles * 64) : nullptr;
+    unsigned short* rtab = runs ? arena_take_t<unsigned short>(ctx, (size_t)ntiles * RT_CAP) : nullptr;
+    int* nruns = runs ? arena_take_t<int>(ctx, (size_t)ntiles) : nullptr;
     int *head = nullptr, *tail = nullptr;
     hp_elem* heap = nullptr;
     hp_elem* gheap = nullptr;
@@ -1728,7 +2016,8 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     // components of the mask with dense ids in T (the order of the ids is irrelevant: components are
     // independent work items and nothing in the output depends on their numbering)
     AMT_HIP_CHECK(hipMemsetAsync(nroots, 0, nlist * 4, ctx->stream));
-    AMT_TRY(amt_i_ccl_tileroots_u8(ctx, mask, L, rootlist, nroots, nplanes, H, W, ccl_scratch));
+    if (runs) AMT_TRY(amt_i_ccl_tileroots_runs_u8(ctx, mask, L, rootlist, nroots, nplanes, H, W, tbits, rtab, nruns));
+    else AMT_TRY(amt_i_ccl_tileroots_u8(ctx, mask, L, rootlist, nroots, nplanes, H, W, ccl_scratch));
     hipLaunchKernelGGL(ws_roots_kernel, dim3(4, trows, nplanes), dim3(256), 0, ctx->stream, L, T, rootlist, nroots, ncomp,
                        lcap, n);
     AMT_LAUNCH_CHECK();
@@ -1739,7 +2028,13 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     int* wl_count = counters + 9 * nplanes;  // [WS_NLISTS][nplanes]
     const int pf_mode = use_d2 ? ws_persist() : 0;  // 0 = class launches, 1 = a whole CU per workgroup, 2 = half a CU
     const int pf_slots = pf_mode == 1 ? ws_pf_slots() : (pf_mode == 2 ? PF_SLOTS_HALF : 0);
-    if (mk_list) {
+    if (runs) {
+        hipLaunchKernelGGL(ws_stats_runs_kernel, dim3((ntiles + 3) / 4), dim3(256), 0, ctx->stream, (const int*)relief, tbits, rtab,
+                           nruns, L, T, rows, row_stride, H, W, segs, trows, ntiles);
+        AMT_LAUNCH_CHECK();
+        hipLaunchKernelGGL(ws_marker_stats_kernel, dim3(16, nplanes), dim3(256), 0, ctx->stream, mk_list, mk_count, mk_cap,
+                           markers, L, T, rows, row_stride, n);
+    } else if (mk_list) {
         // the caller knows where the marker pixels are: the dense pass skips the marker plane
         hipLaunchKernelGGL((ws_stats_kernel<false>), dim3((W + 63) / 64, (H + 31) / 32, nplanes), dim3(256), 0, ctx->stream,
                            use_d2 ? (const int*)relief : (const int*)nullptr, L, T, markers, rows, row_stride, H, W,
@@ -1888,8 +2183,17 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
                            ctx->stream, L, F, out, P, H, W, max_label);
         AMT_LAUNCH_CHECK();
         AMT_TRY(amt_i_drop_and_scan(ctx, P, max_label, fused_count, nplanes));
-        hipLaunchKernelGGL(ws_final_kernel, dim3(amt_grid_for(n, 1024, 4096), nplanes), dim3(256), 0, ctx->stream, L, F, out,
-                           P, fused_labels, n, max_label);
+        if (runs) {
+            hipLaunchKernelGGL(ws_final_map_kernel, dim3(4, trows, nplanes), dim3(256), 0, ctx->stream, F, P, rootlist, nroots, lcap,
+                               n, max_label);
+            AMT_LAUNCH_CHECK();
+        }
+        if (runs)
+            hipLaunchKernelGGL(ws_final_runs_kernel, dim3((ntiles + 3) / 4), dim3(256), 0, ctx->stream, tbits, rtab, nruns, F, out, P,
+                               fused_labels, H, W, segs, trows, ntiles, max_label);
+        else
+            hipLaunchKernelGGL(ws_final_kernel, dim3(amt_grid_for(n, 1024, 4096), nplanes), dim3(256), 0, ctx->stream, L, F, out,
+                               P, fused_labels, n, max_label);
         AMT_LAUNCH_CHECK();
     }
     return AMT_OK;
