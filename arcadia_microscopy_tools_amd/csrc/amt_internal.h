@@ -96,10 +96,23 @@ int amt_i_ccl_tileroots_u8(amt_ctx* ctx, const uint8_t* in, int* L, int* rootlis
 //   rtab[t * RT_CAP + k]  for the tile's k-th run in raster order: (row << 6 | column) of the first pixel of its TILE ROOT
 //   nruns[t]              number of runs
 // A pixel's run: runs of the rows above (prefix sum of the rows' head counts) + heads at or before it in its own row.
+//   roff[t * 64 + row]    runs of the tile's rows above `row` (optional: random look-ups need it, tile-wide passes scan)
 constexpr int RT_CAP = 2048;  // 64 rows x at most 32 runs
 bool amt_i_ccl_runs_ok(const void* in, int H, int W, int nplanes);
+// The watershed's labelling of its mask from run tables alone: 4-connected components of the NON-ZERO bytes; L is written
+// at the tile roots only (L[root] = root, then the seams' unions), the tile roots are listed as amt_i_ccl_tileroots_u8
+// lists them
 int amt_i_ccl_tileroots_runs_u8(amt_ctx* ctx, const uint8_t* in, int* L, int* rootlist, int* nroots, int nplanes, int H,
-                                int W, unsigned long long* tbits, unsigned short* rtab, int* nruns);
+                                int W, unsigned long long* tbits, unsigned short* rtab, int* nruns, unsigned short* roff);
+// what a kernel needs for random look-ups "pixel -> run -> component" (rcomp[t * RT_CAP + k] = the 1-based component id of
+// run k, written by the watershed's statistics pass); tbits == nullptr: no run tables, the caller reads its parent plane
+struct amt_runtabs {
+    const unsigned long long* tbits;
+    const unsigned short* roff;
+    const unsigned short* rtab;
+    const int* rcomp;
+    int segs, trows;
+};
 // A[t] = A[L[t]] for every listed tile root t (lists compressed): a pixel then reaches its component's entry of A
 // with one hop through its tile root
 int amt_i_propagate_roots(amt_ctx* ctx, int* A, const int* L, const int* rootlist, const int* nroots, int nplanes, int H,
@@ -129,6 +142,22 @@ __device__ __forceinline__ int ccl_wave_incl_scan(int v, int lane) {
 __device__ __forceinline__ int ccl_rt_root(const unsigned short* __restrict__ rtab, size_t tile, int k, int ty, int bx,
                                            int W) {
     const int e = rtab[tile * RT_CAP + k];
+    return (ty * 64 + (e >> 6)) * W + bx * 64 + (e & 63);
+}
+// run of pixel (y, x) of `plane`: its index into rtab / rcomp (tile * RT_CAP + ordinal), or -1 for a background pixel
+__device__ __forceinline__ long long amt_rt_px_run(const amt_runtabs& rt, int plane, int y, int x) {
+    const size_t t = ((size_t)plane * rt.trows + (y >> 6)) * rt.segs + (x >> 6);
+    const int row = y & 63, col = x & 63;
+    const unsigned long long w = rt.tbits[t * 64 + row];
+    const int ro = rt.roff[t * 64 + row];
+    if (!((w >> col) & 1ull)) return -1;
+    return (long long)(t * RT_CAP) + ro + __popcll((w & ~(w << 1)) & ((2ull << col) - 1ull)) - 1;
+}
+// flat index (inside its plane) of the tile root of the run with table index ri (as amt_rt_px_run returns it)
+__device__ __forceinline__ int amt_rt_run_root(const amt_runtabs& rt, long long ri, int W) {
+    const size_t t = (size_t)ri / RT_CAP;
+    const int e = rt.rtab[ri];
+    const int bx = (int)(t % rt.segs), ty = (int)((t / rt.segs) % rt.trows);
     return (ty * 64 + (e >> 6)) * W + bx * 64 + (e & 63);
 }
 __device__ __forceinline__ int amt_lane_left(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }

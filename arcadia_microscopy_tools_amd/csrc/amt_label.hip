@@ -504,16 +504,16 @@ __global__ void __launch_bounds__(64) ccl_tile_bits_kernel(const uint8_t* __rest
 // root) into labels: 1 + ~0.2 bytes read and 4 written per pixel.
 // (RT_CAP, ccl_wave_incl_scan, ccl_rt_root: amt_internal.h -- the watershed reads the tables too)
 
-// WS: the watershed's variant -- the mask is a truth value (no fallback, multi unused), the parent plane is written as
-// well (the floods and the sparse look-ups of that stage still read it)
+// WS: the watershed's variant -- the mask is a truth value (no fallback, multi unused) and the rows' run offsets are
+// stored for random look-ups
 template <bool CONN8, bool WS = false>
 __global__ void __launch_bounds__(64) ccl_tile_runs_kernel(const uint8_t* __restrict__ in, int* __restrict__ Lall, int H,
                                                            int W, int* __restrict__ rootlist, int* __restrict__ nroots,
                                                            size_t cap, int* __restrict__ multi,
                                                            unsigned long long* __restrict__ tbits,
-                                                           unsigned short* __restrict__ rtab, int* __restrict__ nruns) {
+                                                           unsigned short* __restrict__ rtab, int* __restrict__ nruns,
+                                                           unsigned short* __restrict__ roff) {
     __shared__ int S[64 * 32];
-    __shared__ unsigned long long bits[WS ? 64 : 1];
     const size_t n = (size_t)H * W;
     const uint8_t* img = in + (size_t)blockIdx.z * n;
     int* L = Lall + (size_t)blockIdx.z * n;
@@ -524,12 +524,12 @@ __global__ void __launch_bounds__(64) ccl_tile_runs_kernel(const uint8_t* __rest
     const unsigned long long w = ccl_bits_load_row<WS>(img, H, W, x0, ty0 + lane, other);
     if (!WS && __ballot(other != 0) && lane == 0) atomicOr(multi, 1);
     tbits[tile * 64 + lane] = w;
-    if (WS) bits[lane] = w;
     const unsigned long long heads = w & ~(w << 1);
     const int nroot = ccl_bits_unionfind<CONN8>(S, w, heads, lane);
     // compact run ordinals (raster order) and the tile's slice of its tile row's root list
     const int cnt = __popcll(heads);
     const int incl = ccl_wave_incl_scan(cnt, lane);
+    if (WS) roff[tile * 64 + lane] = (unsigned short)(incl - cnt);
     const int rincl = ccl_wave_incl_scan(nroot, lane);
     const int tot = __shfl(rincl, 63);
     int base = 0;
@@ -543,40 +543,12 @@ __global__ void __launch_bounds__(64) ccl_tile_runs_kernel(const uint8_t* __rest
         rt[j] = (unsigned short)(((e >> 11) << 6) | (e & 63));
         if ((e >> 6) == own) {
             const int pix = (ty0 + lane) * W + x0 + (e & 63);
-            if (!WS) L[pix] = pix;
+            L[pix] = pix;
             if (pos < cap) rootlist[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * cap + pos] = pix;
             ++pos;
         }
     }
     if (lane == 63) nruns[tile] = incl;
-    if (!WS) return;
-    // ---- the parent plane: a lane owns four consecutive pixels of a row, every pixel points at its tile root ----
-    const int c4 = (lane & 15) * 4, rsub = lane >> 4;
-    const int xg = x0 + c4;
-    if (xg >= W) return;
-#pragma unroll 4
-    for (int jj = 0; jj < 16; ++jj) {
-        const int row = rsub + 4 * jj;
-        const int y = ty0 + row;
-        const unsigned long long ww = bits[row];
-        const unsigned long long hw = ww & ~(ww << 1);
-        const unsigned nib = (unsigned)(ww >> c4) & 15u;
-        int4 o = make_int4(-1, -1, -1, -1);
-        if (nib) {
-            int oo[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int x = c4 + i;
-                oo[i] = -1;
-                if ((nib >> i) & 1u) {
-                    const int e = S[row * 32 + __popcll(hw & ((2ull << x) - 1ull)) - 1];
-                    oo[i] = (ty0 + (e >> 11)) * W + x0 + (e & 63);
-                }
-            }
-            o = make_int4(oo[0], oo[1], oo[2], oo[3]);
-        }
-        if (y < H) *reinterpret_cast<int4*>(L + (size_t)y * W + xg) = o;
-    }
 }
 
 // The seams from the tiles' row words: a wave per tile boundary.  jobs [0, segs * (trows - 1)): the row pair across a
@@ -997,18 +969,17 @@ static int ccl_tileroots(amt_ctx* ctx, const T* in, int* L, int* rootlist, int* 
     return AMT_OK;
 }
 
-// the watershed's labelling of its mask (4-connected components of the NON-ZERO bytes): parent plane + root lists as
-// amt_i_ccl_tileroots_u8 leaves them, and the run tables beside them (amt_internal.h)
+// the watershed's labelling of its mask from run tables (amt_internal.h)
 bool amt_i_ccl_runs_ok(const void* in, int H, int W, int nplanes) {
     return ccl_runs_enabled() && W % 16 == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0 && ((size_t)H * W) % 16 == 0 &&
-           (size_t)nplanes * amt_i_tile_rows(H) * ((W + 63) / 64) * 64 < 0x7fffffffull;
+           (size_t)nplanes * amt_i_tile_rows(H) * ((W + 63) / 64) * RT_CAP < 0x7fffffffull;  // run indices are ints
 }
 
 int amt_i_ccl_tileroots_runs_u8(amt_ctx* ctx, const uint8_t* in, int* L, int* rootlist, int* nroots, int nplanes, int H,
-                                int W, unsigned long long* tbits, unsigned short* rtab, int* nruns) {
+                                int W, unsigned long long* tbits, unsigned short* rtab, int* nruns, unsigned short* roff) {
     const int segs = (W + 63) / 64, trows = amt_i_tile_rows(H);
     hipLaunchKernelGGL((ccl_tile_runs_kernel<false, true>), dim3(segs, trows, nplanes), dim3(64), 0, ctx->stream, in, L, H, W,
-                       rootlist, nroots, amt_i_rootlist_cap(W), (int*)nullptr, tbits, rtab, nruns);
+                       rootlist, nroots, amt_i_rootlist_cap(W), (int*)nullptr, tbits, rtab, nruns, roff);
     AMT_LAUNCH_CHECK();
     const int jobs = segs * (trows - 1) + (segs - 1) * trows;
     if (jobs > 0) {
@@ -1188,10 +1159,10 @@ extern "C" int amt_label(amt_ctx* ctx, const void* in, int in_dtype, int32_t* ou
         dim3 gs(segs, trows, nplanes);
         if (c8)
             hipLaunchKernelGGL((ccl_tile_runs_kernel<true>), gs, dim3(64), 0, ctx->stream, in8, L, H, W, rootlist, nroots, cap,
-                               multi, tbits, rtab, nruns);
+                               multi, tbits, rtab, nruns, (unsigned short*)nullptr);
         else
             hipLaunchKernelGGL((ccl_tile_runs_kernel<false>), gs, dim3(64), 0, ctx->stream, in8, L, H, W, rootlist, nroots, cap,
-                               multi, tbits, rtab, nruns);
+                               multi, tbits, rtab, nruns, (unsigned short*)nullptr);
         AMT_LAUNCH_CHECK();
         hipLaunchKernelGGL(ccl_reset_lists_kernel, dim3(8), dim3(256), 0, ctx->stream, nroots, nlist, (const int*)multi);
         AMT_LAUNCH_CHECK();

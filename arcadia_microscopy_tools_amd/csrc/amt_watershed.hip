@@ -86,9 +86,22 @@ struct comp_row {
 // the HBM flood, which works in `out` itself).
 __global__ void __launch_bounds__(256) ws_seed_kernel(const int* __restrict__ markers, const int* __restrict__ L,
                                                       const int* __restrict__ F, int* __restrict__ out, size_t n,
-                                                      const int* __restrict__ only_planes) {
+                                                      const int* __restrict__ only_planes, amt_runtabs rt, int W) {
     if (only_planes && !only_planes[blockIdx.y]) return;
     const size_t base = (size_t)blockIdx.y * n;
+    if (rt.tbits) {
+        // no parent plane: a look-up per pixel (rare: only planes that hold a component too large for an LDS tile)
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+            const long long ri = amt_rt_px_run(rt, blockIdx.y, (int)(i / W), (int)(i % W));
+            int v = 0;
+            if (ri >= 0) {
+                const int f = F[base + amt_rt_run_root(rt, ri, W)];
+                v = f > 0 ? f : (f == 0 ? markers[base + i] : 0);
+            }
+            out[base + i] = v;
+        }
+        return;
+    }
     for (size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i0 < n; i0 += (size_t)gridDim.x * 1024) {
         if (i0 + 3 < n && ((base + i0) & 3) == 0) {
             const int4 r = *reinterpret_cast<const int4*>(L + base + i0);
@@ -293,7 +306,8 @@ __global__ void __launch_bounds__(256) ws_stats_runs_kernel(const int* __restric
                                                             const unsigned short* __restrict__ rtab,
                                                             const int* __restrict__ nruns, const int* __restrict__ Lall,
                                                             const int* __restrict__ Tall, comp_row* __restrict__ rows,
-                                                            size_t row_stride, int H, int W, int segs, int trows, int ntiles) {
+                                                            size_t row_stride, int H, int W, int segs, int trows, int ntiles,
+                                                            int* __restrict__ rcomp) {
     __shared__ int comp_s[4][SR_CAP];
     __shared__ int cm_s[4][SR_CAP];
     __shared__ unsigned short kr_s[4][SR_CAP];
@@ -324,7 +338,9 @@ __global__ void __launch_bounds__(256) ws_stats_runs_kernel(const int* __restric
         for (int k = lane; k < nr; k += 64) {
             const int e = rtab[(size_t)t * RT_CAP + k];
             const int rrow = e >> 6, rcol = e & 63;
-            comp_s[wv][k] = T[(ty0 + rrow) * W + x0 + rcol];
+            const int cid = T[(ty0 + rrow) * W + x0 + rcol];
+            comp_s[wv][k] = cid;
+            rcomp[(size_t)t * RT_CAP + k] = cid;  // run -> component for the look-ups of the floods, marker lists, frame
             const unsigned long long rw = bits_s[wv][rrow];
             kr_s[wv][k] = (unsigned short)(off_s[wv][rrow] + __popcll((rw & ~(rw << 1)) & ((2ull << rcol) - 1ull)) - 1);
             cm_s[wv][k] = 0;
@@ -346,6 +362,7 @@ __global__ void __launch_bounds__(256) ws_stats_runs_kernel(const int* __restric
             const int k = off + j;
             const int e = rtab[(size_t)t * RT_CAP + k];
             const int c = fast ? comp_s[wv][k] : T[(ty0 + (e >> 6)) * W + x0 + (e & 63)];
+            if (!fast) rcomp[(size_t)t * RT_CAP + k] = c;
             comp_row* cr = prow + (c - 1);
             const int last = b + len - 1;
             if (!(above & rm)) atomicMin(&cr->y0, y);
@@ -414,7 +431,8 @@ __global__ void __launch_bounds__(256) ws_stats_runs_kernel(const int* __restric
 __global__ void __launch_bounds__(256) ws_marker_stats_kernel(const int* __restrict__ mk_list, const int* __restrict__ mk_count,
                                                               int mk_cap, const int* __restrict__ markers,
                                                               const int* __restrict__ L, const int* __restrict__ T,
-                                                              comp_row* __restrict__ rows, size_t row_stride, size_t n) {
+                                                              comp_row* __restrict__ rows, size_t row_stride, size_t n,
+                                                              amt_runtabs rt, int W) {
     const int plane = blockIdx.y;
     const int cnt = mk_count[plane] < mk_cap ? mk_count[plane] : mk_cap;
     const int* lst = mk_list + (size_t)plane * mk_cap;
@@ -422,11 +440,19 @@ __global__ void __launch_bounds__(256) ws_marker_stats_kernel(const int* __restr
     comp_row* prow = rows + (size_t)plane * row_stride;
     for (int k = blockIdx.x * 256 + threadIdx.x; k < cnt; k += gridDim.x * 256) {
         const int p = lst[k];
-        const int r = L[base + p];
-        if (r < 0) continue;  // markers * mask: a marker pixel outside the mask does not exist
+        int cid;
+        if (rt.tbits) {
+            const long long ri = amt_rt_px_run(rt, plane, p / W, p % W);
+            if (ri < 0) continue;
+            cid = rt.rcomp[ri];
+        } else {
+            const int r = L[base + p];
+            if (r < 0) continue;  // markers * mask: a marker pixel outside the mask does not exist
+            cid = T[base + r];
+        }
         const int lab = markers[base + p];
         if (lab == 0) continue;
-        comp_row* c = prow + (T[base + r] - 1);
+        comp_row* c = prow + (cid - 1);
         atomicAdd(&c->mcnt, 1);
         atomicMin(&c->labmin, lab);
         atomicMax(&c->labmax, lab);
@@ -503,14 +529,22 @@ __global__ void __launch_bounds__(256) ws_fill_markers_kernel(const int* __restr
                                                               const comp_row* __restrict__ rows,
                                                               const int* __restrict__ moff, int* __restrict__ cursor,
                                                               int* __restrict__ mlist, const int* __restrict__ has_g,
-                                                              size_t row_stride, size_t n) {
+                                                              size_t row_stride, size_t n, amt_runtabs rt, int W) {
     if (!has_g[blockIdx.y]) return;  // the common case: every component fitted an LDS tile
     const size_t base = (size_t)blockIdx.y * n;
     const size_t cb = (size_t)blockIdx.y * row_stride;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const int r = L[base + i];
-        if (r < 0 || out[base + i] == 0) continue;
-        const int cid = T[base + r] - 1;
+        int cid;
+        if (rt.tbits) {
+            if (out[base + i] == 0) continue;
+            const long long ri = amt_rt_px_run(rt, blockIdx.y, (int)(i / W), (int)(i % W));
+            if (ri < 0) continue;
+            cid = rt.rcomp[ri] - 1;
+        } else {
+            const int r = L[base + i];
+            if (r < 0 || out[base + i] == 0) continue;
+            cid = T[base + r] - 1;
+        }
         if (rows[cb + cid].cls != CLS_G) continue;
         const int pos = atomicAdd(&cursor[cb + cid], 1);
         mlist[base + moff[cb + cid] + pos] = (int)i;
@@ -560,7 +594,7 @@ __global__ void __launch_bounds__(64) ws_flood_lds_kernel(const int* __restrict_
                                                           const int* __restrict__ wl, const int* __restrict__ wl_count,
                                                           int* __restrict__ counters, size_t row_stride, int H, int W,
                                                           int seeds_first, int* __restrict__ ties,
-                                                          const int* __restrict__ mkall) {
+                                                          const int* __restrict__ mkall, amt_runtabs rt) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     unsigned* cell = reinterpret_cast<unsigned*>(smem_raw);
     unsigned* ht = cell + TILE_PX;
@@ -600,13 +634,19 @@ __global__ void __launch_bounds__(64) ws_flood_lds_kernel(const int* __restrict_
                 d4[u] = 0;
                 if (i < npx && ty >= 1 && ty < th - 1 && tx >= 1 && tx < tw - 1) {
                     const size_t g = (size_t)(cr.y0 + ty - 1) * W + (cr.x0 + tx - 1);
-                    rr4[u] = L[g];
+                    if (rt.tbits) {
+                        const long long ri = amt_rt_px_run(rt, plane, cr.y0 + ty - 1, cr.x0 + tx - 1);
+                        rr4[u] = (int)ri;
+                    } else {
+                        rr4[u] = L[g];
+                    }
                     o4[u] = mk[g];
                     d4[u] = d2[g];
                 }
             }
+            const int* idtab = rt.tbits ? rt.rcomp : T;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) rr4[u] = rr4[u] >= 0 ? T[rr4[u]] : 0;  // tile root -> component id (1-based)
+            for (int u = 0; u < 4; ++u) rr4[u] = rr4[u] >= 0 ? idtab[rr4[u]] : 0;  // tile root (or run) -> component id (1-based)
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int i = i0 + u * 64 + lane;
@@ -765,7 +805,8 @@ __device__ __forceinline__ void ws_flood_component(unsigned* cell, unsigned* cnt
                                                    const int* __restrict__ d2, const int* __restrict__ L,
                                                    const int* __restrict__ T, int* __restrict__ out,
                                                    const int* __restrict__ mk, const comp_row& cr, int c, int W,
-                                                   int seeds_first, int* __restrict__ ties, int plane, int lane) {
+                                                   int seeds_first, int* __restrict__ ties, int plane, int lane,
+                                                   const amt_runtabs& rt) {
     auto uni = [&](unsigned v) -> unsigned { return __builtin_amdgcn_readfirstlane(v); };
     const int tw = cr.x1 - cr.x0 + 3, th = cr.y1 - cr.y0 + 3;  // padded tile
     const int npx = tw * th;
@@ -794,13 +835,24 @@ __device__ __forceinline__ void ws_flood_component(unsigned* cell, unsigned* cnt
             gy = gy < cr.y0 ? cr.y0 : (gy > cr.y1 ? cr.y1 : gy);
             gx = gx < cr.x0 ? cr.x0 : (gx > cr.x1 ? cr.x1 : gx);
             const size_t g = (size_t)gy * W + gx;
-            rr4[u] = L[g];
+            if (rt.tbits) {
+                // no parent plane: the pixel's row word and row offset now, its run's component id in the second round
+                const size_t tl = ((size_t)plane * rt.trows + (gy >> 6)) * rt.segs + (gx >> 6);
+                const unsigned long long wd = rt.tbits[tl * 64 + (gy & 63)];
+                const int ro = rt.roff[tl * 64 + (gy & 63)];
+                const int col = gx & 63;
+                const int kk = ro + __popcll((wd & ~(wd << 1)) & ((2ull << col) - 1ull)) - 1;
+                rr4[u] = ((wd >> col) & 1ull) ? (int)(tl * RT_CAP) + kk : -1;
+            } else {
+                rr4[u] = L[g];
+            }
             o4[u] = mk[g];
             d4[u] = d2[g];
         }
         int id4[SU];
+        const int* idtab = rt.tbits ? rt.rcomp : T;
 #pragma unroll
-        for (int u = 0; u < SU; ++u) id4[u] = T[rr4[u] < 0 ? 0 : rr4[u]];  // tile root -> component id (1-based)
+        for (int u = 0; u < SU; ++u) id4[u] = idtab[rr4[u] < 0 ? 0 : rr4[u]];  // tile root (or run) -> component id (1-based)
 #pragma unroll
         for (int u = 0; u < SU; ++u) {
             const int i = i0 + u * 64 + lane;
@@ -1002,7 +1054,7 @@ __global__ void __launch_bounds__(64) ws_flood_batch_kernel(const int* __restric
                                                             const int* __restrict__ wl, const int* __restrict__ wl_count,
                                                             int* __restrict__ counters, size_t row_stride, int H, int W,
                                                             int seeds_first, int* __restrict__ ties,
-                                                            const int* __restrict__ mkall) {
+                                                            const int* __restrict__ mkall, amt_runtabs rt) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     unsigned* cell = reinterpret_cast<unsigned*>(smem_raw);
     unsigned* cnt = cell + TILE_PX;                                       // NB words: histogram, then {hd | tl << 16}
@@ -1026,7 +1078,7 @@ __global__ void __launch_bounds__(64) ws_flood_batch_kernel(const int* __restric
         if (kk >= nwork) break;
         const int c = mylist[kk];
         const comp_row cr = rr[c];
-        ws_flood_component(cell, cnt, offs, queue, d2, L, T, out, mk, cr, c, W, seeds_first, ties, plane, lane);
+        ws_flood_component(cell, cnt, offs, queue, d2, L, T, out, mk, cr, c, W, seeds_first, ties, plane, lane, rt);
     }
 }
 
@@ -1075,7 +1127,7 @@ __global__ void __launch_bounds__(PF_WAVES * 64) ws_flood_persist_kernel(
     const int* __restrict__ d2all, const int* __restrict__ Lall, const int* __restrict__ Tall, int* __restrict__ outall,
     const comp_row* __restrict__ rows, const int* __restrict__ wl, const int* __restrict__ idx, int* __restrict__ ctl,
     size_t row_stride, int H, int W, int seeds_first, int* __restrict__ ties, const int* __restrict__ mkall, int nplanes,
-    int pf_slots) {
+    int pf_slots, amt_runtabs rt) {
     extern __shared__ __attribute__((aligned(16))) char pf_smem[];
     unsigned long long* slotmask = reinterpret_cast<unsigned long long*>(pf_smem + (size_t)pf_slots * PF_SLOT);
     int* first_done = reinterpret_cast<int*>(slotmask + 1);
@@ -1165,7 +1217,7 @@ __global__ void __launch_bounds__(PF_WAVES * 64) ws_flood_persist_kernel(
         unsigned short* offs = reinterpret_cast<unsigned short*>(cnt + nb2);
         unsigned short* queue = offs + nb2;
         ws_flood_component(cell, cnt, offs, queue, d2all + (size_t)plane * n, Lall + (size_t)plane * n, Tall + (size_t)plane * n,
-                           outall + (size_t)plane * n, mkall + (size_t)plane * n, cr, c, W, seeds_first, ties, plane, lane);
+                           outall + (size_t)plane * n, mkall + (size_t)plane * n, cr, c, W, seeds_first, ties, plane, lane, rt);
         __builtin_amdgcn_s_waitcnt(0);
         if (lane == 0) {
             const unsigned long long want = need >= 64 ? ~0ull : ((1ull << need) - 1ull);
@@ -1666,7 +1718,7 @@ __device__ __forceinline__ int ws_pixel_label(int r, const int* __restrict__ F, 
 
 __global__ void __launch_bounds__(256) ws_frame_mark_kernel(const int* __restrict__ L, const int* __restrict__ F,
                                                             const int* __restrict__ ws, int* __restrict__ present, int H,
-                                                            int W, int max_label) {
+                                                            int W, int max_label, amt_runtabs rt) {
     const size_t n = (size_t)H * W;
     const size_t base = (size_t)blockIdx.y * n;
     int* P = present + (size_t)blockIdx.y * (max_label + 1);
@@ -1687,7 +1739,14 @@ __global__ void __launch_bounds__(256) ws_frame_mark_kernel(const int* __restric
             x = W - 1;
         }
         const size_t i = (size_t)y * W + x;
-        const int v = ws_pixel_label(L[base + i], F, ws, base, i);
+        int r;
+        if (rt.tbits) {
+            const long long ri = amt_rt_px_run(rt, blockIdx.y, y, x);
+            r = ri < 0 ? -1 : amt_rt_run_root(rt, ri, W);
+        } else {
+            r = L[base + i];
+        }
+        const int v = ws_pixel_label(r, F, ws, base, i);
         if (v > 0 && v <= max_label) P[v] = 2;
     }
 }
@@ -1968,7 +2027,9 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     const bool runs = use_d2 && fused_labels && mk_list && ws_runs_enabled() && amt_i_ccl_runs_ok(mask, H, W, nplanes) &&
                       (reinterpret_cast<uintptr_t>(fused_labels) & 15) == 0 && (reinterpret_cast<uintptr_t>(relief) & 15) == 0 &&
                       (reinterpret_cast<uintptr_t>(out) & 15) == 0;
-    if (runs) need += amt_align((size_t)ntiles * 64 * 8) + amt_align((size_t)ntiles * RT_CAP * 2) + amt_align((size_t)ntiles * 4);
+    if (runs)
+        need += amt_align((size_t)ntiles * 64 * 8) + amt_align((size_t)ntiles * RT_CAP * 2) + amt_align((size_t)ntiles * 4) +
+                amt_align((size_t)ntiles * 64 * 2) + amt_align((size_t)ntiles * RT_CAP * 4);
     AMT_TRY(amt_arena_begin(ctx, need));
     int* L = arena_take_t<int>(ctx, np);
     int* T = arena_take_t<int>(ctx, np);
@@ -1995,6 +2056,10 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     unsigned long long* tbits = runs ? arena_take_t<unsigned long long>(ctx, (size_t)ntiles * 64) : nullptr;
     unsigned short* rtab = runs ? arena_take_t<unsigned short>(ctx, (size_t)ntiles * RT_CAP) : nullptr;
     int* nruns = runs ? arena_take_t<int>(ctx, (size_t)ntiles) : nullptr;
+    unsigned short* roff = runs ? arena_take_t<unsigned short>(ctx, (size_t)ntiles * 64) : nullptr;
+    int* rcomp = runs ? arena_take_t<int>(ctx, (size_t)ntiles * RT_CAP) : nullptr;  // only the runs that exist are touched
+    // with run tables the parent plane holds tile roots only; every pixel look-up goes through the tables
+    amt_runtabs rt = {tbits, roff, rtab, rcomp, segs, trows};
     int *head = nullptr, *tail = nullptr;
     hp_elem* heap = nullptr;
     hp_elem* gheap = nullptr;
@@ -2016,7 +2081,7 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     // components of the mask with dense ids in T (the order of the ids is irrelevant: components are
     // independent work items and nothing in the output depends on their numbering)
     AMT_HIP_CHECK(hipMemsetAsync(nroots, 0, nlist * 4, ctx->stream));
-    if (runs) AMT_TRY(amt_i_ccl_tileroots_runs_u8(ctx, mask, L, rootlist, nroots, nplanes, H, W, tbits, rtab, nruns));
+    if (runs) AMT_TRY(amt_i_ccl_tileroots_runs_u8(ctx, mask, L, rootlist, nroots, nplanes, H, W, tbits, rtab, nruns, roff));
     else AMT_TRY(amt_i_ccl_tileroots_u8(ctx, mask, L, rootlist, nroots, nplanes, H, W, ccl_scratch));
     hipLaunchKernelGGL(ws_roots_kernel, dim3(4, trows, nplanes), dim3(256), 0, ctx->stream, L, T, rootlist, nroots, ncomp,
                        lcap, n);
@@ -2030,10 +2095,10 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     const int pf_slots = pf_mode == 1 ? ws_pf_slots() : (pf_mode == 2 ? PF_SLOTS_HALF : 0);
     if (runs) {
         hipLaunchKernelGGL(ws_stats_runs_kernel, dim3((ntiles + 3) / 4), dim3(256), 0, ctx->stream, (const int*)relief, tbits, rtab,
-                           nruns, L, T, rows, row_stride, H, W, segs, trows, ntiles);
+                           nruns, L, T, rows, row_stride, H, W, segs, trows, ntiles, rcomp);
         AMT_LAUNCH_CHECK();
         hipLaunchKernelGGL(ws_marker_stats_kernel, dim3(16, nplanes), dim3(256), 0, ctx->stream, mk_list, mk_count, mk_cap,
-                           markers, L, T, rows, row_stride, n);
+                           markers, L, T, rows, row_stride, n, rt, W);
     } else if (mk_list) {
         // the caller knows where the marker pixels are: the dense pass skips the marker plane
         hipLaunchKernelGGL((ws_stats_kernel<false>), dim3((W + 63) / 64, (H + 31) / 32, nplanes), dim3(256), 0, ctx->stream,
@@ -2041,7 +2106,7 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
                            use_d2 ? 1 : 0);
         AMT_LAUNCH_CHECK();
         hipLaunchKernelGGL(ws_marker_stats_kernel, dim3(16, nplanes), dim3(256), 0, ctx->stream, mk_list, mk_count, mk_cap,
-                           markers, L, T, rows, row_stride, n);
+                           markers, L, T, rows, row_stride, n, rt, W);
     } else {
         hipLaunchKernelGGL((ws_stats_kernel<true>), dim3((W + 63) / 64, (H + 31) / 32, nplanes), dim3(256), 0, ctx->stream,
                            use_d2 ? (const int*)relief : (const int*)nullptr, L, T, markers, rows, row_stride, H, W,
@@ -2059,7 +2124,7 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     // such plane (its final pass derives every pixel from F and the flood's sparse writes): it seeds only planes that
     // hold a component for the HBM flood, which works in `out` itself -- same consideration for its grid
     hipLaunchKernelGGL(ws_seed_kernel, dim3(amt_grid_for(n, 1024, fused_labels ? 128 : 4096), nplanes), dim3(256), 0,
-                       ctx->stream, markers, L, F, out, n, fused_labels ? (const int*)has_g : (const int*)nullptr);
+                       ctx->stream, markers, L, F, out, n, fused_labels ? (const int*)has_g : (const int*)nullptr, rt, W);
     AMT_LAUNCH_CHECK();
     // ---- HBM-path bookkeeping (usually empty: only components too large for an LDS tile) ----
     AMT_TRY(amt_scan_excl_dev(ctx, moff, ncomp, row_stride, mtot, nplanes));
@@ -2067,7 +2132,7 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     hipLaunchKernelGGL(ws_fill_value_kernel, dim3(64, nplanes), dim3(256), 0, ctx->stream, cursor, ncomp, row_stride, 0);
     AMT_LAUNCH_CHECK();
     hipLaunchKernelGGL(ws_fill_markers_kernel, g1, dim3(256), 0, ctx->stream, L, T, out, rows, moff, cursor, mlist,
-                       has_g, row_stride, n);
+                       has_g, row_stride, n, rt, W);
     AMT_LAUNCH_CHECK();
     if (use_d2) {
         const size_t ldsXS = (size_t)XS_PX * 6 + (size_t)XS_NB * 6;
@@ -2102,7 +2167,8 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
             int a_H = H, a_W = W, a_sf = seeds_first;
             int* a_ties = ties;
             const int* a_mk = markers;
-            void* args[] = {&a_d2, &a_L, &a_T, &a_out, &a_rows, &a_wl, &a_wlc, &a_cnt, &a_rs, &a_H, &a_W, &a_sf, &a_ties, &a_mk};
+            amt_runtabs a_rt = rt;
+            void* args[] = {&a_d2, &a_L, &a_T, &a_out, &a_rows, &a_wl, &a_wlc, &a_cnt, &a_rs, &a_H, &a_W, &a_sf, &a_ties, &a_mk, &a_rt};
             AMT_HIP_CHECK(hipExtLaunchKernel(fn, dim3(gx, nplanes), dim3(64), args, lds + (cls_slot <= 2 ? ws_lds_pad() : 0), st, nullptr, nullptr,
                                              (any && nflood > 0) ? (int)hipExtAnyOrderLaunch : 0));
             ++nflood;
@@ -2131,8 +2197,9 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
             int a_H = H, a_W = W, a_sf = seeds_first, a_np = nplanes, a_slots = pf_slots;
             int* a_ties = ties;
             const int* a_mk = markers;
+            amt_runtabs a_rt = rt;
             void* args[] = {&a_d2, &a_L, &a_T, &a_out, &a_rows, &a_wl, &a_idx, &a_ctl, &a_rs, &a_H, &a_W, &a_sf, &a_ties, &a_mk,
-                            &a_np, &a_slots};
+                            &a_np, &a_slots, &a_rt};
             const int wgs = pf_mode == 1 ? ctx->num_cus : 2 * ctx->num_cus;
             AMT_HIP_CHECK(hipExtLaunchKernel((const void*)ws_flood_persist_kernel, dim3(wgs), dim3(ws_pf_waves() * 64), args,
                                              (size_t)(pf_slots + 1) * PF_SLOT, ctx->stream, nullptr, nullptr, 0));
@@ -2180,7 +2247,7 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     if (fused_labels) {
         AMT_TRY(amt_i_presence_fill(ctx, P, nlabels_dev, max_label, nplanes));
         hipLaunchKernelGGL(ws_frame_mark_kernel, dim3(amt_grid_for((size_t)2 * W + 2 * H, 256, 64), nplanes), dim3(256), 0,
-                           ctx->stream, L, F, out, P, H, W, max_label);
+                           ctx->stream, L, F, out, P, H, W, max_label, rt);
         AMT_LAUNCH_CHECK();
         AMT_TRY(amt_i_drop_and_scan(ctx, P, max_label, fused_count, nplanes));
         if (runs) {
