@@ -178,6 +178,230 @@ __global__ void __launch_bounds__(256) edt_cols_kernel(const unsigned short* __r
     }
 }
 
+// ---- both passes in one kernel, from a packed plane of zero flags (round 3) -------------------------------------------
+// The row pass wrote g as uint16 (2 bytes per pixel) and the column pass read it back with its halo (3): more traffic
+// than the mask (1) and the result (4) together.  g is a function of the row's ZERO FLAGS alone, and those are one bit per
+// pixel: edt_zero_words_kernel packs them (64 pixels per word, 1/8 byte per pixel), and a column tile computes the g of
+// its 64 x (ROWS + 2 HALO) window itself -- three words per row (its own segment and the ones left / right of it) sit
+// in LDS, a thread owns 8 pixels of a row exactly as edt_rows8_kernel does, and only a row without a zero pixel within 64
+// columns walks further words in global memory.  Searches deeper than the halo evaluate g(y +- k, x) from the words too.
+__global__ void __launch_bounds__(256) edt_zero_words_kernel(const uint8_t* __restrict__ mask, unsigned long long* __restrict__ zw,
+                                                             int H, int W, int WW, size_t nwords, int fast) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nwords) return;
+    const int wi = (int)(i % WW);
+    const size_t row = i / WW;  // plane * H + y
+    const uint8_t* p = mask + row * W + (size_t)wi * 64;
+    const int valid = W - wi * 64 < 64 ? W - wi * 64 : 64;
+    unsigned long long z = 0;
+    if (fast) {  // W % 16 == 0 and a 16-byte aligned plane: 16-byte loads
+        uint4 q[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) q[j] = *reinterpret_cast<const uint4*>(p + (16 * j < valid ? 16 * j : 0));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned v[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
+            unsigned sixteen = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned nz = ((((v[k] & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v[k]) >> 7) & 0x01010101u;  // byte != 0
+                sixteen |= (((nz ^ 0x01010101u) * 0x01020408u) >> 24) << (4 * k);                          // byte i == 0 -> bit i
+            }
+            if (16 * j < valid) z |= (unsigned long long)(sixteen & 0xFFFFu) << (16 * j);
+        }
+    } else {
+        for (int k = 0; k < valid; ++k) z |= (unsigned long long)(p[k] == 0) << k;
+    }
+    zw[i] = z;  // pixels beyond W: "not zero"
+}
+
+// distance of (y, x) to the nearest zero pixel of row y (G_INF if the row has none), from the row's zero-flag words
+__device__ __forceinline__ unsigned edt_g_at(const unsigned long long* __restrict__ zr, int WW, int x) {
+    const int wi = x >> 6, bit = x & 63;
+    const unsigned long long own = zr[wi];
+    if ((own >> bit) & 1ull) return 0u;
+    unsigned dl = G_INF, dr = G_INF;
+    unsigned long long m = own & ((1ull << bit) - 1ull);
+    int w = wi;
+    while (m == 0 && w > 0) m = zr[--w];
+    if (m) dl = (unsigned)(x - (w * 64 + 63 - __clzll((long long)m)));
+    m = bit == 63 ? 0ull : (own >> (bit + 1)) << (bit + 1);
+    w = wi;
+    while (m == 0 && w + 1 < WW) m = zr[++w];
+    if (m) dr = (unsigned)(w * 64 + __ffsll((long long)m) - 1 - x);
+    const unsigned d = dl < dr ? dl : dr;
+    return d >= G_INF ? G_INF : d;
+}
+
+template <int EC_ROWS, int EC_HALO>
+__global__ void __launch_bounds__(256) edt_bits_kernel(const unsigned long long* __restrict__ zw, int* __restrict__ d2_out,
+                                                       double* __restrict__ edt_out, int H, int W, int WW) {
+    constexpr int EC_TROWS = EC_ROWS + 2 * EC_HALO;
+    __shared__ __attribute__((aligned(16))) unsigned short tile[EC_TROWS][64];
+    __shared__ unsigned long long zs[EC_TROWS][3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wi = blockIdx.x;  // the tile's word column
+    const int y0 = blockIdx.y * EC_ROWS;
+    const size_t plane = (size_t)blockIdx.z * H * W;
+    const unsigned long long* zp = zw + (size_t)blockIdx.z * H * WW;
+    // ---- the zero flags of the window: own word, left and right neighbour (outside the image: no zero) ----
+    for (int i = threadIdx.x; i < EC_TROWS * 3; i += 256) {
+        const int r = i / 3, c = i - r * 3;
+        const int y = y0 - EC_HALO + r, w = wi - 1 + c;
+        zs[r][c] = (y >= 0 && y < H && w >= 0 && w < WW) ? zp[(size_t)y * WW + w] : 0ull;
+    }
+    __syncthreads();
+    // ---- g of the window: a thread owns 8 consecutive pixels of a row (edt_rows8_kernel's arithmetic) ----
+    constexpr unsigned BIG = 0x20000u;  // > any distance inside a row (sides are <= 32768)
+#if defined(EDT_EXP) && EDT_EXP == 2
+    for (int task = threadIdx.x; task < EC_TROWS * 8; task += 256) *reinterpret_cast<uint4*>(&tile[task >> 3][(task & 7) * 8]) = make_uint4(0, 0, 0, 0);
+    if (false)
+#endif
+    for (int task = threadIdx.x; task < EC_TROWS * 8; task += 256) {
+        const int r = task >> 3, b = task & 7;
+        const int y = y0 - EC_HALO + r;
+        uint4 out = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);  // rows outside the image: G_INF
+        if (y >= 0 && y < H) {
+            const int bit0 = b * 8, x0 = wi * 64 + bit0;
+            const unsigned long long own = zs[r][1];
+            const unsigned z8 = (unsigned)(own >> bit0) & 0xffu;
+            out = make_uint4(0u, 0u, 0u, 0u);
+            if (z8 != 0xffu) {
+                unsigned dl = BIG, dr = BIG;  // distance of pixel x0 to the nearest zero left of the group / of x0+7 right
+                unsigned long long m = own & ((1ull << bit0) - 1ull);
+                int w = wi;
+                if (m == 0 && w > 0) {
+                    m = zs[r][0];
+                    --w;
+                    const unsigned long long* zr = zp + (size_t)y * WW;
+                    while (m == 0 && w > 0) m = zr[--w];
+                }
+                if (m) dl = (unsigned)(x0 - (w * 64 + 63 - __clzll((long long)m)));
+                const int sh = bit0 + 8;
+                m = sh == 64 ? 0ull : (own >> sh) << sh;
+                w = wi;
+                if (m == 0 && w + 1 < WW) {
+                    m = zs[r][2];
+                    ++w;
+                    const unsigned long long* zr = zp + (size_t)y * WW;
+                    while (m == 0 && w + 1 < WW) m = zr[++w];
+                }
+                if (m) dr = (unsigned)(w * 64 + __ffsll((long long)m) - 1 - (x0 + 7));
+                unsigned L[8], R[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const unsigned prev = i == 0 ? dl : L[i - 1] + 1u;
+                    L[i] = ((z8 >> i) & 1u) ? 0u : (prev < BIG ? prev : BIG);
+                }
+#pragma unroll
+                for (int i = 7; i >= 0; --i) {
+                    const unsigned nxt = i == 7 ? dr : R[i + 1] + 1u;
+                    R[i] = ((z8 >> i) & 1u) ? 0u : (nxt < BIG ? nxt : BIG);
+                }
+                unsigned d[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const unsigned mn = L[i] < R[i] ? L[i] : R[i];
+                    d[i] = mn >= G_INF ? G_INF : mn;
+                }
+                out.x = d[0] | (d[1] << 16);
+                out.y = d[2] | (d[3] << 16);
+                out.z = d[4] | (d[5] << 16);
+                out.w = d[6] | (d[7] << 16);
+            }
+        }
+        *reinterpret_cast<uint4*>(&tile[r][b * 8]) = out;
+    }
+    __syncthreads();
+    // ---- the column search (edt_cols_kernel's, with g beyond the halo evaluated from the words).  A lane owns FOUR
+    // consecutive pixels of a row: one 8-byte LDS read brings the four g of a row above / below, the four searches are
+    // independent chains that share every LDS wait, and the results leave in one 16-byte store (a wave writes 4 rows x
+    // 256 bytes; with a pixel per lane the stores alone took 223 us per 48 planes, 3.6 TB/s) ----
+    const int c4 = (lane & 15) * 4, rsub = lane >> 4;
+    const int xg = wi * 64 + c4;
+    if (xg >= W) return;
+    const bool vec = xg + 3 < W && (W & 3) == 0 && (!d2_out || (reinterpret_cast<uintptr_t>(d2_out) & 15) == 0) &&
+                     (!edt_out || (reinterpret_cast<uintptr_t>(edt_out) & 15) == 0);
+#pragma unroll 1
+    for (int j = 0; j < EC_ROWS / 16; ++j) {
+        const int ly = EC_HALO + wave * (EC_ROWS / 4) + rsub + 4 * j;
+        const int y = y0 - EC_HALO + ly;
+        if (y >= H) continue;
+        unsigned best[4];
+        {
+            const uint2 gq = *reinterpret_cast<const uint2*>(&tile[ly][c4]);
+            const unsigned g0[4] = {gq.x & 0xFFFFu, gq.x >> 16, gq.y & 0xFFFFu, gq.y >> 16};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) best[i] = g0[i] == G_INF ? 0xFFFFFFFFu : g0[i] * g0[i];
+        }
+#if defined(EDT_EXP) && EDT_EXP == 1
+        if (false)
+#endif
+        for (unsigned k = 1; k <= (unsigned)EC_HALO; ++k) {
+            const unsigned kk = k * k;
+            if (!(kk < best[0] || kk < best[1] || kk < best[2] || kk < best[3])) break;
+            const uint2 uq = *reinterpret_cast<const uint2*>(&tile[ly - (int)k][c4]);
+            const uint2 dq = *reinterpret_cast<const uint2*>(&tile[ly + (int)k][c4]);
+            const unsigned gu[4] = {uq.x & 0xFFFFu, uq.x >> 16, uq.y & 0xFFFFu, uq.y >> 16};
+            const unsigned gd[4] = {dq.x & 0xFFFFu, dq.x >> 16, dq.y & 0xFFFFu, dq.y >> 16};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned gm = gu[i] < gd[i] ? gu[i] : gd[i];
+                // gm == G_INF: 65535^2 + k^2 < 2^32 stays above every finite candidate and below the "no zero" mark
+                const unsigned c = gm == G_INF ? 0xFFFFFFFFu : kk + gm * gm;
+                best[i] = c < best[i] ? c : best[i];  // a candidate at distance k cannot beat best <= k^2: no need to mask
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            unsigned bq = best[i];
+            const int x = xg + i;
+            if (bq != 0 && x < W) {
+                for (unsigned kk = EC_HALO + 1; kk < 65536u && (unsigned long long)kk * kk < bq; ++kk) {  // beyond the LDS halo
+                    const int yu = y - (int)kk, yd = y + (int)kk;
+                    if (yu < 0 && yd >= H) break;
+                    unsigned gm = G_INF;
+                    if (yu >= 0) gm = edt_g_at(zp + (size_t)yu * WW, WW, x);
+                    if (yd < H) {
+                        const unsigned gd = edt_g_at(zp + (size_t)yd * WW, WW, x);
+                        gm = gd < gm ? gd : gm;
+                    }
+                    if (gm != G_INF) {
+                        const unsigned c = kk * kk + gm * gm;  // < 2^31: both terms < 2^30
+                        bq = c < bq ? c : bq;
+                    }
+                }
+                // no zero pixel in the whole plane: scipy's feature transform then measures from index (-1, 0)
+                if (bq > 0x7fffffffu) bq = (unsigned)(y + 1) * (unsigned)(y + 1) + (unsigned)x * (unsigned)x;
+            }
+            best[i] = bq;
+        }
+        const size_t i0 = plane + (size_t)y * W + xg;
+        if (vec) {
+            if (d2_out) *reinterpret_cast<int4*>(d2_out + i0) = make_int4((int)best[0], (int)best[1], (int)best[2], (int)best[3]);
+            if (edt_out) {
+                *reinterpret_cast<double2*>(edt_out + i0) = make_double2(sqrt((double)best[0]), sqrt((double)best[1]));
+                *reinterpret_cast<double2*>(edt_out + i0 + 2) = make_double2(sqrt((double)best[2]), sqrt((double)best[3]));
+            }
+        } else {
+            for (int i = 0; i < 4 && xg + i < W; ++i) {
+                if (d2_out) d2_out[i0 + i] = (int)best[i];
+                if (edt_out) edt_out[i0 + i] = sqrt((double)best[i]);
+            }
+        }
+    }
+}
+
+// AMT_EDT_FUSED=0: the two-pass transform through a uint16 plane of row distances (A/B switch; identical results)
+static bool edt_fused_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("AMT_EDT_FUSED");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
+}
+
 extern "C" int amt_edt(amt_ctx* ctx, const uint8_t* mask, int32_t* d2_out, double* edt_out, int nplanes, int H,
                        int W) {
     AMT_TRY(amt_set_device(ctx));
@@ -185,6 +409,25 @@ extern "C" int amt_edt(amt_ctx* ctx, const uint8_t* mask, int32_t* d2_out, doubl
     AMT_REQUIRE(H <= 32768 && W <= 32768, "edt: image larger than 32768 pixels per side");
     if (nplanes == 0) return AMT_OK;
     const size_t n = (size_t)H * W;
+    const size_t tiles64 = (size_t)((W + 63) / 64) * ((H + 63) / 64) * nplanes;
+    if (edt_fused_enabled()) {
+        const int WW = (W + 63) / 64;
+        const size_t nwords = (size_t)nplanes * H * WW;
+        AMT_TRY(amt_arena_begin(ctx, amt_align(nwords * 8)));
+        unsigned long long* zw = arena_take_t<unsigned long long>(ctx, nwords);
+        const int fast = W % 16 == 0 && (reinterpret_cast<uintptr_t>(mask) & 15) == 0;
+        hipLaunchKernelGGL(edt_zero_words_kernel, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, ctx->stream, mask, zw, H,
+                           W, WW, nwords, fast);
+        AMT_LAUNCH_CHECK();
+        if (tiles64 >= 4096 && !edt_out)
+            hipLaunchKernelGGL((edt_bits_kernel<64, 16>), dim3(WW, (H + 63) / 64, nplanes), dim3(256), 0, ctx->stream, zw, d2_out,
+                               edt_out, H, W, WW);
+        else
+            hipLaunchKernelGGL((edt_bits_kernel<32, 24>), dim3(WW, (H + 31) / 32, nplanes), dim3(256), 0, ctx->stream, zw, d2_out,
+                               edt_out, H, W, WW);
+        AMT_LAUNCH_CHECK();
+        return AMT_OK;
+    }
     AMT_TRY(amt_arena_begin(ctx, amt_align((size_t)nplanes * n * 2)));
     unsigned short* g = arena_take_t<unsigned short>(ctx, (size_t)nplanes * n);
     if ((W & 7) == 0 && (reinterpret_cast<uintptr_t>(mask) & 7) == 0)  // g comes from the arena: 256-byte aligned
@@ -194,7 +437,6 @@ extern "C" int amt_edt(amt_ctx* ctx, const uint8_t* mask, int32_t* d2_out, doubl
         hipLaunchKernelGGL(edt_rows_kernel, dim3(H, nplanes), dim3(256), (size_t)((W + 63) / 64) * 8, ctx->stream, mask,
                            g, H, W);
     AMT_LAUNCH_CHECK();
-    const size_t tiles64 = (size_t)((W + 63) / 64) * ((H + 63) / 64) * nplanes;
     if (tiles64 >= 4096 && !edt_out)  // with the float64 output (sqrt + 8-byte stores) the shorter tiles measured faster
         hipLaunchKernelGGL((edt_cols_kernel<64, 16>), dim3((W + 63) / 64, (H + 63) / 64, nplanes), dim3(256), 0,
                            ctx->stream, g, d2_out, edt_out, H, W);

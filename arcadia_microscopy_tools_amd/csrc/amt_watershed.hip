@@ -78,6 +78,7 @@ struct comp_row {
     int labmin, labmax;  // marker label range
     int cls;
     int root;            // flat index of the component's first pixel (its union-find root)
+    int npix;            // pixels of the component (run-table statistics only; 0 = not counted)
 };
 
 // out = label of the component for single-label components, markers * mask elsewhere.
@@ -182,6 +183,7 @@ __global__ void __launch_bounds__(256) ws_rows_init_kernel(comp_row* __restrict_
         c.labmax = 0;
         c.cls = CLS_NONE;
         c.root = -1;
+        c.npix = 0;
         r[i] = c;
     }
 }
@@ -310,6 +312,7 @@ __global__ void __launch_bounds__(256) ws_stats_runs_kernel(const int* __restric
                                                             int* __restrict__ rcomp) {
     __shared__ int comp_s[4][SR_CAP];
     __shared__ int cm_s[4][SR_CAP];
+    __shared__ int np_s[4][SR_CAP];
     __shared__ unsigned short kr_s[4][SR_CAP];
     __shared__ unsigned long long bits_s[4][64];
     __shared__ int off_s[4][64];
@@ -344,6 +347,7 @@ __global__ void __launch_bounds__(256) ws_stats_runs_kernel(const int* __restric
             const unsigned long long rw = bits_s[wv][rrow];
             kr_s[wv][k] = (unsigned short)(off_s[wv][rrow] + __popcll((rw & ~(rw << 1)) & ((2ull << rcol) - 1ull)) - 1);
             cm_s[wv][k] = 0;
+            np_s[wv][k] = 0;
         }
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
@@ -375,7 +379,9 @@ __global__ void __launch_bounds__(256) ws_stats_runs_kernel(const int* __restric
                 const int p = y * W + x0 + b;
                 if (L[p] == p) cr->root = p;
             }
+            if (fast) atomicAdd(&np_s[wv][kr_s[wv][k]], len);  // pixels per tile root (the floods size their queues by it)
             if (!fast) {
+                atomicAdd(&cr->npix, len);
                 int m = 0;
                 for (int x = b; x <= last; ++x) {
                     const int v = d2[(size_t)y * W + x0 + x];
@@ -423,7 +429,11 @@ __global__ void __launch_bounds__(256) ws_stats_runs_kernel(const int* __restric
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
     for (int k = lane; k < nr; k += 64)
-        if (kr_s[wv][k] == k && cm_s[wv][k] > 0) atomicMax(&(prow + (comp_s[wv][k] - 1))->cmax, cm_s[wv][k]);
+        if (kr_s[wv][k] == k) {
+            comp_row* cr = prow + (comp_s[wv][k] - 1);
+            if (cm_s[wv][k] > 0) atomicMax(&cr->cmax, cm_s[wv][k]);
+            atomicAdd(&cr->npix, np_s[wv][k]);
+        }
 }
 
 // marker statistics from the LIST of marker pixels (amt_label_sparse_reuse keeps it): a few thousand pixels per plane
@@ -492,7 +502,8 @@ __global__ void __launch_bounds__(256) ws_classify_kernel(comp_row* __restrict__
             else if (area <= M2_PX && c.cmax < M2_NB) cls = CLS_M2;
             else if (area <= L_PX && c.cmax < L_NB) {
                 // bytes the persistent flood would reserve for it (6 per tile cell and per bucket, 2,560-byte slots)
-                const long long need = ((((area + 1) & ~1ll) + ((c.cmax + 2) & ~1)) * 6 + 2559) / 2560;
+                const long long qn = c.npix > 0 ? c.npix : area;  // queue entries: one per pixel of the component
+                const long long need = (((area + 1) & ~1ll) * 4 + ((qn + 1) & ~1ll) * 2 + ((c.cmax + 2) & ~1) * 6 + 2559) / 2560;
                 cls = (pf_slots > 0 && need > pf_slots) ? CLS_LB : CLS_L;
             }
             else if (area <= X_PX && c.cmax < X_NB) cls = CLS_X;
@@ -1177,7 +1188,10 @@ __global__ void __launch_bounds__(PF_WAVES * 64) ws_flood_persist_kernel(
         const int npx = (cr.x1 - cr.x0 + 3) * (cr.y1 - cr.y0 + 3);
         const int nb = cr.cmax + 1;
         const int npx2 = (npx + 1) & ~1, nb2 = (nb + 1) & ~1;  // keep every array 4-byte aligned
-        const int need = (npx2 * 6 + nb2 * 6 + PF_SLOT - 1) / PF_SLOT;  // slots
+        // a pixel is queued once: with the component's pixel count (run-table statistics) the queue holds that many
+        // entries instead of one per cell of the padded box -- LDS bytes x time is what bounds this launch
+        const int nq2 = ((cr.npix > 0 ? cr.npix : npx) + 1) & ~1;
+        const int need = (npx2 * 4 + nq2 * 2 + nb2 * 6 + PF_SLOT - 1) / PF_SLOT;  // slots
         // the other waves of the workgroup hold back until wave 0 has placed its first (big) component
         if (wave != 0 && first) {
             while (__hip_atomic_load(first_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(8);
@@ -1848,15 +1862,19 @@ __global__ void __launch_bounds__(256) ws_final_runs_kernel(const unsigned long 
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
     if (xg >= W) return;
+#ifndef AMT_WS_FQ
+#define AMT_WS_FQ 4
+#endif
+    constexpr int FQ = AMT_WS_FQ;  // rows per lane whose loads are in flight together
     const int* lb = lab_s[wv];
     auto lab = [&](int k) -> int { return fast ? lb[k] : F[ccl_rt_root(rtab, (size_t)t, k, ty, bx, W)]; };
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        int4 o[8], f[8];
-        bool need[8];
+    for (int half = 0; half < 16 / FQ; ++half) {
+        int4 o[FQ], f[FQ];
+        bool need[FQ];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int row = rsub + 4 * (half * 8 + q);
+        for (int q = 0; q < FQ; ++q) {
+            const int row = rsub + 4 * (half * FQ + q);
             const unsigned long long ww = bits_s[wv][row];
             const unsigned long long hw = ww & ~(ww << 1);
             const unsigned nib = (unsigned)(ww >> c4) & 15u, hnib = (unsigned)(hw >> c4) & 15u;
@@ -1871,13 +1889,13 @@ __global__ void __launch_bounds__(256) ws_final_runs_kernel(const unsigned long 
             need[q] = (o[q].x | o[q].y | o[q].z | o[q].w) < 0;  // pixels of a flooded component: labels in the flood's plane
         }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int y = ty0 + rsub + 4 * (half * 8 + q);
+        for (int q = 0; q < FQ; ++q) {
+            const int y = ty0 + rsub + 4 * (half * FQ + q);
             f[q] = make_int4(0, 0, 0, 0);
             if (need[q]) f[q] = *reinterpret_cast<const int4*>(ws + (size_t)y * W + xg);
         }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < FQ; ++q) {
             if (need[q]) {
                 if (o[q].x < 0) o[q].x = (unsigned)(f[q].x - 1) < ml ? M[f[q].x] : 0;
                 if (o[q].y < 0) o[q].y = (unsigned)(f[q].y - 1) < ml ? M[f[q].y] : 0;
@@ -1886,8 +1904,8 @@ __global__ void __launch_bounds__(256) ws_final_runs_kernel(const unsigned long 
             }
         }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int y = ty0 + rsub + 4 * (half * 8 + q);
+        for (int q = 0; q < FQ; ++q) {
+            const int y = ty0 + rsub + 4 * (half * FQ + q);
             if (y < H) *reinterpret_cast<int4*>(out + (size_t)y * W + xg) = o[q];
         }
     }
