@@ -345,6 +345,9 @@ def stage_roofline(stage_avg: dict, npx: int, PB: int):
         "traffic": None if traffic is None else traffic * PB / 32.0,
         "traffic_source": (os.path.relpath(_profile_path("hbm_pmc"), ROOT) + " (committed PMC passes, FETCH_SIZE x2 "
                            "for wide reads + WRITE_SIZE)") if traffic is not None else None,
+        # the same stage priced by the bytes its kernels really move: well below `frac` when passes are fused or replaced
+        # (round 3: run tables instead of a parent plane) -- what is left of the stage is then latency, not HBM
+        "frac_pmc": None if traffic is None else traffic * PB / 32.0 / (stage_avg[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS,
         "algorithmic_bytes_per_launch": dom_bytes, "launch_ms": stage_avg[dom],
         # the stage is one C-ABI call = several kernels (the flood classes run concurrently): their rocprofv3
         # averages from the committed summary, per 32-FOV launch
