@@ -293,6 +293,10 @@ __global__ void __launch_bounds__(256) rp_perimeter_rows_kernel(const int* __res
             const int r = y0 - 2 + b * PR_BATCH + j;  // row of v0
             int v0 = cur[j];
             v0 = (xin && r >= 0 && r < H && (unsigned)(v0 - 1) < ml) ? v0 : 0;
+#if defined(PR_EXP) && PR_EXP == 1
+            v1 |= v0;  // what-if: the loads alone
+            continue;
+#endif
             if (__ballot((v0 | v1 | v2 | wB) != 0) == 0ull) continue;  // uniform: the window stays all zero
             const int v0l = amt_lane_left(v0), v0r = amt_lane_right(v0);
             // flagged row r-1
@@ -333,6 +337,9 @@ __global__ void __launch_bounds__(256) rp_perimeter_rows_kernel(const int* __res
 #pragma unroll
         for (int j = 0; j < PR_BATCH; ++j) cur[j] = nxt[j];
     }
+#if defined(PR_EXP) && PR_EXP == 1
+    if (v1 == 0x12345678) acc[0] = 1;
+#endif
 }
 
 // ---- convex area (exact integer hull of the pixel diamonds) -------------------------------------

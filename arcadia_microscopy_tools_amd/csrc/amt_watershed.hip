@@ -562,11 +562,112 @@ __global__ void __launch_bounds__(256) ws_fill_markers_kernel(const int* __restr
     }
 }
 
+// exclusive scan of d[0 .. len) in place by one workgroup of 1024 threads; returns the total to every thread
+__device__ __forceinline__ int ws_block_scan_excl(int* d, int len, int* s, int* carry) {
+    if (threadIdx.x == 0) *carry = 0;
+    __syncthreads();
+    for (int start = 0; start < len; start += 1024) {
+        const int i = start + threadIdx.x;
+        const int v = i < len ? d[i] : 0;
+        s[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const int t = threadIdx.x >= off ? s[threadIdx.x - off] : 0;
+            __syncthreads();
+            s[threadIdx.x] += t;
+            __syncthreads();
+        }
+        const int c = *carry;
+        if (i < len) d[i] = c + s[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) *carry = c + s[1023];
+        __syncthreads();
+    }
+    return *carry;
+}
+
+// The HBM flood's preparation on the fused path, ONE launch: a workgroup per plane that leaves at once unless the plane
+// holds a component too large for an LDS tile (almost never on nuclei) -- what used to be six launches that each found
+// nothing to do (seed of the plane, two scans, two fills, the marker lists).  A plane that does hold one is prepared by
+// its one workgroup: slow (two passes of 1,024 threads over the plane), but the flood of such a component takes longer.
+__global__ void __launch_bounds__(1024) ws_g_prep_kernel(const int* __restrict__ markers, const int* __restrict__ Lall,
+                                                         const int* __restrict__ Tall, const int* __restrict__ Fall,
+                                                         int* __restrict__ outall, const comp_row* __restrict__ rows,
+                                                         int* __restrict__ moff, int* __restrict__ boff,
+                                                         int* __restrict__ cursor, int* __restrict__ mlist,
+                                                         int* __restrict__ head, const int* __restrict__ ncomp,
+                                                         int* __restrict__ mtot, int* __restrict__ btot,
+                                                         const int* __restrict__ has_g, size_t row_stride, size_t n,
+                                                         size_t bstride, amt_runtabs rt, int W) {
+    const int plane = blockIdx.x;
+    if (!has_g[plane]) {
+        if (threadIdx.x == 0) mtot[plane] = btot[plane] = 0;
+        return;
+    }
+    __shared__ int s[1024];
+    __shared__ int carry;
+    const size_t base = (size_t)plane * n, cb = (size_t)plane * row_stride;
+    const int* L = Lall + base;
+    const int* T = Tall + base;
+    const int* F = Fall + base;
+    int* out = outall + base;
+    const int nc = ncomp[plane];
+    // out = label of the component for single-label components, markers * mask elsewhere (ws_seed_kernel)
+    for (size_t i = threadIdx.x; i < n; i += 1024) {
+        int r;
+        if (rt.tbits) {
+            const long long ri = amt_rt_px_run(rt, plane, (int)(i / W), (int)(i % W));
+            r = ri < 0 ? -1 : amt_rt_run_root(rt, ri, W);
+        } else {
+            r = L[i];
+        }
+        int v = 0;
+        if (r >= 0) {
+            const int f = F[r];
+            v = f > 0 ? f : (f == 0 ? markers[base + i] : 0);
+        }
+        out[i] = v;
+    }
+    const int mt = ws_block_scan_excl(moff + cb, nc, s, &carry);
+    const int bt = ws_block_scan_excl(boff + cb, nc, s, &carry);
+    if (threadIdx.x == 0) {
+        mtot[plane] = mt;
+        btot[plane] = bt;
+    }
+    for (int i = threadIdx.x; i < nc; i += 1024) cursor[cb + i] = 0;
+    for (int i = threadIdx.x; i < bt; i += 1024) head[(size_t)plane * bstride + i] = -1;
+    __syncthreads();  // `out`, the scanned offsets and the cursors are this workgroup's own writes
+    // marker lists of the HBM-path components (ws_fill_markers_kernel)
+    for (size_t i = threadIdx.x; i < n; i += 1024) {
+        if (out[i] == 0) continue;
+        int cid;
+        if (rt.tbits) {
+            const long long ri = amt_rt_px_run(rt, plane, (int)(i / W), (int)(i % W));
+            if (ri < 0) continue;
+            cid = rt.rcomp[ri] - 1;
+        } else {
+            const int r = L[i];
+            if (r < 0) continue;
+            cid = T[r] - 1;
+        }
+        if (rows[cb + cid].cls != CLS_G) continue;
+        const int pos = atomicAdd(&cursor[cb + cid], 1);
+        mlist[base + moff[cb + cid] + pos] = (int)i;
+    }
+}
+
 __global__ void __launch_bounds__(256) ws_fill_value_kernel(int* __restrict__ buf, const int* __restrict__ total,
                                                             size_t plane_stride, int value) {
     int* b = buf + (size_t)blockIdx.y * plane_stride;
     const int tot = total[blockIdx.y];
     for (int i = blockIdx.x * 256 + threadIdx.x; i < tot; i += gridDim.x * 256) b[i] = value;
+}
+
+__global__ void __launch_bounds__(256) ws_init_kernel(int* __restrict__ a, int na, int* __restrict__ b, int nb, int* __restrict__ c,
+                                                      int nc) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < na; i += gridDim.x * 256) a[i] = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nb; i += gridDim.x * 256) b[i] = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nc; i += gridDim.x * 256) c[i] = 0;
 }
 
 __global__ void ws_zero_counters_kernel(int* c, int n) {
@@ -1799,6 +1900,71 @@ __global__ void __launch_bounds__(256) ws_final_kernel(const int* __restrict__ L
     }
 }
 
+// presence_fill + ws_frame_mark + drop_flagged + presence_scan (amt_label.hip) for one plane per workgroup:
+// P[l] = new label of l (0 = absent or touching the frame), count[plane] = number of survivors
+__global__ void __launch_bounds__(1024) ws_label_map_kernel(const int* __restrict__ L, const int* __restrict__ F,
+                                                            const int* __restrict__ ws, int* __restrict__ present,
+                                                            const int* __restrict__ nlabels, int* __restrict__ count_dev,
+                                                            int H, int W, int max_label, amt_runtabs rt) {
+    __shared__ int s[1024];
+    __shared__ int carry;
+    const int plane = blockIdx.x;
+    const size_t n = (size_t)H * W;
+    const size_t base = (size_t)plane * n;
+    int* P = present + (size_t)plane * (max_label + 1);
+    const int k = nlabels[plane] < max_label ? nlabels[plane] : max_label;
+    for (int l = threadIdx.x; l <= max_label; l += 1024) P[l] = (l >= 1 && l <= k) ? 1 : 0;
+    __syncthreads();
+    const int perim = 2 * W + 2 * H;
+    for (int q = threadIdx.x; q < perim; q += 1024) {
+        int y, x;
+        if (q < W) {
+            y = 0;
+            x = q;
+        } else if (q < 2 * W) {
+            y = H - 1;
+            x = q - W;
+        } else if (q < 2 * W + H) {
+            y = q - 2 * W;
+            x = 0;
+        } else {
+            y = q - 2 * W - H;
+            x = W - 1;
+        }
+        const size_t i = (size_t)y * W + x;
+        int r;
+        if (rt.tbits) {
+            const long long ri = amt_rt_px_run(rt, plane, y, x);
+            r = ri < 0 ? -1 : amt_rt_run_root(rt, ri, W);
+        } else {
+            r = L[base + i];
+        }
+        const int v = ws_pixel_label(r, F, ws, base, i);
+        if (v > 0 && v <= max_label) P[v] = 0;  // touches the frame: dropped
+    }
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int start = 1; start <= max_label; start += 1024) {
+        const int i = start + threadIdx.x;
+        const int v = i <= max_label ? P[i] : 0;
+        s[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const int t = threadIdx.x >= off ? s[threadIdx.x - off] : 0;
+            __syncthreads();
+            s[threadIdx.x] += t;
+            __syncthreads();
+        }
+        const int incl = s[threadIdx.x];
+        const int c = carry;
+        if (i <= max_label) P[i] = v ? c + incl : 0;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = c + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) count_dev[plane] = carry;
+}
+
 // ws_final_kernel from the run tables: a wave per tile turns (row words, run table, the final label of every tile root,
 // the label map) into final labels -- the parent plane is not read; the flood's plane only where a flooded component has
 // pixels.  ws_final_map_kernel first replaces F at every listed tile root by what its pixels are to receive (the mapped
@@ -2091,14 +2257,13 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
     }
 
     int* ncomp = counters + 16 * (size_t)nplanes;
-    hipLaunchKernelGGL(ws_zero_counters_kernel, dim3((nplanes * WS_CTR + 63) / 64), dim3(64), 0, ctx->stream, counters,
-                       nplanes * WS_CTR);
-    AMT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ws_set_flags_kernel, dim3((nplanes + 63) / 64), dim3(64), 0, ctx->stream, ties, nplanes, 0);
+    // counters, tie flags and the root lists' counts in ONE launch (three trivial launches cost ~5 us each in a stage
+    // of 1.2 ms)
+    hipLaunchKernelGGL(ws_init_kernel, dim3(16), dim3(256), 0, ctx->stream, counters, nplanes * WS_CTR, ties, nplanes, nroots,
+                       (int)nlist);
     AMT_LAUNCH_CHECK();
     // components of the mask with dense ids in T (the order of the ids is irrelevant: components are
     // independent work items and nothing in the output depends on their numbering)
-    AMT_HIP_CHECK(hipMemsetAsync(nroots, 0, nlist * 4, ctx->stream));
     if (runs) AMT_TRY(amt_i_ccl_tileroots_runs_u8(ctx, mask, L, rootlist, nroots, nplanes, H, W, tbits, rtab, nruns, roff));
     else AMT_TRY(amt_i_ccl_tileroots_u8(ctx, mask, L, rootlist, nroots, nplanes, H, W, ccl_scratch));
     hipLaunchKernelGGL(ws_roots_kernel, dim3(4, trows, nplanes), dim3(256), 0, ctx->stream, L, T, rootlist, nroots, ncomp,
@@ -2135,23 +2300,30 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
                        wl, wl_count, F, n, nplanes, row_stride, use_d2 ? 1 : 0, pf_slots);
     AMT_LAUNCH_CHECK();
     AMT_TRY(amt_i_propagate_roots(ctx, F, L, rootlist, nroots, nplanes, H, W));
-    // the marker lists of the HBM flood's components: nearly always no plane has one, and 4,096 workgroups per plane
-    // that only read a flag and leave cost 43 us per 48 planes -- 128 (grid-stride) do when a plane does have one
-    dim3 g1(amt_grid_for(n, 256, 128), nplanes);
-    // the seed pass gives `out` its final value everywhere except in flooded components.  The fused path needs no
-    // such plane (its final pass derives every pixel from F and the flood's sparse writes): it seeds only planes that
-    // hold a component for the HBM flood, which works in `out` itself -- same consideration for its grid
-    hipLaunchKernelGGL(ws_seed_kernel, dim3(amt_grid_for(n, 1024, fused_labels ? 128 : 4096), nplanes), dim3(256), 0,
-                       ctx->stream, markers, L, F, out, n, fused_labels ? (const int*)has_g : (const int*)nullptr, rt, W);
-    AMT_LAUNCH_CHECK();
-    // ---- HBM-path bookkeeping (usually empty: only components too large for an LDS tile) ----
-    AMT_TRY(amt_scan_excl_dev(ctx, moff, ncomp, row_stride, mtot, nplanes));
-    AMT_TRY(amt_scan_excl_dev(ctx, boff, ncomp, row_stride, btot, nplanes));
-    hipLaunchKernelGGL(ws_fill_value_kernel, dim3(64, nplanes), dim3(256), 0, ctx->stream, cursor, ncomp, row_stride, 0);
-    AMT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ws_fill_markers_kernel, g1, dim3(256), 0, ctx->stream, L, T, out, rows, moff, cursor, mlist,
-                       has_g, row_stride, n, rt, W);
-    AMT_LAUNCH_CHECK();
+    const bool gprep = fused_labels && use_d2;  // the fused chain: the HBM flood's whole preparation in one launch
+    if (gprep) {
+        hipLaunchKernelGGL(ws_g_prep_kernel, dim3(nplanes), dim3(1024), 0, ctx->stream, markers, L, T, F, out, rows, moff, boff,
+                           cursor, mlist, head, ncomp, mtot, btot, has_g, row_stride, n, bstride, rt, W);
+        AMT_LAUNCH_CHECK();
+    } else {
+        // the marker lists of the HBM flood's components: nearly always no plane has one, and 4,096 workgroups per plane
+        // that only read a flag and leave cost 43 us per 48 planes -- 128 (grid-stride) do when a plane does have one
+        dim3 g1(amt_grid_for(n, 256, 128), nplanes);
+        // the seed pass gives `out` its final value everywhere except in flooded components.  The fused path needs no
+        // such plane (its final pass derives every pixel from F and the flood's sparse writes): it seeds only planes that
+        // hold a component for the HBM flood, which works in `out` itself -- same consideration for its grid
+        hipLaunchKernelGGL(ws_seed_kernel, dim3(amt_grid_for(n, 1024, fused_labels ? 128 : 4096), nplanes), dim3(256), 0,
+                           ctx->stream, markers, L, F, out, n, fused_labels ? (const int*)has_g : (const int*)nullptr, rt, W);
+        AMT_LAUNCH_CHECK();
+        // ---- HBM-path bookkeeping (usually empty: only components too large for an LDS tile) ----
+        AMT_TRY(amt_scan_excl_dev(ctx, moff, ncomp, row_stride, mtot, nplanes));
+        AMT_TRY(amt_scan_excl_dev(ctx, boff, ncomp, row_stride, btot, nplanes));
+        hipLaunchKernelGGL(ws_fill_value_kernel, dim3(64, nplanes), dim3(256), 0, ctx->stream, cursor, ncomp, row_stride, 0);
+        AMT_LAUNCH_CHECK();
+        hipLaunchKernelGGL(ws_fill_markers_kernel, g1, dim3(256), 0, ctx->stream, L, T, out, rows, moff, cursor, mlist,
+                           has_g, row_stride, n, rt, W);
+        AMT_LAUNCH_CHECK();
+    }
     if (use_d2) {
         const size_t ldsXS = (size_t)XS_PX * 6 + (size_t)XS_NB * 6;
         const size_t ldsS = (size_t)S_PX * 6 + (size_t)S_NB * 6;
@@ -2161,8 +2333,10 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
         const size_t ldsX = (size_t)X_PX * 4 + (size_t)X_NB * 4;
         // the LDS classes and the HBM path are independent, latency-bound and use few waves each:
         // run them side by side (fork / join on the context's auxiliary streams)
-        hipLaunchKernelGGL(ws_fill_value_kernel, dim3(256, nplanes), dim3(256), 0, ctx->stream, head, btot, bstride, -1);
-        AMT_LAUNCH_CHECK();
+        if (!gprep) {
+            hipLaunchKernelGGL(ws_fill_value_kernel, dim3(256, nplanes), dim3(256), 0, ctx->stream, head, btot, bstride, -1);
+            AMT_LAUNCH_CHECK();
+        }
         AMT_TRY(amt_fork(ctx));
         // workgroups per plane and class (a workgroup only takes components of its own plane).  Measured: 2 x / 4 x as
         // many change nothing at 1, 12 or 32 planes per launch -- the chains per workgroup are not what bounds a class
@@ -2263,11 +2437,11 @@ static int watershed_common(amt_ctx* ctx, const void* relief, bool use_d2, const
         AMT_LAUNCH_CHECK();
     }
     if (fused_labels) {
-        AMT_TRY(amt_i_presence_fill(ctx, P, nlabels_dev, max_label, nplanes));
-        hipLaunchKernelGGL(ws_frame_mark_kernel, dim3(amt_grid_for((size_t)2 * W + 2 * H, 256, 64), nplanes), dim3(256), 0,
-                           ctx->stream, L, F, out, P, H, W, max_label, rt);
+        // the label map of clear_border + relabel_sequential: present labels, frame-touching ones dropped, survivors
+        // numbered -- one workgroup per plane does the four steps (they were four launches over a few thousand entries)
+        hipLaunchKernelGGL(ws_label_map_kernel, dim3(nplanes), dim3(1024), 0, ctx->stream, L, F, out, P, nlabels_dev, fused_count,
+                           H, W, max_label, rt);
         AMT_LAUNCH_CHECK();
-        AMT_TRY(amt_i_drop_and_scan(ctx, P, max_label, fused_count, nplanes));
         if (runs) {
             hipLaunchKernelGGL(ws_final_map_kernel, dim3(4, trows, nplanes), dim3(256), 0, ctx->stream, F, P, rootlist, nroots, lcap,
                                n, max_label);

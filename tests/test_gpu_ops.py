@@ -519,6 +519,17 @@ def test_watershed_every_flood_class(ctx, ops):
         cleared = skops.clear_border(refs[b])
         ref = skops.relabel_sequential(cleared) if cleared.max() > 0 else cleared
         assert np.array_equal(lab.numpy()[b], ref) and cnt.numpy()[b] == ref.max(), b
+    # ... and through the marker-list entry point (the chain's): at this width (a multiple of 16) the stage works from the
+    # mask's run tables instead of a parent plane -- statistics, every flood class incl. the HBM queue path, frame marks,
+    # final mapping
+    cap = int(max(np.count_nonzero(m) for m in mks)) + 8
+    klist, kcount = np.zeros((2, cap), np.int32), np.zeros(2, np.int32)
+    for b in range(2):
+        idx = np.flatnonzero(mks[b])
+        klist[b, :idx.size], kcount[b] = idx, idx.size
+    lab2, cnt2 = ops.watershed_edt_cleared(d2, dmk, dm, nl, int(max(m.max() for m in mks)), ctx.empty(masks.shape, np.int32),
+                                           marker_list=(ctx.asarray(klist), ctx.asarray(kcount)))
+    assert np.array_equal(lab2.numpy(), lab.numpy()) and np.array_equal(cnt2.numpy(), cnt.numpy())
 
 
 def test_watershed_skimage_golden_cases(ctx, ops, golden):
