@@ -140,7 +140,10 @@ __global__ void __launch_bounds__(64) rp_label_kernel(const int* __restrict__ la
         mn[c] = 0xffffffffu;
         mx[c] = 0;
     }
-    constexpr int RPS = 8;  // rows per step
+#ifndef AMT_RP_RPS
+#define AMT_RP_RPS 3
+#endif
+    constexpr int RPS = AMT_RP_RPS;  // rows per step
     // eight rows per step: their label loads are issued together, then the intensity loads of the hits
     for (int yb = y0; yb <= y1; yb += RPS) {
         int rmin[RPS], rmax[RPS];
@@ -151,28 +154,40 @@ __global__ void __launch_bounds__(64) rp_label_kernel(const int* __restrict__ la
         }
         for (int xb = x0; xb <= x1; xb += 64) {
             const int x = xb + lane;
+            // a lane's pixels of this block share ONE column: sx, sxx and sxy follow from the lane's pixel count and row
+            // sum at the end of the block (x * count, x^2 * count, x * sum of y) -- per row a lane only counts and adds y
+            unsigned bcnt = 0, bsy = 0;  // <= 8 rows: no overflow
+            // ONE round trip per step: the labels and the intensities of the box's eight rows are requested together,
+            // unconditionally, from clamped coordinates (the intensities used to wait for the labels they depend on: two
+            // dependent round trips per step of a wave that has nothing else to do); what lies outside the box or the
+            // label is discarded where it is used
+            const int xc = x <= x1 ? x : x1;
             int lv[RPS];
 #pragma unroll
-            for (int j = 0; j < RPS; ++j) lv[j] = (x <= x1 && yb + j <= y1) ? L[(size_t)(yb + j) * W + x] : 0;
+            for (int j = 0; j < RPS; ++j) {
+                const int yc = yb + j <= y1 ? yb + j : y1;
+                lv[j] = L[(size_t)yc * W + xc];
+            }
             unsigned iv[RPS][RP_MAXC];
             if (I) {
 #pragma unroll
-                for (int j = 0; j < RPS; ++j)
+                for (int j = 0; j < RPS; ++j) {
+                    const int yc = yb + j <= y1 ? yb + j : y1;
 #pragma unroll
-                    for (int c = 0; c < RP_MAXC; ++c)
-                        iv[j][c] = (c < nc && lv[j] == want) ? I[(size_t)c * n + (size_t)(yb + j) * W + x] : 0u;
+                    for (int c = 0; c < RP_MAXC; ++c) iv[j][c] = I[(size_t)(c < nc ? c : 0) * n + (size_t)yc * W + xc];
+                }
             }
+#pragma unroll
+            for (int j = 0; j < RPS; ++j)
+                if (x > x1 || yb + j > y1) lv[j] = 0;
 #pragma unroll
             for (int j = 0; j < RPS; ++j) {
                 const int y = yb + j;
                 const bool m = lv[j] == want;
                 if (m) {
-                    cnt += 1;
-                    sy += (u64)y;
-                    sx += (u64)x;
-                    syy += (u64)y * (u64)y;
-                    sxx += (u64)x * (u64)x;
-                    sxy += (u64)y * (u64)x;
+                    bcnt += 1u;
+                    bsy += (unsigned)y;
+                    syy += (u64)(unsigned)y * (unsigned)y;
                     if (I) {
 #pragma unroll
                         for (int c = 0; c < RP_MAXC; ++c)
@@ -193,6 +208,11 @@ __global__ void __launch_bounds__(64) rp_label_kernel(const int* __restrict__ la
                     rmax[j] = last > rmax[j] ? last : rmax[j];
                 }
             }
+            cnt += bcnt;
+            sy += bsy;
+            sx += (u64)(unsigned)x * bcnt;
+            sxx += (u64)(unsigned)x * (unsigned)x * bcnt;
+            sxy += (u64)(unsigned)x * bsy;
         }
         if (rows_ok && lane == 0) {
 #pragma unroll
@@ -606,6 +626,107 @@ __global__ void __launch_bounds__(64) rp_hull_lds_kernel(const int* __restrict__
     trow[AMT_RP_AREA_CONVEX] = (double)count;
 }
 
+// The same, TWO lanes per label (round 3): the kernel above is a chain of dependent instructions per lane -- ~100 steps in
+// Y with two monotone stacks each -- on ~1,000 waves per 48 planes, one per SIMD, nothing to hide a latency behind (222 us).
+// The left and the right chain are independent: lane 2 i builds the left one, lane 2 i + 1 the right one (a pop is
+// "cr <= 0" on the left, "cr >= 0" on the right), each interpolates its own bound per row, the pair exchanges bounds by a
+// lane swap; half the LDS per wave, twice the waves.
+__global__ void __launch_bounds__(64) rp_hull_lds2_kernel(const int* __restrict__ bbox, const int* __restrict__ hoff,
+                                                          const int* __restrict__ htot, const int2* __restrict__ rows,
+                                                          size_t cap, double* __restrict__ table, int max_label) {
+    __shared__ unsigned short s_rows[HULL_HMAX * 32];
+    __shared__ unsigned short s_ch[HULL_CH * 64];
+    const int plane = blockIdx.y;
+    const int lane = threadIdx.x, side = lane & 1, pr = lane >> 1;
+    const int l = blockIdx.x * 32 + pr;
+    if (l >= max_label) return;
+    const size_t li = (size_t)plane * max_label + l;
+    double* trow = table + li * AMT_RP_NCOLS;
+    const int miny = bbox[li * 4 + 0], x0 = bbox[li * 4 + 1], maxy = bbox[li * 4 + 2], x1 = bbox[li * 4 + 3];
+    if (maxy < miny) {
+        if (side == 0) trow[AMT_RP_AREA_CONVEX] = 0.0;
+        return;
+    }
+    const int h = maxy - miny + 1;
+    if (h > HULL_HMAX || x1 - x0 + 1 > HULL_WMAX) return;  // rp_hull_kernel takes it
+    const size_t off = (size_t)hoff[li];
+    if ((size_t)htot[plane] > cap || off + (size_t)h > cap) {  // capacity exceeded (fragmented labels)
+        if (side == 0) trow[AMT_RP_AREA_CONVEX] = __longlong_as_double(0x7ff8000000000000ll);
+        return;
+    }
+    const int2* r = rows + (size_t)plane * cap + off;
+    // the pair shares the loading: lane `side` takes the rows k = side (mod 2), eight per round trip
+    for (int k0 = side; k0 < h; k0 += 16) {
+        int2 e[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) e[u] = r[min(k0 + 2 * u, h - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (k0 + 2 * u < h)  // an empty row (max < min) keeps that property: 255 | 0 << 8
+                s_rows[(k0 + 2 * u) * 32 + pr] =
+                    e[u].y >= e[u].x ? (unsigned short)((e[u].x - x0) | ((e[u].y - x0) << 8)) : (unsigned short)255;
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    // doubled, box-relative coordinates: Yr = Y - (2 miny - 1) in [0, 2h], Xr = X - (2 x0 - 1) in [0, 2w]
+    int nc = 0;
+    for (int Yr = 0; Yr <= 2 * h; ++Yr) {
+        int mn = 0x7fffffff, mx = -1;
+        if (!(Yr & 1)) {  // odd Y: shared by the rows above and below
+            const int ka = (Yr >> 1) - 1, kb = Yr >> 1;
+            if (ka >= 0) {
+                const unsigned e = s_rows[ka * 32 + pr];
+                if ((e >> 8) >= (e & 255)) {
+                    mn = min(mn, 2 * (int)(e & 255) + 1);
+                    mx = max(mx, 2 * (int)(e >> 8) + 1);
+                }
+            }
+            if (kb < h) {
+                const unsigned e = s_rows[kb * 32 + pr];
+                if ((e >> 8) >= (e & 255)) {
+                    mn = min(mn, 2 * (int)(e & 255) + 1);
+                    mx = max(mx, 2 * (int)(e >> 8) + 1);
+                }
+            }
+        } else {
+            const unsigned e = s_rows[(Yr >> 1) * 32 + pr];
+            if ((e >> 8) >= (e & 255)) {
+                mn = 2 * (int)(e & 255);
+                mx = 2 * (int)(e >> 8) + 2;
+            }
+        }
+        if (mx < mn) continue;  // no pixel of this label contributes at this Y
+        const int val = side ? mx : mn;
+        while (nc >= 2) {
+            const int v0 = s_ch[(nc - 2) * 64 + lane], v1 = s_ch[(nc - 1) * 64 + lane];
+            const int cr = ((v1 >> 9) - (v0 >> 9)) * (val - (v0 & 511)) - ((v1 & 511) - (v0 & 511)) * (Yr - (v0 >> 9));
+            if (side ? cr >= 0 : cr <= 0) --nc; else break;
+        }
+        s_ch[(nc++) * 64 + lane] = (unsigned short)((Yr << 9) | val);
+    }
+    // count pixel centres: row k sits at Yr = 2k + 1; pixel x at Xr = 2 (x - x0) + 1
+    int count = 0;
+    int ic = 0;
+    for (int k = 0; k < h; ++k) {
+        const int Yr = 2 * k + 1;
+        while (ic + 1 < nc && (int)(s_ch[(ic + 1) * 64 + lane] >> 9) <= Yr) ++ic;
+        int b;  // this lane's bound of the pixel index: XL <= 2 x + 1 (left, rounded up) or 2 x + 1 <= XR (right, down)
+        const int v0 = s_ch[ic * 64 + lane];
+        if ((v0 >> 9) == Yr || ic + 1 >= nc) {
+            b = side ? floor_div32((v0 & 511) - 1, 2) : ceil_div32((v0 & 511) - 1, 2);
+        } else {
+            const int v1 = s_ch[(ic + 1) * 64 + lane];
+            const int dY = (v1 >> 9) - (v0 >> 9);  // > 0
+            const int num = ((v0 & 511) - 1) * dY + ((v1 & 511) - (v0 & 511)) * (Yr - (v0 >> 9));  // (X - 1) * dY
+            b = side ? floor_div32(num, 2 * dY) : ceil_div32(num, 2 * dY);
+        }
+        const int other = __shfl_xor(b, 1);
+        const int xmin = side ? other : b, xmax = side ? b : other;
+        if (xmax >= xmin) count += xmax - xmin + 1;
+    }
+    if (side == 0) trow[AMT_RP_AREA_CONVEX] = (double)count;
+}
+
 // ---- final per-label columns ------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) rp_final_kernel(const u64* __restrict__ acc, const int* __restrict__ bbox,
                                                        double* __restrict__ table, size_t nlab) {
@@ -713,8 +834,13 @@ static int regionprops_common(amt_ctx* ctx, const int32_t* labels, const uint16_
         AMT_LAUNCH_CHECK();
         const int skip_h = HULL_HMAX;
         {
-            hipLaunchKernelGGL(rp_hull_lds_kernel, dim3((max_label + 63) / 64, nplanes), dim3(64), 0, ctx->stream, bbox,
-                               hoff, htot, rows, cap, table_dev, max_label);
+            static const bool two = !(getenv("AMT_RP_HULL2") && getenv("AMT_RP_HULL2")[0] == '0');  // A/B switch; same results
+            if (two)
+                hipLaunchKernelGGL(rp_hull_lds2_kernel, dim3((max_label + 31) / 32, nplanes), dim3(64), 0, ctx->stream, bbox,
+                                   hoff, htot, rows, cap, table_dev, max_label);
+            else
+                hipLaunchKernelGGL(rp_hull_lds_kernel, dim3((max_label + 63) / 64, nplanes), dim3(64), 0, ctx->stream, bbox,
+                                   hoff, htot, rows, cap, table_dev, max_label);
             AMT_LAUNCH_CHECK();
         }
         // labels taller than HULL_HMAX rows or wider than HULL_WMAX columns: chains in HBM scratch
