@@ -325,14 +325,20 @@ __global__ void __launch_bounds__(256) rp_perimeter_rows_kernel(const int* __res
             const int w1l = amt_lane_left(w1), w1r = amt_lane_right(w1);
             // bounding box: runs of row r-1 (above v2, below v0)
             const int yb = r - 1;
-            if (bbp && inner && v1 != 0 && yb >= y0 && yb < y0 + PR_ROWS) {
-                int* B = bbp + (size_t)(v1 - 1) * 4;
-                if (v1l != v1) {  // head of a run
-                    if (v2 != v1) atomicMin(&B[0], yb);
-                    if (v0 != v1) atomicMax(&B[2], yb);
-                    if (v2l != v1 && v0l != v1) atomicMin(&B[1], x);
+            if (bbp && yb >= y0 && yb < y0 + PR_ROWS) {  // uniform
+                // the four requests as flat per-lane conditions behind ONE uniform test: interior rows of a blob ask for
+                // nothing (their runs have the label above, below and further out on either side), and every divergent
+                // block costs scalar issue slots whether a lane enters it or not
+                const bool live = inner && v1 != 0, head = live && v1l != v1;
+                const bool q0 = head && v2 != v1, q2 = head && v0 != v1, q1 = head && v2l != v1 && v0l != v1;
+                const bool q3 = live && v1r != v1 && v2r != v1 && v0r != v1;  // tail of a run
+                if (__ballot(q0 || q1 || q2 || q3)) {
+                    int* B = bbp + (size_t)(v1 - 1) * 4;
+                    if (q0) atomicMin(&B[0], yb);
+                    if (q2) atomicMax(&B[2], yb);
+                    if (q1) atomicMin(&B[1], x);
+                    if (q3) atomicMax(&B[3], x);
                 }
-                if (v1r != v1 && v2r != v1 && v0r != v1) atomicMax(&B[3], x);  // tail of a run
             }
             // perimeter code of row r-2 (centre wA, above wB, below w1)
             const int yo = r - 2;
@@ -340,13 +346,11 @@ __global__ void __launch_bounds__(256) rp_perimeter_rows_kernel(const int* __res
                 const int key = wA;
                 const int code = 1 + 2 * ((wB == key) + (w1 == key) + (wAl == key) + (wAr == key)) +
                                  10 * ((wBl == key) + (wBr == key) + (w1l == key) + (w1r == key));
-                int cls = -1;
-                switch (code) {
-                    case 5: case 7: case 15: case 17: case 25: case 27: cls = A_C1; break;
-                    case 21: case 33: cls = A_C2; break;
-                    case 13: case 23: cls = A_C3; break;
-                    default: break;
-                }
+                // class of the code without a branch per case (the pass is bound by SCALAR issue: every divergent block
+                // costs an exec save, a branch and a restore): codes are <= 49, the three sets are bit masks
+                constexpr unsigned long long M1 = (1ull << 5) | (1ull << 7) | (1ull << 15) | (1ull << 17) | (1ull << 25) | (1ull << 27);
+                constexpr unsigned long long M2 = (1ull << 21) | (1ull << 33), M3 = (1ull << 13) | (1ull << 23);
+                const int cls = ((M1 >> code) & 1ull) ? A_C1 : ((M2 >> code) & 1ull) ? A_C2 : ((M3 >> code) & 1ull) ? A_C3 : -1;
                 if (cls >= 0) atomicAdd(&accp[(size_t)((key & 0x7fffffff) - 1) * A_NACC + cls], 1ull);
             }
             wB = wA, wBl = wAl, wBr = wAr;
