@@ -691,10 +691,13 @@ __global__ void __launch_bounds__(256) ccl_expand_runs_kernel(const unsigned lon
         if (nib) {
             // the run of pixel c4 + i = heads at or before it, minus one
             const int k0 = off_s[wv][row] + __popcll(hw & ((1ull << c4) - 1ull)) - 1;
-            if (nib & 1u) o.x = lab(k0 + (int)(hnib & 1u));
-            if (nib & 2u) o.y = lab(k0 + __popc(hnib & 3u));
-            if (nib & 4u) o.z = lab(k0 + __popc(hnib & 7u));
-            if (nib & 8u) o.w = lab(k0 + __popc(hnib));
+            // selects, not a block per pixel (scalar issue); a background pixel reads the run left of it or run 0
+            const int ka = k0 + (int)(hnib & 1u), kb = k0 + __popc(hnib & 3u), kc = k0 + __popc(hnib & 7u), kd = k0 + __popc(hnib);
+            const int la = lab(ka < 0 ? 0 : ka), lb2 = lab(kb < 0 ? 0 : kb), lc = lab(kc < 0 ? 0 : kc), ld = lab(kd < 0 ? 0 : kd);
+            o.x = (nib & 1u) ? la : 0;
+            o.y = (nib & 2u) ? lb2 : 0;
+            o.z = (nib & 4u) ? lc : 0;
+            o.w = (nib & 8u) ? ld : 0;
         }
         if (y < H) *reinterpret_cast<int4*>(out + (size_t)y * W + xg) = o;
     }

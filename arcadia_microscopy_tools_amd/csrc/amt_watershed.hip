@@ -2046,11 +2046,15 @@ __global__ void __launch_bounds__(256) ws_final_runs_kernel(const unsigned long 
             const unsigned nib = (unsigned)(ww >> c4) & 15u, hnib = (unsigned)(hw >> c4) & 15u;
             o[q] = make_int4(0, 0, 0, 0);
             if (nib) {
+                // one divergent block, selects inside (a block per pixel costs scalar issue slots: exec save, branch,
+                // restore); a background pixel reads the run left of it, or run 0 of the tile when there is none
                 const int k0 = off_s[wv][row] + __popcll(hw & ((1ull << c4) - 1ull)) - 1;
-                if (nib & 1u) o[q].x = lab(k0 + (int)(hnib & 1u));
-                if (nib & 2u) o[q].y = lab(k0 + __popc(hnib & 3u));
-                if (nib & 4u) o[q].z = lab(k0 + __popc(hnib & 7u));
-                if (nib & 8u) o[q].w = lab(k0 + __popc(hnib));
+                const int ka = k0 + (int)(hnib & 1u), kb = k0 + __popc(hnib & 3u), kc = k0 + __popc(hnib & 7u), kd = k0 + __popc(hnib);
+                const int la = lab(ka < 0 ? 0 : ka), lb2 = lab(kb < 0 ? 0 : kb), lc = lab(kc < 0 ? 0 : kc), ld = lab(kd < 0 ? 0 : kd);
+                o[q].x = (nib & 1u) ? la : 0;
+                o[q].y = (nib & 2u) ? lb2 : 0;
+                o[q].z = (nib & 4u) ? lc : 0;
+                o[q].w = (nib & 8u) ? ld : 0;
             }
             need[q] = (o[q].x | o[q].y | o[q].z | o[q].w) < 0;  // pixels of a flooded component: labels in the flood's plane
         }
