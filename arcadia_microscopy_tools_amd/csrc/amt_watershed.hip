@@ -1007,6 +1007,9 @@ __device__ __forceinline__ void ws_flood_component(unsigned* cell, unsigned* cnt
     __builtin_amdgcn_wave_barrier();
     int cur = -1;    // current bucket (-1: none yet)
     int raise = -1;  // highest bucket that received a push since the last switch
+    // a lane's own cell of the ring's top row (cells 0 .. tw - 1, all 0xFFFF and never a target): where its LDS operations
+    // go when it has nothing to claim, so that they need no divergent block and do not pile up on one address
+    const int dmy = lane - (int)(((unsigned long long)(unsigned)lane * inv_tw) >> 32) * tw;
     const int offN = -tw, offW = -1, offE = 1, offS = tw;
     // One step over the pixels p (one per active lane, lane order = pop order).  `limit`: the bucket the pixels
     // were popped from (a target above it cuts the step) or a value above every bucket (marker spreading).
@@ -1044,21 +1047,24 @@ __device__ __forceinline__ void ws_flood_component(unsigned* cell, unsigned* cnt
         } else if (__ballot(tN || tW || tE || tS)) {
             // tickets: the smallest (lane, neighbour) pair holds the largest ticket
             const unsigned tk = 0x100u - (unsigned)(lane * 4);
+            // (the atomics keep their blocks: unconditional ones on per-lane ring cells measured no faster)
             if (tN) atomicMax(&cell[qN], (cN & 0xFFFF0000u) | (tk - 0));
             if (tW) atomicMax(&cell[qW], (cW & 0xFFFF0000u) | (tk - 1));
             if (tE) atomicMax(&cell[qE], (cE & 0xFFFF0000u) | (tk - 2));
             if (tS) atomicMax(&cell[qS], (cS & 0xFFFF0000u) | (tk - 3));
-            const unsigned rN = tN ? cell[qN] : 0, rW = tW ? cell[qW] : 0, rE = tE ? cell[qE] : 0,
-                           rS = tS ? cell[qS] : 0;
+            // re-reads and label writes WITHOUT a divergent block each (a lone wave pays every exec save / branch /
+            // restore in full): lanes without a claim read and rewrite cell `dmy`, theirs in the top row of the sentinel ring that no
+            // flood ever claims (its value, 0xFFFF, is what they write back)
+            const unsigned rN = cell[tN ? qN : dmy], rW = cell[tW ? qW : dmy], rE = cell[tE ? qE : dmy], rS = cell[tS ? qS : dmy];
             wN = tN && (rN & 0xFFFFu) == tk - 0;
             wW = tW && (rW & 0xFFFFu) == tk - 1;
             wE = tE && (rE & 0xFFFFu) == tk - 2;
             wS = tS && (rS & 0xFFFFu) == tk - 3;
             const unsigned lab = cp & 0xFFFFu;
-            if (wN) cell[qN] = (cN & 0xFFFF0000u) | lab;
-            if (wW) cell[qW] = (cW & 0xFFFF0000u) | lab;
-            if (wE) cell[qE] = (cE & 0xFFFF0000u) | lab;
-            if (wS) cell[qS] = (cS & 0xFFFF0000u) | lab;
+            cell[wN ? qN : dmy] = wN ? ((cN & 0xFFFF0000u) | lab) : 0xFFFFu;
+            cell[wW ? qW : dmy] = wW ? ((cW & 0xFFFF0000u) | lab) : 0xFFFFu;
+            cell[wE ? qE : dmy] = wE ? ((cE & 0xFFFF0000u) | lab) : 0xFFFFu;
+            cell[wS ? qS : dmy] = wS ? ((cS & 0xFFFF0000u) | lab) : 0xFFFFu;
         }
         // append the winners, one destination bucket at a time, in (lane, N-W-E-S) order.  Every bucket is handled
         // once per step, so its cursor word is fetched for all claims up front (one LDS round trip, not one per
@@ -1067,11 +1073,11 @@ __device__ __forceinline__ void ws_flood_component(unsigned* cell, unsigned* cnt
         // claims each.)
         unsigned long long pend = __ballot(wN || wW || wE || wS);
         unsigned hN = 0, hW = 0, hE = 0, hS = 0;
-        if (pend) {
-            hN = wN ? cnt[dN] : 0u;
-            hW = wW ? cnt[dW] : 0u;
-            hE = wE ? cnt[dE] : 0u;
-            hS = wS ? cnt[dS] : 0u;
+        if (pend) {  // (uniform) unconditional reads, bucket 0 for lanes without a claim
+            hN = cnt[wN ? dN : 0];
+            hW = cnt[wW ? dW : 0];
+            hE = cnt[wE ? dE : 0];
+            hS = cnt[wS ? dS : 0];
         }
         const unsigned long long lt_mask = (1ull << lane) - 1ull;
 #ifdef WS_STATS
