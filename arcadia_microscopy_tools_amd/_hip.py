@@ -110,6 +110,7 @@ _SIGS = {
                                     c_double]),
     "amt_subtract": (c_int, [_P, _P, _P, _P, c_int, c_size_t]),
     "amt_label": (c_int, [_P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int]),
+    "amt_label_mask": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int]),
     "amt_label_sparse": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int]),
     "amt_label_sparse_reuse": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "amt_clear_border": (c_int, [_P, _P, _P, c_int, c_int, c_int]),

@@ -529,7 +529,7 @@ __global__ void __launch_bounds__(64) ccl_tile_runs_kernel(const uint8_t* __rest
     // compact run ordinals (raster order) and the tile's slice of its tile row's root list
     const int cnt = __popcll(heads);
     const int incl = ccl_wave_incl_scan(cnt, lane);
-    if (WS) roff[tile * 64 + lane] = (unsigned short)(incl - cnt);
+    if (WS && roff) roff[tile * 64 + lane] = (unsigned short)(incl - cnt);
     const int rincl = ccl_wave_incl_scan(nroot, lane);
     const int tot = __shfl(rincl, 63);
     int base = 0;
@@ -643,7 +643,7 @@ __global__ void __launch_bounds__(256) ccl_expand_runs_kernel(const unsigned lon
                                                               const int* __restrict__ nruns, const int* __restrict__ Tall,
                                                               int* __restrict__ outall, int H, int W, int segs, int trows,
                                                               int ntiles, const int* __restrict__ multi) {
-    if (*multi) return;
+    if (multi && *multi) return;
     __shared__ int lab_s[4][XR_CAP];
     __shared__ unsigned long long bits_s[4][64];
     __shared__ int off_s[4][64];
@@ -1109,8 +1109,23 @@ int amt_i_rank_roots(amt_ctx* ctx, const int* L, int* T, int* blk, int* count_de
     return AMT_OK;
 }
 
+static int label_impl(amt_ctx* ctx, const void* in, int in_dtype, int32_t* out, int32_t* count_dev, int nplanes, int H, int W,
+                      int connectivity, bool truth);
+
 extern "C" int amt_label(amt_ctx* ctx, const void* in, int in_dtype, int32_t* out, int32_t* count_dev, int nplanes,
                          int H, int W, int connectivity) {
+    return label_impl(ctx, in, in_dtype, out, count_dev, nplanes, H, W, connectivity, false);
+}
+
+extern "C" int amt_label_mask(amt_ctx* ctx, const uint8_t* mask, int32_t* out, int32_t* count_dev, int nplanes, int H, int W,
+                              int connectivity) {
+    return label_impl(ctx, mask, AMT_U8, out, count_dev, nplanes, H, W, connectivity, true);
+}
+
+// truth: the uint8 input is a truth value (foreground = byte != 0, as for a bool array): the run-table path then needs no
+// "other byte values" flag and none of the byte kernels that stand by for it
+static int label_impl(amt_ctx* ctx, const void* in, int in_dtype, int32_t* out, int32_t* count_dev, int nplanes, int H, int W,
+                      int connectivity, bool truth) {
     AMT_TRY(amt_set_device(ctx));
     AMT_REQUIRE(in && out && nplanes >= 0 && H > 0 && W > 0, "label: bad arguments");
     AMT_REQUIRE(in_dtype == AMT_U8 || in_dtype == AMT_I32, "label: in_dtype must be AMT_U8 or AMT_I32");
@@ -1141,9 +1156,8 @@ extern "C" int amt_label(amt_ctx* ctx, const void* in, int in_dtype, int32_t* ou
     int* blk = arena_take_t<int>(ctx, (size_t)nplanes * nblk);
     int* nroots = arena_take_t<int>(ctx, nlist);
     unsigned long long* bitmap = arena_take_t<unsigned long long>(ctx, (size_t)nplanes * nwords);
-    AMT_HIP_CHECK(hipMemsetAsync(blk, 0, (size_t)nplanes * nblk * 4, ctx->stream));
-    AMT_HIP_CHECK(hipMemsetAsync(nroots, 0, nlist * 4, ctx->stream));
-    AMT_HIP_CHECK(hipMemsetAsync(bitmap, 0, (size_t)nplanes * nwords * 8, ctx->stream));
+    // chunk counts, list counts and the root bitmap were taken from the arena one after the other: ONE fill clears them
+    AMT_HIP_CHECK(hipMemsetAsync(blk, 0, (size_t)((char*)(bitmap + (size_t)nplanes * nwords) - (char*)blk), ctx->stream));
     // tile-local union-find + seams; only the listed tile roots are compressed, pixels resolve in two hops
     const int segs = (W + 63) / 64;
     const int ntiles = nplanes * trows * segs;
@@ -1158,8 +1172,39 @@ extern "C" int amt_label(amt_ctx* ctx, const void* in, int in_dtype, int32_t* ou
         int* nruns = arena_take_t<int>(ctx, (size_t)ntiles);
         const uint8_t* in8 = (const uint8_t*)in;
         const bool c8 = connectivity == 2;
-        AMT_HIP_CHECK(hipMemsetAsync(multi, 0, sizeof(int), ctx->stream));
         dim3 gs(segs, trows, nplanes);
+        if (truth) {
+            // a truth-value mask: tile pass, seams, the numbering of the listed tile roots, expansion -- nothing stands by
+            if (c8)
+                hipLaunchKernelGGL((ccl_tile_runs_kernel<true, true>), gs, dim3(64), 0, ctx->stream, in8, L, H, W, rootlist, nroots,
+                                   cap, (int*)nullptr, tbits, rtab, nruns, (unsigned short*)nullptr);
+            else
+                hipLaunchKernelGGL((ccl_tile_runs_kernel<false, true>), gs, dim3(64), 0, ctx->stream, in8, L, H, W, rootlist, nroots,
+                                   cap, (int*)nullptr, tbits, rtab, nruns, (unsigned short*)nullptr);
+            AMT_LAUNCH_CHECK();
+            const int jobs = segs * (trows - 1) + (segs - 1) * trows;
+            if (jobs > 0) {
+                if (c8)
+                    hipLaunchKernelGGL((ccl_seams_runs_kernel<true>), dim3((jobs + 3) / 4, 1, nplanes), dim3(256), 0, ctx->stream,
+                                       tbits, rtab, nruns, L, H, W, segs, trows, (const int*)nullptr);
+                else
+                    hipLaunchKernelGGL((ccl_seams_runs_kernel<false>), dim3((jobs + 3) / 4, 1, nplanes), dim3(256), 0, ctx->stream,
+                                       tbits, rtab, nruns, L, H, W, segs, trows, (const int*)nullptr);
+                AMT_LAUNCH_CHECK();
+            }
+            hipLaunchKernelGGL(roots_compress_count_kernel, dim3(4, trows, nplanes), dim3(256), 0, ctx->stream, L, rootlist,
+                               nroots, blk, bitmap, cap, n, nblk);
+            AMT_LAUNCH_CHECK();
+            AMT_TRY(amt_scan_excl(ctx, blk, nblk, (size_t)nblk, count_dev, nplanes));
+            hipLaunchKernelGGL(roots_rank_kernel, dim3(4, trows, nplanes), dim3(256), 0, ctx->stream, T, L, rootlist, nroots,
+                               blk, bitmap, cap, n, nblk);
+            AMT_LAUNCH_CHECK();
+            hipLaunchKernelGGL(ccl_expand_runs_kernel, dim3((ntiles + 3) / 4), dim3(256), 0, ctx->stream, tbits, rtab, nruns, T, out,
+                               H, W, segs, trows, ntiles, (const int*)nullptr);
+            AMT_LAUNCH_CHECK();
+            return AMT_OK;
+        }
+        AMT_HIP_CHECK(hipMemsetAsync(multi, 0, sizeof(int), ctx->stream));
         if (c8)
             hipLaunchKernelGGL((ccl_tile_runs_kernel<true>), gs, dim3(64), 0, ctx->stream, in8, L, H, W, rootlist, nroots, cap,
                                multi, tbits, rtab, nruns, (unsigned short*)nullptr);

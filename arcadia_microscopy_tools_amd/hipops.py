@@ -629,6 +629,11 @@ def label(a: DeviceArray, connectivity: int = 2, out: DeviceArray | None = None,
         raise TypeError(f"label: unsupported dtype {a.dtype}")
     o = _out(ctx, out, a.shape, np.int32)
     c = _out(ctx, count, (n,), np.int32)
+    if code == _hip.U8 and a.is_bool:
+        # a bool array (0 / 1 bytes by construction): the truth-value entry point, whose run-table path launches nothing
+        # that stands by for other byte values
+        _hip.check(_lib().amt_label_mask(ctx.handle, a.ptr, o.ptr, c.ptr, n, H, W, int(connectivity)), "amt_label_mask")
+        return o, c
     _hip.check(_lib().amt_label(ctx.handle, a.ptr, code, o.ptr, c.ptr, n, H, W, int(connectivity)), "amt_label")
     return o, c
 

@@ -259,6 +259,11 @@ int amt_subtract(amt_ctx* ctx, const void* a, const void* b, void* out, int dtyp
  * order of each component's first pixel; count_dev[plane] = K. */
 int amt_label(amt_ctx* ctx, const void* in, int in_dtype, int32_t* out, int32_t* count_dev, int nplanes, int H, int W,
               int connectivity);
+/* amt_label for a uint8 plane batch that is a TRUTH VALUE (foreground = byte != 0; what skimage.measure.label does with
+ * a bool array, R/masks.py:63 on a mask): same labels as amt_label on the 0 / 1 image, without the launches that stand by
+ * for "other byte values" (planes whose width is a multiple of 16; others take amt_label's path and REQUIRE 0 / 1 bytes). */
+int amt_label_mask(amt_ctx* ctx, const uint8_t* mask, int32_t* out, int32_t* count_dev, int nplanes, int H, int W,
+                   int connectivity);
 /* Same result as amt_label for uint8 masks with at most `capacity` foreground pixels per plane (e.g. the EDT
  * peak markers): foreground is compacted in raster order and labelled on the compact list.  If a plane has
  * more foreground pixels than `capacity`, count_dev[plane] = -1 and that plane's labels are invalid. */

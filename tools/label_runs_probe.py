@@ -39,7 +39,8 @@ for case in range(ncases):
         m = ((yy // p + xx // p) % 2 == 0) if rng.random() < 0.5 else (xx % 2 == 0) & (rng.random((H, W)) < 0.9)
     nb = int(rng.integers(1, 4))
     stack = np.stack([m] + [rng.random((H, W)) < 0.5 for _ in range(nb - 1)])
-    d = ctx.asarray(stack.astype(np.uint8))
+    # uint8 bytes take amt_label (other byte values would be noticed), bool arrays amt_label_mask (truth value)
+    d = ctx.asarray(stack.astype(np.uint8)) if case % 2 else ctx.asarray(stack)
     for conn in (1, 2):
         lab, cnt = hipops.label(d, connectivity=conn)
         got, gc = lab.numpy(), cnt.numpy()
