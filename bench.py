@@ -451,6 +451,16 @@ def run_ops(args):
     dom = max(stage_avg, key=stage_avg.get)
     chain_bytes = sum(v["bytes_per_px"] for v in per_stage.values()) * npx
     chain_ms = sum(stage_avg.values())
+    if "dog" in per_stage:
+        # The DoG is bound by float64 ISSUE, not by HBM: per pixel two passes of the narrow Gaussian
+        # (radius 2: 2 + 3 + 2 operations each), two of the wide one (radius 64: 64 + 65 + 64 each) and the subtraction.
+        # Bit-exactness forbids fused multiply-add, so the vector unit's ceiling is one float64 operation per lane and
+        # clock: 256 CUs x 64 lanes x 2.4 GHz = 39.3 T operations/s (half the 78.6 TFLOP/s that counts an FMA as two;
+        # derived from the CU count and the nominal clock -- the guide quotes no float64 figure)
+        ops = (2 * 7 + 2 * 193 + 1) * npx
+        tops = ops / (stage_avg["dog"] * 1e-3) / 1e12
+        per_stage["dog"]["fp64"] = {"operations_per_px": 401, "achieved_Tops": tops, "peak_Tops_without_fma": 39.3,
+                                    "frac": tops / 39.3}
     out = {
         "metric": f"planes/sec (2048^2 uint16) through the {args.workload} operator chain", "value": B * args.steps / elapsed,
         "unit": "planes/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
