@@ -535,9 +535,14 @@ def run_c5(args, json_fd):
     log(f"rank {rank}: stand-in network {sum(p.numel() for p in net.parameters()) / 1e6:.2f} M parameters, "
         f"{flops / T / 1e9:.1f} GFLOP per tile; {nuniq} synthetic flow fields in {gen_s:.1f}s")
 
+    # the forward with its elementwise glue fused into HIP passes (cellpose_hip.FusedStandIn; AMT_C5_FUSED=0: eager PyTorch)
+    fused = None
+    if os.environ.get("AMT_C5_FUSED", "1") == "1" and os.environ.get("AMT_C5_LAYOUT", "nhwc") == "nhwc":
+        fused = ch.FusedStandIn(net, Context(local_rank))
+
     def step():
         with torch.no_grad():
-            y = net(x)
+            y = fused(x) if fused is not None else net(x)
         # CellposeModel.eval's own post-processing: 200 flow steps, flow-error filter at the reference's default 0.4
         # (R/model.py:69), size floor 15 and hole filling
         hipops.cellpose_masks(dP, pr, 0.0, 200, out=labels, count=counts, flow_threshold=0.4, fill_holes=True)
@@ -571,11 +576,22 @@ def run_c5(args, json_fd):
     for _ in range(5):
         e0.record()
         with torch.no_grad():
-            net(x)
+            fused(x) if fused is not None else net(x)  # (the fused forward joins torch's current stream when it returns)
         e1.record()
         e1.synchronize()
         fwd.append(e0.elapsed_time(e1))
     fwd_ms = float(np.median(fwd))
+    eager_ms = None
+    if fused is not None:  # the eager forward beside it: what the fused glue bought
+        eg = []
+        for _ in range(3):
+            e0.record()
+            with torch.no_grad():
+                net(x)
+            e1.record()
+            e1.synchronize()
+            eg.append(e0.elapsed_time(e1))
+        eager_ms = float(np.median(eg))
     tm = ctx.timer()
     post = []
     for _ in range(3):
@@ -606,7 +622,11 @@ def run_c5(args, json_fd):
                 "postprocessing_input": "synthetic flow fields (~1,200 disks per tile), resident on the device",
                 "masks_per_tile_mean": float(nmask.mean()),
             },
-            "roofline": {"bound": "mfma", "kernel": "network forward (MIOpen / hipBLASLt convolutions via PyTorch-ROCm)",
+            "roofline": {"bound": "mfma",
+                         "kernel": "network forward (MIOpen convolutions via PyTorch-ROCm" +
+                                   ("; batch norm / ReLU / additions / upsampling fused into amt_nn_affine_act_bf16 passes)"
+                                    if fused is not None else ", eager)"),
+                         "eager_forward_ms": eager_ms,
                          "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": None,
                          "flops_per_launch": flops, "launch_ms": fwd_ms,

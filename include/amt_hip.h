@@ -475,6 +475,15 @@ int amt_overlay(amt_ctx* ctx, const double* background, const double* const* lay
                 const double* luts_host, const double* opacity_host, const int32_t* mode_host, double* out_rgb, int H,
                 int W);
 
+/* ---- glue of the config-5 flow network (BASELINE configs[4]; R/model.py:211: the network's convolutions run through
+ * PyTorch-ROCm) ---- every convolution of Cellpose's residual U-Net is "batch norm -> [ReLU] -> conv" on a sum of up to
+ * three terms; one pass prepares its input instead of one framework kernel per operation:
+ *   out[n,h,w,c] = act(((upsample ? x[n,h/2,w/2,c] : x[n,h,w,c]) + y[n,h,w,c] + style[n,c]) * scale[c] + shift[c])
+ * x, y (nullable), out, sum_out (nullable: receives x + y, without the style term) are bf16 NHWC (channels-last) tensors,
+ * style (nullable) float32 [N][C], scale / shift float32 [C] (the folded inference-time batch norm); C % 8 == 0. */
+int amt_nn_affine_act_bf16(amt_ctx* ctx, const void* x, const void* y, const float* style, const float* scale,
+                           const float* shift, void* out, void* sum_out, int N, int H, int W, int C, int relu, int upsample);
+
 #ifdef __cplusplus
 }
 #endif

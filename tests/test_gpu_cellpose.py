@@ -317,3 +317,54 @@ def test_config5_at_its_stated_size():
                                      fill_holes=True)
     assert int(cnt.numpy()[0]) == int(want.max()) > 300
     assert np.array_equal(lab.numpy()[0], want)
+
+
+def test_fused_standin_forward_equals_the_eager_one():
+    """cellpose_hip.FusedStandIn (the stand-in's forward with batch norm / ReLU / additions / upsampling fused into
+    amt_nn_affine_act_bf16 passes) against the eager bf16 forward and a float32 forward of the same weights: the fused
+    pass rounds to bf16 once per fused group instead of once per operation, so it must be at least about as close to
+    float32 as the eager bf16 pass is.  Also the fused kernel by itself against its definition."""
+    import torch
+
+    from arcadia_microscopy_tools_amd import cellpose_hip as ch
+    from arcadia_microscopy_tools_amd.device import Context
+
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(3)
+    ref32 = ch.make_standin().to(dev).float().eval()
+    for m in ref32.modules():  # running statistics that are not the identity, so that the folded batch norm is exercised
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.uniform_(-0.2, 0.2)
+            m.running_var.uniform_(0.6, 1.4)
+            m.weight.data.uniform_(0.7, 1.3)
+            m.bias.data.uniform_(-0.2, 0.2)
+    import copy
+
+    net, dt = ch.prepare_network(copy.deepcopy(ref32), dev, "bf16")
+    fused = ch.FusedStandIn(net, Context(0))
+    x32 = torch.randn(2, 2, 256, 256, device=dev)
+    x = x32.to(dt).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        want32 = ref32(x.float())
+        eager = net(x).float()
+    got = fused(x)
+    torch.cuda.synchronize()
+    assert got.shape == (2, 3, 256, 256) and got.dtype == torch.bfloat16
+    got = got.float()
+    scale = float(want32.abs().mean())
+    err_eager = float((eager - want32).abs().mean()) / scale
+    err_fused = float((got - want32).abs().mean()) / scale
+    assert err_fused < 0.05 and err_fused <= 1.25 * err_eager + 1e-3, (err_fused, err_eager)
+    # the kernel against its definition: upsampled input + skip + style, affine map, ReLU; and the x + y side output
+    bn = torch.nn.BatchNorm2d(64).to(dev).eval()
+    bn.running_mean.uniform_(-1, 1), bn.running_var.uniform_(0.5, 2), bn.weight.data.uniform_(0.5, 2), bn.bias.data.uniform_(-1, 1)
+    xs = torch.randn(2, 64, 8, 12, device=dev).to(dt).contiguous(memory_format=torch.channels_last)
+    ys = torch.randn(2, 64, 16, 24, device=dev).to(dt).contiguous(memory_format=torch.channels_last)
+    st = torch.randn(2, 64, device=dev)
+    out, ssum = fused._glue(xs, bn, True, y=ys, style=st, upsample=True, want_sum=True)
+    torch.cuda.synchronize()
+    up = torch.nn.functional.interpolate(xs.float(), scale_factor=2, mode="nearest")
+    s_ref = up + ys.float()
+    o_ref = torch.relu(bn(s_ref + st[:, :, None, None]))
+    assert torch.equal(ssum.float(), s_ref.to(dt).float())
+    assert torch.allclose(out.float(), o_ref.to(dt).float(), rtol=2 ** -7, atol=1e-6)
