@@ -111,7 +111,7 @@ _SIGS = {
     "amt_subtract": (c_int, [_P, _P, _P, _P, c_int, c_size_t]),
     "amt_label": (c_int, [_P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int]),
     "amt_label_mask": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int]),
-    "amt_nn_affine_act_bf16": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "amt_nn_affine_act_bf16": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int]),
     "amt_label_sparse": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int]),
     "amt_label_sparse_reuse": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "amt_clear_border": (c_int, [_P, _P, _P, c_int, c_int, c_int]),

@@ -297,8 +297,33 @@ class FusedStandIn:
             f = self._folded[id(bn)] = (scale.contiguous(), shift.contiguous())
         return f
 
-    def _glue(self, x, bn, relu, y=None, style=None, upsample=False, want_sum=False):
+    # An activation travels as (tensor, bias): a convolution is run WITHOUT its bias (the framework would add it in an
+    # elementwise pass of its own) and the bias is added by whichever fused pass reads the tensor next.
+    def _conv(self, conv, x):
         torch = _torch()
+        y = torch.nn.functional.conv2d(x, conv.weight, None, conv.stride, conv.padding)
+        return y, (self._bias(conv) if conv.bias is not None else None)
+
+    def _bias(self, conv):
+        f = self._folded.get(id(conv))
+        if f is None:
+            f = self._folded[id(conv)] = conv.bias.detach().float().contiguous()
+        return f
+
+    def _pre(self, bx, by):
+        if bx is None or by is None:
+            return bx if by is None else by
+        key = (id(bx), id(by))
+        f = self._folded.get(key)
+        if f is None:
+            f = self._folded[key] = (bx + by).contiguous()
+        return f
+
+    def _glue(self, xb, bn, relu, yb=None, style=None, upsample=False, want_sum=False):
+        """One fused pass; ``bn`` = a BatchNorm2d, or None for the identity map (a plain sum)."""
+        torch = _torch()
+        x, bx = xb
+        y, by = yb if yb is not None else (None, None)
         N, C, H, W = x.shape
         if upsample:
             H, W = 2 * H, 2 * W
@@ -306,48 +331,59 @@ class FusedStandIn:
             x = x.contiguous(memory_format=torch.channels_last)
         if y is not None and not y.is_contiguous(memory_format=torch.channels_last):
             y = y.contiguous(memory_format=torch.channels_last)
-        scale, shift = self._affine(bn)
+        scale, shift = self._affine(bn) if bn is not None else self._identity(C)
+        pre = self._pre(bx, by)
         out = torch.empty((N, C, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         s = torch.empty_like(out) if want_sum else None
         _hip.check(self._lib.amt_nn_affine_act_bf16(self.ctx.handle, x.data_ptr(), y.data_ptr() if y is not None else None,
-                                                    style.data_ptr() if style is not None else None, scale.data_ptr(),
+                                                    style.data_ptr() if style is not None else None,
+                                                    pre.data_ptr() if pre is not None else None, scale.data_ptr(),
                                                     shift.data_ptr(), out.data_ptr(), s.data_ptr() if s is not None else None,
                                                     N, H, W, C, 1 if relu else 0, 1 if upsample else 0),
                    "amt_nn_affine_act_bf16")
         return (out, s) if want_sum else out
 
-    def _bconv(self, seq, x, **kw):
-        """nn.Sequential(BatchNorm2d, ReLU, Conv2d) on the fused sum."""
-        if x.shape[1] % 8:
-            if kw:
-                raise ValueError("unfused fallback only for a plain input")
-            return seq(x)  # the 2-channel input layer
-        return seq[2](self._glue(x, seq[0], True, **kw))
+    def _identity(self, C):
+        f = self._folded.get(("id", C))
+        if f is None:
+            torch = _torch()
+            f = self._folded[("id", C)] = (torch.ones(C, device=self.device), torch.zeros(C, device=self.device))
+        return f
 
-    def _proj(self, seq, x, upsample=False):
-        """nn.Sequential(BatchNorm2d, Conv2d 1x1)."""
-        if x.shape[1] % 8:
-            return seq(x)
-        return seq[1](self._glue(x, seq[0], False, upsample=upsample))
+    def _bconv(self, seq, xb, **kw):
+        """nn.Sequential(BatchNorm2d, ReLU, Conv2d) on the fused sum -> (tensor, pending bias)."""
+        if xb[0].shape[1] % 8:
+            if kw or xb[1] is not None:
+                raise ValueError("unfused fallback only for a plain input")
+            return seq(xb[0]), None  # the 2-channel input layer
+        return self._conv(seq[2], self._glue(xb, seq[0], True, **kw))
+
+    def _proj(self, seq, xb, upsample=False):
+        """nn.Sequential(BatchNorm2d, Conv2d 1x1) -> (tensor, pending bias)."""
+        if xb[0].shape[1] % 8:
+            return seq(xb[0]), None
+        return self._conv(seq[1], self._glue(xb, seq[0], False, upsample=upsample))
 
     def _res_down(self, blk, x):
-        p = self._proj(blk.proj, x)
-        b = self._bconv(blk.conv[1], self._bconv(blk.conv[0], x))
-        g, x1 = self._glue(p, blk.conv[2][0], True, y=b, want_sum=True)  # x1 = proj + conv path, g = relu(bn(x1))
-        d = self._bconv(blk.conv[3], blk.conv[2][2](g))
-        return x1 + d
+        xb = (x, None)
+        p = self._proj(blk.proj, xb)
+        b = self._bconv(blk.conv[1], self._bconv(blk.conv[0], xb))
+        g, x1 = self._glue(p, blk.conv[2][0], True, yb=b, want_sum=True)  # x1 = proj + conv path, g = relu(bn(x1))
+        d = self._bconv(blk.conv[3], self._conv(blk.conv[2][2], g))
+        return self._glue((x1, None), None, False, yb=d)  # x1 + d (+ d's bias)
 
     def _style(self, cs, style):
         return cs.full(style).float().contiguous()  # (N, cout) float32
 
     def _res_up(self, blk, x, y, style, upsample):
-        a = blk.conv0[2](self._glue(x, blk.conv0[0], True, upsample=upsample))
-        p = self._proj(blk.proj, x, upsample=upsample)
-        b = blk.c1.conv[2](self._glue(a, blk.c1.conv[0], True, y=y, style=self._style(blk.c1, style)))
-        g, x1 = self._glue(p, blk.c2.conv[0], True, y=b, style=self._style(blk.c2, style), want_sum=True)
-        c = blk.c2.conv[2](g)
-        d = blk.c3.conv[2](self._glue(c, blk.c3.conv[0], True, style=self._style(blk.c3, style)))
-        return x1 + d
+        xb = (x, None)
+        a = self._conv(blk.conv0[2], self._glue(xb, blk.conv0[0], True, upsample=upsample))
+        p = self._proj(blk.proj, xb, upsample=upsample)
+        b = self._conv(blk.c1.conv[2], self._glue(a, blk.c1.conv[0], True, yb=(y, None), style=self._style(blk.c1, style)))
+        g, x1 = self._glue(p, blk.c2.conv[0], True, yb=b, style=self._style(blk.c2, style), want_sum=True)
+        c = self._conv(blk.c2.conv[2], g)
+        d = self._conv(blk.c3.conv[2], self._glue(c, blk.c3.conv[0], True, style=self._style(blk.c3, style)))
+        return self._glue((x1, None), None, False, yb=d)
 
     def __call__(self, x):
         torch = _torch()
@@ -364,6 +400,6 @@ class FusedStandIn:
             x = self._res_up(net.up[0], feats[-1], feats[-1], style, False)
             for j, blk in enumerate(net.up[1:], start=1):
                 x = self._res_up(blk, x, feats[-1 - j], style, True)  # the upsampling is read, not made
-            y = net.out[2](self._glue(x, net.out[0], True))
+            y = net.out[2](self._glue((x, None), net.out[0], True))
         cur.wait_stream(self.stream)
         return y

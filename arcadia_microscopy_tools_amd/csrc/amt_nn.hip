@@ -6,8 +6,9 @@
 // operation -- batch norm 8.8 ms (35 launches), ReLU 3.8, the additions of skip / style / residual 3.4, and three
 // nearest-neighbour upsamplings at 3.5 ms apiece (35 x what their bytes need).  Every convolution of the network is
 // "batch norm -> [ReLU] -> conv" on a sum of up to three terms, so ONE pass can feed it:
-//     out = act(((x | upsample2x(x)) + y + style[n, c]) * scale[c] + shift[c])
-// with scale / shift = the folded inference-time batch norm.  bf16 in and out, arithmetic in float32, one rounding.
+//     out = act(((x | upsample2x(x)) + y + pre_bias[c] + style[n, c]) * scale[c] + shift[c])
+// with scale / shift = the folded inference-time batch norm and pre_bias = the biases of the convolutions that produced
+// x and y (the framework adds a convolution's bias in a pass of its own: 3.8 ms per forward; they run without it).  bf16 in and out, arithmetic in float32, one rounding.
 #include "amt_internal.h"
 
 __device__ __forceinline__ float nn_bf16_to_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
@@ -19,6 +20,7 @@ __device__ __forceinline__ unsigned short nn_f32_to_bf16(float f) {  // round to
 // one thread = 8 consecutive channels of one output pixel (16-byte loads / stores); C % 8 == 0
 __global__ void __launch_bounds__(256) nn_affine_act_kernel(const uint4* __restrict__ x, const uint4* __restrict__ y,
                                                             const float* __restrict__ style,
+                                                            const float* __restrict__ pre_bias,
                                                             const float* __restrict__ scale,
                                                             const float* __restrict__ shift, uint4* __restrict__ out,
                                                             uint4* __restrict__ sum_out, size_t total, int H, int W, int C8,
@@ -46,6 +48,10 @@ __global__ void __launch_bounds__(256) nn_affine_act_kernel(const uint4* __restr
             v[2 * k + 1] = nn_bf16_to_f32((unsigned short)(xs[k] >> 16)) + nn_bf16_to_f32((unsigned short)(ys[k] >> 16));
         }
         const int c0 = cg * 8;
+        if (pre_bias) {  // the biases of the convolutions that produced x and y (run without them)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] += pre_bias[c0 + k];
+        }
         if (sum_out) {  // x + y itself is a value of the network (a block's residual input): kept in bf16, style not in it
             uint4 s;
             s.x = nn_f32_to_bf16(v[0]) | ((unsigned)nn_f32_to_bf16(v[1]) << 16);
@@ -75,8 +81,8 @@ __global__ void __launch_bounds__(256) nn_affine_act_kernel(const uint4* __restr
     }
 }
 
-extern "C" int amt_nn_affine_act_bf16(amt_ctx* ctx, const void* x, const void* y, const float* style, const float* scale,
-                                      const float* shift, void* out, void* sum_out, int N, int H, int W, int C, int relu,
+extern "C" int amt_nn_affine_act_bf16(amt_ctx* ctx, const void* x, const void* y, const float* style,
+                                      const float* pre_bias, const float* scale, const float* shift, void* out, void* sum_out, int N, int H, int W, int C, int relu,
                                       int upsample) {
     AMT_TRY(amt_set_device(ctx));
     AMT_REQUIRE(x && scale && shift && out && N >= 0 && H > 0 && W > 0 && C > 0, "nn_affine_act: bad arguments");
@@ -88,7 +94,7 @@ extern "C" int amt_nn_affine_act_bf16(amt_ctx* ctx, const void* x, const void* y
     if (N == 0) return AMT_OK;
     const size_t total = (size_t)N * H * W * (C / 8);
     hipLaunchKernelGGL(nn_affine_act_kernel, dim3(amt_grid_for(total, 256, 65536)), dim3(256), 0, ctx->stream,
-                       (const uint4*)x, (const uint4*)y, style, scale, shift, (uint4*)out, (uint4*)sum_out, total, H, W, C / 8,
+                       (const uint4*)x, (const uint4*)y, style, pre_bias, scale, shift, (uint4*)out, (uint4*)sum_out, total, H, W, C / 8,
                        relu, upsample);
     AMT_LAUNCH_CHECK();
     return AMT_OK;

@@ -478,11 +478,13 @@ int amt_overlay(amt_ctx* ctx, const double* background, const double* const* lay
 /* ---- glue of the config-5 flow network (BASELINE configs[4]; R/model.py:211: the network's convolutions run through
  * PyTorch-ROCm) ---- every convolution of Cellpose's residual U-Net is "batch norm -> [ReLU] -> conv" on a sum of up to
  * three terms; one pass prepares its input instead of one framework kernel per operation:
- *   out[n,h,w,c] = act(((upsample ? x[n,h/2,w/2,c] : x[n,h,w,c]) + y[n,h,w,c] + style[n,c]) * scale[c] + shift[c])
- * x, y (nullable), out, sum_out (nullable: receives x + y, without the style term) are bf16 NHWC (channels-last) tensors,
- * style (nullable) float32 [N][C], scale / shift float32 [C] (the folded inference-time batch norm); C % 8 == 0. */
-int amt_nn_affine_act_bf16(amt_ctx* ctx, const void* x, const void* y, const float* style, const float* scale,
-                           const float* shift, void* out, void* sum_out, int N, int H, int W, int C, int relu, int upsample);
+ *   s = (upsample ? x[n,h/2,w/2,c] : x[n,h,w,c]) + y[n,h,w,c] + pre_bias[c];  out = act((s + style[n,c]) * scale[c] + shift[c])
+ * x, y (nullable), out, sum_out (nullable: receives s) are bf16 NHWC (channels-last) tensors, style (nullable) float32
+ * [N][C], pre_bias (nullable: the biases of the convolutions that produced x and y, run without them), scale / shift
+ * float32 [C] (the folded inference-time batch norm); C % 8 == 0. */
+int amt_nn_affine_act_bf16(amt_ctx* ctx, const void* x, const void* y, const float* style, const float* pre_bias,
+                           const float* scale, const float* shift, void* out, void* sum_out, int N, int H, int W, int C,
+                           int relu, int upsample);
 
 #ifdef __cplusplus
 }

@@ -361,10 +361,11 @@ def test_fused_standin_forward_equals_the_eager_one():
     xs = torch.randn(2, 64, 8, 12, device=dev).to(dt).contiguous(memory_format=torch.channels_last)
     ys = torch.randn(2, 64, 16, 24, device=dev).to(dt).contiguous(memory_format=torch.channels_last)
     st = torch.randn(2, 64, device=dev)
-    out, ssum = fused._glue(xs, bn, True, y=ys, style=st, upsample=True, want_sum=True)
+    pre = torch.randn(64, device=dev)
+    out, ssum = fused._glue((xs, pre), bn, True, yb=(ys, None), style=st, upsample=True, want_sum=True)
     torch.cuda.synchronize()
     up = torch.nn.functional.interpolate(xs.float(), scale_factor=2, mode="nearest")
-    s_ref = up + ys.float()
+    s_ref = up + ys.float() + pre[None, :, None, None]
     o_ref = torch.relu(bn(s_ref + st[:, :, None, None]))
     assert torch.equal(ssum.float(), s_ref.to(dt).float())
     assert torch.allclose(out.float(), o_ref.to(dt).float(), rtol=2 ** -7, atol=1e-6)
