@@ -155,8 +155,15 @@ class SegmentationModel:
         if self._net is None:
             from . import cellpose_hip
 
-            net = cellpose_hip.make_standin() if isinstance(self.network, str) and self.network == "standin" else self.network
-            self._net = cellpose_hip.prepare_network(net, self.device, self.compute_dtype)
+            standin = isinstance(self.network, str) and self.network == "standin"
+            net = cellpose_hip.make_standin() if standin else self.network
+            net, dt = cellpose_hip.prepare_network(net, self.device, self.compute_dtype)
+            if standin and self.compute_dtype == "bf16":
+                # the stand-in's own graph is known: its forward runs with the elementwise glue fused into HIP passes
+                from .device import get_context
+
+                net = cellpose_hip.FusedStandIn(net, get_context())
+            self._net = (net, dt)
         return self._net
 
     def _segment_network(self, intensities: np.ndarray, params: CellposeParams, cellpose_kwargs=None) -> Int64Array:
