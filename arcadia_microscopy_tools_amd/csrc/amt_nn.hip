@@ -17,26 +17,27 @@ __device__ __forceinline__ unsigned short nn_f32_to_bf16(float f) {  // round to
     return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
 }
 
-// one thread = 8 consecutive channels of one output pixel (16-byte loads / stores); C % 8 == 0
+// one thread = 8 consecutive channels of one output pixel (16-byte loads / stores); C % 8 == 0.  A workgroup works inside
+// ONE image row (blockIdx.y = n * H + h), so the only per-thread index arithmetic is the split of its position in the row
+// into (pixel, channel group) -- a shift when C / 8 is a power of two (it is for every layer of the network); with a flat
+// index the three divisions by runtime values cost more than the 16 bytes a thread moves.
 __global__ void __launch_bounds__(256) nn_affine_act_kernel(const uint4* __restrict__ x, const uint4* __restrict__ y,
                                                             const float* __restrict__ style,
                                                             const float* __restrict__ pre_bias,
                                                             const float* __restrict__ scale,
                                                             const float* __restrict__ shift, uint4* __restrict__ out,
-                                                            uint4* __restrict__ sum_out, size_t total, int H, int W, int C8,
-                                                            int relu, int upsample) {
-    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (size_t)gridDim.x * 256) {
-        const int cg = (int)(t % C8);
-        const size_t pix = t / C8;
-        size_t src = t;
-        int n_img = 0;
-        if (upsample || style) {
-            const int w = (int)(pix % W);
-            const size_t r = pix / W;
-            const int h = (int)(r % H);
-            n_img = (int)(r / H);
-            if (upsample) src = (((size_t)n_img * (H >> 1) + (h >> 1)) * (W >> 1) + (w >> 1)) * C8 + cg;
-        }
+                                                            uint4* __restrict__ sum_out, int H, int W, int C8, int c8_shift,
+                                                            int relu, int upsample, int row0) {
+    const int row = row0 + (int)blockIdx.y;  // n * H + h
+    const int n_img = row / H, h = row - n_img * H;  // uniform
+    const int per_row = W * C8;
+    const size_t row_base = (size_t)row * per_row;
+    const size_t src_row = upsample ? ((size_t)n_img * (H >> 1) + (h >> 1)) * (size_t)((W >> 1) * C8) : row_base;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < per_row; i += gridDim.x * 256) {
+        const int w = c8_shift >= 0 ? i >> c8_shift : i / C8;
+        const int cg = i - w * C8;
+        const size_t t = row_base + i;
+        const size_t src = upsample ? src_row + (size_t)(w >> 1) * C8 + cg : t;
         const uint4 xv = x[src];
         uint4 yv = make_uint4(0, 0, 0, 0);
         if (y) yv = y[t];
@@ -92,10 +93,18 @@ extern "C" int amt_nn_affine_act_bf16(amt_ctx* ctx, const void* x, const void* y
                   reinterpret_cast<uintptr_t>(sum_out)) & 15) == 0,
                 "nn_affine_act: tensors must be 16-byte aligned");
     if (N == 0) return AMT_OK;
-    const size_t total = (size_t)N * H * W * (C / 8);
-    hipLaunchKernelGGL(nn_affine_act_kernel, dim3(amt_grid_for(total, 256, 65536)), dim3(256), 0, ctx->stream,
-                       (const uint4*)x, (const uint4*)y, style, pre_bias, scale, shift, (uint4*)out, (uint4*)sum_out, total, H, W, C / 8,
-                       relu, upsample);
+    AMT_REQUIRE((size_t)N * H < 0x7fffffffull && (size_t)W * (C / 8) < 0x7fffffffull, "nn_affine_act: tensor too large");
+    const int C8 = C / 8;
+    int c8_shift = -1;
+    if ((C8 & (C8 - 1)) == 0)
+        for (c8_shift = 0; (1 << c8_shift) < C8; ++c8_shift) {}
+    const int rows = N * H;
+    for (int row0 = 0; row0 < rows; row0 += 65535) {  // grid.y is limited to 65,535 rows per launch
+        const int nr = rows - row0 < 65535 ? rows - row0 : 65535;
+        hipLaunchKernelGGL(nn_affine_act_kernel, dim3(amt_grid_for((size_t)W * C8, 256, 64), (unsigned)nr), dim3(256), 0,
+                           ctx->stream, (const uint4*)x, (const uint4*)y, style, pre_bias, scale, shift, (uint4*)out,
+                           (uint4*)sum_out, H, W, C8, c8_shift, relu, upsample, row0);
+    }
     AMT_LAUNCH_CHECK();
     return AMT_OK;
 }
