@@ -75,6 +75,84 @@ __global__ void __launch_bounds__(256) cp_follow_kernel(const float* __restrict_
     }
 }
 
+// The same in two kernels (round 3): cp_follow_kernel keeps a whole wave in its 200-step loop for the one pixel in four
+// that moves, and every bilinear tap costs three gathers, a select and two divisions.  cp_follow_prep_kernel computes the
+// field the taps really read -- (cell ? dP : 0) / 5 as one float2 per pixel, the same float32 operations once instead of
+// 800 times -- writes the resting pixels' positions and LISTS the moving pixels; cp_follow_list_kernel then follows the
+// listed pixels, full waves, one 8-byte gather per tap.  Same arithmetic in the same order: bit-identical positions.
+__global__ void __launch_bounds__(256) cp_follow_prep_kernel(const float* __restrict__ dP, const float* __restrict__ prob,
+                                                             float thr, float2* __restrict__ fld, unsigned* __restrict__ pos,
+                                                             int* __restrict__ list, int* __restrict__ nlist, int H, int W) {
+    const size_t n = (size_t)H * W;
+    const float* dY = dP + (size_t)blockIdx.y * 2 * n;
+    const float* dX = dY + n;
+    const float* pr = prob + (size_t)blockIdx.y * n;
+    float2* f = fld + (size_t)blockIdx.y * n;
+    unsigned* po = pos + (size_t)blockIdx.y * n;
+    int* lst = list + (size_t)blockIdx.y * n;
+    const int lane = threadIdx.x & 63;
+    for (size_t i0 = (size_t)blockIdx.x * 256; i0 < n; i0 += (size_t)gridDim.x * 256) {  // block-uniform bounds
+        const size_t i = i0 + threadIdx.x;
+        bool moves = false;
+        if (i < n) {
+            const bool cell = pr[i] > thr;
+            const float vy = (cell ? dY[i] : 0.0f) / 5.0f, vx = (cell ? dX[i] : 0.0f) / 5.0f;
+            f[i] = make_float2(vy, vx);
+            moves = cell && fabsf(dY[i] / 5.0f) > 1e-3f;
+            if (!moves) {
+                const int y0 = (int)(i / W), x0 = (int)(i - (size_t)y0 * W);
+                po[i] = ((unsigned)(y0 + CP_RPAD) << 16) | (unsigned)(x0 + CP_RPAD);
+            }
+        }
+        const unsigned long long m = __ballot(moves);
+        if (m) {
+            const int leader = __ffsll((long long)m) - 1;
+            int base = 0;
+            if (lane == leader) base = atomicAdd(&nlist[blockIdx.y], __popcll(m));
+            base = __shfl(base, leader);
+            if (moves) lst[base + __popcll(m & ((1ull << lane) - 1ull))] = (int)i;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) cp_follow_list_kernel(const float2* __restrict__ fld, int niter,
+                                                             unsigned* __restrict__ pos, const int* __restrict__ list,
+                                                             const int* __restrict__ nlist, int H, int W) {
+    const size_t n = (size_t)H * W;
+    const float2* f = fld + (size_t)blockIdx.y * n;
+    unsigned* po = pos + (size_t)blockIdx.y * n;
+    const int* lst = list + (size_t)blockIdx.y * n;
+    const int cnt = nlist[blockIdx.y];
+    const float sy = (float)H / (float)(H - 1), sx = (float)W / (float)(W - 1);
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < cnt; k += gridDim.x * 256) {
+        const int i = lst[k];
+        const int y0 = i / W, x0 = i - y0 * W;
+        float y = (float)y0, x = (float)x0;
+        for (int t = 0; t < niter; ++t) {
+            const float fy = y * sy - 0.5f, fx = x * sx - 0.5f;
+            const float gy = floorf(fy), gx = floorf(fx);
+            const int iy = (int)gy, ix = (int)gx;
+            const float wy = fy - gy, wx = fx - gx;
+            float vy = 0.0f, vx = 0.0f;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int yy = iy + a, xx = ix + b;
+                    if (yy >= 0 && yy < H && xx >= 0 && xx < W) {  // zero padding outside
+                        const float2 v = f[(size_t)yy * W + xx];
+                        const float w = (a ? wy : 1.0f - wy) * (b ? wx : 1.0f - wx);
+                        vy += w * v.x;
+                        vx += w * v.y;
+                    }
+                }
+            y = fminf(fmaxf(y + vy, 0.0f), (float)(H - 1));
+            x = fminf(fmaxf(x + vx, 0.0f), (float)(W - 1));
+        }
+        po[i] = ((unsigned)((int)y + CP_RPAD) << 16) | (unsigned)((int)x + CP_RPAD);
+    }
+}
+
 // ---- 3: histogram, seeds -----------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) cp_hist_kernel(const unsigned* __restrict__ pos, int* __restrict__ hist, size_t n,
                                                       int Wp, size_t hn) {
@@ -771,8 +849,13 @@ static int cellpose_masks_impl(amt_ctx* ctx, const float* dP, const float* cellp
         need += amt_align(nl * sizeof(cp_box)) + amt_align(nl * 4) + amt_align(nl * 16) + 2 * amt_align(nl * 8) +
                 2 * amt_align((size_t)nplanes * 4) + 2 * amt_align((size_t)nplanes * n * 8) +
                 cp_finish_bytes(nplanes, n, cap, fill_holes);
+    need += amt_align((size_t)nplanes * n * 8) + amt_align((size_t)nplanes * n * 4) + amt_align((size_t)nplanes * 4);
     AMT_TRY(amt_arena_begin(ctx, need));
     unsigned* pos = arena_take_t<unsigned>(ctx, (size_t)nplanes * n);
+    float2* fld = arena_take_t<float2>(ctx, (size_t)nplanes * n);  // (cell ? dP : 0) / 5, y and x
+    int* mvlist = arena_take_t<int>(ctx, (size_t)nplanes * n);     // the pixels that move
+    int* nmv = arena_take_t<int>(ctx, nplanes);
+    AMT_HIP_CHECK(hipMemsetAsync(nmv, 0, (size_t)nplanes * 4, ctx->stream));
     int* hist = arena_take_t<int>(ctx, (size_t)nplanes * hn);
     int* M = arena_take_t<int>(ctx, (size_t)nplanes * hn);
     unsigned long long* seeds = arena_take_t<unsigned long long>(ctx, (size_t)nplanes * cap);
@@ -789,7 +872,16 @@ static int cellpose_masks_impl(amt_ctx* ctx, const float* dP, const float* cellp
     hipLaunchKernelGGL(cp_fill_kernel, dim3(amt_grid_for(nl, 256, 1024)), dim3(256), 0, ctx->stream, first, nl, 0x7fffffff);
     AMT_LAUNCH_CHECK();
     dim3 gpx(amt_grid_for(n, 256, 4096), nplanes), ghist(amt_grid_for(hn, 256, 4096), nplanes);
-    hipLaunchKernelGGL(cp_follow_kernel, gpx, dim3(256), 0, ctx->stream, dP, cellprob, cellprob_threshold, niter, pos, H, W);
+    if (n < 0x7fffffffull) {
+        // the field the taps read, the resting pixels' positions and the list of the moving ones; then the listed pixels
+        hipLaunchKernelGGL(cp_follow_prep_kernel, gpx, dim3(256), 0, ctx->stream, dP, cellprob, cellprob_threshold, fld, pos,
+                           mvlist, nmv, H, W);
+        AMT_LAUNCH_CHECK();
+        hipLaunchKernelGGL(cp_follow_list_kernel, gpx, dim3(256), 0, ctx->stream, (const float2*)fld, niter, pos,
+                           (const int*)mvlist, (const int*)nmv, H, W);
+    } else {
+        hipLaunchKernelGGL(cp_follow_kernel, gpx, dim3(256), 0, ctx->stream, dP, cellprob, cellprob_threshold, niter, pos, H, W);
+    }
     AMT_LAUNCH_CHECK();
     hipLaunchKernelGGL(cp_hist_kernel, gpx, dim3(256), 0, ctx->stream, pos, hist, n, Wp, hn);
     AMT_LAUNCH_CHECK();
