@@ -279,12 +279,24 @@ __global__ void __launch_bounds__(256) cp_assign_kernel(const unsigned* __restri
     int* l = lab + (size_t)blockIdx.y * n;
     int* c = count + (size_t)blockIdx.y * (cap + 1);
     int* f = first + (size_t)blockIdx.y * (cap + 1);
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const unsigned p = po[i];
-        const int v = m[(size_t)(p >> 16) * Wp + (p & 0xFFFFu)];
-        l[i] = v;
-        if (v > 0) {
-            atomicAdd(&c[v], 1);
+    const int lane = threadIdx.x & 63;
+    for (size_t i0 = (size_t)blockIdx.x * 256; i0 < n; i0 += (size_t)gridDim.x * 256) {  // block-uniform: whole waves below
+        const size_t i = i0 + threadIdx.x;
+        int v = 0;
+        if (i < n) {
+            const unsigned p = po[i];
+            v = m[(size_t)(p >> 16) * Wp + (p & 0xFFFFu)];
+            l[i] = v;
+        }
+        // neighbouring pixels mostly share their label: ONE pair of atomics per run of equal labels inside the wave (the
+        // run's first lane adds the run's length; its index is the run's smallest) instead of one pair per pixel
+        const int vl = amt_lane_left(v);
+        const bool head = v > 0 && (lane == 0 || vl != v);
+        const unsigned long long bounds = __ballot(head || v <= 0);
+        if (head) {
+            const unsigned long long later = lane == 63 ? 0ull : bounds & ~((2ull << lane) - 1ull);
+            const int end = later ? __ffsll((long long)later) - 1 : 64;
+            atomicAdd(&c[v], end - lane);
             atomicMin(&f[v], (int)i);
         }
     }
