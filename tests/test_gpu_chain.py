@@ -440,3 +440,22 @@ def test_host_tables_deliver_what_the_segmenters_computed():
             else:
                 np.testing.assert_allclose(table[:, j], want[:, j], rtol=1e-5, atol=1e-6, err_msg=f"{step} {name}")
     ht.close()
+
+
+def test_c3_on_widths_that_take_the_run_table_path():
+    """Config 3 on planes whose width is a multiple of 16 but not of 64 and whose height is not a multiple of 64 (tiles
+    cut by the image's edge on the run-table path of the watershed stage, the one-pass EDT's tail columns): labels
+    identical to the oracle."""
+    from arcadia_microscopy_tools_amd import synth
+    from arcadia_microscopy_tools_amd.device import get_context
+    from arcadia_microscopy_tools_amd.segment import FovSegmenter
+    from oracle import chains
+
+    ctx = get_context()
+    for H, W in ((129, 208), (300, 464), (200, 80)):
+        fov = np.stack([synth.synth_fov(40 + i, size=max(H, W))[:, :H, :W].copy() for i in range(2)])
+        seg = FovSegmenter(2, 4, H, W, ctx=ctx, max_cells=4096)
+        lab = seg.run_c3(ctx.asarray(fov)).numpy()
+        for b in range(2):
+            ref, _ = chains.c3_chain(fov[b])
+            assert np.array_equal(lab[b], ref), (H, W, b)
