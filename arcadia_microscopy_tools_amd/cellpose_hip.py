@@ -402,4 +402,5 @@ class FusedStandIn:
                 x = self._res_up(blk, x, feats[-1 - j], style, True)  # the upsampling is read, not made
             y = net.out[2](self._glue((x, None), net.out[0], True))
         cur.wait_stream(self.stream)
+        y.record_stream(cur)  # allocated on self.stream, used by the caller on its own: the allocator must know
         return y
