@@ -310,6 +310,9 @@ int amt_peak_mask(amt_ctx* ctx, const int32_t* d2, const uint8_t* mask, uint8_t*
                   int min_distance);
 /* Priority flood restricted to `mask` (skimage.segmentation.watershed, no compactness, no watershed line;
  * SURVEY.md A.1).  Priority = (value, insertion age); labels are assigned at push time.
+ * `mask` holds 0 / 1 bytes (what a bool array is on the device): scikit-image takes the mask as a truth value, and only
+ * amt_watershed_edt_cleared_sparse on widths that are a multiple of 16 reads other non-zero bytes that way -- elsewhere
+ * differing non-zero byte values would split a region.
  *   amt_watershed_edt : relief = -sqrt(d2) given as the exact integer d2 (bucket queue).  seeds_first = 1 is the
  *                       config-3 recipe (oracle/skops.py:seeded_flood_image): marker pixels are spread first, in
  *                       raster order -- i.e. the relief with every marker pixel lowered to a distinct lowest value;
